@@ -1,0 +1,397 @@
+"""ctypes wrapper over oracle/libtrino_oracle.so -- the CPU restatement of the reference algorithms.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
+never by the product package.  See trino_oracle.h for the reference citations of every function.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtrino_oracle.so")
+
+BIGINT, INTEGER, DATE, DOUBLE, BOOLEAN, VARCHAR = 1, 2, 3, 4, 5, 6
+_NP = {BIGINT: np.int64, INTEGER: np.int32, DATE: np.int32, DOUBLE: np.float64, BOOLEAN: np.uint8}
+
+OK, ERR_INVALID, ERR_NUMERIC_VALUE_OUT_OF_RANGE, ERR_INSUFFICIENT_RESOURCES, ERR_DIVISION_BY_ZERO = 0, -1, -2, -3, -7
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "trino_oracle.c")
+    hdr = os.path.join(_HERE, "trino_oracle.h")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libtrino_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class OColumn(C.Structure):
+    _fields_ = [("type", C.c_int32), ("n", C.c_int32), ("values", C.c_void_p), ("nulls", C.c_void_p), ("offsets", C.c_void_p)]
+
+
+class OExprNode(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("type", C.c_int32), ("op", C.c_int32), ("n_args", C.c_int32),
+                ("args", C.c_int32 * 3), ("is_null", C.c_int32), ("ival", C.c_int64), ("dval", C.c_double),
+                ("slen", C.c_int32), ("pad", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        i32, i64, f64, vp = C.c_int32, C.c_int64, C.c_double, C.c_void_p
+        sig = {
+            "o_hash_long": (i64, [i64]), "o_hash_int": (i64, [i32]), "o_hash_double": (i64, [f64]),
+            "o_hash_boolean": (i64, [C.c_uint8]),
+            "o_xxh64": (C.c_uint64, [vp, C.c_size_t, C.c_uint64]), "o_xxh64_long": (i64, [i64]),
+            "o_combine_hash": (i64, [i64, i64]), "o_murmur3_fmix": (C.c_uint64, [C.c_uint64]),
+            "o_array_size": (i32, [i32, C.c_float]), "o_calculate_max_fill": (i32, [i32]),
+            "o_hash_rows": (None, [vp, i32, i32, vp]),
+            "o_partition_remote": (i32, [i64, i32]), "o_partition_local": (i32, [i64, i32]),
+            "o_bigint_gbh_new": (vp, [i32]), "o_bigint_gbh_free": (None, [vp]),
+            "o_bigint_gbh_get_group_ids": (i32, [vp, vp, vp]), "o_bigint_gbh_contains": (i32, [vp, vp, i32]),
+            "o_bigint_gbh_group_count": (i32, [vp]), "o_bigint_gbh_capacity": (i32, [vp]),
+            "o_bigint_gbh_hash_collisions": (i64, [vp]), "o_bigint_gbh_rehash_count": (i32, [vp]),
+            "o_bigint_gbh_values": (None, [vp, vp, vp, vp]),
+            "o_multi_gbh_new": (vp, [i32, vp, i32]), "o_multi_gbh_free": (None, [vp]),
+            "o_multi_gbh_get_group_ids": (i32, [vp, vp, vp, i32, vp]),
+            "o_multi_gbh_contains": (i32, [vp, vp, i32, i64]),
+            "o_multi_gbh_group_count": (i32, [vp]), "o_multi_gbh_capacity": (i32, [vp]),
+            "o_multi_gbh_rehash_count": (i32, [vp]), "o_multi_gbh_group_rows": (None, [vp, vp, vp]),
+            "o_agg_double_sum": (None, [vp, vp, vp, vp, i32, vp, vp]),
+            "o_agg_long_avg": (None, [vp, vp, vp, vp, i32, vp, vp]),
+            "o_agg_long_sum": (i32, [vp, vp, vp, vp, i32, vp, vp]),
+            "o_agg_count": (None, [vp, vp, vp, i32, vp]),
+            "o_exact_sum": (f64, [vp, i64]),
+            "o_agg_double_sum_exact": (None, [vp, vp, vp, vp, i64, i32, vp, vp]),
+            "o_pages_hash_new": (vp, [vp, i32, i32, vp]), "o_pages_hash_free": (None, [vp]),
+            "o_pages_hash_size": (i32, [vp]), "o_pages_hash_link_count": (i32, [vp]),
+            "o_pages_hash_links": (vp, [vp]), "o_pages_hash_keys": (vp, [vp]), "o_pages_hash_collisions": (i64, [vp]),
+            "o_pages_hash_get_address_index": (i32, [vp, vp, i32, i64]),
+            "o_join_probe": (i64, [vp, vp, i32, vp, i32, vp, vp, i64]),
+            "o_filter": (i32, [vp, i32, C.c_char_p, vp, i32, vp, vp]),
+            "o_project": (i32, [vp, i32, C.c_char_p, vp, vp, i32, vp, vp, vp]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Col:
+    """Flat column: the oracle-side mirror of LongArrayBlock / IntArrayBlock / ByteArrayBlock / VariableWidthBlock."""
+
+    def __init__(self, type_id, values, nulls=None, offsets=None):
+        self.type = type_id
+        if type_id == VARCHAR:
+            if offsets is None:  # list of python str/bytes/None
+                items = list(values)
+                nl = np.array([v is None for v in items], dtype=np.uint8)
+                bs = [b"" if v is None else (v.encode("utf-8") if isinstance(v, str) else bytes(v)) for v in items]
+                offsets = np.zeros(len(bs) + 1, dtype=np.int32)
+                if bs:
+                    offsets[1:] = np.cumsum([len(b) for b in bs])
+                values = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if sum(len(b) for b in bs) else np.zeros(1, dtype=np.uint8)
+                if nulls is None and nl.any():
+                    nulls = nl
+            self.values = np.ascontiguousarray(values, dtype=np.uint8)
+            self.offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+            self.n = len(self.offsets) - 1
+        else:
+            self.values = np.ascontiguousarray(values, dtype=_NP[type_id])
+            self.offsets = None
+            self.n = len(self.values)
+        self.nulls = None if nulls is None else np.ascontiguousarray(nulls, dtype=np.uint8)
+
+    def struct(self):
+        return OColumn(self.type, self.n, _ptr(self.values), _ptr(self.nulls), _ptr(self.offsets))
+
+
+def col_array(cols):
+    arr = (OColumn * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        arr[i] = c.struct()
+    return arr
+
+
+# ---- hashes -------------------------------------------------------------------------------------
+def hash_long(v):
+    return lib().o_hash_long(int(v))
+
+
+def hash_double(v):
+    return lib().o_hash_double(float(v))
+
+
+def xxh64(data: bytes, seed=0):
+    buf = np.frombuffer(data, dtype=np.uint8).copy() if len(data) else np.zeros(1, dtype=np.uint8)
+    return lib().o_xxh64(_ptr(buf), len(data), seed)
+
+
+def xxh64_long(v):
+    return lib().o_xxh64_long(int(v))
+
+
+def hash_rows(cols):
+    n = cols[0].n
+    out = np.zeros(n, dtype=np.int64)
+    lib().o_hash_rows(col_array(cols), len(cols), n, _ptr(out))
+    return out
+
+
+def partition_remote(raw_hashes, count):
+    L = lib()
+    return np.array([L.o_partition_remote(int(h), count) for h in raw_hashes], dtype=np.int32)
+
+
+def partition_local(raw_hashes, count):
+    L = lib()
+    return np.array([L.o_partition_local(int(h), count) for h in raw_hashes], dtype=np.int32)
+
+
+# ---- group by -----------------------------------------------------------------------------------
+class BigintGroupByHash:
+    def __init__(self, expected_size):
+        self.h = lib().o_bigint_gbh_new(expected_size)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().o_bigint_gbh_free(self.h)
+            self.h = None
+
+    def get_group_ids(self, col):
+        out = np.zeros(col.n, dtype=np.int64)
+        s = col.struct()
+        rc = lib().o_bigint_gbh_get_group_ids(self.h, C.byref(s), _ptr(out))
+        if rc != 0:
+            raise OracleError(rc)
+        return out
+
+    def contains(self, col, pos):
+        s = col.struct()
+        return bool(lib().o_bigint_gbh_contains(self.h, C.byref(s), pos))
+
+    @property
+    def group_count(self):
+        return lib().o_bigint_gbh_group_count(self.h)
+
+    @property
+    def capacity(self):
+        return lib().o_bigint_gbh_capacity(self.h)
+
+    @property
+    def rehash_count(self):
+        return lib().o_bigint_gbh_rehash_count(self.h)
+
+    def values(self):
+        n = self.group_count
+        v = np.zeros(n, dtype=np.int64)
+        nl = np.zeros(n, dtype=np.uint8)
+        rh = np.zeros(n, dtype=np.int64)
+        lib().o_bigint_gbh_values(self.h, _ptr(v), _ptr(nl), _ptr(rh))
+        return v, nl, rh
+
+
+class MultiChannelGroupByHash:
+    def __init__(self, types, expected_size):
+        t = np.array(types, dtype=np.int32)
+        self.h = lib().o_multi_gbh_new(len(types), _ptr(t), expected_size)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().o_multi_gbh_free(self.h)
+            self.h = None
+
+    def get_group_ids(self, cols, hashes=None):
+        n = cols[0].n
+        out = np.zeros(n, dtype=np.int64)
+        hs = None if hashes is None else np.ascontiguousarray(hashes, dtype=np.int64)
+        rc = lib().o_multi_gbh_get_group_ids(self.h, col_array(cols), _ptr(hs), n, _ptr(out))
+        if rc != 0:
+            raise OracleError(rc)
+        return out
+
+    def contains(self, cols, pos, raw_hash):
+        return bool(lib().o_multi_gbh_contains(self.h, col_array(cols), pos, int(raw_hash)))
+
+    @property
+    def group_count(self):
+        return lib().o_multi_gbh_group_count(self.h)
+
+    @property
+    def capacity(self):
+        return lib().o_multi_gbh_capacity(self.h)
+
+    @property
+    def rehash_count(self):
+        return lib().o_multi_gbh_rehash_count(self.h)
+
+    def group_rows(self):
+        n = self.group_count
+        fr = np.zeros(n, dtype=np.int64)
+        rh = np.zeros(n, dtype=np.int64)
+        lib().o_multi_gbh_group_rows(self.h, _ptr(fr), _ptr(rh))
+        return fr, rh
+
+
+class OracleError(Exception):
+    def __init__(self, code, row=None):
+        super().__init__(f"oracle error {code} at row {row}")
+        self.code = code
+        self.row = row
+
+
+# ---- accumulators -------------------------------------------------------------------------------
+def _gid(gids):
+    return None if gids is None else np.ascontiguousarray(gids, dtype=np.int64)
+
+
+def agg_double_sum(gids, values, ngroups, nulls=None, mask=None):
+    counts = np.zeros(ngroups, dtype=np.int64)
+    sums = np.zeros(ngroups, dtype=np.float64)
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    g = _gid(gids)
+    lib().o_agg_double_sum(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), _ptr(counts), _ptr(sums))
+    return counts, sums
+
+
+def agg_double_sum_exact(gids, values, ngroups, nulls=None, mask=None):
+    counts = np.zeros(ngroups, dtype=np.int64)
+    sums = np.zeros(ngroups, dtype=np.float64)
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    g = _gid(gids)
+    lib().o_agg_double_sum_exact(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), ngroups, _ptr(counts), _ptr(sums))
+    return counts, sums
+
+
+def agg_long_avg(gids, values, ngroups, nulls=None, mask=None):
+    counts = np.zeros(ngroups, dtype=np.int64)
+    sums = np.zeros(ngroups, dtype=np.float64)
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    g = _gid(gids)
+    lib().o_agg_long_avg(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), _ptr(counts), _ptr(sums))
+    return counts, sums
+
+
+def agg_long_sum(gids, values, ngroups, nulls=None, mask=None):
+    counts = np.zeros(ngroups, dtype=np.int64)
+    sums = np.zeros(ngroups, dtype=np.int64)
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    g = _gid(gids)
+    rc = lib().o_agg_long_sum(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), _ptr(counts), _ptr(sums))
+    if rc != 0:
+        raise OracleError(rc)
+    return counts, sums
+
+
+def agg_count(gids, n, ngroups, nulls=None, mask=None):
+    counts = np.zeros(ngroups, dtype=np.int64)
+    g = _gid(gids)
+    lib().o_agg_count(_ptr(g), _ptr(nulls), _ptr(mask), n, _ptr(counts))
+    return counts
+
+
+def exact_sum(values):
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    return lib().o_exact_sum(_ptr(v), len(v))
+
+
+# ---- join ---------------------------------------------------------------------------------------
+class PagesHash:
+    def __init__(self, key_cols, hashes=None):
+        self.cols = list(key_cols)  # keep buffers alive
+        self.n = key_cols[0].n
+        self._arr = col_array(self.cols)
+        self.hashes = None if hashes is None else np.ascontiguousarray(hashes, dtype=np.int64)
+        self.h = lib().o_pages_hash_new(self._arr, len(self.cols), self.n, _ptr(self.hashes))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().o_pages_hash_free(self.h)
+            self.h = None
+
+    @property
+    def hash_size(self):
+        return lib().o_pages_hash_size(self.h)
+
+    @property
+    def link_count(self):
+        return lib().o_pages_hash_link_count(self.h)
+
+    def links(self):
+        p = lib().o_pages_hash_links(self.h)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(max(self.n, 1),))[: self.n].copy()
+
+    def get_address_index(self, probe_cols, pos, raw_hash):
+        return lib().o_pages_hash_get_address_index(self.h, col_array(probe_cols), pos, int(raw_hash))
+
+    def probe(self, probe_cols, hashes=None, probe_outer=False):
+        n = probe_cols[0].n
+        hs = None if hashes is None else np.ascontiguousarray(hashes, dtype=np.int64)
+        cap = max(16, 2 * n)
+        while True:
+            op = np.zeros(cap, dtype=np.int32)
+            ob = np.zeros(cap, dtype=np.int32)
+            cnt = lib().o_join_probe(self.h, col_array(probe_cols), n, _ptr(hs), int(probe_outer), _ptr(op), _ptr(ob), cap)
+            if cnt >= 0:
+                return op[:cnt].copy(), ob[:cnt].copy()
+            cap = -cnt
+
+
+# ---- expressions --------------------------------------------------------------------------------
+EX_INPUT, EX_CONST, EX_CALL, EX_SPECIAL = 0, 1, 2, 3
+OPS = {"ADD": 1, "SUBTRACT": 2, "MULTIPLY": 3, "DIVIDE": 4, "MODULUS": 5, "NEGATE": 6, "EQUAL": 7, "NOT_EQUAL": 8,
+       "LESS_THAN": 9, "LESS_THAN_OR_EQUAL": 10, "GREATER_THAN": 11, "GREATER_THAN_OR_EQUAL": 12, "NOT": 13, "CAST": 14}
+FORMS = {"AND": 1, "OR": 2, "IF": 3, "IS_NULL": 4, "COALESCE": 5, "BETWEEN": 6}
+
+
+def encode_nodes(flat_nodes, pool: bytes):
+    """flat_nodes: list of dicts {kind,type,op,args,is_null,ival,dval,slen} (the product's serialisation)."""
+    arr = (OExprNode * len(flat_nodes))()
+    for i, nd in enumerate(flat_nodes):
+        e = arr[i]
+        e.kind, e.type, e.op = nd["kind"], nd["type"], nd["op"]
+        e.n_args = len(nd.get("args", []))
+        for k, a in enumerate(nd.get("args", [])):
+            e.args[k] = a
+        e.is_null = int(nd.get("is_null", 0))
+        e.ival = int(nd.get("ival", 0))
+        e.dval = float(nd.get("dval", 0.0))
+        e.slen = int(nd.get("slen", 0))
+    return arr
+
+
+def filter_positions(flat_nodes, root, pool, cols):
+    n = cols[0].n if cols else 0
+    arr = encode_nodes(flat_nodes, pool)
+    pos = np.zeros(max(n, 1), dtype=np.int32)
+    err_row = C.c_int32(-1)
+    rc = lib().o_filter(arr, root, pool, col_array(cols), n, _ptr(pos), C.byref(err_row))
+    if rc < 0:
+        raise OracleError(rc, err_row.value)
+    return pos[:rc].copy()
+
+
+def project(flat_nodes, root, pool, cols, positions):
+    arr = encode_nodes(flat_nodes, pool)
+    t = flat_nodes[root]["type"]
+    n_sel = len(positions)
+    out = np.zeros(max(n_sel, 1), dtype=_NP[t])
+    nulls = np.zeros(max(n_sel, 1), dtype=np.uint8)
+    pos = np.ascontiguousarray(positions, dtype=np.int32)
+    err_row = C.c_int32(-1)
+    rc = lib().o_project(arr, root, pool, col_array(cols), _ptr(pos), n_sel, _ptr(out), _ptr(nulls), C.byref(err_row))
+    if rc < 0:
+        raise OracleError(rc, err_row.value)
+    return out[:n_sel], nulls[:n_sel]

@@ -1,0 +1,226 @@
+"""Pins the CPU oracle against the known answers the reference's own tests hold (tests/golden/reference_vectors.json).
+CPU only.  The oracle is the checker for every GPU parity test, so it must be right first."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from seqpages import BIGINT, BOOLEAN, DOUBLE, VARCHAR, sequence_page, sequence_values
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+
+
+def test_xxhash64_literals(oracle):
+    for case in GOLD["xxhash64"]["cases"]:
+        got = oracle.xxh64(case["input_utf8"].encode())
+        assert f"{got:016X}" == case["digest_hex_big_endian"]
+
+
+def test_xxhash64_matches_xxhash_package(oracle):
+    xxhash = pytest.importorskip("xxhash")
+    rng = np.random.default_rng(7)
+    for n in [0, 1, 3, 4, 7, 8, 15, 16, 31, 32, 33, 63, 64, 100, 1000]:
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert oracle.xxh64(b) == xxhash.xxh64(b, seed=0).intdigest()
+    # XxHash64.hash(long) = XXH64 of the 8 little-endian bytes (no literal in the reference: cross-check only)
+    for v in [0, 1, -1, 2**63 - 1, -2**63, 123456789]:
+        want = xxhash.xxh64(int(v).to_bytes(8, "little", signed=True), seed=0).intdigest()
+        assert oracle.xxh64_long(v) & (2**64 - 1) == want
+
+
+def test_hash_long_is_xxhash_mix(oracle):
+    # S/type/AbstractLongType.java:126-130 written out with python ints
+    def ref(v):
+        m = (1 << 64) - 1
+        x = (v & m) * 0xC2B2AE3D27D4EB4F & m
+        x = ((x << 31) | (x >> 33)) & m
+        x = x * 0x9E3779B185EBCA87 & m
+        return x - (1 << 64) if x >> 63 else x
+    for v in [0, 1, -1, 42, 2**62, -2**63]:
+        assert oracle.hash_long(v) == ref(v)
+    assert oracle.hash_double(-0.0) == oracle.hash_double(0.0)
+    assert oracle.hash_double(float("nan")) == oracle.hash_long(0x7ff8000000000000)
+
+
+def test_array_size_and_max_fill(oracle):
+    L = oracle.lib()
+    assert L.o_array_size(1, 0.75) == 2
+    assert L.o_array_size(4, 0.75) == 8
+    assert L.o_array_size(100, 0.75) == 256
+    assert L.o_array_size(10_000, 0.75) == 16384
+    assert L.o_calculate_max_fill(2) == 1
+    assert L.o_calculate_max_fill(256) == 192
+
+
+def test_group_by_hash_add_page_and_get_group_ids(oracle):
+    max_gid = GOLD["group_by_hash"]["testAddPage_testGetGroupIds"]["max_group_id"]
+    gbh = oracle.BigintGroupByHash(100)
+    for tries in range(2):
+        for value in range(max_gid):
+            col = oracle.Col(BIGINT, [value])
+            for _ in range(10):
+                ids = gbh.get_group_ids(col)
+                assert ids[0] == value
+                assert gbh.group_count == (value + 1 if tries == 0 else max_gid)
+    # the same through MultiChannelGroupByHash with a precomputed hash channel
+    m = oracle.MultiChannelGroupByHash([BIGINT], 100)
+    for value in range(max_gid):
+        col = oracle.Col(BIGINT, [value])
+        ids = m.get_group_ids([col], oracle.hash_rows([col]))
+        assert ids[0] == value
+
+
+def test_group_by_hash_null_group(oracle):
+    gbh = oracle.BigintGroupByHash(100)
+    gbh.get_group_ids(oracle.Col(BIGINT, [0], nulls=[1]))
+    gbh.get_group_ids(oracle.Col(BIGINT, sequence_values(BIGINT, 1, 132748)))
+    assert gbh.contains(oracle.Col(BIGINT, [0]), 0) is GOLD["group_by_hash"]["testNullGroup"]["expect_contains_0"]
+    assert gbh.contains(oracle.Col(BIGINT, [0], nulls=[1]), 0)
+    assert gbh.group_count == 132748
+
+
+def test_group_by_hash_append_to_varchar(oracle):
+    col = oracle.Col(VARCHAR, sequence_values(VARCHAR, 0, 100))
+    hashes = oracle.hash_rows([col])
+    m = oracle.MultiChannelGroupByHash([VARCHAR], 100)
+    ids = m.get_group_ids([col], hashes)
+    assert list(ids) == list(range(100))
+    assert m.group_count == 100
+    first_rows, raw = m.group_rows()
+    assert list(first_rows) == list(range(100))       # keys round-trip in group-id order
+    assert np.array_equal(raw, hashes)                # and so does the hash channel
+
+
+def test_group_by_hash_multiple_tuples_per_group(oracle):
+    exp = GOLD["group_by_hash"]["testAppendToMultipleTuplesPerGroup"]
+    vals = np.arange(100, dtype=np.int64) % 50
+    gbh = oracle.BigintGroupByHash(100)
+    ids = gbh.get_group_ids(oracle.Col(BIGINT, vals))
+    assert gbh.group_count == exp["expect_group_count"]
+    assert np.array_equal(ids, vals)
+    v, nl, _ = gbh.values()
+    assert list(v) == list(range(50)) and not nl.any()
+
+
+def test_group_by_hash_contains_double(oracle):
+    col = oracle.Col(DOUBLE, sequence_values(DOUBLE, 0, 10))
+    m = oracle.MultiChannelGroupByHash([DOUBLE], 100)
+    m.get_group_ids([col], oracle.hash_rows([col]))
+    for v, want in [(3.0, True), (11.0, False)]:
+        t = oracle.Col(DOUBLE, [v])
+        assert m.contains([t], 0, oracle.hash_rows([t])[0]) is want
+
+
+def test_group_by_hash_force_rehash(oracle):
+    col = oracle.Col(VARCHAR, sequence_values(VARCHAR, 0, 100))
+    hashes = oracle.hash_rows([col])
+    m = oracle.MultiChannelGroupByHash([VARCHAR], 4)
+    m.get_group_ids([col], hashes)
+    assert all(m.contains([col], i, hashes[i]) for i in range(100))
+    assert m.capacity == 256 and m.rehash_count == 5
+
+
+@pytest.mark.parametrize("type_id", [BIGINT, VARCHAR])
+def test_group_by_hash_rehash_count(oracle, type_id):
+    # T/operator/TestGroupByHash.java:254-289: rehash count == floor(log2(length / 0.75)) from expectedSize 1
+    length = 1_000_000
+    want = math.floor(math.log2(length / 0.75))
+    assert want == 20
+    col = oracle.Col(type_id, sequence_values(type_id, 0, length))
+    if type_id == BIGINT:
+        g = oracle.BigintGroupByHash(1)
+        g.get_group_ids(col)
+    else:
+        g = oracle.MultiChannelGroupByHash([VARCHAR], 1)
+        g.get_group_ids([col], oracle.hash_rows([col]))
+    assert g.rehash_count == want
+    assert g.group_count == length
+
+
+def test_position_links_chain_order(oracle):
+    # T/operator/TestPositionLinks.java:37-61 exercised through PagesHash: duplicates chain newest -> oldest
+    keys = np.array([7, 7, 7, 7, 4, 5, 6, 8, 9, 10, 11, 11, 11], dtype=np.int64)  # positions 0-3 equal, 10-12 equal
+    ph = oracle.PagesHash([oracle.Col(BIGINT, keys)])
+    links = ph.links()
+    exp = GOLD["position_links"]["testArrayPositionLinks"]
+    for left, right in exp["links"]:
+        if left < len(links):
+            assert links[left] == right
+    assert links[0] == -1 and links[4] == -1 and links[10] == -1
+    assert ph.link_count == 5
+    op, ob = ph.probe([oracle.Col(BIGINT, [7, 4, 11, 99])])
+    assert list(op) == [0, 0, 0, 0, 1, 2, 2, 2]
+    assert list(ob) == exp["chains"]["3"] + exp["chains"]["4"] + exp["chains"]["12"]
+
+
+def _join_rows(oracle, build_cols, probe_cols, probe_outer=False, with_hash=False):
+    bh = oracle.hash_rows(build_cols[:1]) if with_hash else None
+    ph_ = oracle.hash_rows(probe_cols[:1]) if with_hash else None
+    ph = oracle.PagesHash(build_cols[:1], bh)
+    return ph.probe(probe_cols[:1], ph_, probe_outer)
+
+
+@pytest.mark.parametrize("with_hash", [False, True])
+def test_hash_join_inner(oracle, with_hash):
+    exp = GOLD["hash_join"]["testInnerJoin"]["expect_rows"]
+    types = [VARCHAR, BIGINT, BIGINT]
+    b = sequence_page(types, 10, 20, 30, 40)
+    p = sequence_page(types, 1000, 0, 1000, 2000)
+    bc = [oracle.Col(t, v) for t, v in zip(types, b)]
+    pc = [oracle.Col(t, v) for t, v in zip(types, p)]
+    op, ob = _join_rows(oracle, bc, pc, with_hash=with_hash)
+    rows = [[p[0][i], int(p[1][i]), int(p[2][i]), b[0][j], int(b[1][j]), int(b[2][j])] for i, j in zip(op, ob)]
+    assert rows == exp
+
+
+@pytest.mark.parametrize("name", ["testInnerJoinWithNullProbe", "testInnerJoinWithNullBuild", "testInnerJoinWithNullOnBothSides"])
+def test_hash_join_nulls(oracle, name):
+    case = GOLD["hash_join"][name]
+    bc = [oracle.Col(VARCHAR, case["build"])]
+    pc = [oracle.Col(VARCHAR, case["probe"])]
+    op, ob = _join_rows(oracle, bc, pc)
+    rows = sorted([case["probe"][i], case["build"][j]] for i, j in zip(op, ob))
+    assert rows == sorted(case["expect_rows"])
+
+
+def test_hash_join_probe_outer(oracle):
+    types = [VARCHAR, BIGINT, BIGINT]
+    b = sequence_page(types, 10, 20, 30, 40)
+    p = sequence_page(types, 15, 20, 1020, 2020)
+    op, ob = _join_rows(oracle, [oracle.Col(t, v) for t, v in zip(types, b)], [oracle.Col(t, v) for t, v in zip(types, p)], probe_outer=True)
+    assert list(op) == list(range(15))
+    assert list(ob) == list(range(10)) + [-1] * 5
+
+
+def test_hash_aggregation_golden(oracle):
+    # T/operator/TestHashAggregationOperator.java:161-220 (the aggregates the oracle restates: count, sum, avg)
+    n = GOLD["hash_aggregation"]["testHashAggregation"]["rows"]
+    types = [VARCHAR, VARCHAR, VARCHAR, BIGINT, BOOLEAN]
+    pages = [sequence_page(types, n, 100, 0, base, 0, 500) for base in (100_000, 200_000, 300_000)]
+    m = oracle.MultiChannelGroupByHash([VARCHAR], 100_000)
+    counts = np.zeros(n, dtype=np.int64)
+    sums = np.zeros(n, dtype=np.int64)
+    acnt = np.zeros(n, dtype=np.int64)
+    asum = np.zeros(n, dtype=np.float64)
+    for pg in pages:
+        key = oracle.Col(VARCHAR, pg[1])
+        gids = m.get_group_ids([key], oracle.hash_rows([key]))
+        counts += oracle.agg_count(gids, n, n)
+        c, s = oracle.agg_long_sum(gids, pg[3], n)
+        sums += s
+        c2, s2 = oracle.agg_long_avg(gids, pg[3], n)
+        acnt += c2
+        asum += s2
+    assert m.group_count == n
+    i = np.arange(n)
+    assert np.array_equal(counts, np.full(n, 3))
+    assert np.array_equal(sums, 3 * i)
+    assert np.array_equal(asum / acnt, i.astype(np.float64))
+
+
+def test_exact_sum_matches_fsum(oracle):
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(20000) * 10.0 ** rng.integers(-8, 8, 20000)
+    assert oracle.exact_sum(v) == math.fsum(v)
