@@ -1,0 +1,250 @@
+/*
+ * tgpu.h -- C ABI of the MI355X-native operator hot path (libtgpu.so).
+ *
+ * This is the drop-in boundary: exactly what a JNI shim for core/trino-main would bind (INTEGRATION.md shows
+ * that shim).  Plain C: opaque handles, plain pointers and sizes, int32 status codes.  No torch / HIP types.
+ *
+ * Reference interfaces replaced (paths relative to the reference root;
+ * M/ = core/trino-main/src/main/java/io/trino/ , S/ = core/trino-spi/src/main/java/io/trino/spi/):
+ *   - tgpu_operator_*            <-> M/operator/Operator.java:20-102
+ *   - tgpu_operator_factory_*    <-> M/operator/OperatorFactory.java:18-50
+ *   - tgpu_block / tgpu_page     <-> S/Page.java:33-73, S/block/LongArrayBlock.java:38-75, IntArrayBlock.java,
+ *                                    ByteArrayBlock.java, VariableWidthBlock.java:38-83, DictionaryBlock.java:40-100,
+ *                                    RunLengthEncodedBlock.java:30-70
+ *   - tgpu_filter_project_*      <-> M/operator/FilterAndProjectOperator.java:73-88 + M/sql/gen/ExpressionCompiler.java:94-122
+ *   - tgpu_hash_aggregation_*    <-> M/operator/HashAggregationOperator.java:54-262
+ *   - tgpu_hash_builder_* / tgpu_lookup_join_* <-> M/operator/HashBuilderOperator.java:54-152,
+ *                                    M/operator/LookupJoinOperatorFactory.java:40-113, LookupJoinOperators.java:30-63
+ *   - tgpu_group_by_hash_*       <-> M/operator/GroupByHash.java:45-99
+ *   - tgpu_hash_page             <-> M/operator/InterpretedHashGenerator.java:56-70
+ *   - tgpu_partition_page        <-> M/operator/PartitionedOutputOperator.java:406-426 + HashGenerator.java:24-35
+ *
+ * Threading rule = the reference's (M/operator/Driver.java:55-62): one caller at a time per handle; distinct
+ * handles are independent; a built lookup source is immutable and shared read-only by probe operators.
+ * Ownership rule: input buffers are only read during the call (the library copies/uploads what it keeps);
+ * output pages are owned by the library until tgpu_output_page_release.
+ */
+#ifndef TGPU_H
+#define TGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: 0 ok, >0 informational, <0 error mirroring io.trino.spi.StandardErrorCode ---- */
+#define TGPU_OK 0
+#define TGPU_ERR_INVALID_ARGUMENT (-1)              /* GENERIC_INTERNAL_ERROR / IllegalArgumentException */
+#define TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE (-2)    /* M/type/BigintOperators.java:47-79 */
+#define TGPU_ERR_INSUFFICIENT_RESOURCES (-3)        /* GENERIC_INSUFFICIENT_RESOURCES: BigintGroupByHash.java:264-267, PagesIndex.java:234-236 */
+#define TGPU_ERR_COMPILER (-4)                      /* COMPILER_ERROR: M/sql/gen/PageFunctionCompiler.java:199-205 */
+#define TGPU_ERR_INTERNAL (-5)                      /* GENERIC_INTERNAL_ERROR (illegal operator state etc.) */
+#define TGPU_ERR_DEVICE (-6)                        /* no HIP device / HIP runtime failure: the library never falls back to CPU */
+#define TGPU_ERR_DIVISION_BY_ZERO (-7)              /* DIVISION_BY_ZERO */
+#define TGPU_ERR_NOT_SUPPORTED (-8)                 /* NOT_SUPPORTED */
+
+/* ---- types (S/type): storage is what the reference's flat blocks hold ---- */
+typedef enum tgpu_type {
+    TGPU_BIGINT = 1,   /* int64   LongArrayBlock */
+    TGPU_INTEGER = 2,  /* int32   IntArrayBlock */
+    TGPU_DATE = 3,     /* int32   IntArrayBlock (days) */
+    TGPU_DOUBLE = 4,   /* IEEE double, LongArrayBlock bits */
+    TGPU_BOOLEAN = 5,  /* 1 byte  ByteArrayBlock */
+    TGPU_VARCHAR = 6   /* VariableWidthBlock: byte pool + int32 offsets[n+1] */
+} tgpu_type;
+
+typedef enum tgpu_encoding { TGPU_FLAT = 0, TGPU_DICTIONARY = 1, TGPU_RLE = 2 } tgpu_encoding;
+typedef enum tgpu_memory { TGPU_HOST = 0, TGPU_DEVICE = 1 } tgpu_memory;
+
+/* One Block.  All pointers of one block live in the same memory space (`memory`). */
+typedef struct tgpu_block {
+    int32_t type;            /* tgpu_type */
+    int32_t encoding;        /* tgpu_encoding */
+    int32_t memory;          /* tgpu_memory */
+    int32_t position_count;
+    const void *values;      /* FLAT fixed width: position_count elements (arrayOffset already applied); VARCHAR: byte pool */
+    const uint8_t *nulls;    /* FLAT: one byte per position (Java boolean[] valueIsNull), NULL = no nulls */
+    const int32_t *offsets;  /* FLAT VARCHAR: position_count + 1 */
+    const int32_t *ids;      /* DICTIONARY: position_count ids into `dictionary` */
+    const struct tgpu_block *dictionary; /* DICTIONARY: the dictionary; RLE: the single-position value block */
+} tgpu_block;
+
+typedef struct tgpu_page {
+    int32_t position_count;
+    int32_t channel_count;
+    const tgpu_block *blocks;
+} tgpu_page;
+
+typedef struct tgpu_context tgpu_context;
+typedef struct tgpu_operator_factory tgpu_operator_factory;
+typedef struct tgpu_operator tgpu_operator;
+typedef struct tgpu_lookup_source_factory tgpu_lookup_source_factory;
+typedef struct tgpu_group_by_hash tgpu_group_by_hash;
+typedef struct tgpu_output_page tgpu_output_page;
+
+/* ---- context: one HIP device + one stream; all handles created from it launch on that stream ---- */
+int32_t tgpu_context_create(int32_t device, void *hip_stream /* hipStream_t or NULL = null stream */, tgpu_context **out);
+void tgpu_context_destroy(tgpu_context *ctx);
+int32_t tgpu_context_synchronize(tgpu_context *ctx);
+/* last error message of the calling thread (messages mirror the reference's, e.g. "bigint multiplication overflow: 3 * 4") */
+const char *tgpu_last_error(void);
+const char *tgpu_version(void);
+/* directory holding the JIT kernel sources/cache (defaults to the directory of libtgpu.so) */
+int32_t tgpu_set_resource_dir(const char *dir);
+
+/* per-kernel HIP-event timing on the context's stream (bench.py's roofline leg) */
+int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled);
+int32_t tgpu_profile_reset(tgpu_context *ctx);
+/* writes a JSON object {"kernel": {"count": n, "total_ms": t, "min_ms": a, "max_ms": b}, ...}; returns needed length */
+int64_t tgpu_profile_dump(tgpu_context *ctx, char *buf, int64_t buf_len);
+
+/* ---- RowExpression IR (M/sql/relational/{CallExpression,ConstantExpression,InputReferenceExpression,SpecialForm}.java) ---- */
+typedef enum tgpu_expr_kind { TGPU_EX_INPUT = 0, TGPU_EX_CONST = 1, TGPU_EX_CALL = 2, TGPU_EX_SPECIAL = 3 } tgpu_expr_kind;
+typedef enum tgpu_expr_op {
+    TGPU_OP_ADD = 1, TGPU_OP_SUBTRACT, TGPU_OP_MULTIPLY, TGPU_OP_DIVIDE, TGPU_OP_MODULUS, TGPU_OP_NEGATE,
+    TGPU_OP_EQUAL, TGPU_OP_NOT_EQUAL, TGPU_OP_LESS_THAN, TGPU_OP_LESS_THAN_OR_EQUAL, TGPU_OP_GREATER_THAN,
+    TGPU_OP_GREATER_THAN_OR_EQUAL, TGPU_OP_NOT, TGPU_OP_CAST
+} tgpu_expr_op;
+typedef enum tgpu_special_form { /* M/sql/relational/SpecialForm.java:137-152 */
+    TGPU_SF_AND = 1, TGPU_SF_OR, TGPU_SF_IF, TGPU_SF_IS_NULL, TGPU_SF_COALESCE, TGPU_SF_BETWEEN
+} tgpu_special_form;
+
+typedef struct tgpu_expr_node {
+    int32_t kind;      /* tgpu_expr_kind */
+    int32_t type;      /* result tgpu_type */
+    int32_t op;        /* CALL: tgpu_expr_op; SPECIAL: tgpu_special_form; INPUT: channel */
+    int32_t n_args;
+    int32_t args[3];   /* indices into the node array */
+    int32_t is_null;   /* CONST: null literal */
+    int64_t ival;      /* CONST BIGINT/INTEGER/DATE/BOOLEAN value; VARCHAR: offset into string_pool */
+    double dval;       /* CONST DOUBLE */
+    int32_t slen;      /* CONST VARCHAR length */
+    int32_t pad;
+} tgpu_expr_node;
+
+/* A page processor = optional filter + projections over one shared node array (ExpressionCompiler.compilePageProcessor) */
+typedef struct tgpu_page_processor_spec {
+    const tgpu_expr_node *nodes;
+    int32_t node_count;
+    const char *string_pool;
+    int32_t string_pool_len;
+    int32_t filter_root;            /* -1 = no filter */
+    int32_t projection_count;
+    const int32_t *projection_roots;
+} tgpu_page_processor_spec;
+
+/* ---- operator factories ---- */
+/* FilterAndProjectOperator.createOperatorFactory (M/operator/FilterAndProjectOperator.java:73-88).  The expressions are
+ * compiled to one fused gfx950 kernel (the GPU counterpart of M/sql/gen/PageFunctionCompiler.java). */
+int32_t tgpu_filter_project_factory_create(tgpu_context *ctx, int32_t operator_id,
+                                           int32_t input_type_count, const int32_t *input_types,
+                                           const tgpu_page_processor_spec *spec,
+                                           tgpu_operator_factory **out);
+
+typedef enum tgpu_agg_function {
+    TGPU_AGG_COUNT_ALL = 1,     /* count(*)        M/operator/aggregation/CountAggregation.java:34-56 */
+    TGPU_AGG_COUNT_COLUMN = 2,  /* count(col)      CountColumn.java */
+    TGPU_AGG_SUM_BIGINT = 3,    /* sum(bigint)     LongSumAggregation.java:34-63 */
+    TGPU_AGG_SUM_DOUBLE = 4,    /* sum(double)     DoubleSumAggregation.java:34-63 */
+    TGPU_AGG_AVG_BIGINT = 5,    /* avg(bigint)     AverageAggregations.java:35-80 */
+    TGPU_AGG_AVG_DOUBLE = 6     /* avg(double)     AverageAggregations.java:42-80 */
+} tgpu_agg_function;
+
+typedef struct tgpu_agg_spec {
+    int32_t function;       /* tgpu_agg_function */
+    int32_t input_channel;  /* -1 for count(*) */
+    int32_t mask_channel;   /* BOOLEAN channel or -1 (AccumulatorCompiler.java:487-566 mask handling) */
+} tgpu_agg_spec;
+
+typedef enum tgpu_agg_step { TGPU_STEP_SINGLE = 0, TGPU_STEP_PARTIAL = 1, TGPU_STEP_FINAL = 2 } tgpu_agg_step;
+
+/* HashAggregationOperatorFactory (M/operator/HashAggregationOperator.java:54-262).  Output channels: group-by keys,
+ * [hash channel if hash_channel >= 0], then one channel per aggregate (PARTIAL: two channels per sum/avg = count BIGINT,
+ * sum DOUBLE|BIGINT -- the flattened LongDoubleState / LongLongState; FINAL consumes that layout). */
+int32_t tgpu_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator_id,
+                                             int32_t group_by_count, const int32_t *group_by_types, const int32_t *group_by_channels,
+                                             int32_t hash_channel /* -1 = none */, int32_t step,
+                                             int32_t agg_count, const tgpu_agg_spec *aggs,
+                                             int32_t expected_groups, int32_t produce_default_output,
+                                             tgpu_operator_factory **out);
+
+/* HashBuilderOperatorFactory + its JoinBridge (M/operator/HashBuilderOperator.java:54-152;
+ * PartitionedLookupSourceFactory.java:110-124 with one partition per GPU). */
+int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
+                                         int32_t type_count, const int32_t *types,
+                                         int32_t output_channel_count, const int32_t *output_channels,
+                                         int32_t hash_channel_count, const int32_t *hash_channels /* join key channels */,
+                                         int32_t precomputed_hash_channel /* -1 = none */, int32_t expected_positions,
+                                         tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out);
+void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge);
+/* statistics of the built table (valid once the build operator finished): positions, table slots, position links */
+int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count);
+
+typedef enum tgpu_join_type { TGPU_JOIN_INNER = 0, TGPU_JOIN_PROBE_OUTER = 1 } tgpu_join_type;
+
+/* LookupJoinOperators.innerJoin / probeOuterJoin (M/operator/LookupJoinOperators.java:30-63).  Output page = probe output
+ * channels then the build side's output channels (M/operator/LookupJoinPageBuilder.java:101-131). */
+int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge,
+                                        int32_t probe_type_count, const int32_t *probe_types,
+                                        int32_t probe_join_channel_count, const int32_t *probe_join_channels,
+                                        int32_t probe_hash_channel /* -1 = none */,
+                                        int32_t probe_output_channel_count, const int32_t *probe_output_channels,
+                                        int32_t join_type, tgpu_operator_factory **out);
+
+/* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
+int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);
+int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory);
+void tgpu_operator_factory_destroy(tgpu_operator_factory *factory);
+
+/* ---- Operator (M/operator/Operator.java:20-102).  Boolean queries return 1/0, or <0 on error. ---- */
+int32_t tgpu_operator_needs_input(tgpu_operator *op);
+int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page);
+/* *out = NULL when no page is available (Operator.getOutput() == null) */
+int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out);
+int32_t tgpu_operator_finish(tgpu_operator *op);
+int32_t tgpu_operator_is_finished(tgpu_operator *op);
+int32_t tgpu_operator_is_blocked(tgpu_operator *op);    /* 1 = isBlocked() future not done (probe waiting for the build) */
+int64_t tgpu_operator_memory_bytes(tgpu_operator *op);  /* what the shim reports to LocalMemoryContext.setBytes */
+void tgpu_operator_close(tgpu_operator *op);            /* Operator.close(); also frees the handle */
+
+/* ---- output pages (device resident, library owned) ---- */
+int32_t tgpu_output_page_position_count(const tgpu_output_page *page);
+int32_t tgpu_output_page_channel_count(const tgpu_output_page *page);
+/* the page as device-memory blocks (valid until release); lets a downstream GPU operator consume it without a copy */
+int32_t tgpu_output_page_as_page(const tgpu_output_page *page, tgpu_page *out);
+/* sizes needed to host-materialise channel `ch`: value bytes (VARCHAR: byte-pool size) and whether it may hold nulls */
+int32_t tgpu_output_page_block_info(const tgpu_output_page *page, int32_t ch, int32_t *type, int64_t *value_bytes, int32_t *may_have_nulls);
+/* D2H copy of one channel into caller buffers: values (value_bytes), nulls (position_count bytes, may be NULL),
+ * offsets ((position_count+1) int32, VARCHAR only) */
+int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, void *values, uint8_t *nulls, int32_t *offsets);
+void tgpu_output_page_release(tgpu_output_page *page);
+
+/* ---- GroupByHash (M/operator/GroupByHash.java:45-99; BigintGroupByHash / MultiChannelGroupByHash semantics) ---- */
+int32_t tgpu_group_by_hash_create(tgpu_context *ctx, int32_t type_count, const int32_t *types, const int32_t *hash_channels,
+                                  int32_t input_hash_channel /* -1 = none */, int32_t expected_size, tgpu_group_by_hash **out);
+void tgpu_group_by_hash_destroy(tgpu_group_by_hash *gbh);
+int32_t tgpu_group_by_hash_add_page(tgpu_group_by_hash *gbh, const tgpu_page *page);
+/* group id of every position (first-seen order, bit-exact with the Java classes) into group_ids[position_count] (host) */
+int32_t tgpu_group_by_hash_get_group_ids(tgpu_group_by_hash *gbh, const tgpu_page *page, int64_t *group_ids, int64_t *group_count);
+int32_t tgpu_group_by_hash_contains(tgpu_group_by_hash *gbh, int32_t position, const tgpu_page *page, int32_t *result);
+int64_t tgpu_group_by_hash_group_count(tgpu_group_by_hash *gbh);
+int32_t tgpu_group_by_hash_capacity(tgpu_group_by_hash *gbh);   /* the Java table's capacity for this many groups */
+int64_t tgpu_group_by_hash_estimated_size(tgpu_group_by_hash *gbh);
+/* appendValuesTo for group ids [0, group_count): key channels (+ raw hash channel when input_hash_channel >= 0) */
+int32_t tgpu_group_by_hash_append_values(tgpu_group_by_hash *gbh, tgpu_output_page **out);
+
+/* ---- hash / partition kernels exposed for parity tests and the exchange ---- */
+/* InterpretedHashGenerator.hashPosition for every row: hashes[position_count] (host) */
+int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel_count, const int32_t *channels, int64_t *hashes);
+/* PagePartitioner.partitionPage: rows of `page` scattered into `partition_count` contiguous segments, ordered by partition
+ * then by input position.  hash_channel >= 0 uses the precomputed raw hash, else the key channels are hashed.
+ * partition = (rawHash & 0x7fff...) % partition_count (HashGenerator.java:24-35).  counts[partition_count] (host). */
+int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels,
+                            int32_t hash_channel, int32_t partition_count, int64_t *counts, tgpu_output_page **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGPU_H */

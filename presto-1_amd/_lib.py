@@ -1,0 +1,136 @@
+"""ctypes binding of libtgpu.so (include/tgpu.h).  No CPU fallback: a missing or stale library is a hard error."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libtgpu.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class TgpuError(RuntimeError):
+    """Mirror of io.trino.spi.TrinoException: `code` is the tgpu.h status (StandardErrorCode mirror)."""
+
+    NAMES = {-1: "INVALID_ARGUMENT", -2: "NUMERIC_VALUE_OUT_OF_RANGE", -3: "GENERIC_INSUFFICIENT_RESOURCES", -4: "COMPILER_ERROR",
+             -5: "GENERIC_INTERNAL_ERROR", -6: "DEVICE_ERROR", -7: "DIVISION_BY_ZERO", -8: "NOT_SUPPORTED"}
+
+    def __init__(self, code, message):
+        super().__init__(f"{self.NAMES.get(code, code)}: {message}")
+        self.code = code
+        self.message = message
+
+
+def build(force=False, jobs=8):
+    """Compile every HIP source of the package for gfx950 into libtgpu.so (in-tree)."""
+    args = ["make", "-C", CSRC, f"-j{jobs}"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return SO_PATH
+
+
+class Block(C.Structure):
+    pass
+
+
+Block._fields_ = [("type", C.c_int32), ("encoding", C.c_int32), ("memory", C.c_int32), ("position_count", C.c_int32),
+                  ("values", C.c_void_p), ("nulls", C.c_void_p), ("offsets", C.c_void_p), ("ids", C.c_void_p),
+                  ("dictionary", C.POINTER(Block))]
+
+
+class Page(C.Structure):
+    _fields_ = [("position_count", C.c_int32), ("channel_count", C.c_int32), ("blocks", C.POINTER(Block))]
+
+
+class ExprNode(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("type", C.c_int32), ("op", C.c_int32), ("n_args", C.c_int32), ("args", C.c_int32 * 3),
+                ("is_null", C.c_int32), ("ival", C.c_int64), ("dval", C.c_double), ("slen", C.c_int32), ("pad", C.c_int32)]
+
+
+class PageProcessorSpec(C.Structure):
+    _fields_ = [("nodes", C.POINTER(ExprNode)), ("node_count", C.c_int32), ("string_pool", C.c_char_p), ("string_pool_len", C.c_int32),
+                ("filter_root", C.c_int32), ("projection_count", C.c_int32), ("projection_roots", C.POINTER(C.c_int32))]
+
+
+class AggSpec(C.Structure):
+    _fields_ = [("function", C.c_int32), ("input_channel", C.c_int32), ("mask_channel", C.c_int32)]
+
+
+_lib = None
+
+# every symbol include/tgpu.h declares: (restype, argtypes)
+i32, i64, vp, cp = C.c_int32, C.c_int64, C.c_void_p, C.c_char_p
+P = C.POINTER
+SYMBOLS = {
+    "tgpu_context_create": (i32, [i32, vp, P(vp)]),
+    "tgpu_context_destroy": (None, [vp]),
+    "tgpu_context_synchronize": (i32, [vp]),
+    "tgpu_last_error": (cp, []),
+    "tgpu_version": (cp, []),
+    "tgpu_set_resource_dir": (i32, [cp]),
+    "tgpu_profile_enable": (i32, [vp, i32]),
+    "tgpu_profile_reset": (i32, [vp]),
+    "tgpu_profile_dump": (i64, [vp, cp, i64]),
+    "tgpu_filter_project_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), P(vp)]),
+    "tgpu_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, i32, P(vp)]),
+    "tgpu_hash_builder_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, P(i32), i32, i32, P(vp), P(vp)]),
+    "tgpu_lookup_source_factory_destroy": (None, [vp]),
+    "tgpu_lookup_source_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
+    "tgpu_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
+    "tgpu_operator_factory_create_operator": (i32, [vp, P(vp)]),
+    "tgpu_operator_factory_no_more_operators": (i32, [vp]),
+    "tgpu_operator_factory_destroy": (None, [vp]),
+    "tgpu_operator_needs_input": (i32, [vp]),
+    "tgpu_operator_add_input": (i32, [vp, P(Page)]),
+    "tgpu_operator_get_output": (i32, [vp, P(vp)]),
+    "tgpu_operator_finish": (i32, [vp]),
+    "tgpu_operator_is_finished": (i32, [vp]),
+    "tgpu_operator_is_blocked": (i32, [vp]),
+    "tgpu_operator_memory_bytes": (i64, [vp]),
+    "tgpu_operator_close": (None, [vp]),
+    "tgpu_output_page_position_count": (i32, [vp]),
+    "tgpu_output_page_channel_count": (i32, [vp]),
+    "tgpu_output_page_as_page": (i32, [vp, P(Page)]),
+    "tgpu_output_page_block_info": (i32, [vp, i32, P(i32), P(i64), P(i32)]),
+    "tgpu_output_page_copy_block": (i32, [vp, i32, vp, vp, vp]),
+    "tgpu_output_page_release": (None, [vp]),
+    "tgpu_group_by_hash_create": (i32, [vp, i32, P(i32), P(i32), i32, i32, P(vp)]),
+    "tgpu_group_by_hash_destroy": (None, [vp]),
+    "tgpu_group_by_hash_add_page": (i32, [vp, P(Page)]),
+    "tgpu_group_by_hash_get_group_ids": (i32, [vp, P(Page), vp, P(i64)]),
+    "tgpu_group_by_hash_contains": (i32, [vp, i32, P(Page), P(i32)]),
+    "tgpu_group_by_hash_group_count": (i64, [vp]),
+    "tgpu_group_by_hash_capacity": (i32, [vp]),
+    "tgpu_group_by_hash_estimated_size": (i64, [vp]),
+    "tgpu_group_by_hash_append_values": (i32, [vp, P(vp)]),
+    "tgpu_hash_page": (i32, [vp, P(Page), i32, P(i32), vp]),
+    "tgpu_partition_page": (i32, [vp, P(Page), i32, P(i32), i32, i32, vp, P(vp)]),
+}
+# helpers outside tgpu.h (build / diagnostics)
+EXTRA_SYMBOLS = {
+    "tgpu_precompile_page_processor": (i32, [i32, P(i32), P(PageProcessorSpec)]),
+    "tgpu_page_processor_source": (i64, [i32, P(i32), P(PageProcessorSpec), cp, i64]),
+    "tgpu_group_by_hash_rehash_count": (i32, [vp]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise TgpuError(-6, f"{SO_PATH} is missing: build it with `python -c \"import __graft_entry__ as g; g.build()\"` "
+                                "(there is no CPU fallback)")
+        L = C.CDLL(SO_PATH)
+        for table in (SYMBOLS, EXTRA_SYMBOLS):
+            for name, (res, args) in table.items():
+                f = getattr(L, name)
+                f.restype = res
+                f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise TgpuError(rc, lib().tgpu_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,410 @@
+// agg.hip -- grouped accumulators (K6) for count / sum / avg.
+#include "agg.h"
+#include "kernels.h"
+
+namespace tgpu {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct AggView {
+    int32_t function;
+    int32_t pad;
+    const void *input;           // values of the input channel (or nullptr for count(*))
+    const uint8_t *input_nulls;
+    const uint8_t *mask;         // BOOLEAN mask channel values
+    const uint8_t *mask_nulls;
+    const void *input2;          // FINAL: the sum channel (input = the count channel)
+    const uint8_t *input2_nulls;
+    long long *counts;
+    long long *limbs;
+    unsigned int *special;
+    unsigned long long *i128;
+};
+
+struct AggArgs {
+    int32_t n_aggs;
+    int32_t pad;
+    AggView a[kMaxAggs];
+};
+
+// exact accumulation of one double into the limb array of its group (order independent)
+__device__ __forceinline__ void kulisch_add(long long *limbs, unsigned int *special, double v)
+{
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned int e = (unsigned int)((bits >> 52) & 0x7ff);
+    unsigned long long m = bits & 0xfffffffffffffULL;
+    const bool neg = (bits >> 63) != 0;
+    if (e == 0x7ff) {
+        atomicOr(special, m ? 1u : (neg ? 4u : 2u));
+        return;
+    }
+    int p = 0;
+    if (e) { m |= 1ULL << 52; p = (int)e - 1; }
+    if (m == 0) return;
+    const int j = p >> 5, s = p & 31;
+    // (m << s) as three 32-bit limbs
+    const unsigned long long lo64 = m << s;                      // low 64 bits
+    const unsigned long long hi64 = s ? (m >> (64 - s)) : 0ULL;  // bits 64..84
+    long long l0 = (long long)(lo64 & 0xffffffffULL), l1 = (long long)(lo64 >> 32), l2 = (long long)hi64;
+    if (neg) { l0 = -l0; l1 = -l1; l2 = -l2; }
+    if (l0) atomicAdd((unsigned long long *)&limbs[j], (unsigned long long)l0);
+    if (l1) atomicAdd((unsigned long long *)&limbs[j + 1], (unsigned long long)l1);
+    if (l2) atomicAdd((unsigned long long *)&limbs[j + 2], (unsigned long long)l2);
+}
+
+__device__ __forceinline__ void i128_add(unsigned long long *acc, long long v)
+{
+    const unsigned long long uv = (unsigned long long)v;
+    const unsigned long long old = atomicAdd(&acc[0], uv);
+    const unsigned long long carry = (old + uv) < old ? 1ULL : 0ULL;
+    const unsigned long long hi_add = (v < 0 ? ~0ULL : 0ULL) + carry;
+    if (hi_add) atomicAdd(&acc[1], hi_add);
+}
+
+template <bool INTERMEDIATE>
+__global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, const int32_t *__restrict__ gids, int64_t n)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        const int64_t g = gids ? gids[r] : 0;
+        for (int k = 0; k < args.n_aggs; k++) {
+            const AggView &a = args.a[k];
+            if (INTERMEDIATE) {
+                // combine(): DoubleSumAggregation.java:48-52, AverageAggregations.java:63-67, CountAggregation.java:46-49
+                const long long cnt = ((const long long *)a.input)[r];
+                if (a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN) {
+                    if (cnt) atomicAdd((unsigned long long *)&a.counts[g], (unsigned long long)cnt);
+                    continue;
+                }
+                if (cnt == 0) continue;  // empty partial state
+                atomicAdd((unsigned long long *)&a.counts[g], (unsigned long long)cnt);
+                if (a.function == TGPU_AGG_SUM_BIGINT) i128_add(&a.i128[g * 2], ((const long long *)a.input2)[r]);
+                else kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input2)[r]);
+                continue;
+            }
+            if (a.mask && ((a.mask_nulls && a.mask_nulls[r]) || !a.mask[r])) continue;
+            if (a.function == TGPU_AGG_COUNT_ALL) {
+                atomicAdd((unsigned long long *)&a.counts[g], 1ULL);
+                continue;
+            }
+            if (a.input_nulls && a.input_nulls[r]) continue;
+            atomicAdd((unsigned long long *)&a.counts[g], 1ULL);
+            switch (a.function) {
+            case TGPU_AGG_SUM_BIGINT: i128_add(&a.i128[g * 2], ((const long long *)a.input)[r]); break;
+            case TGPU_AGG_SUM_DOUBLE:
+            case TGPU_AGG_AVG_DOUBLE: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input)[r]); break;
+            case TGPU_AGG_AVG_BIGINT: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], (double)((const long long *)a.input)[r]); break;
+            default: break;
+            }
+        }
+    }
+}
+
+// limbs -> correctly rounded double (round half to even)
+__device__ double kulisch_round(const long long *limbs, unsigned int special)
+{
+    if (special) {
+        if ((special & 1u) || ((special & 2u) && (special & 4u))) return __longlong_as_double(0x7ff8000000000000LL);
+        return (special & 2u) ? __longlong_as_double(0x7ff0000000000000LL) : __longlong_as_double((long long)0xfff0000000000000ULL);
+    }
+    unsigned int d[kLimbs];
+    long long carry = 0;
+    for (int i = 0; i < kLimbs; i++) {
+        long long v = limbs[i] + carry;
+        d[i] = (unsigned int)(v & 0xffffffffLL);
+        carry = v >> 32;
+    }
+    bool neg = carry < 0;
+    if (neg) {  // two's complement negate
+        unsigned long long c = 1;
+        for (int i = 0; i < kLimbs; i++) {
+            unsigned long long v = (unsigned long long)(~d[i]) + c;
+            d[i] = (unsigned int)v;
+            c = v >> 32;
+        }
+    }
+    int top = -1;
+    for (int i = kLimbs - 1; i >= 0; i--)
+        if (d[i]) { top = i; break; }
+    if (top < 0) return 0.0;
+    const int t = top * 32 + (31 - __clz((int)d[top]));  // index of the highest set bit
+    auto bit_at = [&](int b) -> unsigned long long { return b < 0 ? 0ULL : (unsigned long long)((d[b >> 5] >> (b & 31)) & 1u); };
+    unsigned long long bits;
+    if (t <= 52) {
+        // denormal or the smallest normals: exactly representable, the integer IS the bit pattern
+        bits = ((unsigned long long)d[1] << 32) | d[0];
+    }
+    else {
+        unsigned long long mant = 0;
+        for (int b = t; b >= t - 52; b--) mant = (mant << 1) | bit_at(b);
+        const unsigned long long guard = bit_at(t - 53);
+        bool sticky = false;
+        const int q = t - 54;  // highest bit that only contributes to the sticky flag
+        if (q >= 0) {
+            const int li = q >> 5, lb = q & 31;
+            const unsigned int msk = lb == 31 ? 0xffffffffu : ((1u << (lb + 1)) - 1u);
+            sticky = (d[li] & msk) != 0;
+            for (int i = li - 1; i >= 0 && !sticky; i--) sticky = d[i] != 0;
+        }
+        long long e = (long long)t - 51;
+        if (guard && (sticky || (mant & 1ULL))) {
+            mant++;
+            if (mant >> 53) { mant >>= 1; e++; }
+        }
+        if (e >= 2047) bits = 0x7ff0000000000000ULL;
+        else bits = ((unsigned long long)e << 52) | (mant & 0xfffffffffffffULL);
+    }
+    if (neg) bits |= 1ULL << 63;
+    return __longlong_as_double((long long)bits);
+}
+
+struct EvalView {
+    int32_t function;
+    int32_t partial;
+    const long long *counts;
+    const long long *limbs;
+    const unsigned int *special;
+    const unsigned long long *i128;
+    void *out0;           // final value, or (partial) the count channel
+    uint8_t *out0_nulls;
+    void *out1;           // partial: the sum channel
+};
+struct EvalArgs {
+    int32_t n_aggs;
+    int32_t pad;
+    EvalView a[kMaxAggs];
+};
+
+__global__ void __launch_bounds__(kBlock) agg_evaluate_kernel(EvalArgs args, int64_t groups, unsigned int *error)
+{
+    const int64_t total = groups * args.n_aggs;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int k = (int)(i % args.n_aggs);
+        const int64_t g = i / args.n_aggs;
+        const EvalView &a = args.a[k];
+        const long long cnt = a.counts[g];
+        if (a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN) {
+            ((long long *)a.out0)[g] = cnt;  // CountAggregation.java:52-56 never null
+            continue;
+        }
+        double dsum = 0.0;
+        long long lsum = 0;
+        if (a.function == TGPU_AGG_SUM_BIGINT) {
+            const unsigned long long lo = a.i128[g * 2], hi = a.i128[g * 2 + 1];
+            lsum = (long long)lo;
+            const unsigned long long expect_hi = lsum < 0 ? ~0ULL : 0ULL;
+            if (hi != expect_hi) atomicOr(error, 1u);  // BigintOperators.add overflow (M/type/BigintOperators.java:47-57)
+        }
+        else {
+            dsum = kulisch_round(&a.limbs[g * kLimbs], a.special[g]);
+        }
+        if (a.partial) {
+            ((long long *)a.out0)[g] = cnt;
+            if (a.function == TGPU_AGG_SUM_BIGINT) ((long long *)a.out1)[g] = lsum;
+            else ((double *)a.out1)[g] = dsum;
+            continue;
+        }
+        a.out0_nulls[g] = cnt == 0 ? 1 : 0;  // DoubleSumAggregation.java:54-63, AverageAggregations.java:69-80
+        switch (a.function) {
+        case TGPU_AGG_SUM_BIGINT: ((long long *)a.out0)[g] = cnt ? lsum : 0; break;
+        case TGPU_AGG_SUM_DOUBLE: ((double *)a.out0)[g] = cnt ? dsum : 0.0; break;
+        default: ((double *)a.out0)[g] = cnt ? dsum / (double)cnt : 0.0; break;
+        }
+    }
+}
+
+int grid_for(Context *ctx, int64_t n)
+{
+    int64_t blocks = ceil_div(n, kBlock);
+    int64_t cap = (int64_t)ctx->cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+bool is_double_state(int32_t f) { return f == TGPU_AGG_SUM_DOUBLE || f == TGPU_AGG_AVG_DOUBLE || f == TGPU_AGG_AVG_BIGINT; }
+bool is_count(int32_t f) { return f == TGPU_AGG_COUNT_ALL || f == TGPU_AGG_COUNT_COLUMN; }
+
+BufferPtr grow(Context *ctx, BufferPtr old, int64_t old_elems, int64_t new_elems, int elem_bytes)
+{
+    BufferPtr nb = ctx->alloc_zero((size_t)new_elems * elem_bytes);
+    if (old && old_elems) HIP_CHECK(hipMemcpyAsync(nb->ptr(), old->ptr(), (size_t)old_elems * elem_bytes, hipMemcpyDeviceToDevice, ctx->stream()));
+    return nb;
+}
+
+}  // namespace
+
+GroupedAccumulators::GroupedAccumulators(Context *ctx, std::vector<tgpu_agg_spec> specs, int32_t step) : ctx_(ctx), step_(step)
+{
+    TG_CHECK_ARG((int)specs.size() <= kMaxAggs, "at most 16 aggregates per operator");
+    for (auto &s : specs) {
+        TG_CHECK_ARG(s.function >= TGPU_AGG_COUNT_ALL && s.function <= TGPU_AGG_AVG_DOUBLE, "unknown aggregate function");
+        State st;
+        st.spec = s;
+        states_.push_back(st);
+    }
+    error_ = ctx_->alloc_zero(4);
+}
+
+int GroupedAccumulators::output_channel_count() const
+{
+    return step_ == TGPU_STEP_PARTIAL ? intermediate_channel_count() : (int)states_.size();
+}
+
+int GroupedAccumulators::intermediate_channel_count() const
+{
+    int n = 0;
+    for (auto &s : states_) n += is_count(s.spec.function) ? 1 : 2;
+    return n;
+}
+
+int64_t GroupedAccumulators::estimated_size() const
+{
+    int64_t s = 0;
+    for (auto &st : states_) {
+        s += st.cap * 8;
+        if (st.limbs) s += st.cap * (kLimbs * 8 + 4);
+        if (st.i128) s += st.cap * 16;
+    }
+    return s;
+}
+
+void GroupedAccumulators::ensure(int64_t groups)
+{
+    for (auto &st : states_) {
+        if (groups <= st.cap) continue;
+        int64_t cap = st.cap ? st.cap : 256;
+        while (cap < groups) cap <<= 1;
+        st.counts = grow(ctx_, st.counts, st.cap, cap, 8);
+        if (is_double_state(st.spec.function)) {
+            st.limbs = grow(ctx_, st.limbs, st.cap * kLimbs, cap * kLimbs, 8);
+            st.special = grow(ctx_, st.special, st.cap, cap, 4);
+        }
+        if (st.spec.function == TGPU_AGG_SUM_BIGINT) st.i128 = grow(ctx_, st.i128, st.cap * 2, cap * 2, 8);
+        st.cap = cap;
+    }
+}
+
+static void check_channel(const DevicePage &page, int ch, int32_t want_type, const char *what)
+{
+    TG_CHECK_ARG(ch >= 0 && ch < (int)page.cols.size(), std::string(what) + ": channel out of range");
+    if (want_type) TG_CHECK_ARG(page.cols[ch].type == want_type, std::string(what) + ": unexpected channel type " + type_name(page.cols[ch].type));
+}
+
+void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
+{
+    if (states_.empty() || n <= 0) return;
+    ensure(group_count > 0 ? group_count : 1);
+    AggArgs args{};
+    args.n_aggs = (int32_t)states_.size();
+    for (size_t k = 0; k < states_.size(); k++) {
+        State &st = states_[k];
+        AggView &a = args.a[k];
+        a.function = st.spec.function;
+        if (st.spec.function != TGPU_AGG_COUNT_ALL) {
+            int32_t want = 0;
+            if (st.spec.function == TGPU_AGG_SUM_BIGINT || st.spec.function == TGPU_AGG_AVG_BIGINT) want = TGPU_BIGINT;
+            if (st.spec.function == TGPU_AGG_SUM_DOUBLE || st.spec.function == TGPU_AGG_AVG_DOUBLE) want = TGPU_DOUBLE;
+            check_channel(page, st.spec.input_channel, want, "aggregate input");
+            a.input = page.cols[st.spec.input_channel].values;
+            a.input_nulls = page.cols[st.spec.input_channel].nulls;
+        }
+        if (st.spec.mask_channel >= 0) {
+            check_channel(page, st.spec.mask_channel, TGPU_BOOLEAN, "aggregate mask");
+            a.mask = (const uint8_t *)page.cols[st.spec.mask_channel].values;
+            a.mask_nulls = page.cols[st.spec.mask_channel].nulls;
+        }
+        a.counts = st.counts->as<long long>();
+        a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
+        a.special = st.special ? st.special->as<unsigned int>() : nullptr;
+        a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+    }
+    ProfileScope ps(ctx_, "agg_accumulate");
+    agg_accumulate_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, gids, n);
+    check_launch("agg_accumulate");
+}
+
+void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
+{
+    if (states_.empty() || n <= 0) return;
+    ensure(group_count > 0 ? group_count : 1);
+    AggArgs args{};
+    args.n_aggs = (int32_t)states_.size();
+    for (size_t k = 0; k < states_.size(); k++) {
+        State &st = states_[k];
+        AggView &a = args.a[k];
+        a.function = st.spec.function;
+        int ch = st.spec.input_channel;
+        check_channel(page, ch, TGPU_BIGINT, "intermediate count");
+        a.input = page.cols[ch].values;
+        ch++;
+        if (!is_count(st.spec.function)) {
+            check_channel(page, ch, st.spec.function == TGPU_AGG_SUM_BIGINT ? TGPU_BIGINT : TGPU_DOUBLE, "intermediate sum");
+            a.input2 = page.cols[ch].values;
+            ch++;
+        }
+        a.counts = st.counts->as<long long>();
+        a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
+        a.special = st.special ? st.special->as<unsigned int>() : nullptr;
+        a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+    }
+    ProfileScope ps(ctx_, "agg_combine");
+    agg_accumulate_kernel<true><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, gids, n);
+    check_launch("agg_combine");
+}
+
+void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &out)
+{
+    if (states_.empty()) return;
+    ensure(groups > 0 ? groups : 1);
+    EvalArgs args{};
+    args.n_aggs = (int32_t)states_.size();
+    const bool partial = step_ == TGPU_STEP_PARTIAL;
+    const int64_t alloc_n = groups > 0 ? groups : 1;
+    for (size_t k = 0; k < states_.size(); k++) {
+        State &st = states_[k];
+        EvalView &a = args.a[k];
+        a.function = st.spec.function;
+        a.partial = partial ? 1 : 0;
+        a.counts = st.counts->as<long long>();
+        a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
+        a.special = st.special ? st.special->as<unsigned int>() : nullptr;
+        a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+        DeviceColumn c0;
+        c0.n = groups;
+        c0.values_buf = ctx_->alloc((size_t)alloc_n * 8);
+        c0.values = c0.values_buf->ptr();
+        a.out0 = c0.values_buf->ptr();
+        if (is_count(st.spec.function) || partial) {
+            c0.type = TGPU_BIGINT;
+            out.push_back(c0);
+            if (partial && !is_count(st.spec.function)) {
+                DeviceColumn c1;
+                c1.n = groups;
+                c1.type = st.spec.function == TGPU_AGG_SUM_BIGINT ? TGPU_BIGINT : TGPU_DOUBLE;
+                c1.values_buf = ctx_->alloc((size_t)alloc_n * 8);
+                c1.values = c1.values_buf->ptr();
+                a.out1 = c1.values_buf->ptr();
+                out.push_back(c1);
+            }
+        }
+        else {
+            c0.type = st.spec.function == TGPU_AGG_SUM_BIGINT ? TGPU_BIGINT : TGPU_DOUBLE;
+            c0.nulls_buf = ctx_->alloc((size_t)alloc_n);
+            c0.nulls = c0.nulls_buf->as<uint8_t>();
+            a.out0_nulls = c0.nulls_buf->as<uint8_t>();
+            out.push_back(c0);
+        }
+    }
+    if (groups <= 0) return;
+    HIP_CHECK(hipMemsetAsync(error_->ptr(), 0, 4, ctx_->stream()));
+    {
+        ProfileScope ps(ctx_, "agg_evaluate");
+        agg_evaluate_kernel<<<grid_for(ctx_, groups * args.n_aggs), kBlock, 0, ctx_->stream()>>>(args, groups, error_->as<unsigned int>());
+        check_launch("agg_evaluate");
+    }
+    unsigned int err = ctx_->read_scalar(error_->as<unsigned int>());
+    if (err) fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "bigint addition overflow");
+}
+
+}  // namespace tgpu

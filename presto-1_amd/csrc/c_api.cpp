@@ -1,0 +1,525 @@
+// c_api.cpp -- the extern "C" boundary (include/tgpu.h): exceptions -> status codes, handles -> C++ objects.
+#include <cstdlib>
+
+#include "kernels.h"
+#include "operators.h"
+
+namespace tgpu {
+const std::string &last_error();
+}
+
+using namespace tgpu;
+
+namespace {
+
+template <typename F> int32_t guard(F &&f)
+{
+    try {
+        f();
+        return TGPU_OK;
+    }
+    catch (const Error &e) {
+        set_last_error(e.what());
+        return e.code;
+    }
+    catch (const std::bad_alloc &) {
+        set_last_error("out of host memory");
+        return TGPU_ERR_INSUFFICIENT_RESOURCES;
+    }
+    catch (const std::exception &e) {
+        set_last_error(e.what());
+        return TGPU_ERR_INTERNAL;
+    }
+}
+
+std::vector<int32_t> vec(const int32_t *p, int32_t n)
+{
+    TG_CHECK_ARG(n >= 0 && (n == 0 || p != nullptr), "null array argument");
+    return std::vector<int32_t>(p, p + n);
+}
+
+std::unique_ptr<OutputPage> make_output(Context *ctx, DevicePage &&p)
+{
+    auto o = std::make_unique<OutputPage>();
+    o->ctx = ctx;
+    o->page = std::move(p);
+    return o;
+}
+
+tgpu_output_page *release_output(std::unique_ptr<OutputPage> o) { return static_cast<tgpu_output_page *>(o.release()); }
+
+}  // namespace
+
+extern "C" {
+
+int32_t tgpu_context_create(int32_t device, void *hip_stream, tgpu_context **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(out != nullptr, "out is null");
+        auto c = std::make_unique<tgpu_context>();
+        c->ctx = std::make_unique<Context>(device, (hipStream_t)hip_stream);
+        *out = c.release();
+    });
+}
+
+void tgpu_context_destroy(tgpu_context *ctx) { delete ctx; }
+
+int32_t tgpu_context_synchronize(tgpu_context *ctx)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        ctx->ctx->sync();
+    });
+}
+
+const char *tgpu_last_error(void) { return last_error().c_str(); }
+const char *tgpu_version(void) { return "tgpu 0.1 (gfx950)"; }
+
+int32_t tgpu_set_resource_dir(const char *dir)
+{
+    return guard([&] {
+        TG_CHECK_ARG(dir != nullptr, "dir is null");
+        set_resource_dir(dir);
+    });
+}
+
+int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        ctx->ctx->set_profiling(enabled != 0);
+    });
+}
+
+int32_t tgpu_profile_reset(tgpu_context *ctx)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        ctx->ctx->profile_reset();
+    });
+}
+
+int64_t tgpu_profile_dump(tgpu_context *ctx, char *buf, int64_t buf_len)
+{
+    int64_t need = 0;
+    int32_t rc = guard([&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        std::string s = ctx->ctx->profile_json();
+        need = (int64_t)s.size() + 1;
+        if (buf && buf_len >= need) memcpy(buf, s.c_str(), (size_t)need);
+    });
+    return rc == TGPU_OK ? need : rc;
+}
+
+// ---- factories ------------------------------------------------------------------------------------------------------
+int32_t tgpu_filter_project_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t input_type_count, const int32_t *input_types,
+                                           const tgpu_page_processor_spec *spec, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out, "null argument");
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<FilterAndProjectOperatorFactory>(ctx->ctx.get(), operator_id, vec(input_types, input_type_count), spec);
+        *out = f.release();
+    });
+}
+
+// compile-only entry (no GPU needed): lets build() pre-warm the on-disk kernel cache
+int32_t tgpu_precompile_page_processor(int32_t input_type_count, const int32_t *input_types, const tgpu_page_processor_spec *spec)
+{
+    return guard([&] {
+        PageProcessorGpu p(vec(input_types, input_type_count), spec);
+        p.precompile();
+    });
+}
+
+// returns the generated kernel source (diagnostics / DESIGN.md listings); returns needed length
+int64_t tgpu_page_processor_source(int32_t input_type_count, const int32_t *input_types, const tgpu_page_processor_spec *spec, char *buf, int64_t buf_len)
+{
+    int64_t need = 0;
+    int32_t rc = guard([&] {
+        PageProcessorGpu p(vec(input_types, input_type_count), spec);
+        need = (int64_t)p.source().size() + 1;
+        if (buf && buf_len >= need) memcpy(buf, p.source().c_str(), (size_t)need);
+    });
+    return rc == TGPU_OK ? need : rc;
+}
+
+int32_t tgpu_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t group_by_count, const int32_t *group_by_types,
+                                             const int32_t *group_by_channels, int32_t hash_channel, int32_t step, int32_t agg_count,
+                                             const tgpu_agg_spec *aggs, int32_t expected_groups, int32_t produce_default_output,
+                                             tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out, "null argument");
+        TG_CHECK_ARG(agg_count >= 0 && (agg_count == 0 || aggs != nullptr), "null aggregate array");
+        HashAggregationConfig cfg;
+        cfg.group_by_types = vec(group_by_types, group_by_count);
+        cfg.group_by_channels = vec(group_by_channels, group_by_count);
+        cfg.hash_channel = hash_channel;
+        cfg.step = step;
+        cfg.aggs.assign(aggs, aggs + agg_count);
+        cfg.expected_groups = expected_groups;
+        cfg.produce_default_output = produce_default_output != 0;
+        if (const char *env = getenv("TGPU_MAX_PARTIAL_AGGREGATION_MEMORY")) cfg.max_partial_memory = atoll(env);
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<HashAggregationOperatorFactory>(ctx->ctx.get(), operator_id, std::move(cfg));
+        *out = f.release();
+    });
+}
+
+int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types,
+                                         int32_t output_channel_count, const int32_t *output_channels, int32_t hash_channel_count,
+                                         const int32_t *hash_channels, int32_t precomputed_hash_channel, int32_t expected_positions,
+                                         tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out && bridge_out, "null argument");
+        HashBuilderConfig cfg;
+        cfg.types = vec(types, type_count);
+        cfg.output_channels = vec(output_channels, output_channel_count);
+        cfg.hash_channels = vec(hash_channels, hash_channel_count);
+        cfg.precomputed_hash_channel = precomputed_hash_channel;
+        cfg.expected_positions = expected_positions;
+        auto bridge = std::make_unique<tgpu_lookup_source_factory>();
+        bridge->bridge = std::make_shared<LookupSourceFactory>();
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<HashBuilderOperatorFactory>(ctx->ctx.get(), operator_id, std::move(cfg), bridge->bridge);
+        *bridge_out = bridge.release();
+        *out = f.release();
+    });
+}
+
+void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge) { delete bridge; }
+
+int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count)
+{
+    return guard([&] {
+        TG_CHECK_ARG(bridge != nullptr, "bridge is null");
+        auto s = bridge->bridge->lookup_source();
+        TG_CHECK_STATE(s != nullptr, "Lookup source has not been built yet");
+        if (positions) *positions = s->position_count();
+        if (hash_size) *hash_size = s->hash_size();
+        if (link_count) *link_count = s->link_count();
+    });
+}
+
+int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge, int32_t probe_type_count,
+                                        const int32_t *probe_types, int32_t probe_join_channel_count, const int32_t *probe_join_channels,
+                                        int32_t probe_hash_channel, int32_t probe_output_channel_count, const int32_t *probe_output_channels,
+                                        int32_t join_type, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out && bridge, "null argument");
+        LookupJoinConfig cfg;
+        cfg.probe_types = vec(probe_types, probe_type_count);
+        cfg.probe_join_channels = vec(probe_join_channels, probe_join_channel_count);
+        cfg.probe_output_channels = vec(probe_output_channels, probe_output_channel_count);
+        cfg.probe_hash_channel = probe_hash_channel;
+        cfg.join_type = join_type;
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<LookupJoinOperatorFactory>(ctx->ctx.get(), operator_id, std::move(cfg), bridge->bridge);
+        *out = f.release();
+    });
+}
+
+int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(factory && out, "null argument");
+        auto o = std::make_unique<tgpu_operator>();
+        o->op = factory->f->create_operator();
+        *out = o.release();
+    });
+}
+
+int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory)
+{
+    return guard([&] {
+        TG_CHECK_ARG(factory != nullptr, "factory is null");
+        factory->f->no_more_operators();
+    });
+}
+
+void tgpu_operator_factory_destroy(tgpu_operator_factory *factory) { delete factory; }
+
+// ---- Operator -------------------------------------------------------------------------------------------------------
+#define OP_BOOL(expr)                                            \
+    int32_t result = 0;                                          \
+    int32_t rc = guard([&] {                                     \
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed"); \
+        result = (expr) ? 1 : 0;                                 \
+    });                                                          \
+    return rc == TGPU_OK ? result : rc;
+
+int32_t tgpu_operator_needs_input(tgpu_operator *op) { OP_BOOL(op->op->needs_input()) }
+int32_t tgpu_operator_is_finished(tgpu_operator *op) { OP_BOOL(op->op->is_finished()) }
+int32_t tgpu_operator_is_blocked(tgpu_operator *op) { OP_BOOL(op->op->is_blocked()) }
+
+int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page)
+{
+    return guard([&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        TG_CHECK_ARG(page != nullptr, "page is null");
+        TG_CHECK_STATE(op->op->needs_input(), "Operator does not need input");
+        op->op->add_input(page);
+    });
+}
+
+int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(op != nullptr && op->op && out, "null argument");
+        *out = nullptr;
+        std::unique_ptr<OutputPage> p = op->op->get_output();
+        if (p) *out = release_output(std::move(p));
+    });
+}
+
+int32_t tgpu_operator_finish(tgpu_operator *op)
+{
+    return guard([&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        op->op->finish();
+    });
+}
+
+int64_t tgpu_operator_memory_bytes(tgpu_operator *op)
+{
+    int64_t v = 0;
+    int32_t rc = guard([&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        v = op->op->memory_bytes();
+    });
+    return rc == TGPU_OK ? v : rc;
+}
+
+void tgpu_operator_close(tgpu_operator *op)
+{
+    if (!op) return;
+    guard([&] {
+        if (op->op) op->op->close();
+    });
+    delete op;
+}
+
+// ---- output pages ---------------------------------------------------------------------------------------------------
+int32_t tgpu_output_page_position_count(const tgpu_output_page *page) { return page ? (int32_t)page->page.n : TGPU_ERR_INVALID_ARGUMENT; }
+int32_t tgpu_output_page_channel_count(const tgpu_output_page *page) { return page ? (int32_t)page->page.cols.size() : TGPU_ERR_INVALID_ARGUMENT; }
+
+int32_t tgpu_output_page_as_page(const tgpu_output_page *page, tgpu_page *out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(page && out, "null argument");
+        auto *p = const_cast<tgpu_output_page *>(page);
+        p->blocks.clear();
+        for (auto &c : p->page.cols) {
+            tgpu_block b{};
+            b.type = c.type;
+            b.encoding = TGPU_FLAT;
+            b.memory = TGPU_DEVICE;
+            b.position_count = (int32_t)p->page.n;
+            b.values = c.values;
+            b.nulls = c.nulls;
+            b.offsets = c.offsets;
+            p->blocks.push_back(b);
+        }
+        out->position_count = (int32_t)p->page.n;
+        out->channel_count = (int32_t)p->blocks.size();
+        out->blocks = p->blocks.data();
+    });
+}
+
+int32_t tgpu_output_page_block_info(const tgpu_output_page *page, int32_t ch, int32_t *type, int64_t *value_bytes, int32_t *may_have_nulls)
+{
+    return guard([&] {
+        TG_CHECK_ARG(page != nullptr && ch >= 0 && ch < (int)page->page.cols.size(), "bad page / channel");
+        const DeviceColumn &c = page->page.cols[(size_t)ch];
+        if (type) *type = c.type;
+        if (may_have_nulls) *may_have_nulls = c.nulls ? 1 : 0;
+        if (value_bytes) {
+            if (c.type == TGPU_VARCHAR) {
+                // region views keep absolute offsets: the bytes of this block are [offsets[0], offsets[n])
+                int32_t a = 0, b = 0;
+                if (page->page.n > 0) {
+                    page->ctx->download(&a, c.offsets, 4);
+                    page->ctx->download(&b, c.offsets + page->page.n, 4);
+                }
+                *value_bytes = (int64_t)b - a;
+            }
+            else *value_bytes = page->page.n * type_width(c.type);
+        }
+    });
+}
+
+int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, void *values, uint8_t *nulls, int32_t *offsets)
+{
+    return guard([&] {
+        TG_CHECK_ARG(page != nullptr && ch >= 0 && ch < (int)page->page.cols.size(), "bad page / channel");
+        const DeviceColumn &c = page->page.cols[(size_t)ch];
+        const int64_t n = page->page.n;
+        Context *ctx = page->ctx;
+        if (nulls) {
+            if (c.nulls) ctx->download(nulls, c.nulls, (size_t)n);
+            else memset(nulls, 0, (size_t)n);
+        }
+        if (c.type == TGPU_VARCHAR) {
+            TG_CHECK_ARG(offsets != nullptr, "offsets buffer required for VARCHAR");
+            ctx->download(offsets, c.offsets, (size_t)(n + 1) * 4);
+            const int32_t base = n > 0 ? offsets[0] : 0;
+            const int64_t bytes = n > 0 ? (int64_t)offsets[n] - base : 0;
+            if (bytes && values) ctx->download(values, (const uint8_t *)c.values + base, (size_t)bytes);
+            for (int64_t i = 0; i <= n; i++) offsets[i] -= base;
+            if (n == 0) offsets[0] = 0;
+        }
+        else if (values && n > 0) {
+            ctx->download(values, c.values, (size_t)n * type_width(c.type));
+        }
+    });
+}
+
+void tgpu_output_page_release(tgpu_output_page *page) { delete static_cast<OutputPage *>(page); }
+
+// ---- GroupByHash ----------------------------------------------------------------------------------------------------
+int32_t tgpu_group_by_hash_create(tgpu_context *ctx, int32_t type_count, const int32_t *types, const int32_t *hash_channels, int32_t input_hash_channel,
+                                  int32_t expected_size, tgpu_group_by_hash **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out, "null argument");
+        auto g = std::make_unique<tgpu_group_by_hash>();
+        g->ctx = ctx->ctx.get();
+        g->hash_channels = vec(hash_channels, type_count);
+        g->input_hash_channel = input_hash_channel;
+        g->gbh = std::make_unique<GroupByHashGpu>(ctx->ctx.get(), vec(types, type_count), input_hash_channel >= 0, expected_size);
+        *out = g.release();
+    });
+}
+
+void tgpu_group_by_hash_destroy(tgpu_group_by_hash *gbh) { delete gbh; }
+
+static void gbh_inputs(tgpu_group_by_hash *g, const DevicePage &in, std::vector<const DeviceColumn *> &keys, const int64_t *&hashes)
+{
+    for (int32_t ch : g->hash_channels) {
+        TG_CHECK_ARG(ch >= 0 && ch < (int)in.cols.size(), "hash channel out of range");
+        keys.push_back(&in.cols[(size_t)ch]);
+    }
+    hashes = nullptr;
+    if (g->input_hash_channel >= 0) {
+        TG_CHECK_ARG(g->input_hash_channel < (int)in.cols.size() && in.cols[(size_t)g->input_hash_channel].type == TGPU_BIGINT, "bad input hash channel");
+        hashes = (const int64_t *)in.cols[(size_t)g->input_hash_channel].values;
+    }
+}
+
+int32_t tgpu_group_by_hash_get_group_ids(tgpu_group_by_hash *gbh, const tgpu_page *page, int64_t *group_ids, int64_t *group_count)
+{
+    return guard([&] {
+        TG_CHECK_ARG(gbh && page, "null argument");
+        DevicePage in = ingest_page(gbh->ctx, page);
+        std::vector<const DeviceColumn *> keys;
+        const int64_t *hashes;
+        gbh_inputs(gbh, in, keys, hashes);
+        BufferPtr gids = gbh->ctx->alloc((size_t)(in.n > 0 ? in.n : 1) * 4);
+        gbh->gbh->get_group_ids(keys, hashes, in.n, gids->as<int32_t>());
+        if (group_ids && in.n > 0) {
+            BufferPtr wide = gbh->ctx->alloc((size_t)in.n * 8);
+            k::widen_i32_to_i64(gbh->ctx, gids->as<int32_t>(), wide->as<int64_t>(), in.n);
+            gbh->ctx->download(group_ids, wide->ptr(), (size_t)in.n * 8);
+        }
+        else gbh->ctx->sync();
+        if (group_count) *group_count = gbh->gbh->group_count();
+    });
+}
+
+int32_t tgpu_group_by_hash_add_page(tgpu_group_by_hash *gbh, const tgpu_page *page) { return tgpu_group_by_hash_get_group_ids(gbh, page, nullptr, nullptr); }
+
+int32_t tgpu_group_by_hash_contains(tgpu_group_by_hash *gbh, int32_t position, const tgpu_page *page, int32_t *result)
+{
+    return guard([&] {
+        TG_CHECK_ARG(gbh && page && result, "null argument");
+        DevicePage in = ingest_page(gbh->ctx, page);
+        TG_CHECK_ARG(position >= 0 && position < in.n, "position out of range");
+        std::vector<const DeviceColumn *> keys;
+        const int64_t *hashes;
+        gbh_inputs(gbh, in, keys, hashes);
+        std::vector<DeviceColumn> one;
+        for (auto *c : keys) one.push_back(k::region_of(gbh->ctx, *c, position, 1));
+        std::vector<const DeviceColumn *> kp;
+        for (auto &c : one) kp.push_back(&c);
+        BufferPtr out = gbh->ctx->alloc(4);
+        gbh->gbh->lookup(kp, hashes ? hashes + position : nullptr, 1, out->as<int32_t>());
+        *result = gbh->ctx->read_scalar(out->as<int32_t>()) >= 0 ? 1 : 0;
+    });
+}
+
+int64_t tgpu_group_by_hash_group_count(tgpu_group_by_hash *gbh) { return gbh ? gbh->gbh->group_count() : TGPU_ERR_INVALID_ARGUMENT; }
+int32_t tgpu_group_by_hash_capacity(tgpu_group_by_hash *gbh) { return gbh ? gbh->gbh->java_capacity() : TGPU_ERR_INVALID_ARGUMENT; }
+int64_t tgpu_group_by_hash_estimated_size(tgpu_group_by_hash *gbh) { return gbh ? gbh->gbh->estimated_size() : TGPU_ERR_INVALID_ARGUMENT; }
+int32_t tgpu_group_by_hash_rehash_count(tgpu_group_by_hash *gbh) { return gbh ? gbh->gbh->java_rehash_count() : TGPU_ERR_INVALID_ARGUMENT; }
+
+int32_t tgpu_group_by_hash_append_values(tgpu_group_by_hash *gbh, tgpu_output_page **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(gbh && out, "null argument");
+        DevicePage p = gbh->gbh->key_page(gbh->input_hash_channel >= 0);
+        *out = release_output(make_output(gbh->ctx, std::move(p)));
+    });
+}
+
+// ---- hash / partition -----------------------------------------------------------------------------------------------
+int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel_count, const int32_t *channels, int64_t *hashes)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && page && hashes, "null argument");
+        Context *c = ctx->ctx.get();
+        DevicePage in = ingest_page(c, page);
+        std::vector<const DeviceColumn *> keys;
+        for (int32_t ch : vec(channels, channel_count)) {
+            TG_CHECK_ARG(ch >= 0 && ch < (int)in.cols.size(), "channel out of range");
+            keys.push_back(&in.cols[(size_t)ch]);
+        }
+        if (in.n == 0) return;
+        BufferPtr out = c->alloc((size_t)in.n * 8);
+        k::hash_rows(c, key_cols_of(keys), in.n, out->as<int64_t>());
+        c->download(hashes, out->ptr(), (size_t)in.n * 8);
+    });
+}
+
+int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels, int32_t hash_channel,
+                            int32_t partition_count, int64_t *counts, tgpu_output_page **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && page && counts && out, "null argument");
+        TG_CHECK_ARG(partition_count > 0 && partition_count <= 1024, "partition count must be in 1..1024");
+        Context *c = ctx->ctx.get();
+        DevicePage in = ingest_page(c, page);
+        *out = nullptr;
+        for (int32_t p = 0; p < partition_count; p++) counts[p] = 0;
+        BufferPtr own_hashes;
+        const int64_t *hashes = nullptr;
+        if (hash_channel >= 0) {
+            TG_CHECK_ARG(hash_channel < (int)in.cols.size() && in.cols[(size_t)hash_channel].type == TGPU_BIGINT, "bad hash channel");
+            hashes = (const int64_t *)in.cols[(size_t)hash_channel].values;
+        }
+        else {
+            std::vector<const DeviceColumn *> keys;
+            for (int32_t ch : vec(key_channels, key_channel_count)) {
+                TG_CHECK_ARG(ch >= 0 && ch < (int)in.cols.size(), "channel out of range");
+                keys.push_back(&in.cols[(size_t)ch]);
+            }
+            TG_CHECK_ARG(!keys.empty(), "partitioning needs key channels or a hash channel");
+            own_hashes = c->alloc((size_t)(in.n > 0 ? in.n : 1) * 8);
+            k::hash_rows(c, key_cols_of(keys), in.n, own_hashes->as<int64_t>());
+            hashes = own_hashes->as<int64_t>();
+        }
+        const int64_t n = in.n;
+        BufferPtr ids = c->alloc((size_t)(n > 0 ? n : 1) * 4), pos = c->alloc((size_t)(n > 0 ? n : 1) * 4), cnt = c->alloc((size_t)partition_count * 8);
+        k::partition_ids(c, hashes, n, partition_count, ids->as<int32_t>());
+        k::partition_positions(c, ids->as<int32_t>(), n, partition_count, pos->as<int32_t>(), cnt->as<int64_t>());
+        c->download(counts, cnt->ptr(), (size_t)partition_count * 8);
+        DevicePage o;
+        o.n = n;
+        for (auto &col : in.cols) o.cols.push_back(k::gather_column(c, col, pos->as<int32_t>(), n, false));
+        *out = release_output(make_output(c, std::move(o)));
+    });
+}
+
+}  // extern "C"

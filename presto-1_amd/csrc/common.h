@@ -1,0 +1,232 @@
+// common.h -- runtime plumbing shared by every translation unit of libtgpu.so:
+// error propagation, the per-context stream + caching device allocator + kernel timer,
+// and the device-side column / page model (flat columns in HBM).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tgpu.h"
+
+namespace tgpu {
+
+// ---- errors: C++ exceptions inside, int32 codes at the C ABI ------------------------------------------------------
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string &msg) : std::runtime_error(msg), code(c) {}
+};
+
+[[noreturn]] inline void fail(int32_t code, const std::string &msg) { throw Error(code, msg); }
+
+#define TG_CHECK_ARG(cond, msg)                                            \
+    do {                                                                   \
+        if (!(cond)) ::tgpu::fail(TGPU_ERR_INVALID_ARGUMENT, (msg));       \
+    } while (0)
+
+#define TG_CHECK_STATE(cond, msg)                                          \
+    do {                                                                   \
+        if (!(cond)) ::tgpu::fail(TGPU_ERR_INTERNAL, (msg));               \
+    } while (0)
+
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess)                                                                             \
+            ::tgpu::fail(TGPU_ERR_DEVICE, std::string("HIP error: ") + hipGetErrorString(_e) + " at " +   \
+                                              __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")"); \
+    } while (0)
+
+void set_last_error(const std::string &msg);
+
+inline int type_width(int32_t t)
+{
+    switch (t) {
+    case TGPU_BIGINT: case TGPU_DOUBLE: return 8;
+    case TGPU_INTEGER: case TGPU_DATE: return 4;
+    case TGPU_BOOLEAN: return 1;
+    default: return 0;
+    }
+}
+inline bool valid_type(int32_t t) { return t >= TGPU_BIGINT && t <= TGPU_VARCHAR; }
+const char *type_name(int32_t t);
+
+class Context;
+
+// ---- device memory: RAII buffer handed out by the context's caching allocator ---------------------------------------
+class DeviceBuffer {
+public:
+    DeviceBuffer(Context *ctx, void *ptr, size_t bytes, size_t capacity) : ctx_(ctx), ptr_(ptr), bytes_(bytes), capacity_(capacity) {}
+    ~DeviceBuffer();
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void *ptr() const { return ptr_; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(ptr_); }
+    size_t bytes() const { return bytes_; }
+    size_t capacity() const { return capacity_; }
+
+private:
+    Context *ctx_;
+    void *ptr_;
+    size_t bytes_, capacity_;
+};
+using BufferPtr = std::shared_ptr<DeviceBuffer>;
+
+// ---- kernel timer: hipEvent pairs recorded on the context's stream around each launch -------------------------------
+struct KernelStat {
+    int64_t count = 0;
+    double total_ms = 0, min_ms = 1e30, max_ms = 0;
+};
+
+class Context {
+public:
+    Context(int device, hipStream_t stream);
+    ~Context();
+
+    int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
+    void sync();
+
+    // stream-ordered caching allocator (all work of a context is on one stream, so reuse after free is ordered)
+    BufferPtr alloc(size_t bytes);
+    BufferPtr alloc_zero(size_t bytes);
+    void release(void *ptr, size_t capacity);
+    size_t bytes_in_use() const { return in_use_; }
+
+    // pinned host staging (uploads / small readbacks)
+    void *pinned(size_t bytes);
+    void upload(void *dst, const void *src, size_t bytes);          // async H2D through pinned staging when small
+    void download(void *dst, const void *src, size_t bytes);        // D2H + sync
+    template <typename T> T read_scalar(const T *dptr)
+    {
+        T v;
+        download(&v, dptr, sizeof(T));
+        return v;
+    }
+
+    // profiling
+    bool profiling() const { return profiling_; }
+    void set_profiling(bool on);
+    void profile_reset();
+    void profile_begin(const char *name);
+    void profile_end();
+    void profile_collect();
+    std::string profile_json();
+
+    int cu_count() const { return cu_count_; }
+
+private:
+    int device_;
+    hipStream_t stream_;
+    bool own_stream_ = false;
+    int cu_count_ = 256;
+    std::multimap<size_t, void *> free_;
+    size_t in_use_ = 0, cached_ = 0;
+    void *pinned_ = nullptr;
+    size_t pinned_bytes_ = 0;
+    bool profiling_ = false;
+    struct Pending { std::string name; hipEvent_t a, b; };
+    std::vector<Pending> pending_;
+    std::vector<hipEvent_t> event_pool_;
+    std::map<std::string, KernelStat> stats_;
+    const char *cur_name_ = nullptr;
+    hipEvent_t cur_a_ = nullptr;
+    std::mutex mu_;
+};
+
+// RAII: times everything launched on the stream between construction and destruction under one name
+struct ProfileScope {
+    Context *ctx;
+    ProfileScope(Context *c, const char *name) : ctx(c)
+    {
+        if (ctx->profiling()) ctx->profile_begin(name);
+    }
+    ~ProfileScope()
+    {
+        if (ctx->profiling()) ctx->profile_end();
+    }
+};
+
+inline void check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fail(TGPU_ERR_DEVICE, std::string("kernel launch failed (") + what + "): " + hipGetErrorString(e));
+}
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device columns: always FLAT in HBM (dictionary / RLE inputs are flattened at ingest) ---------------------------
+// Layout in HBM = the reference's block arrays: values[n] (8/4/1 bytes), nulls[n] one byte per row or absent,
+// VARCHAR: byte pool + int32 offsets[n+1].
+struct DeviceColumn {
+    int32_t type = 0;
+    int64_t n = 0;
+    const void *values = nullptr;
+    const uint8_t *nulls = nullptr;     // nullptr = no nulls
+    const int32_t *offsets = nullptr;   // VARCHAR
+    int64_t pool_bytes = 0;             // VARCHAR byte pool size
+    BufferPtr values_buf, nulls_buf, offsets_buf;  // owners (may be empty for borrowed device input)
+
+    int64_t value_bytes() const { return type == TGPU_VARCHAR ? pool_bytes : n * type_width(type); }
+    int64_t size_in_bytes() const { return value_bytes() + (nulls ? n : 0) + (offsets ? (n + 1) * 4 : 0); }
+};
+
+struct DevicePage {
+    int64_t n = 0;
+    std::vector<DeviceColumn> cols;
+    int64_t size_in_bytes() const
+    {
+        int64_t s = 0;
+        for (auto &c : cols) s += c.size_in_bytes();
+        return s;
+    }
+};
+
+// plain struct passed by value to kernels
+struct ColView {
+    const void *values;
+    const uint8_t *nulls;
+    const int32_t *offsets;
+    int32_t type;
+    int32_t pad;
+};
+constexpr int kMaxKeyChannels = 8;
+struct KeyCols {
+    int32_t n;
+    int32_t pad;
+    ColView c[kMaxKeyChannels];
+};
+
+inline ColView view_of(const DeviceColumn &c) { return ColView{c.values, c.nulls, c.offsets, c.type, 0}; }
+inline KeyCols key_cols_of(const std::vector<const DeviceColumn *> &cols)
+{
+    TG_CHECK_ARG((int)cols.size() <= kMaxKeyChannels, "at most 8 key channels are supported");
+    KeyCols k{};
+    k.n = (int32_t)cols.size();
+    for (size_t i = 0; i < cols.size(); i++) k.c[i] = view_of(*cols[i]);
+    return k;
+}
+
+// ingest: tgpu_page (host or device memory, any encoding) -> flat device columns.  columns.cpp
+DevicePage ingest_page(Context *ctx, const tgpu_page *page);
+DeviceColumn ingest_block(Context *ctx, const tgpu_block *block);
+
+// output pages handed across the C ABI
+struct OutputPage {
+    Context *ctx;
+    DevicePage page;
+    std::vector<tgpu_block> blocks;  // filled lazily by as_page
+};
+
+}  // namespace tgpu
+
+struct tgpu_output_page : tgpu::OutputPage {};

@@ -1,0 +1,221 @@
+// context.cpp -- Context: device/stream binding, caching allocator, pinned staging, HIP-event kernel timer.
+#include "common.h"
+
+#include <sstream>
+
+namespace tgpu {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+const std::string &last_error() { return g_last_error; }
+
+const char *type_name(int32_t t)
+{
+    switch (t) {
+    case TGPU_BIGINT: return "bigint";
+    case TGPU_INTEGER: return "integer";
+    case TGPU_DATE: return "date";
+    case TGPU_DOUBLE: return "double";
+    case TGPU_BOOLEAN: return "boolean";
+    case TGPU_VARCHAR: return "varchar";
+    default: return "?";
+    }
+}
+
+DeviceBuffer::~DeviceBuffer()
+{
+    if (ptr_) ctx_->release(ptr_, capacity_);
+}
+
+Context::Context(int device, hipStream_t stream) : device_(device), stream_(stream)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        fail(TGPU_ERR_DEVICE, "no HIP device available: libtgpu has no CPU fallback");
+    TG_CHECK_ARG(device >= 0 && device < count, "device ordinal out of range");
+    HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+}
+
+Context::~Context()
+{
+    hipSetDevice(device_);
+    hipStreamSynchronize(stream_);
+    for (auto &kv : free_) hipFree(kv.second);
+    for (auto &p : pending_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto ev : event_pool_) hipEventDestroy(ev);
+    if (pinned_) hipHostFree(pinned_);
+}
+
+void Context::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+static size_t round_capacity(size_t bytes)
+{
+    if (bytes < 256) return 256;
+    if (bytes <= (1u << 20)) {  // next power of two below 1 MiB
+        size_t c = 256;
+        while (c < bytes) c <<= 1;
+        return c;
+    }
+    const size_t g = 2u << 20;  // 2 MiB granules above
+    return (bytes + g - 1) / g * g;
+}
+
+BufferPtr Context::alloc(size_t bytes)
+{
+    size_t cap = round_capacity(bytes ? bytes : 1);
+    void *p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = free_.lower_bound(cap);
+        if (it != free_.end() && it->first <= cap + cap / 4 + 4096) {
+            p = it->second;
+            cap = it->first;
+            cached_ -= cap;
+            free_.erase(it);
+        }
+    }
+    if (!p) {
+        HIP_CHECK(hipSetDevice(device_));
+        hipError_t e = hipMalloc(&p, cap);
+        if (e != hipSuccess) {
+            // drop the cache and retry once
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                hipStreamSynchronize(stream_);
+                for (auto &kv : free_) hipFree(kv.second);
+                free_.clear();
+                cached_ = 0;
+            }
+            (void)hipGetLastError();
+            e = hipMalloc(&p, cap);
+            if (e != hipSuccess)
+                fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "out of device memory allocating " + std::to_string(cap) + " bytes");
+        }
+    }
+    in_use_ += cap;
+    return std::make_shared<DeviceBuffer>(this, p, bytes, cap);
+}
+
+BufferPtr Context::alloc_zero(size_t bytes)
+{
+    BufferPtr b = alloc(bytes);
+    if (bytes) HIP_CHECK(hipMemsetAsync(b->ptr(), 0, bytes, stream_));
+    return b;
+}
+
+void Context::release(void *ptr, size_t capacity)
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    in_use_ -= capacity;
+    // keep at most 64 GiB cached; beyond that give memory back to the driver
+    if (cached_ + capacity > (64ull << 30)) {
+        hipStreamSynchronize(stream_);
+        hipFree(ptr);
+        return;
+    }
+    free_.emplace(capacity, ptr);
+    cached_ += capacity;
+}
+
+void *Context::pinned(size_t bytes)
+{
+    if (bytes > pinned_bytes_) {
+        if (pinned_) {
+            HIP_CHECK(hipStreamSynchronize(stream_));
+            HIP_CHECK(hipHostFree(pinned_));
+        }
+        size_t cap = 1 << 20;
+        while (cap < bytes) cap <<= 1;
+        HIP_CHECK(hipHostMalloc(&pinned_, cap, hipHostMallocDefault));
+        pinned_bytes_ = cap;
+    }
+    return pinned_;
+}
+
+void Context::upload(void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return;
+    // Java heap arrays are pageable; hipMemcpyAsync from pageable memory stages internally and returns once the
+    // source has been consumed, which is what the ownership rule needs (the caller may reuse src after the call).
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
+}
+
+void Context::download(void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return;
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Context::set_profiling(bool on) { profiling_ = on; }
+
+void Context::profile_reset()
+{
+    profile_collect();
+    stats_.clear();
+}
+
+void Context::profile_begin(const char *name)
+{
+    if (cur_name_) return;  // nested scopes: the outermost wins
+    hipEvent_t a;
+    if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); }
+    else HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventRecord(a, stream_));
+    cur_name_ = name;
+    cur_a_ = a;
+}
+
+void Context::profile_end()
+{
+    if (!cur_name_) return;
+    hipEvent_t b;
+    if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); }
+    else HIP_CHECK(hipEventCreate(&b));
+    HIP_CHECK(hipEventRecord(b, stream_));
+    pending_.push_back(Pending{cur_name_, cur_a_, b});
+    cur_name_ = nullptr;
+    cur_a_ = nullptr;
+    if (pending_.size() > 4096) profile_collect();
+}
+
+void Context::profile_collect()
+{
+    if (pending_.empty()) return;
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    for (auto &p : pending_) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            KernelStat &s = stats_[p.name];
+            s.count++;
+            s.total_ms += ms;
+            if (ms < s.min_ms) s.min_ms = ms;
+            if (ms > s.max_ms) s.max_ms = ms;
+        }
+        event_pool_.push_back(p.a);
+        event_pool_.push_back(p.b);
+    }
+    pending_.clear();
+}
+
+std::string Context::profile_json()
+{
+    profile_collect();
+    std::ostringstream os;
+    os << "{";
+    bool first = true;
+    for (auto &kv : stats_) {
+        if (!first) os << ", ";
+        first = false;
+        os << "\"" << kv.first << "\": {\"count\": " << kv.second.count << ", \"total_ms\": " << kv.second.total_ms
+           << ", \"min_ms\": " << kv.second.min_ms << ", \"max_ms\": " << kv.second.max_ms << "}";
+    }
+    os << "}";
+    return os.str();
+}
+
+}  // namespace tgpu

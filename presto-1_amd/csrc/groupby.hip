@@ -1,0 +1,489 @@
+// groupby.hip -- GroupByHash on the GPU (K4/K5).
+//
+// Table: one uint64 word per slot in HBM.
+//     EMPTY           = all ones
+//     NEW(tag, row)   = 01 | tag16 << 32 | row32   -- claimed in the sub-batch being processed by input row `row`
+//     OLD(tag, gid)   = 00 | tag16 << 32 | gid32   -- key of group `gid`, stored in the key store
+// tag = bits 48..63 of fmix64(rawHash) (the reference keeps a 1-byte tag: MultiChannelGroupByHash.java:441-447);
+// slot = fmix64(rawHash) & mask (H6).  The table layout is not observable through the reference's API -- only the
+// group ids are -- so it is free to differ from the Java arrays; the ids are not:
+//
+// Bit-exact first-seen ids in parallel (SURVEY.md hard part 1):
+//   1. insert : every row probes; an empty slot is claimed with CAS(EMPTY -> NEW(tag,row)); a row that meets a NEW slot
+//               of its own key lowers the slot's row with atomicMin, so after the kernel each new key's slot holds the
+//               MINIMUM input row carrying that key.
+//   2. mark   : flag[row] = 1 iff the slot of the row's key holds exactly this row (= the key's first occurrence).
+//   3. scan   : rank = exclusive prefix sum of the flags = how many new keys were first seen before this row.
+//   4. final  : gid = nextGroupId + rank; the slot becomes OLD(tag,gid) and the key is copied into the key store at gid.
+//   5. resolve: rows that hit a NEW slot read their gid from the (now OLD) slot.
+// Java does `groupId = nextGroupId++` in row order (BigintGroupByHash.java:246-253), which is exactly rank order.
+#include "groupby.h"
+#include "kernels.h"
+#include "device_hash.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace tgpu {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr uint64_t kEmpty = ~0ull;
+
+__device__ __forceinline__ uint64_t make_new(uint32_t tag, uint32_t row) { return (1ull << 62) | ((uint64_t)tag << 32) | row; }
+__device__ __forceinline__ uint64_t make_old(uint32_t tag, uint32_t gid) { return ((uint64_t)tag << 32) | gid; }
+
+// IS NOT DISTINCT FROM per channel (JoinCompiler.java positionNotDistinctFromRow; DoubleType.java:181-192 NaN rule)
+__device__ __forceinline__ bool rows_not_distinct(const KeyCols &a, int64_t ra, const KeyCols &b, int64_t rb)
+{
+    for (int c = 0; c < a.n; c++) {
+        const ColView &x = a.c[c], &y = b.c[c];
+        bool nx = x.nulls && x.nulls[ra], ny = y.nulls && y.nulls[rb];
+        if (nx || ny) {
+            if (nx != ny) return false;
+            continue;
+        }
+        switch (x.type) {
+        case TGPU_BIGINT:
+            if (((const int64_t *)x.values)[ra] != ((const int64_t *)y.values)[rb]) return false;
+            break;
+        case TGPU_INTEGER:
+        case TGPU_DATE:
+            if (((const int32_t *)x.values)[ra] != ((const int32_t *)y.values)[rb]) return false;
+            break;
+        case TGPU_DOUBLE: {
+            double u = ((const double *)x.values)[ra], v = ((const double *)y.values)[rb];
+            if (!((u != u && v != v) || u == v)) return false;
+            break;
+        }
+        case TGPU_BOOLEAN:
+            if ((((const uint8_t *)x.values)[ra] != 0) != (((const uint8_t *)y.values)[rb] != 0)) return false;
+            break;
+        case TGPU_VARCHAR: {
+            int32_t ax = x.offsets[ra], lx = x.offsets[ra + 1] - ax;
+            int32_t ay = y.offsets[rb], ly = y.offsets[rb + 1] - ay;
+            if (lx != ly) return false;
+            const uint8_t *px = (const uint8_t *)x.values + ax, *py = (const uint8_t *)y.values + ay;
+            for (int32_t i = 0; i < lx; i++)
+                if (px[i] != py[i]) return false;
+            break;
+        }
+        default: return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ uint64_t load_word(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// counters: [0] pending rows, [2] error
+template <bool INSERT>
+__global__ void __launch_bounds__(kBlock) gbh_probe_kernel(KeyCols batch, const int64_t *__restrict__ hashes, int64_t n, uint64_t *words,
+                                                            uint64_t mask, KeyCols store, int32_t *__restrict__ out, unsigned long long *counters)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        const uint64_t m = tg_fmix64((uint64_t)hashes[r]);
+        uint64_t pos = m & mask;
+        const uint32_t tag = (uint32_t)(m >> 48);
+        int32_t result = -1;
+        bool pending = false;
+        for (uint64_t iter = 0; iter <= mask; iter++) {
+            uint64_t w = load_word(&words[pos]);
+            if (w == kEmpty) {
+                if (!INSERT) break;
+                uint64_t old = atomicCAS((unsigned long long *)&words[pos], (unsigned long long)kEmpty, (unsigned long long)make_new(tag, (uint32_t)r));
+                if (old == kEmpty) {
+                    result = -(int32_t)(pos + 2);
+                    pending = true;
+                    break;
+                }
+                w = old;
+            }
+            if ((uint32_t)((w >> 32) & 0xffff) == tag) {
+                if ((w >> 62) == 0) {
+                    uint32_t gid = (uint32_t)w;
+                    if (rows_not_distinct(batch, r, store, gid)) {
+                        result = (int32_t)gid;
+                        break;
+                    }
+                }
+                else if (INSERT) {
+                    uint32_t r2 = (uint32_t)w;
+                    if (r2 == (uint32_t)r || rows_not_distinct(batch, r, batch, r2)) {
+                        if ((uint32_t)r < r2) atomicMin((unsigned long long *)&words[pos], (unsigned long long)make_new(tag, (uint32_t)r));
+                        result = -(int32_t)(pos + 2);
+                        pending = true;
+                        break;
+                    }
+                }
+            }
+            pos = (pos + 1) & mask;
+            if (iter == mask) atomicExch(&counters[2], 1ull);  // table full: cannot happen by construction
+        }
+        out[r] = result;
+        if (INSERT) {
+            unsigned long long b = __ballot(pending);
+            if (pending && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) gbh_mark_kernel(const int32_t *__restrict__ out, int64_t n, const uint64_t *__restrict__ words, int32_t *__restrict__ flags)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        int32_t o = out[r];
+        int32_t f = 0;
+        if (o < -1) {
+            uint64_t w = words[(uint64_t)(-(o + 2))];
+            f = ((uint32_t)w == (uint32_t)r) ? 1 : 0;
+        }
+        flags[r] = f;
+    }
+}
+
+// step 4: first-occurrence rows publish their group: slot -> OLD, fixed-width keys + raw hash into the store,
+// varchar lengths into len[ch][rank] for the byte copy that follows
+struct VarLens {
+    int32_t *len[kMaxKeyChannels];
+};
+
+__global__ void __launch_bounds__(kBlock) gbh_finalize_kernel(KeyCols batch, const int64_t *__restrict__ hashes, int64_t n, uint64_t *words,
+                                                               const int32_t *__restrict__ out, const int32_t *__restrict__ flags,
+                                                               const int32_t *__restrict__ rank, int64_t base_gid, KeyCols store,
+                                                               int64_t *__restrict__ raw_hash, VarLens lens)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        if (!flags[r]) continue;
+        const uint64_t pos = (uint64_t)(-(out[r] + 2));
+        const int64_t gid = base_gid + rank[r];
+        const uint64_t w = words[pos];
+        words[pos] = make_old((uint32_t)((w >> 32) & 0xffff), (uint32_t)gid);
+        raw_hash[gid] = hashes[r];
+        for (int c = 0; c < batch.n; c++) {
+            const ColView &s = batch.c[c];
+            const ColView &d = store.c[c];
+            const bool isnull = s.nulls && s.nulls[r];
+            ((uint8_t *)d.nulls)[gid] = isnull ? 1 : 0;
+            switch (s.type) {
+            case TGPU_BIGINT:
+            case TGPU_DOUBLE: ((int64_t *)d.values)[gid] = isnull ? 0 : ((const int64_t *)s.values)[r]; break;
+            case TGPU_INTEGER:
+            case TGPU_DATE: ((int32_t *)d.values)[gid] = isnull ? 0 : ((const int32_t *)s.values)[r]; break;
+            case TGPU_BOOLEAN: ((uint8_t *)d.values)[gid] = isnull ? 0 : ((const uint8_t *)s.values)[r]; break;
+            case TGPU_VARCHAR: lens.len[c][rank[r]] = isnull ? 0 : s.offsets[r + 1] - s.offsets[r]; break;
+            default: break;
+            }
+        }
+    }
+}
+
+// varchar key bytes of the new groups: store.offsets[gid+1] = pool_base + off[rank] + len
+__global__ void __launch_bounds__(kBlock) gbh_copy_varchar_kernel(ColView src, int64_t n, const int32_t *__restrict__ flags,
+                                                                   const int32_t *__restrict__ rank, int64_t base_gid, const int32_t *__restrict__ off,
+                                                                   int64_t pool_base, uint8_t *__restrict__ pool, int32_t *__restrict__ store_offsets)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        if (!flags[r]) continue;
+        const int32_t k = rank[r];
+        const bool isnull = src.nulls && src.nulls[r];
+        const int32_t a = src.offsets[r], len = isnull ? 0 : src.offsets[r + 1] - a;
+        const int64_t dst = pool_base + off[k];
+        const uint8_t *p = (const uint8_t *)src.values + a;
+        for (int32_t i = 0; i < len; i++) pool[dst + i] = p[i];
+        store_offsets[base_gid + k + 1] = (int32_t)(dst + len);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) gbh_resolve_kernel(int32_t *__restrict__ out, int64_t n, const uint64_t *__restrict__ words)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        int32_t o = out[r];
+        if (o < -1) out[r] = (int32_t)(uint32_t)words[(uint64_t)(-(o + 2))];
+    }
+}
+
+// grow: re-insert every group into the new table (keys are distinct: only an empty slot is needed)
+__global__ void __launch_bounds__(kBlock) gbh_rehash_kernel(const int64_t *__restrict__ raw_hash, int64_t groups, uint64_t *words, uint64_t mask)
+{
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        const uint64_t m = tg_fmix64((uint64_t)raw_hash[g]);
+        uint64_t pos = m & mask;
+        const uint64_t w = make_old((uint32_t)(m >> 48), (uint32_t)g);
+        while (atomicCAS((unsigned long long *)&words[pos], (unsigned long long)kEmpty, (unsigned long long)w) != kEmpty) pos = (pos + 1) & mask;
+    }
+}
+
+int grid_for(Context *ctx, int64_t n)
+{
+    int64_t blocks = ceil_div(n, kBlock);
+    int64_t cap = (int64_t)ctx->cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// fastutil HashCommon.arraySize + BigintGroupByHash.calculateMaxFill, to report the Java table's capacity
+int32_t java_array_size(int32_t expected)
+{
+    float q = (float)expected / 0.75f;
+    int64_t c = (int64_t)std::ceil((double)q);
+    int64_t s = 1;
+    while (s < c) s <<= 1;
+    if (s < 2) s = 2;
+    return (int32_t)s;
+}
+int32_t java_max_fill(int32_t hash_size)
+{
+    int32_t mf = (int32_t)std::ceil((double)((float)hash_size * 0.75f));
+    if (mf == hash_size) mf--;
+    return mf;
+}
+
+}  // namespace
+
+GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool has_input_hash, int32_t expected_size)
+    : ctx_(ctx), types_(std::move(types)), has_input_hash_(has_input_hash)
+{
+    TG_CHECK_ARG(!types_.empty() && (int)types_.size() <= kMaxKeyChannels, "group by needs 1..8 key channels");
+    TG_CHECK_ARG(expected_size > 0, "expectedSize must be greater than zero");
+    for (int32_t t : types_) TG_CHECK_ARG(valid_type(t), "unknown group-by key type");
+    java_capacity_ = java_array_size(expected_size);
+    java_max_fill_ = java_max_fill(java_capacity_);
+    store_.resize(types_.size());
+    for (size_t i = 0; i < types_.size(); i++) store_[i].type = types_[i];
+    const char *env = getenv("TGPU_GBH_SUBBATCH");
+    sub_batch_ = env ? atoll(env) : (1ll << 24);
+    if (sub_batch_ < 1) sub_batch_ = 1;
+    counters_ = ctx_->alloc_zero(8 * 8);
+}
+
+int64_t GroupByHashGpu::estimated_size() const
+{
+    int64_t s = capacity_ * 8 + raw_hash_cap_ * 8;
+    for (auto &k : store_) s += k.cap * (type_width(k.type) + 1) + (k.type == TGPU_VARCHAR ? k.cap * 4 + k.pool_cap : 0);
+    return s;
+}
+
+void GroupByHashGpu::advance_java_capacity()
+{
+    // BigintGroupByHash.java:256-259,262-318: after adding a group, rehash (x2) while nextGroupId >= maxFill
+    while (groups_ >= java_max_fill_) {
+        if ((int64_t)java_capacity_ * 2 > 0x7fffffffLL)
+            fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "Size of hash table cannot exceed 1 billion entries");
+        java_capacity_ *= 2;
+        java_max_fill_ = java_max_fill(java_capacity_);
+        java_rehashes_++;
+    }
+}
+
+void GroupByHashGpu::ensure_table(int64_t need_groups)
+{
+    int64_t want = 1024;
+    while ((double)want * 0.75 < (double)need_groups + 1) want <<= 1;
+    if (want <= capacity_) return;
+    if (want > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "Size of hash table cannot exceed 1 billion entries");
+    BufferPtr nw = ctx_->alloc((size_t)want * 8);
+    k::fill_u64(ctx_, nw->as<uint64_t>(), kEmpty, want);
+    if (groups_ > 0) {
+        ProfileScope ps(ctx_, "gbh_rehash");
+        gbh_rehash_kernel<<<grid_for(ctx_, groups_), kBlock, 0, ctx_->stream()>>>(raw_hash_->as<int64_t>(), groups_, nw->as<uint64_t>(), (uint64_t)want - 1);
+        check_launch("gbh_rehash");
+    }
+    words_ = nw;
+    capacity_ = want;
+}
+
+void GroupByHashGpu::ensure_store(int64_t need)
+{
+    if (need > raw_hash_cap_) {
+        int64_t cap = raw_hash_cap_ ? raw_hash_cap_ : 1024;
+        while (cap < need) cap <<= 1;
+        BufferPtr nb = ctx_->alloc((size_t)cap * 8);
+        if (groups_) HIP_CHECK(hipMemcpyAsync(nb->ptr(), raw_hash_->ptr(), (size_t)groups_ * 8, hipMemcpyDeviceToDevice, ctx_->stream()));
+        raw_hash_ = nb;
+        raw_hash_cap_ = cap;
+    }
+    for (auto &ks : store_) {
+        if (need <= ks.cap) continue;
+        int64_t cap = ks.cap ? ks.cap : 1024;
+        while (cap < need) cap <<= 1;
+        BufferPtr nn = ctx_->alloc((size_t)cap);
+        if (groups_) HIP_CHECK(hipMemcpyAsync(nn->ptr(), ks.nulls->ptr(), (size_t)groups_, hipMemcpyDeviceToDevice, ctx_->stream()));
+        ks.nulls = nn;
+        if (ks.type == TGPU_VARCHAR) {
+            BufferPtr no = ctx_->alloc((size_t)(cap + 1) * 4);
+            if (ks.offsets) HIP_CHECK(hipMemcpyAsync(no->ptr(), ks.offsets->ptr(), (size_t)(groups_ + 1) * 4, hipMemcpyDeviceToDevice, ctx_->stream()));
+            else HIP_CHECK(hipMemsetAsync(no->ptr(), 0, 4, ctx_->stream()));
+            ks.offsets = no;
+            if (!ks.values) {
+                ks.pool_cap = 4096;
+                ks.values = ctx_->alloc((size_t)ks.pool_cap);
+            }
+        }
+        else {
+            const int w = type_width(ks.type);
+            BufferPtr nv = ctx_->alloc((size_t)cap * w);
+            if (groups_) HIP_CHECK(hipMemcpyAsync(nv->ptr(), ks.values->ptr(), (size_t)groups_ * w, hipMemcpyDeviceToDevice, ctx_->stream()));
+            ks.values = nv;
+        }
+        ks.cap = cap;
+    }
+}
+
+void GroupByHashGpu::ensure_pool(KeyStore &ks, int64_t need_bytes)
+{
+    if (need_bytes <= ks.pool_cap) return;
+    if (need_bytes > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "group-by key store cannot exceed 2GB of variable width data");
+    int64_t cap = ks.pool_cap ? ks.pool_cap : 4096;
+    while (cap < need_bytes) cap <<= 1;
+    BufferPtr nv = ctx_->alloc((size_t)cap);
+    if (ks.pool_used) HIP_CHECK(hipMemcpyAsync(nv->ptr(), ks.values->ptr(), (size_t)ks.pool_used, hipMemcpyDeviceToDevice, ctx_->stream()));
+    ks.values = nv;
+    ks.pool_cap = cap;
+}
+
+KeyCols GroupByHashGpu::store_view() const
+{
+    KeyCols k{};
+    k.n = (int32_t)store_.size();
+    for (size_t i = 0; i < store_.size(); i++) {
+        const KeyStore &s = store_[i];
+        k.c[i] = ColView{s.values ? s.values->ptr() : nullptr, s.nulls ? s.nulls->as<uint8_t>() : nullptr,
+                         s.offsets ? s.offsets->as<int32_t>() : nullptr, s.type, 0};
+    }
+    return k;
+}
+
+void GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hashes, int64_t n, int32_t *out)
+{
+    ensure_table(groups_ + n);
+    ensure_store(groups_ > 0 ? groups_ : 1);  // the store view must be addressable for OLD slots
+    unsigned long long *ctr = counters_->as<unsigned long long>();
+    HIP_CHECK(hipMemsetAsync(ctr, 0, 8 * 8, ctx_->stream()));
+    const int g = grid_for(ctx_, n);
+    {
+        ProfileScope ps(ctx_, "gbh_insert");
+        gbh_probe_kernel<true><<<g, kBlock, 0, ctx_->stream()>>>(batch, hashes, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), out, ctr);
+        check_launch("gbh_insert");
+    }
+    unsigned long long host_ctr[3];
+    ctx_->download(host_ctr, ctr, sizeof(host_ctr));
+    TG_CHECK_STATE(host_ctr[2] == 0, "group-by table overflow");
+    if (host_ctr[0] == 0) return;  // every row hit an existing group
+
+    BufferPtr flags = ctx_->alloc((size_t)n * 4), rank = ctx_->alloc((size_t)n * 4);
+    {
+        ProfileScope ps(ctx_, "gbh_assign");
+        gbh_mark_kernel<<<g, kBlock, 0, ctx_->stream()>>>(out, n, words_->as<uint64_t>(), flags->as<int32_t>());
+        k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), rank->as<int32_t>(), n, (int64_t *)&ctr[1]);
+    }
+    const int64_t new_groups = (int64_t)ctx_->read_scalar((const unsigned long long *)&ctr[1]);
+    TG_CHECK_STATE(new_groups > 0, "pending rows without new groups");
+    ensure_store(groups_ + new_groups);
+
+    VarLens lens{};
+    std::vector<BufferPtr> len_bufs(store_.size()), off_bufs(store_.size());
+    for (size_t c = 0; c < store_.size(); c++) {
+        if (store_[c].type == TGPU_VARCHAR) {
+            len_bufs[c] = ctx_->alloc((size_t)new_groups * 4);
+            off_bufs[c] = ctx_->alloc((size_t)new_groups * 4);
+            lens.len[c] = len_bufs[c]->as<int32_t>();
+        }
+    }
+    {
+        ProfileScope ps(ctx_, "gbh_finalize");
+        gbh_finalize_kernel<<<g, kBlock, 0, ctx_->stream()>>>(batch, hashes, n, words_->as<uint64_t>(), out, flags->as<int32_t>(), rank->as<int32_t>(),
+                                                             groups_, store_view(), raw_hash_->as<int64_t>(), lens);
+        check_launch("gbh_finalize");
+        for (size_t c = 0; c < store_.size(); c++) {
+            KeyStore &ks = store_[c];
+            if (ks.type != TGPU_VARCHAR) continue;
+            k::exclusive_scan_i32(ctx_, len_bufs[c]->as<int32_t>(), off_bufs[c]->as<int32_t>(), new_groups, (int64_t *)&ctr[3]);
+            const int64_t add_bytes = (int64_t)ctx_->read_scalar((const unsigned long long *)&ctr[3]);
+            ensure_pool(ks, ks.pool_used + add_bytes);
+            gbh_copy_varchar_kernel<<<g, kBlock, 0, ctx_->stream()>>>(batch.c[c], n, flags->as<int32_t>(), rank->as<int32_t>(), groups_,
+                                                                     off_bufs[c]->as<int32_t>(), ks.pool_used, ks.values->as<uint8_t>(), ks.offsets->as<int32_t>());
+            check_launch("gbh_copy_varchar");
+            ks.pool_used += add_bytes;
+        }
+        gbh_resolve_kernel<<<g, kBlock, 0, ctx_->stream()>>>(out, n, words_->as<uint64_t>());
+        check_launch("gbh_resolve");
+    }
+    groups_ += new_groups;
+    advance_java_capacity();
+}
+
+void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids)
+{
+    TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
+    for (size_t i = 0; i < keys.size(); i++) TG_CHECK_ARG(keys[i]->type == types_[i], "group-by key channel type mismatch");
+    if (n <= 0) return;
+    BufferPtr own_hashes;
+    if (!hashes) {
+        own_hashes = ctx_->alloc((size_t)n * 8);
+        k::hash_rows(ctx_, key_cols_of(keys), n, own_hashes->as<int64_t>());
+        hashes = own_hashes->as<int64_t>();
+    }
+    for (int64_t start = 0; start < n; start += sub_batch_) {
+        const int64_t len = std::min(sub_batch_, n - start);
+        std::vector<DeviceColumn> views;
+        views.reserve(keys.size());
+        for (auto *c : keys) views.push_back(k::region_of(ctx_, *c, start, len));
+        std::vector<const DeviceColumn *> vp;
+        for (auto &v : views) vp.push_back(&v);
+        process_sub_batch(key_cols_of(vp), hashes + start, len, out_gids + start);
+    }
+}
+
+void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids)
+{
+    TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
+    if (n <= 0) return;
+    BufferPtr own_hashes;
+    if (!hashes) {
+        own_hashes = ctx_->alloc((size_t)n * 8);
+        k::hash_rows(ctx_, key_cols_of(keys), n, own_hashes->as<int64_t>());
+        hashes = own_hashes->as<int64_t>();
+    }
+    ensure_table(groups_);
+    ensure_store(groups_ > 0 ? groups_ : 1);
+    gbh_probe_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(key_cols_of(keys), hashes, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
+                                                                              store_view(), out_gids, counters_->as<unsigned long long>());
+    check_launch("gbh_lookup");
+}
+
+DevicePage GroupByHashGpu::key_page(bool with_hash)
+{
+    DevicePage p;
+    p.n = groups_;
+    ensure_store(groups_ > 0 ? groups_ : 1);
+    for (auto &ks : store_) {
+        DeviceColumn c;
+        c.type = ks.type;
+        c.n = groups_;
+        c.values_buf = ks.values;
+        c.values = ks.values->ptr();
+        c.nulls_buf = ks.nulls;
+        c.nulls = ks.nulls->as<uint8_t>();
+        if (ks.type == TGPU_VARCHAR) {
+            c.offsets_buf = ks.offsets;
+            c.offsets = ks.offsets->as<int32_t>();
+            c.pool_bytes = ks.pool_used;
+        }
+        p.cols.push_back(c);
+    }
+    if (with_hash) {
+        DeviceColumn c;
+        c.type = TGPU_BIGINT;
+        c.n = groups_;
+        c.values_buf = raw_hash_;
+        c.values = raw_hash_->ptr();
+        p.cols.push_back(c);
+    }
+    return p;
+}
+
+}  // namespace tgpu

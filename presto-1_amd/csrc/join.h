@@ -1,0 +1,68 @@
+// join.h -- hash join on the GPU: PagesIndex (J2), PagesHash build (J5/J6, K7) and probe (J8/J9, K8) + gather (K9).
+#pragma once
+
+#include "common.h"
+
+namespace tgpu {
+
+// M/operator/PagesIndex.java:209-240: the build side's pages appended into contiguous per-channel HBM columns.
+// SyntheticAddress(pageIndex, position) collapses to the flat row number because pages are stored back to back.
+class PagesIndexGpu {
+public:
+    PagesIndexGpu(Context *ctx, std::vector<int32_t> types);
+    void add_page(const DevicePage &page);
+    int64_t position_count() const { return n_; }
+    int64_t estimated_size() const;
+    DeviceColumn column(int ch) const;
+    const std::vector<int32_t> &types() const { return types_; }
+
+private:
+    struct Store {
+        int32_t type;
+        BufferPtr values, nulls, offsets;
+        int64_t cap = 0, pool_cap = 0, pool_used = 0;
+        bool has_nulls = false;
+    };
+    void reserve(int64_t rows);
+    Context *ctx_;
+    std::vector<int32_t> types_;
+    std::vector<Store> cols_;
+    int64_t n_ = 0;
+};
+
+// The built lookup source: PagesHash + ArrayPositionLinks behind JoinHash (M/operator/JoinHash.java:44-125).
+class LookupSourceGpu {
+public:
+    LookupSourceGpu(Context *ctx, std::shared_ptr<PagesIndexGpu> index, std::vector<int32_t> key_channels, int32_t hash_channel,
+                    std::vector<int32_t> output_channels);
+    void build();  // PagesHash constructor (M/operator/PagesHash.java:53-125)
+
+    int64_t position_count() const { return n_; }
+    int64_t hash_size() const { return capacity_; }
+    int64_t link_count() const { return link_count_; }
+    int64_t estimated_size() const;
+    const std::vector<int32_t> &output_channels() const { return output_channels_; }
+    std::vector<int32_t> output_types() const;
+    std::vector<int32_t> key_types() const;
+
+    // probe one page: (probe position, build position) pairs in the reference's output order (probe positions ascending,
+    // each probe row's matches newest build position first); build position -1 = PROBE_OUTER row without a match.
+    void probe(const std::vector<const DeviceColumn *> &probe_keys, const int64_t *probe_hashes, int64_t n_probe, bool probe_outer,
+               BufferPtr &out_probe_idx, BufferPtr &out_build_idx, int64_t &out_count);
+    DeviceColumn gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const;
+
+private:
+    Context *ctx_;
+    std::shared_ptr<PagesIndexGpu> index_;
+    std::vector<int32_t> key_channels_, output_channels_;
+    int32_t hash_channel_;
+    int64_t n_ = 0, capacity_ = 0, link_count_ = 0;
+    bool int_key_fast_ = false;  // single BIGINT / INTEGER / DATE key: key stored inline in the slot
+    BufferPtr heads_;            // int32[capacity], -1 empty          (PagesHash.key)
+    BufferPtr slots16_;          // fast path: {int64 key, int32 head, int32 pad}[capacity]
+    BufferPtr tags_;             // uint8[n]                           (PagesHash.positionToHashes)
+    BufferPtr links_;            // int32[n] or empty when no duplicates (ArrayPositionLinks)
+    std::vector<DeviceColumn> key_cols_;
+};
+
+}  // namespace tgpu

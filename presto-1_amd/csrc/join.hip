@@ -1,0 +1,522 @@
+// join.hip -- hash-join build (K7) and probe (K8) kernels + PagesIndex storage.
+//
+// Build (PagesHash constructor, M/operator/PagesHash.java:53-125): the Java loop inserts rows in position order; equal keys
+// chain newest -> oldest (ArrayPositionLinks.link(new, existing), M/operator/ArrayPositionLinks.java:45-50), so the slot of a
+// key holds its MAXIMUM build position and links[p] is the next smaller position with the same key.  That end state is
+// reproduced in parallel: every non-null row claims / joins its key's slot with CAS + atomicMax (slot = max position), and --
+// only when duplicates exist -- (slot, position) pairs are radix-sorted so that each position's predecessor is its link.
+// The table layout itself (which slot a key lands in) is unobservable through JoinHash and is free to differ.
+//
+// Probe (PagesHash.getAddressIndex :157-169 + JoinHash.getNextJoinPosition + PageJoiner.joinCurrentPosition,
+// M/operator/LookupJoinOperator.java:299-347): one lane per probe row; pass 1 counts the row's matches, a scan turns counts
+// into output offsets (probe positions stay ascending as LookupJoinPageBuilder.java:144-153 asserts), pass 2 writes the pairs.
+#include "join.h"
+#include "kernels.h"
+#include "device_hash.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace tgpu {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+int grid_for(Context *ctx, int64_t n)
+{
+    int64_t blocks = ceil_div(n, kBlock);
+    int64_t cap = (int64_t)ctx->cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+struct Slot16 {
+    long long key;
+    int head;
+    int pad;
+};
+
+// EQUAL operators on non-null cells (S/type/AbstractLongType.java:132-136, DoubleType.java:157-161: NaN != NaN, -0 == +0)
+__device__ __forceinline__ bool rows_equal_nonnull(const KeyCols &a, int64_t ra, const KeyCols &b, int64_t rb)
+{
+    for (int c = 0; c < a.n; c++) {
+        const ColView &x = a.c[c], &y = b.c[c];
+        switch (x.type) {
+        case TGPU_BIGINT:
+            if (((const int64_t *)x.values)[ra] != ((const int64_t *)y.values)[rb]) return false;
+            break;
+        case TGPU_INTEGER:
+        case TGPU_DATE:
+            if (((const int32_t *)x.values)[ra] != ((const int32_t *)y.values)[rb]) return false;
+            break;
+        case TGPU_DOUBLE:
+            if (!(((const double *)x.values)[ra] == ((const double *)y.values)[rb])) return false;
+            break;
+        case TGPU_BOOLEAN:
+            if ((((const uint8_t *)x.values)[ra] != 0) != (((const uint8_t *)y.values)[rb] != 0)) return false;
+            break;
+        case TGPU_VARCHAR: {
+            int32_t ax = x.offsets[ra], lx = x.offsets[ra + 1] - ax;
+            int32_t ay = y.offsets[rb], ly = y.offsets[rb + 1] - ay;
+            if (lx != ly) return false;
+            const uint8_t *px = (const uint8_t *)x.values + ax, *py = (const uint8_t *)y.values + ay;
+            for (int32_t i = 0; i < lx; i++)
+                if (px[i] != py[i]) return false;
+            break;
+        }
+        default: return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool row_has_null(const KeyCols &k, int64_t r)
+{
+    for (int c = 0; c < k.n; c++)
+        if (k.c[c].nulls && k.c[c].nulls[r]) return true;
+    return false;
+}
+
+__device__ __forceinline__ long long int_key_at(const ColView &c, int64_t r)
+{
+    return c.type == TGPU_BIGINT ? ((const long long *)c.values)[r] : (long long)((const int *)c.values)[r];
+}
+
+__global__ void __launch_bounds__(kBlock) append_offsets_kernel(const int32_t *__restrict__ src, int64_t n, int32_t src_base, int32_t dst_base,
+                                                                 int32_t *__restrict__ dst)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) dst[i + 1] = dst_base + (src[i + 1] - src_base);
+}
+
+__global__ void __launch_bounds__(kBlock) tags_kernel(const int64_t *__restrict__ hashes, int64_t n, uint8_t *__restrict__ tags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) tags[i] = (uint8_t)hashes[i];
+}
+
+// counters[0] = rows that joined an existing key (ArrayPositionLinks.FactoryBuilder.size()), counters[1] = error
+__global__ void __launch_bounds__(kBlock) build_insert_kernel(KeyCols keys, const int64_t *__restrict__ hashes, const uint8_t *__restrict__ tags, int64_t n,
+                                                               int *heads, uint64_t mask, int32_t *__restrict__ row_slot, unsigned long long *counters)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        bool dup = false;
+        int32_t slot = -1;
+        if (!row_has_null(keys, r)) {  // PagesHash.java:94-96: rows with a null key are not indexed
+            const int64_t h = hashes[r];
+            uint64_t pos = tg_fmix64((uint64_t)h) & mask;
+            for (uint64_t iter = 0; iter <= mask; iter++) {
+                int cur = __hip_atomic_load(&heads[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == -1) {
+                    int old = atomicCAS(&heads[pos], -1, (int)r);
+                    if (old == -1) { slot = (int32_t)pos; break; }
+                    cur = old;
+                }
+                if (tags[cur] == (uint8_t)h && rows_equal_nonnull(keys, cur, keys, r)) {
+                    atomicMax(&heads[pos], (int)r);
+                    slot = (int32_t)pos;
+                    dup = true;
+                    break;
+                }
+                pos = (pos + 1) & mask;
+                if (iter == mask) atomicExch(&counters[1], 1ull);
+            }
+        }
+        row_slot[r] = slot;
+        unsigned long long b = __ballot(dup);
+        if (dup && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) sort_keys_kernel(const int32_t *__restrict__ row_slot, int64_t n, unsigned long long *__restrict__ keys)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        int32_t s = row_slot[r];
+        keys[r] = s < 0 ? ~0ull : (((unsigned long long)(uint32_t)s << 32) | (unsigned long long)(uint32_t)r);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long *__restrict__ sorted, int64_t n, int32_t *__restrict__ links)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        unsigned long long k = sorted[i];
+        if (k == ~0ull) continue;  // null-key rows: links stay -1
+        int32_t link = -1;
+        if (i > 0) {
+            unsigned long long p = sorted[i - 1];
+            if ((p >> 32) == (k >> 32)) link = (int32_t)(uint32_t)p;
+        }
+        links[(uint32_t)k] = link;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) pack_slots_kernel(const int *__restrict__ heads, int64_t capacity, ColView key, Slot16 *__restrict__ slots)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * kBlock) {
+        int h = heads[i];
+        Slot16 s;
+        s.head = h;
+        s.pad = 0;
+        s.key = h >= 0 ? int_key_at(key, h) : 0;
+        slots[i] = s;
+    }
+}
+
+struct ProbeTable {
+    const int *heads;
+    const Slot16 *slots;
+    const uint8_t *tags;
+    const int32_t *links;
+    uint64_t mask;
+};
+
+// head build position of the probe row's key, or -1 (PagesHash.getAddressIndex)
+template <bool FAST>
+__device__ __forceinline__ int find_head(const ProbeTable &t, const KeyCols &build, const KeyCols &probe, int64_t r, int64_t h)
+{
+    uint64_t pos = tg_fmix64((uint64_t)h) & t.mask;
+    if (FAST) {
+        const long long key = int_key_at(probe.c[0], r);
+        for (uint64_t iter = 0; iter <= t.mask; iter++) {
+            const Slot16 s = t.slots[pos];
+            if (s.head < 0) return -1;
+            if (s.key == key) return s.head;
+            pos = (pos + 1) & t.mask;
+        }
+        return -1;
+    }
+    for (uint64_t iter = 0; iter <= t.mask; iter++) {
+        const int b = t.heads[pos];
+        if (b < 0) return -1;
+        if (t.tags[b] == (uint8_t)h && rows_equal_nonnull(build, b, probe, r)) return b;  // positionEqualsCurrentRowIgnoreNulls :198-209
+        pos = (pos + 1) & t.mask;
+    }
+    return -1;
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(kBlock) probe_count_kernel(ProbeTable t, KeyCols build, KeyCols probe, const int64_t *__restrict__ hashes, int64_t n,
+                                                              int probe_outer, int32_t *__restrict__ heads_out, int32_t *__restrict__ counts)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        int head = -1;
+        if (!row_has_null(probe, r)) head = find_head<FAST>(t, build, probe, r, hashes[r]);  // JoinProbe.java:87-97
+        int32_t c = 0;
+        if (head >= 0) {
+            c = 1;
+            if (t.links)
+                for (int p = t.links[head]; p >= 0; p = t.links[p]) c++;
+        }
+        else if (probe_outer) c = 1;
+        heads_out[r] = head;
+        counts[r] = c;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) probe_write_kernel(const int32_t *__restrict__ links, const int32_t *__restrict__ heads, const int32_t *__restrict__ offsets,
+                                                              int64_t n, int probe_outer, int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        int head = heads[r];
+        int64_t o = offsets[r];
+        if (head >= 0) {
+            for (int p = head; p >= 0; p = links ? links[p] : -1) {
+                out_probe[o] = (int32_t)r;
+                out_build[o] = p;
+                o++;
+            }
+        }
+        else if (probe_outer) {
+            out_probe[o] = (int32_t)r;
+            out_build[o] = -1;
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+PagesIndexGpu::PagesIndexGpu(Context *ctx, std::vector<int32_t> types) : ctx_(ctx), types_(std::move(types))
+{
+    cols_.resize(types_.size());
+    for (size_t i = 0; i < types_.size(); i++) {
+        TG_CHECK_ARG(valid_type(types_[i]), "unknown type");
+        cols_[i].type = types_[i];
+    }
+}
+
+int64_t PagesIndexGpu::estimated_size() const
+{
+    int64_t s = 0;
+    for (auto &c : cols_) s += c.cap * type_width(c.type) + (c.nulls ? c.cap : 0) + (c.offsets ? (c.cap + 1) * 4 : 0) + c.pool_cap;
+    return s;
+}
+
+void PagesIndexGpu::reserve(int64_t rows)
+{
+    for (auto &c : cols_) {
+        if (rows <= c.cap) continue;
+        int64_t cap = c.cap ? c.cap : 1024;
+        while (cap < rows) cap <<= 1;
+        if (c.cap == 0) cap = std::max<int64_t>(rows, 1024);  // first page: exact fit (a single big build page needs no slack)
+        if (c.type == TGPU_VARCHAR) {
+            BufferPtr no = ctx_->alloc((size_t)(cap + 1) * 4);
+            if (c.offsets) HIP_CHECK(hipMemcpyAsync(no->ptr(), c.offsets->ptr(), (size_t)(n_ + 1) * 4, hipMemcpyDeviceToDevice, ctx_->stream()));
+            else HIP_CHECK(hipMemsetAsync(no->ptr(), 0, 4, ctx_->stream()));
+            c.offsets = no;
+        }
+        else {
+            const int w = type_width(c.type);
+            BufferPtr nv = ctx_->alloc((size_t)cap * w);
+            if (n_) HIP_CHECK(hipMemcpyAsync(nv->ptr(), c.values->ptr(), (size_t)n_ * w, hipMemcpyDeviceToDevice, ctx_->stream()));
+            c.values = nv;
+        }
+        if (c.nulls) {
+            BufferPtr nn = ctx_->alloc_zero((size_t)cap);
+            if (n_) HIP_CHECK(hipMemcpyAsync(nn->ptr(), c.nulls->ptr(), (size_t)n_, hipMemcpyDeviceToDevice, ctx_->stream()));
+            c.nulls = nn;
+        }
+        c.cap = cap;
+    }
+}
+
+void PagesIndexGpu::add_page(const DevicePage &page)
+{
+    TG_CHECK_ARG(page.cols.size() == types_.size(), "page channel count does not match the index");
+    if (page.n == 0) return;
+    if (n_ + page.n > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "Size of pages index cannot exceed 2 billion entries");  // PagesIndex.java:234-236
+    reserve(n_ + page.n);
+    for (size_t i = 0; i < cols_.size(); i++) {
+        Store &c = cols_[i];
+        const DeviceColumn &src = page.cols[i];
+        TG_CHECK_ARG(src.type == c.type, "page channel type does not match the index");
+        if (src.nulls) {
+            if (!c.nulls) c.nulls = ctx_->alloc_zero((size_t)c.cap);
+            HIP_CHECK(hipMemcpyAsync(c.nulls->as<uint8_t>() + n_, src.nulls, (size_t)page.n, hipMemcpyDeviceToDevice, ctx_->stream()));
+            c.has_nulls = true;
+        }
+        if (c.type == TGPU_VARCHAR) {
+            int32_t a = 0, b = 0;
+            ctx_->download(&a, src.offsets, 4);
+            ctx_->download(&b, src.offsets + page.n, 4);
+            const int64_t bytes = (int64_t)b - a;
+            if (c.pool_used + bytes > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "variable width channel of the pages index cannot exceed 2GB");
+            if (c.pool_used + bytes > c.pool_cap) {
+                int64_t cap = c.pool_cap ? c.pool_cap : 4096;
+                while (cap < c.pool_used + bytes) cap <<= 1;
+                BufferPtr nv = ctx_->alloc((size_t)cap);
+                if (c.pool_used) HIP_CHECK(hipMemcpyAsync(nv->ptr(), c.values->ptr(), (size_t)c.pool_used, hipMemcpyDeviceToDevice, ctx_->stream()));
+                c.values = nv;
+                c.pool_cap = cap;
+            }
+            if (bytes) HIP_CHECK(hipMemcpyAsync(c.values->as<uint8_t>() + c.pool_used, (const uint8_t *)src.values + a, (size_t)bytes, hipMemcpyDeviceToDevice, ctx_->stream()));
+            append_offsets_kernel<<<grid_for(ctx_, page.n), kBlock, 0, ctx_->stream()>>>(src.offsets, page.n, a, (int32_t)c.pool_used, c.offsets->as<int32_t>() + n_);
+            check_launch("append_offsets");
+            c.pool_used += bytes;
+        }
+        else {
+            const int w = type_width(c.type);
+            HIP_CHECK(hipMemcpyAsync(c.values->as<uint8_t>() + n_ * w, src.values, (size_t)page.n * w, hipMemcpyDeviceToDevice, ctx_->stream()));
+        }
+    }
+    n_ += page.n;
+}
+
+DeviceColumn PagesIndexGpu::column(int ch) const
+{
+    TG_CHECK_ARG(ch >= 0 && ch < (int)cols_.size(), "channel out of range");
+    const Store &s = cols_[ch];
+    DeviceColumn c;
+    c.type = s.type;
+    c.n = n_;
+    c.values_buf = s.values;
+    c.values = s.values ? s.values->ptr() : nullptr;
+    if (s.has_nulls) {
+        c.nulls_buf = s.nulls;
+        c.nulls = s.nulls->as<uint8_t>();
+    }
+    if (s.type == TGPU_VARCHAR) {
+        c.offsets_buf = s.offsets;
+        c.offsets = s.offsets ? s.offsets->as<int32_t>() : nullptr;
+        c.pool_bytes = s.pool_used;
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+LookupSourceGpu::LookupSourceGpu(Context *ctx, std::shared_ptr<PagesIndexGpu> index, std::vector<int32_t> key_channels, int32_t hash_channel,
+                                 std::vector<int32_t> output_channels)
+    : ctx_(ctx), index_(std::move(index)), key_channels_(std::move(key_channels)), output_channels_(std::move(output_channels)), hash_channel_(hash_channel)
+{
+    TG_CHECK_ARG(!key_channels_.empty() && (int)key_channels_.size() <= kMaxKeyChannels, "join needs 1..8 key channels");
+}
+
+std::vector<int32_t> LookupSourceGpu::output_types() const
+{
+    std::vector<int32_t> t;
+    for (int32_t ch : output_channels_) t.push_back(index_->types()[ch]);
+    return t;
+}
+
+std::vector<int32_t> LookupSourceGpu::key_types() const
+{
+    std::vector<int32_t> t;
+    for (int32_t ch : key_channels_) t.push_back(index_->types()[ch]);
+    return t;
+}
+
+int64_t LookupSourceGpu::estimated_size() const
+{
+    return index_->estimated_size() + capacity_ * (int_key_fast_ ? 16 : 4) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0);
+}
+
+void LookupSourceGpu::build()
+{
+    n_ = index_->position_count();
+    key_cols_.clear();
+    for (int32_t ch : key_channels_) key_cols_.push_back(index_->column(ch));
+    // table size: the reference uses arraySize(n, 0.75) (PagesHash.java:63); any power of two >= n / 0.75 gives the same results
+    capacity_ = 1024;
+    while ((double)capacity_ * 0.75 < (double)n_) capacity_ <<= 1;
+    if (capacity_ > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "hash table size cannot exceed 2 billion slots");
+    heads_ = ctx_->alloc((size_t)capacity_ * 4);
+    k::fill_i32(ctx_, heads_->as<int32_t>(), -1, capacity_);
+    int_key_fast_ = key_cols_.size() == 1 && (key_cols_[0].type == TGPU_BIGINT || key_cols_[0].type == TGPU_INTEGER || key_cols_[0].type == TGPU_DATE);
+    link_count_ = 0;
+    links_.reset();
+    if (n_ == 0) {
+        if (int_key_fast_) {
+            slots16_ = ctx_->alloc((size_t)capacity_ * 16);
+            pack_slots_kernel<<<grid_for(ctx_, capacity_), kBlock, 0, ctx_->stream()>>>(heads_->as<int>(), capacity_, ColView{}, slots16_->as<Slot16>());
+            check_launch("pack_slots");
+        }
+        return;
+    }
+    std::vector<const DeviceColumn *> kp;
+    for (auto &c : key_cols_) kp.push_back(&c);
+    const KeyCols keys = key_cols_of(kp);
+
+    BufferPtr own_hashes;
+    const int64_t *hashes;
+    DeviceColumn hash_col;
+    if (hash_channel_ >= 0) {  // precomputed $hashvalue channel: JoinCompiler.java:405-428
+        hash_col = index_->column(hash_channel_);
+        TG_CHECK_ARG(hash_col.type == TGPU_BIGINT, "hash channel must be BIGINT");
+        hashes = (const int64_t *)hash_col.values;
+    }
+    else {
+        own_hashes = ctx_->alloc((size_t)n_ * 8);
+        k::hash_rows(ctx_, keys, n_, own_hashes->as<int64_t>());
+        hashes = own_hashes->as<int64_t>();
+    }
+    tags_ = ctx_->alloc((size_t)n_);
+    BufferPtr row_slot = ctx_->alloc((size_t)n_ * 4);
+    BufferPtr counters = ctx_->alloc_zero(16);
+    const int g = grid_for(ctx_, n_);
+    {
+        ProfileScope ps(ctx_, "join_build_insert");
+        tags_kernel<<<g, kBlock, 0, ctx_->stream()>>>(hashes, n_, tags_->as<uint8_t>());
+        build_insert_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys, hashes, tags_->as<uint8_t>(), n_, heads_->as<int>(), (uint64_t)capacity_ - 1,
+                                                             row_slot->as<int32_t>(), counters->as<unsigned long long>());
+        check_launch("build_insert");
+    }
+    unsigned long long host_ctr[2];
+    ctx_->download(host_ctr, counters->ptr(), 16);
+    TG_CHECK_STATE(host_ctr[1] == 0, "join table overflow");
+    link_count_ = (int64_t)host_ctr[0];
+    if (link_count_ > 0) {
+        // duplicates: links[p] = next smaller position with the same key (= same slot)
+        ProfileScope ps(ctx_, "join_build_links");
+        links_ = ctx_->alloc((size_t)n_ * 4);
+        k::fill_i32(ctx_, links_->as<int32_t>(), -1, n_);
+        BufferPtr keys_in = ctx_->alloc((size_t)n_ * 8), keys_out = ctx_->alloc((size_t)n_ * 8);
+        sort_keys_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys_in->as<unsigned long long>());
+        size_t temp_bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_keys(nullptr, temp_bytes, keys_in->as<unsigned long long>(), keys_out->as<unsigned long long>(), (size_t)n_, 0, 64, ctx_->stream()));
+        BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
+        HIP_CHECK(rocprim::radix_sort_keys(temp->ptr(), temp_bytes, keys_in->as<unsigned long long>(), keys_out->as<unsigned long long>(), (size_t)n_, 0, 64, ctx_->stream()));
+        links_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys_out->as<unsigned long long>(), n_, links_->as<int32_t>());
+        check_launch("links");
+    }
+    if (int_key_fast_) {
+        ProfileScope ps(ctx_, "join_build_pack");
+        slots16_ = ctx_->alloc((size_t)capacity_ * 16);
+        pack_slots_kernel<<<grid_for(ctx_, capacity_), kBlock, 0, ctx_->stream()>>>(heads_->as<int>(), capacity_, keys.c[0], slots16_->as<Slot16>());
+        check_launch("pack_slots");
+    }
+}
+
+void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys, const int64_t *probe_hashes, int64_t n, bool probe_outer,
+                            BufferPtr &out_probe_idx, BufferPtr &out_build_idx, int64_t &out_count)
+{
+    TG_CHECK_ARG(probe_keys.size() == key_channels_.size(), "probe key channel count differs from the build side's");
+    for (size_t i = 0; i < probe_keys.size(); i++) {
+        const int32_t bt = index_->types()[key_channels_[i]];
+        const bool int_like = (bt == TGPU_BIGINT || bt == TGPU_INTEGER || bt == TGPU_DATE);
+        TG_CHECK_ARG(probe_keys[i]->type == bt || (int_key_fast_ && int_like && probe_keys[i]->type == bt), "probe key type differs from the build key type");
+    }
+    out_count = 0;
+    if (n <= 0) {
+        out_probe_idx = ctx_->alloc(4);
+        out_build_idx = ctx_->alloc(4);
+        return;
+    }
+    const KeyCols probe = key_cols_of(probe_keys);
+    std::vector<const DeviceColumn *> kp;
+    for (auto &c : key_cols_) kp.push_back(&c);
+    const KeyCols build = key_cols_.empty() ? KeyCols{} : key_cols_of(kp);
+    BufferPtr own_hashes;
+    if (!probe_hashes) {  // hashRow: JoinCompiler.java:449-477
+        own_hashes = ctx_->alloc((size_t)n * 8);
+        k::hash_rows(ctx_, probe, n, own_hashes->as<int64_t>());
+        probe_hashes = own_hashes->as<int64_t>();
+    }
+    ProbeTable t{};
+    t.heads = heads_->as<int>();
+    t.slots = slots16_ ? slots16_->as<Slot16>() : nullptr;
+    t.tags = tags_ ? tags_->as<uint8_t>() : nullptr;
+    t.links = links_ ? links_->as<int32_t>() : nullptr;
+    t.mask = (uint64_t)capacity_ - 1;
+    BufferPtr heads = ctx_->alloc((size_t)n * 4), counts = ctx_->alloc((size_t)n * 4), offsets = ctx_->alloc((size_t)n * 4), total = ctx_->alloc(8);
+    const int g = grid_for(ctx_, n);
+    {
+        ProfileScope ps(ctx_, "join_probe_count");
+        if (int_key_fast_)
+            probe_count_kernel<true><<<g, kBlock, 0, ctx_->stream()>>>(t, build, probe, probe_hashes, n, probe_outer ? 1 : 0, heads->as<int32_t>(), counts->as<int32_t>());
+        else
+            probe_count_kernel<false><<<g, kBlock, 0, ctx_->stream()>>>(t, build, probe, probe_hashes, n, probe_outer ? 1 : 0, heads->as<int32_t>(), counts->as<int32_t>());
+        check_launch("probe_count");
+    }
+    {
+        ProfileScope ps(ctx_, "join_probe_scan");
+        k::exclusive_scan_i32(ctx_, counts->as<int32_t>(), offsets->as<int32_t>(), n, total->as<int64_t>());
+    }
+    out_count = ctx_->read_scalar(total->as<int64_t>());
+    if (out_count > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "join output of one probe page cannot exceed 2 billion rows");
+    out_probe_idx = ctx_->alloc((size_t)(out_count > 0 ? out_count : 1) * 4);
+    out_build_idx = ctx_->alloc((size_t)(out_count > 0 ? out_count : 1) * 4);
+    if (out_count > 0) {
+        ProfileScope ps(ctx_, "join_probe_write");
+        probe_write_kernel<<<g, kBlock, 0, ctx_->stream()>>>(t.links, heads->as<int32_t>(), offsets->as<int32_t>(), n, probe_outer ? 1 : 0,
+                                                            out_probe_idx->as<int32_t>(), out_build_idx->as<int32_t>());
+        check_launch("probe_write");
+    }
+}
+
+DeviceColumn LookupSourceGpu::gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const
+{
+    DeviceColumn src = index_->column(output_channels_[out_idx]);
+    if (src.type != TGPU_VARCHAR && src.values == nullptr) {  // empty build side
+        BufferPtr dummy = ctx_->alloc(8);
+        src.values_buf = dummy;
+        src.values = dummy->ptr();
+    }
+    if (src.type == TGPU_VARCHAR && src.offsets == nullptr) {
+        BufferPtr off = ctx_->alloc_zero(8), pool = ctx_->alloc(8);
+        src.offsets_buf = off;
+        src.offsets = off->as<int32_t>();
+        src.values_buf = pool;
+        src.values = pool->ptr();
+    }
+    return k::gather_column(ctx_, src, build_positions, n, negative_is_null);
+}
+
+}  // namespace tgpu

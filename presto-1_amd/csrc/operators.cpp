@@ -1,0 +1,368 @@
+// operators.cpp -- the hot-path operators as host-side state machines (same names, call protocol and error behaviour as
+// the reference's Java operators; the work inside addInput / getOutput runs in the gfx950 kernels).
+#include "operators.h"
+
+#include "kernels.h"
+
+namespace tgpu {
+
+// =====================================================================================================================
+// FilterAndProjectOperator: WorkProcessorOperatorAdapter protocol (M/operator/WorkProcessorOperatorAdapter.java:138-216)
+// around PageProcessor (M/operator/FilterAndProjectOperator.java:56-64).  One output page per input page that selects
+// at least one row; MergePages (M/operator/project/MergePages.java) is not applied (page boundaries are not part of the
+// operator's contract: the reference's tests compare rows, T/operator/OperatorAssertion.java).
+// =====================================================================================================================
+class FilterAndProjectOperator : public Operator {
+public:
+    FilterAndProjectOperator(Context *ctx, int32_t id, std::shared_ptr<PageProcessorGpu> p) : Operator(ctx, id), processor_(std::move(p)) {}
+
+    bool needs_input() override { return !finishing_ && !pending_; }
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        TG_CHECK_STATE(!pending_, "Operator still has pending output");
+        DevicePage in = ingest_page(ctx_, page);
+        DevicePage out;
+        if (processor_->process(ctx_, in, out)) {
+            retained_ = std::move(in);  // identity projections may alias input blocks
+            pending_ = wrap(std::move(out));
+        }
+    }
+
+    std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finishing_ && !pending_; }
+    int64_t memory_bytes() override { return pending_ ? pending_->page.size_in_bytes() : 0; }
+
+private:
+    std::shared_ptr<PageProcessorGpu> processor_;
+    std::unique_ptr<OutputPage> pending_;
+    DevicePage retained_;
+    bool finishing_ = false;
+};
+
+FilterAndProjectOperatorFactory::FilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types,
+                                                                 const tgpu_page_processor_spec *spec)
+    : ctx_(ctx), operator_id_(operator_id), processor_(std::make_shared<PageProcessorGpu>(std::move(input_types), spec))
+{
+}
+
+std::unique_ptr<Operator> FilterAndProjectOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<FilterAndProjectOperator>(ctx_, operator_id_, processor_);
+}
+
+// =====================================================================================================================
+// HashAggregationOperator + InMemoryHashAggregationBuilder
+// =====================================================================================================================
+class HashAggregationOperator : public Operator {
+public:
+    HashAggregationOperator(Context *ctx, int32_t id, const HashAggregationConfig &cfg) : Operator(ctx, id), cfg_(cfg)
+    {
+        TG_CHECK_ARG(cfg_.group_by_types.size() == cfg_.group_by_channels.size(), "group-by types and channels differ in length");
+        TG_CHECK_ARG(cfg_.step >= TGPU_STEP_SINGLE && cfg_.step <= TGPU_STEP_FINAL, "unknown aggregation step");
+    }
+
+    // HashAggregationOperator.java:367-378
+    bool needs_input() override
+    {
+        if (finishing_) return false;
+        if (builder_full()) return false;
+        return true;
+    }
+
+    // :381-440 -> InMemoryHashAggregationBuilder.processPage (builder/InMemoryHashAggregationBuilder.java:139-155)
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        TG_CHECK_STATE(!builder_full(), "Aggregation buffer is full");
+        input_processed_ = true;
+        DevicePage in = ingest_page(ctx_, page);
+        ensure_builder();
+        if (in.n == 0) return;
+        const int32_t *gids = nullptr;
+        BufferPtr gid_buf;
+        if (gbh_) {
+            std::vector<const DeviceColumn *> keys;
+            for (int32_t ch : cfg_.group_by_channels) {
+                TG_CHECK_ARG(ch >= 0 && ch < (int)in.cols.size(), "group-by channel out of range");
+                keys.push_back(&in.cols[(size_t)ch]);
+            }
+            const int64_t *hashes = nullptr;
+            if (cfg_.hash_channel >= 0) {
+                TG_CHECK_ARG(cfg_.hash_channel < (int)in.cols.size() && in.cols[(size_t)cfg_.hash_channel].type == TGPU_BIGINT, "bad hash channel");
+                hashes = (const int64_t *)in.cols[(size_t)cfg_.hash_channel].values;
+            }
+            gid_buf = ctx_->alloc((size_t)in.n * 4);
+            gbh_->get_group_ids(keys, hashes, in.n, gid_buf->as<int32_t>());
+            gids = gid_buf->as<int32_t>();
+        }
+        const int64_t groups = gbh_ ? gbh_->group_count() : 1;
+        if (cfg_.step == TGPU_STEP_FINAL) accs_->add_intermediate(gids, in.n, in, groups);
+        else accs_->add_input(gids, in.n, in, groups);
+    }
+
+    // :470-518
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (finished_) return nullptr;
+        if (finishing_) {
+            if (!input_processed_ && cfg_.produce_default_output && cfg_.group_by_types.empty()) {
+                // global aggregation without input: one row of default values (count 0, sum NULL) :481-485
+                ensure_builder();
+            }
+            finished_ = true;
+            if (!builder_) return nullptr;
+            std::unique_ptr<OutputPage> out = build_result();
+            reset_builder();
+            return out;
+        }
+        if (!builder_full()) return nullptr;  // only flush when finishing or full :494-497
+        std::unique_ptr<OutputPage> out = build_result();
+        reset_builder();
+        return out;
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finished_; }
+    int64_t memory_bytes() override { return (gbh_ ? gbh_->estimated_size() : 0) + (accs_ ? accs_->estimated_size() : 0); }
+
+private:
+    void ensure_builder()
+    {
+        if (builder_) return;
+        if (!cfg_.group_by_types.empty())
+            gbh_ = std::make_unique<GroupByHashGpu>(ctx_, cfg_.group_by_types, cfg_.hash_channel >= 0, cfg_.expected_groups);
+        accs_ = std::make_unique<GroupedAccumulators>(ctx_, cfg_.aggs, cfg_.step);
+        builder_ = true;
+    }
+    void reset_builder()
+    {
+        gbh_.reset();
+        accs_.reset();
+        builder_ = false;
+    }
+    // InMemoryHashAggregationBuilder.isFull :208-215: only partial aggregations have a memory limit
+    bool builder_full()
+    {
+        if (!builder_ || cfg_.step != TGPU_STEP_PARTIAL) return false;
+        // the limit is on the logical size of the partial state (what the Java builder would hold: 13 B per slot at 0.75
+        // fill + keys + accumulator state), not on this implementation's over-provisioned device buffers
+        const int64_t groups = gbh_ ? gbh_->group_count() : 1;
+        const int64_t per_group = 18 + 9 * (int64_t)cfg_.group_by_types.size() + 16 * (int64_t)cfg_.aggs.size();
+        return groups * per_group > cfg_.max_partial_memory;
+    }
+    // buildResult :244-298: groups in group-id order; keys, [hash], aggregates
+    std::unique_ptr<OutputPage> build_result()
+    {
+        DevicePage out;
+        const int64_t groups = gbh_ ? gbh_->group_count() : 1;
+        if (gbh_) out = gbh_->key_page(cfg_.hash_channel >= 0);
+        out.n = groups;
+        accs_->evaluate(groups, out.cols);
+        if (groups == 0) return nullptr;
+        return wrap(std::move(out));
+    }
+
+    HashAggregationConfig cfg_;
+    std::unique_ptr<GroupByHashGpu> gbh_;
+    std::unique_ptr<GroupedAccumulators> accs_;
+    bool builder_ = false, finishing_ = false, finished_ = false, input_processed_ = false;
+};
+
+HashAggregationOperatorFactory::HashAggregationOperatorFactory(Context *ctx, int32_t operator_id, HashAggregationConfig cfg)
+    : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg))
+{
+    TG_CHECK_ARG(cfg_.group_by_types.size() == cfg_.group_by_channels.size(), "group-by types and channels differ in length");
+    TG_CHECK_ARG((int)cfg_.group_by_types.size() <= kMaxKeyChannels, "at most 8 group-by channels");
+    TG_CHECK_ARG((int)cfg_.aggs.size() <= kMaxAggs, "at most 16 aggregates");
+    TG_CHECK_ARG(cfg_.expected_groups > 0, "expectedGroups must be positive");
+    for (auto &a : cfg_.aggs) TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_AVG_DOUBLE, "unknown aggregate function");
+}
+
+std::unique_ptr<Operator> HashAggregationOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<HashAggregationOperator>(ctx_, operator_id_, cfg_);
+}
+
+// =====================================================================================================================
+// HashBuilderOperator (M/operator/HashBuilderOperator.java:155-191 state machine, spill states omitted: the GPU path reports
+// its memory as non-revocable and never spills)
+// =====================================================================================================================
+class HashBuilderOperator : public Operator {
+public:
+    enum class State { CONSUMING_INPUT, LOOKUP_SOURCE_BUILT, CLOSED };
+
+    HashBuilderOperator(Context *ctx, int32_t id, const HashBuilderConfig &cfg, std::shared_ptr<LookupSourceFactory> bridge)
+        : Operator(ctx, id), cfg_(cfg), bridge_(std::move(bridge)), index_(std::make_shared<PagesIndexGpu>(ctx, cfg.types))
+    {
+    }
+
+    bool needs_input() override { return state_ == State::CONSUMING_INPUT; }
+
+    // :318-350 -> PagesIndex.addPage
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(state_ == State::CONSUMING_INPUT, "Operator is already finishing");
+        DevicePage in = ingest_page(ctx_, page);
+        index_->add_page(in);  // copies: PagesIndex retains the build side for the table's lifetime (PagesIndex.java:221-228)
+    }
+
+    std::unique_ptr<OutputPage> get_output() override { return nullptr; }
+
+    // :478-496 finishInput -> buildLookupSource -> lendPartitionLookupSource
+    void finish() override
+    {
+        if (state_ != State::CONSUMING_INPUT) return;
+        auto source = std::make_shared<LookupSourceGpu>(ctx_, index_, cfg_.hash_channels, cfg_.precomputed_hash_channel, cfg_.output_channels);
+        source->build();
+        source_ = source;
+        bridge_->lend(source);
+        state_ = State::LOOKUP_SOURCE_BUILT;
+    }
+
+    // the operator stays alive (blocked) until the probes no longer need the table (:429-470)
+    bool is_blocked() override { return state_ == State::LOOKUP_SOURCE_BUILT && !bridge_->destroyed(); }
+
+    bool is_finished() override
+    {
+        if (state_ == State::LOOKUP_SOURCE_BUILT && bridge_->destroyed()) close();
+        return state_ == State::CLOSED;
+    }
+
+    int64_t memory_bytes() override { return source_ ? source_->estimated_size() : index_->estimated_size(); }
+
+    void close() override
+    {
+        state_ = State::CLOSED;
+        source_.reset();
+    }
+
+private:
+    HashBuilderConfig cfg_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    std::shared_ptr<PagesIndexGpu> index_;
+    std::shared_ptr<LookupSourceGpu> source_;
+    State state_ = State::CONSUMING_INPUT;
+};
+
+HashBuilderOperatorFactory::HashBuilderOperatorFactory(Context *ctx, int32_t operator_id, HashBuilderConfig cfg, std::shared_ptr<LookupSourceFactory> bridge)
+    : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg)), bridge_(std::move(bridge))
+{
+    const int nt = (int)cfg_.types.size();
+    for (int32_t t : cfg_.types) TG_CHECK_ARG(valid_type(t), "unknown type");
+    for (int32_t ch : cfg_.output_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "output channel out of range");
+    TG_CHECK_ARG(!cfg_.hash_channels.empty(), "hash join needs at least one join channel");
+    for (int32_t ch : cfg_.hash_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "join channel out of range");
+    TG_CHECK_ARG(cfg_.precomputed_hash_channel < nt, "hash channel out of range");
+    for (int32_t ch : cfg_.output_channels) bridge_->build_output_types.push_back(cfg_.types[(size_t)ch]);
+}
+
+std::unique_ptr<Operator> HashBuilderOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    TG_CHECK_STATE(!created_, "one build operator per lookup source partition (one partition per GPU)");
+    created_ = true;
+    return std::make_unique<HashBuilderOperator>(ctx_, operator_id_, cfg_, bridge_);
+}
+
+// =====================================================================================================================
+// LookupJoinOperator / PageJoiner (M/operator/LookupJoinOperator.java:208-378)
+// =====================================================================================================================
+class LookupJoinOperator : public Operator {
+public:
+    LookupJoinOperator(Context *ctx, int32_t id, const LookupJoinConfig &cfg, std::shared_ptr<LookupSourceFactory> bridge)
+        : Operator(ctx, id), cfg_(cfg), bridge_(std::move(bridge))
+    {
+        bridge_->probe_created();
+    }
+    ~LookupJoinOperator() override { close(); }
+
+    // blocked on lookupSourceProviderFuture until the build side lends the table (:235-243)
+    bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
+    bool needs_input() override { return !finishing_ && !pending_ && !is_blocked(); }
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        TG_CHECK_STATE(!pending_, "Operator still has pending output");
+        std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
+        TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
+        DevicePage in = ingest_page(ctx_, page);
+        TG_CHECK_ARG(in.cols.size() == cfg_.probe_types.size(), "probe page channel count differs from the operator's types");
+        if (in.n == 0) return;
+        std::vector<const DeviceColumn *> keys;
+        for (int32_t ch : cfg_.probe_join_channels) keys.push_back(&in.cols[(size_t)ch]);
+        const int64_t *hashes = nullptr;
+        if (cfg_.probe_hash_channel >= 0) {
+            TG_CHECK_ARG(in.cols[(size_t)cfg_.probe_hash_channel].type == TGPU_BIGINT, "probe hash channel must be BIGINT");
+            hashes = (const int64_t *)in.cols[(size_t)cfg_.probe_hash_channel].values;
+        }
+        const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER;
+        BufferPtr probe_idx, build_idx;
+        int64_t count = 0;
+        source->probe(keys, hashes, in.n, outer, probe_idx, build_idx, count);
+        if (count == 0) return;  // no output page for this probe page (:276-283 pageBuilder.isEmpty)
+        // LookupJoinPageBuilder.build (M/operator/LookupJoinPageBuilder.java:101-131): probe columns by probe index,
+        // then the build side's output columns
+        DevicePage out;
+        out.n = count;
+        ProfileScope ps(ctx_, "join_gather");
+        for (int32_t ch : cfg_.probe_output_channels) out.cols.push_back(k::gather_column(ctx_, in.cols[(size_t)ch], probe_idx->as<int32_t>(), count, false));
+        const int nb = (int)source->output_channels().size();
+        for (int i = 0; i < nb; i++) out.cols.push_back(source->gather_build(i, build_idx->as<int32_t>(), count, outer));
+        pending_ = wrap(std::move(out));
+    }
+
+    std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
+    void finish() override { finishing_ = true; }
+    bool is_finished() override
+    {
+        bool done = finishing_ && !pending_;
+        if (done) close();
+        return done;
+    }
+    int64_t memory_bytes() override { return pending_ ? pending_->page.size_in_bytes() : 0; }
+    void close() override
+    {
+        if (!closed_) {
+            closed_ = true;
+            bridge_->probe_closed();
+        }
+    }
+
+private:
+    LookupJoinConfig cfg_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    std::unique_ptr<OutputPage> pending_;
+    bool finishing_ = false, closed_ = false;
+};
+
+LookupJoinOperatorFactory::LookupJoinOperatorFactory(Context *ctx, int32_t operator_id, LookupJoinConfig cfg, std::shared_ptr<LookupSourceFactory> bridge)
+    : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg)), bridge_(std::move(bridge))
+{
+    const int nt = (int)cfg_.probe_types.size();
+    for (int32_t t : cfg_.probe_types) TG_CHECK_ARG(valid_type(t), "unknown type");
+    TG_CHECK_ARG(!cfg_.probe_join_channels.empty(), "hash join needs at least one join channel");
+    for (int32_t ch : cfg_.probe_join_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe join channel out of range");
+    for (int32_t ch : cfg_.probe_output_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe output channel out of range");
+    TG_CHECK_ARG(cfg_.probe_hash_channel < nt, "probe hash channel out of range");
+    TG_CHECK_ARG(cfg_.join_type == TGPU_JOIN_INNER || cfg_.join_type == TGPU_JOIN_PROBE_OUTER, "only INNER and PROBE_OUTER joins are supported");
+}
+
+std::unique_ptr<Operator> LookupJoinOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<LookupJoinOperator>(ctx_, operator_id_, cfg_, bridge_);
+}
+
+void LookupJoinOperatorFactory::no_more_operators()
+{
+    closed_ = true;
+    bridge_->no_more_probes();
+}
+
+}  // namespace tgpu

@@ -1,0 +1,158 @@
+// operators.h -- host-side mirror of the reference's operator interfaces (M/operator/Operator.java:20-102,
+// OperatorFactory.java:18-50) and the four hot-path operators, as state machines over the device kernels.
+#pragma once
+
+#include "agg.h"
+#include "common.h"
+#include "groupby.h"
+#include "jit.h"
+#include "join.h"
+
+namespace tgpu {
+
+class Operator {
+public:
+    explicit Operator(Context *ctx, int32_t operator_id) : ctx_(ctx), operator_id_(operator_id) {}
+    virtual ~Operator() {}
+    virtual bool needs_input() = 0;
+    virtual void add_input(const tgpu_page *page) = 0;
+    virtual std::unique_ptr<OutputPage> get_output() = 0;  // nullptr = no page available
+    virtual void finish() = 0;
+    virtual bool is_finished() = 0;
+    virtual bool is_blocked() { return false; }
+    virtual int64_t memory_bytes() { return 0; }
+    virtual void close() {}
+    Context *context() const { return ctx_; }
+
+protected:
+    std::unique_ptr<OutputPage> wrap(DevicePage &&p)
+    {
+        auto o = std::make_unique<OutputPage>();
+        o->ctx = ctx_;
+        o->page = std::move(p);
+        return o;
+    }
+    Context *ctx_;
+    int32_t operator_id_;
+};
+
+class OperatorFactory {
+public:
+    virtual ~OperatorFactory() {}
+    virtual std::unique_ptr<Operator> create_operator() = 0;
+    virtual void no_more_operators() { closed_ = true; }
+
+protected:
+    bool closed_ = false;
+};
+
+// ---- FilterAndProjectOperator (M/operator/FilterAndProjectOperator.java:37-65,117-147) ----------------------------
+class FilterAndProjectOperatorFactory : public OperatorFactory {
+public:
+    FilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::shared_ptr<PageProcessorGpu> processor_;
+};
+
+// ---- HashAggregationOperator (M/operator/HashAggregationOperator.java:54-262,367-518) -----------------------------
+struct HashAggregationConfig {
+    std::vector<int32_t> group_by_types, group_by_channels;
+    int32_t hash_channel = -1;
+    int32_t step = TGPU_STEP_SINGLE;
+    std::vector<tgpu_agg_spec> aggs;
+    int32_t expected_groups = 1024;
+    bool produce_default_output = false;
+    int64_t max_partial_memory = 16ll << 20;  // TaskManagerConfig.java:47 (max_partial_aggregation_memory)
+};
+
+class HashAggregationOperatorFactory : public OperatorFactory {
+public:
+    HashAggregationOperatorFactory(Context *ctx, int32_t operator_id, HashAggregationConfig cfg);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    HashAggregationConfig cfg_;
+};
+
+// ---- join bridge: PartitionedLookupSourceFactory with one partition (M/operator/PartitionedLookupSourceFactory.java:146-205)
+class LookupSourceFactory {
+public:
+    std::shared_ptr<LookupSourceGpu> lookup_source() const { return source_; }
+    void lend(std::shared_ptr<LookupSourceGpu> s) { source_ = std::move(s); }
+    void probe_created() { live_probes_++; any_probe_ = true; }
+    void probe_closed() { live_probes_--; }
+    void no_more_probes() { no_more_probes_ = true; }
+    // the build operator may release the table once every probe operator is done (HashBuilderOperator.java:429-470)
+    bool destroyed() const { return no_more_probes_ && live_probes_ == 0; }
+    std::vector<int32_t> build_output_types;
+
+private:
+    std::shared_ptr<LookupSourceGpu> source_;
+    int live_probes_ = 0;
+    bool any_probe_ = false, no_more_probes_ = false;
+};
+
+struct HashBuilderConfig {
+    std::vector<int32_t> types, output_channels, hash_channels;
+    int32_t precomputed_hash_channel = -1;
+    int32_t expected_positions = 0;
+};
+
+class HashBuilderOperatorFactory : public OperatorFactory {
+public:
+    HashBuilderOperatorFactory(Context *ctx, int32_t operator_id, HashBuilderConfig cfg, std::shared_ptr<LookupSourceFactory> bridge);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    HashBuilderConfig cfg_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    bool created_ = false;
+};
+
+struct LookupJoinConfig {
+    std::vector<int32_t> probe_types, probe_join_channels, probe_output_channels;
+    int32_t probe_hash_channel = -1;
+    int32_t join_type = TGPU_JOIN_INNER;
+};
+
+class LookupJoinOperatorFactory : public OperatorFactory {
+public:
+    LookupJoinOperatorFactory(Context *ctx, int32_t operator_id, LookupJoinConfig cfg, std::shared_ptr<LookupSourceFactory> bridge);
+    std::unique_ptr<Operator> create_operator() override;
+    void no_more_operators() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    LookupJoinConfig cfg_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+};
+
+}  // namespace tgpu
+
+struct tgpu_context {
+    std::unique_ptr<tgpu::Context> ctx;
+};
+struct tgpu_operator_factory {
+    std::unique_ptr<tgpu::OperatorFactory> f;
+};
+struct tgpu_operator {
+    std::unique_ptr<tgpu::Operator> op;
+};
+struct tgpu_lookup_source_factory {
+    std::shared_ptr<tgpu::LookupSourceFactory> bridge;
+};
+struct tgpu_group_by_hash {
+    tgpu::Context *ctx;
+    std::unique_ptr<tgpu::GroupByHashGpu> gbh;
+    std::vector<int32_t> hash_channels;
+    int32_t input_hash_channel;
+};

@@ -1,0 +1,317 @@
+"""Host-side mirror of the reference's operator API over the C ABI (include/tgpu.h).
+
+Same names and call protocol as io.trino.operator.Operator / OperatorFactory (M/operator/Operator.java:20-102,
+OperatorFactory.java:18-50) so parity tests read like the reference's own operator tests
+(T/operator/TestHashAggregationOperator.java, TestHashJoinOperator.java, TestFilterAndProjectOperator.java).
+Everything here is a thin wrapper: the state machines live in csrc/operators.cpp, the work in the HIP kernels.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib
+from .expressions import FlatProgram
+from .spi import OutputPage, Page
+
+COUNT_ALL, COUNT_COLUMN, SUM_BIGINT, SUM_DOUBLE, AVG_BIGINT, AVG_DOUBLE = 1, 2, 3, 4, 5, 6
+SINGLE, PARTIAL, FINAL = 0, 1, 2
+INNER, PROBE_OUTER = 0, 1
+
+
+def _i32(seq):
+    seq = list(seq)
+    return (C.c_int32 * max(1, len(seq)))(*seq), len(seq)
+
+
+class Context:
+    """One HIP device + stream (tgpu_context).  stream: a hipStream_t address (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_context_create(device, stream, C.byref(h)))
+        self.handle = h
+
+    def synchronize(self):
+        _lib.check(_lib.lib().tgpu_context_synchronize(self.handle))
+
+    def profile_enable(self, on=True):
+        _lib.check(_lib.lib().tgpu_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        _lib.check(_lib.lib().tgpu_profile_reset(self.handle))
+
+    def profile(self):
+        L = _lib.lib()
+        need = L.tgpu_profile_dump(self.handle, None, 0)
+        buf = C.create_string_buffer(int(need))
+        L.tgpu_profile_dump(self.handle, buf, need)
+        return json.loads(buf.value.decode())
+
+    def hash_page(self, page: Page, channels):
+        ch, n = _i32(channels)
+        out = np.zeros(max(page.position_count, 1), dtype=np.int64)
+        cp, keep = page.to_c()
+        _lib.check(_lib.lib().tgpu_hash_page(self.handle, C.byref(cp), n, ch, out.ctypes.data))
+        return out[: page.position_count]
+
+    def partition_page(self, page: Page, key_channels, partition_count, hash_channel=-1):
+        ch, n = _i32(key_channels)
+        counts = np.zeros(partition_count, dtype=np.int64)
+        out = C.c_void_p()
+        cp, keep = page.to_c()
+        _lib.check(_lib.lib().tgpu_partition_page(self.handle, C.byref(cp), n, ch, hash_channel, partition_count, counts.ctypes.data, C.byref(out)))
+        return counts, OutputPage(out)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().tgpu_context_destroy(self.handle)
+            self.handle = None
+
+
+class Operator:
+    def __init__(self, handle):
+        self.handle = handle
+
+    def needsInput(self):
+        return bool(_lib.check(_lib.lib().tgpu_operator_needs_input(self.handle)))
+
+    def addInput(self, page: Page):
+        cp, keep = page.to_c()
+        _lib.check(_lib.lib().tgpu_operator_add_input(self.handle, C.byref(cp)))
+
+    def getOutput(self):
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_operator_get_output(self.handle, C.byref(out)))
+        return OutputPage(out) if out.value else None
+
+    def finish(self):
+        _lib.check(_lib.lib().tgpu_operator_finish(self.handle))
+
+    def isFinished(self):
+        return bool(_lib.check(_lib.lib().tgpu_operator_is_finished(self.handle)))
+
+    def isBlocked(self):
+        return bool(_lib.check(_lib.lib().tgpu_operator_is_blocked(self.handle)))
+
+    def memoryBytes(self):
+        return _lib.lib().tgpu_operator_memory_bytes(self.handle)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().tgpu_operator_close(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class OperatorFactory:
+    def __init__(self, handle, keep=None):
+        self.handle = handle
+        self._keep = keep
+
+    def createOperator(self):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_operator_factory_create_operator(self.handle, C.byref(h)))
+        return Operator(h)
+
+    def noMoreOperators(self):
+        _lib.check(_lib.lib().tgpu_operator_factory_no_more_operators(self.handle))
+
+    def close(self):
+        if self.handle:
+            _lib.lib().tgpu_operator_factory_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class FilterAndProjectOperatorFactory(OperatorFactory):
+    """FilterAndProjectOperator.createOperatorFactory (M/operator/FilterAndProjectOperator.java:73-88): the PageProcessor
+    (filter + projections as RowExpressions) is compiled into one fused gfx950 kernel pair."""
+
+    def __init__(self, ctx: Context, operator_id, input_types, filter_expr, projections):
+        self.program = FlatProgram(filter_expr, projections)
+        spec, keep = self.program.to_c()
+        types, n = _i32(input_types)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_filter_project_factory_create(ctx.handle, operator_id, n, types, C.byref(spec), C.byref(h)))
+        super().__init__(h, keep)
+
+
+def precompile_page_processor(input_types, filter_expr, projections):
+    """Compile the kernels of a page processor into the on-disk cache (no GPU needed)."""
+    prog = FlatProgram(filter_expr, projections)
+    spec, keep = prog.to_c()
+    types, n = _i32(input_types)
+    _lib.check(_lib.lib().tgpu_precompile_page_processor(n, types, C.byref(spec)))
+
+
+def page_processor_source(input_types, filter_expr, projections):
+    prog = FlatProgram(filter_expr, projections)
+    spec, keep = prog.to_c()
+    types, n = _i32(input_types)
+    L = _lib.lib()
+    need = _lib.check(L.tgpu_page_processor_source(n, types, C.byref(spec), None, 0))
+    buf = C.create_string_buffer(int(need))
+    L.tgpu_page_processor_source(n, types, C.byref(spec), buf, need)
+    return buf.value.decode()
+
+
+class HashAggregationOperatorFactory(OperatorFactory):
+    """M/operator/HashAggregationOperator.java:54-262.  aggs: list of (function, input_channel, mask_channel)."""
+
+    def __init__(self, ctx: Context, operator_id, group_by_types, group_by_channels, aggs, step=SINGLE, hash_channel=-1,
+                 expected_groups=10_000, produce_default_output=False):
+        gt, ng = _i32(group_by_types)
+        gc, _ = _i32(group_by_channels)
+        arr = (_lib.AggSpec * max(1, len(aggs)))()
+        for i, a in enumerate(aggs):
+            f, ch = a[0], a[1]
+            arr[i] = _lib.AggSpec(f, ch, a[2] if len(a) > 2 else -1)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_hash_aggregation_factory_create(ctx.handle, operator_id, ng, gt, gc, hash_channel, step, len(aggs), arr,
+                                                                   expected_groups, int(produce_default_output), C.byref(h)))
+        super().__init__(h)
+
+
+class LookupSourceFactory:
+    """The JoinBridge between the build and probe pipelines (M/operator/PartitionedLookupSourceFactory.java)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().tgpu_lookup_source_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(positions=a.value, hash_size=b.value, link_count=c.value)
+
+    def close(self):
+        if self.handle:
+            _lib.lib().tgpu_lookup_source_factory_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class HashBuilderOperatorFactory(OperatorFactory):
+    """M/operator/HashBuilderOperator.java:54-152.  `lookup_source_factory` is the bridge to hand to the probe factory."""
+
+    def __init__(self, ctx: Context, operator_id, types, output_channels, hash_channels, precomputed_hash_channel=-1, expected_positions=100):
+        t, nt = _i32(types)
+        oc, no = _i32(output_channels)
+        hc, nh = _i32(hash_channels)
+        bridge, h = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().tgpu_hash_builder_factory_create(ctx.handle, operator_id, nt, t, no, oc, nh, hc, precomputed_hash_channel,
+                                                               expected_positions, C.byref(bridge), C.byref(h)))
+        super().__init__(h)
+        self.lookup_source_factory = LookupSourceFactory(bridge)
+
+
+class LookupJoinOperatorFactory(OperatorFactory):
+    """LookupJoinOperators.innerJoin / probeOuterJoin (M/operator/LookupJoinOperators.java:30-63)."""
+
+    def __init__(self, ctx: Context, operator_id, lookup_source_factory: LookupSourceFactory, probe_types, probe_join_channels,
+                 probe_hash_channel=-1, probe_output_channels=None, join_type=INNER):
+        if probe_output_channels is None:
+            probe_output_channels = list(range(len(probe_types)))
+        t, nt = _i32(probe_types)
+        jc, nj = _i32(probe_join_channels)
+        oc, no = _i32(probe_output_channels)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_lookup_join_factory_create(ctx.handle, operator_id, lookup_source_factory.handle, nt, t, nj, jc,
+                                                              probe_hash_channel, no, oc, join_type, C.byref(h)))
+        super().__init__(h)
+        self._bridge = lookup_source_factory
+
+
+class GroupByHash:
+    """GroupByHash.createGroupByHash (M/operator/GroupByHash.java:45-59) over the GPU table."""
+
+    def __init__(self, ctx: Context, types, hash_channels, input_hash_channel=None, expected_size=100):
+        t, n = _i32(types)
+        hc, _ = _i32(hash_channels)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_group_by_hash_create(ctx.handle, n, t, hc, -1 if input_hash_channel is None else input_hash_channel,
+                                                        expected_size, C.byref(h)))
+        self.handle = h
+
+    def addPage(self, page: Page):
+        cp, keep = page.to_c()
+        _lib.check(_lib.lib().tgpu_group_by_hash_add_page(self.handle, C.byref(cp)))
+
+    def getGroupIds(self, page: Page):
+        out = np.zeros(max(page.position_count, 1), dtype=np.int64)
+        gc = C.c_int64()
+        cp, keep = page.to_c()
+        _lib.check(_lib.lib().tgpu_group_by_hash_get_group_ids(self.handle, C.byref(cp), out.ctypes.data, C.byref(gc)))
+        return out[: page.position_count]
+
+    def contains(self, position, page: Page):
+        r = C.c_int32()
+        cp, keep = page.to_c()
+        _lib.check(_lib.lib().tgpu_group_by_hash_contains(self.handle, position, C.byref(cp), C.byref(r)))
+        return bool(r.value)
+
+    def getGroupCount(self):
+        return _lib.lib().tgpu_group_by_hash_group_count(self.handle)
+
+    def getCapacity(self):
+        return _lib.lib().tgpu_group_by_hash_capacity(self.handle)
+
+    def getRehashCount(self):
+        return _lib.lib().tgpu_group_by_hash_rehash_count(self.handle)
+
+    def getEstimatedSize(self):
+        return _lib.lib().tgpu_group_by_hash_estimated_size(self.handle)
+
+    def appendValues(self) -> Page:
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_group_by_hash_append_values(self.handle, C.byref(out)))
+        op = OutputPage(out)
+        pg = op.to_host()
+        op.release()
+        return pg
+
+    def close(self):
+        if self.handle:
+            _lib.lib().tgpu_group_by_hash_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+def to_pages(operator: Operator, input_pages, to_host=True):
+    """The reference's mini driver loop, T/operator/OperatorAssertion.java:82-137 (toPages)."""
+    outputs = []
+    it = iter(input_pages)
+    pending = next(it, None)
+    loops = 0
+    while pending is not None and loops < 10_000_000:
+        loops += 1
+        if operator.isBlocked():
+            raise RuntimeError("operator is blocked")
+        if operator.needsInput():
+            operator.addInput(pending)
+            pending = next(it, None)
+        out = operator.getOutput()
+        if out is not None and out.position_count > 0:
+            outputs.append(out)
+    operator.finish()
+    loops = 0
+    while not operator.isFinished() and loops < 1_000_000:
+        loops += 1
+        out = operator.getOutput()
+        if out is not None and out.position_count > 0:
+            outputs.append(out)
+    assert operator.isFinished() and not operator.needsInput() and not operator.isBlocked()
+    if not to_host:
+        return outputs
+    host = [o.to_host() for o in outputs]
+    for o in outputs:
+        o.release()
+    return host

@@ -1,0 +1,512 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every case goes through the C ABI (include/tgpu.h) and is checked
+against the CPU oracle on the same inputs -- bit-exact for hashes, group ids, join matches and BIGINT results; DOUBLE
+aggregates against the exactly rounded sum (tolerance stated in each test)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gpu_common import ocol, rand_block, ulp_diff
+from seqpages import sequence_page, sequence_values
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_vectors.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def blocks_of(pkg, types, columns):
+    return [pkg.Block(t, v) for t, v in zip(types, columns)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K3 hashes
+# ---------------------------------------------------------------------------------------------------------------------
+def test_hash_page_all_types(pkg, ctx, oracle):
+    rng = np.random.default_rng(1)
+    n = 5000
+    types = [pkg.BIGINT, pkg.INTEGER, pkg.DATE, pkg.DOUBLE, pkg.BOOLEAN, pkg.VARCHAR]
+    blocks = [rand_block(pkg, rng, t, n, null_frac=0.1) for t in types]
+    blocks[3].values[:4] = [0.0, -0.0, np.nan, np.inf]
+    page = pkg.Page(*blocks)
+    for chans in ([0], [1], [2], [3], [4], [5], [0, 5], list(range(6))):
+        got = ctx.hash_page(page, chans)
+        want = oracle.hash_rows([ocol(oracle, blocks[c]) for c in chans])
+        assert np.array_equal(got, want), chans
+
+
+def test_hash_page_long_strings_and_encodings(pkg, ctx, oracle):
+    rng = np.random.default_rng(2)
+    strs = ["", "a", "hashme"] + ["".join(chr(97 + int(x)) for x in rng.integers(0, 26, k)) for k in (7, 8, 9, 31, 32, 33, 64, 100, 257)]
+    flat = pkg.Block(pkg.VARCHAR, strs)
+    want = oracle.hash_rows([ocol(oracle, flat)])
+    assert np.array_equal(ctx.hash_page(pkg.Page(flat), [0]), want)
+    # reference literal (T/operator/scalar/TestVarbinaryFunctions.java:334-335) straight off the GPU
+    assert int(ctx.hash_page(pkg.Page(flat), [0])[2]) & (2**64 - 1) == 0xF9D96E0E1165E892
+    ids = rng.integers(0, len(strs), 500).astype(np.int32)
+    dic = pkg.DictionaryBlock(flat, ids)
+    assert np.array_equal(ctx.hash_page(pkg.Page(dic), [0]), want[ids])
+    rle = pkg.RunLengthEncodedBlock(pkg.Block(pkg.VARCHAR, ["hashme"]), 17)
+    assert np.array_equal(ctx.hash_page(pkg.Page(rle), [0]), np.full(17, want[2]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K4/K5 GroupByHash
+# ---------------------------------------------------------------------------------------------------------------------
+def test_group_by_hash_reference_cases(pkg, ctx, oracle):
+    # T/operator/TestGroupByHash.java:69-96,121-140 (one-row pages, value == group id)
+    gbh = pkg.GroupByHash(ctx, [pkg.BIGINT], [0], input_hash_channel=1, expected_size=100)
+    for tries in range(2):
+        for value in range(0, 500, 7):
+            blk = pkg.Block(pkg.BIGINT, np.array([value], dtype=np.int64))
+            page = pkg.Page(blk, pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, blk)])))
+            ids = gbh.getGroupIds(page)
+            assert ids[0] == value // 7
+    # :180-202 values i % 50
+    vals = np.arange(100, dtype=np.int64) % 50
+    blk = pkg.Block(pkg.BIGINT, vals)
+    gbh = pkg.GroupByHash(ctx, [pkg.BIGINT], [0], expected_size=100)
+    assert np.array_equal(gbh.getGroupIds(pkg.Page(blk)), vals)
+    assert gbh.getGroupCount() == 50
+    assert gbh.appendValues().getBlock(0).to_list() == list(range(50))
+
+
+def test_group_by_hash_null_group_and_capacity(pkg, ctx, oracle):
+    # :98-118 null group + forced rehash, then contains(0) is false
+    gbh = pkg.GroupByHash(ctx, [pkg.BIGINT], [0], expected_size=100)
+    o = oracle.BigintGroupByHash(100)
+    for blk in (pkg.Block(pkg.BIGINT, [None]), pkg.Block(pkg.BIGINT, sequence_values(pkg.BIGINT, 1, 132748))):
+        got = gbh.getGroupIds(pkg.Page(blk))
+        assert np.array_equal(got, o.get_group_ids(ocol(oracle, blk)))
+    assert not gbh.contains(0, pkg.Page(pkg.Block(pkg.BIGINT, np.array([0], dtype=np.int64))))
+    assert gbh.contains(0, pkg.Page(pkg.Block(pkg.BIGINT, [None])))
+    assert gbh.getGroupCount() == o.group_count == 132748
+    assert gbh.getCapacity() == o.capacity
+    assert gbh.getRehashCount() == o.rehash_count
+
+
+def test_group_by_hash_varchar_append_to(pkg, ctx, oracle):
+    # :150-178
+    blk = pkg.Block(pkg.VARCHAR, sequence_values(pkg.VARCHAR, 0, 100))
+    hashes = oracle.hash_rows([ocol(oracle, blk)])
+    gbh = pkg.GroupByHash(ctx, [pkg.VARCHAR], [0], input_hash_channel=1, expected_size=100)
+    ids = gbh.getGroupIds(pkg.Page(blk, pkg.Block(pkg.BIGINT, hashes)))
+    assert list(ids) == list(range(100))
+    out = gbh.appendValues()
+    assert out.getBlock(0).to_list() == blk.to_list()
+    assert np.array_equal(out.getBlock(1).values, hashes)
+    # :237-252 forced rehash from expectedSize 4
+    g2 = pkg.GroupByHash(ctx, [pkg.VARCHAR], [0], input_hash_channel=1, expected_size=4)
+    page = pkg.Page(blk, pkg.Block(pkg.BIGINT, hashes))
+    g2.getGroupIds(page)
+    assert all(g2.contains(i, page) for i in range(0, 100, 9))
+    assert g2.getCapacity() == 256
+
+
+@pytest.mark.parametrize("types,domains", [
+    (["BIGINT"], [(0, 3000)]),
+    (["VARCHAR"], [(0, 500)]),
+    (["BIGINT", "DATE", "INTEGER"], [(0, 50), (8000, 8040), (0, 3)]),
+    (["DOUBLE", "VARCHAR"], [(0, 30), (0, 30)]),
+    (["BOOLEAN", "BIGINT"], [None, (-5, 5)]),
+])
+@pytest.mark.parametrize("with_hash", [False, True])
+def test_group_by_hash_random_vs_oracle(pkg, ctx, oracle, types, domains, with_hash):
+    rng = np.random.default_rng(hash((tuple(types), with_hash)) % 2**32)
+    tids = [getattr(pkg, t) for t in types]
+    gbh = pkg.GroupByHash(ctx, tids, list(range(len(tids))), input_hash_channel=len(tids) if with_hash else None, expected_size=16)
+    single_bigint = tids == [pkg.BIGINT]
+    o = oracle.BigintGroupByHash(16) if single_bigint else oracle.MultiChannelGroupByHash(tids, 16)
+    for n in (1, 257, 20_000, 3, 50_000):
+        blocks = [rand_block(pkg, rng, t, n, null_frac=0.05, domain=d) for t, d in zip(tids, domains)]
+        ocols = [ocol(oracle, b) for b in blocks]
+        hashes = oracle.hash_rows(ocols)
+        page = pkg.Page(*(blocks + ([pkg.Block(pkg.BIGINT, hashes)] if with_hash else [])))
+        got = gbh.getGroupIds(page)
+        want = o.get_group_ids(ocols[0]) if single_bigint else o.get_group_ids(ocols, hashes if with_hash else None)
+        assert np.array_equal(got, want)
+        assert gbh.getGroupCount() == o.group_count
+        assert gbh.getCapacity() == o.capacity
+
+
+def test_group_by_hash_sub_batches(pkg, oracle, monkeypatch):
+    # the device implementation processes big pages in sub-batches; ids must not depend on the split
+    monkeypatch.setenv("TGPU_GBH_SUBBATCH", "1000")
+    c = pkg.Context(0)
+    rng = np.random.default_rng(5)
+    blk = rand_block(pkg, rng, pkg.BIGINT, 12_345, null_frac=0.01, domain=(0, 4000))
+    gbh = pkg.GroupByHash(c, [pkg.BIGINT], [0], expected_size=10)
+    o = oracle.BigintGroupByHash(10)
+    assert np.array_equal(gbh.getGroupIds(pkg.Page(blk)), o.get_group_ids(ocol(oracle, blk)))
+    gbh.close()
+    c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hash aggregation operator
+# ---------------------------------------------------------------------------------------------------------------------
+def run_agg(pkg, ctx, pages, group_types, group_channels, aggs, step=0, hash_channel=-1, expected=100):
+    f = pkg.HashAggregationOperatorFactory(ctx, 0, group_types, group_channels, aggs, step=step, hash_channel=hash_channel, expected_groups=expected)
+    op = f.createOperator()
+    out = pkg.to_pages(op, pages)
+    op.close()
+    rows = []
+    for p in out:
+        rows.extend(p.rows())
+    return rows
+
+
+def test_hash_aggregation_golden(pkg, ctx, oracle):
+    # T/operator/TestHashAggregationOperator.java:161-220 (count, sum, avg, count(col) columns; max(varchar) is out of scope)
+    n = GOLD["hash_aggregation"]["testHashAggregation"]["rows"]
+    types = [pkg.VARCHAR, pkg.VARCHAR, pkg.VARCHAR, pkg.BIGINT, pkg.BOOLEAN]
+    pages = []
+    for base in (100_000, 200_000, 300_000):
+        cols = sequence_page(types, n, 100, 0, base, 0, 500)
+        blocks = blocks_of(pkg, types, cols)
+        hashes = oracle.hash_rows([ocol(oracle, blocks[1])])
+        pages.append(pkg.Page(*(blocks + [pkg.Block(pkg.BIGINT, hashes)])))
+    aggs = [(pkg.COUNT_ALL, -1), (pkg.SUM_BIGINT, 3), (pkg.AVG_BIGINT, 3), (pkg.COUNT_COLUMN, 0), (pkg.COUNT_COLUMN, 4)]
+    rows = run_agg(pkg, ctx, pages, [pkg.VARCHAR], [1], aggs, hash_channel=5, expected=100_000)
+    assert len(rows) == n
+    for i, r in enumerate(rows):  # output is in group-id order = first-seen order = i
+        assert r[0] == str(i) and r[2] == 3 and r[3] == 3 * i and r[4] == float(i) and r[5] == 3 and r[6] == 3, (i, r)
+    hk = oracle.hash_rows([oracle.Col(pkg.VARCHAR, [str(i) for i in range(0, n, 997)])])
+    assert [rows[i][1] for i in range(0, n, 997)] == list(hk)
+
+
+def test_hash_aggregation_doubles_exact(pkg, ctx, oracle):
+    """DOUBLE policy: the GPU sum is the correctly rounded exact sum -> 0 ULP vs the exact oracle; and it equals the Java
+    left-to-right sum whenever that sum is exact (integer-valued inputs)."""
+    rng = np.random.default_rng(11)
+    n, g = 200_000, 7
+    keys = rng.integers(0, g, n).astype(np.int64)
+    vals = rng.standard_normal(n) * 10.0 ** rng.integers(-12, 13, n)
+    ints = rng.integers(-1000, 1000, n).astype(np.float64)
+    nulls = (rng.random(n) < 0.1).astype(np.uint8)
+    mask = rng.integers(0, 2, n).astype(np.uint8)
+    page = pkg.Page(pkg.Block(pkg.BIGINT, keys), pkg.Block(pkg.DOUBLE, vals, nulls), pkg.Block(pkg.DOUBLE, ints), pkg.Block(pkg.BOOLEAN, mask))
+    aggs = [(pkg.SUM_DOUBLE, 1), (pkg.AVG_DOUBLE, 1), (pkg.SUM_DOUBLE, 2), (pkg.SUM_DOUBLE, 1, 3), (pkg.COUNT_ALL, -1, 3)]
+    rows = run_agg(pkg, ctx, [page], [pkg.BIGINT], [0], aggs)
+    o = oracle.BigintGroupByHash(100)
+    gids = o.get_group_ids(oracle.Col(pkg.BIGINT, keys))
+    ng = o.group_count
+    cnt, exact = oracle.agg_double_sum_exact(gids, vals, ng, nulls=nulls)
+    _, java_ints = oracle.agg_double_sum(gids, ints, ng)
+    cnt_m, exact_m = oracle.agg_double_sum_exact(gids, vals, ng, nulls=nulls, mask=mask)
+    count_m = oracle.agg_count(gids, n, ng, mask=mask)
+    got = np.array([[r[1], r[2], r[3], r[4]] for r in rows], dtype=np.float64)
+    assert ulp_diff(got[:, 0], exact).max() == 0           # tolerance: 0 ULP vs the exact sum
+    assert ulp_diff(got[:, 1], exact / cnt).max() == 0     # avg = exact sum / count, one IEEE division
+    assert np.array_equal(got[:, 2], java_ints)            # bit-equal to the Java order when that order is exact
+    assert ulp_diff(got[:, 3], exact_m).max() == 0
+    assert [r[5] for r in rows] == list(count_m)
+    # vs the Java-order oracle: differs only by the Java order's own rounding drift, bounded by n * eps * sum|v|
+    _, java = oracle.agg_double_sum(gids, vals, ng, nulls=nulls)
+    bound = n * np.finfo(np.float64).eps * np.abs(vals).sum()
+    assert np.all(np.abs(got[:, 0] - java) <= bound)
+
+
+def test_hash_aggregation_special_doubles_and_overflow(pkg, ctx, oracle):
+    keys = np.array([0, 0, 1, 1, 2, 2, 3, 3, 4], dtype=np.int64)
+    vals = np.array([np.inf, 1.0, np.inf, -np.inf, np.nan, 1.0, 1e308, 1e308, 5e-324])
+    rows = run_agg(pkg, ctx, [pkg.Page(pkg.Block(pkg.BIGINT, keys), pkg.Block(pkg.DOUBLE, vals))], [pkg.BIGINT], [0], [(pkg.SUM_DOUBLE, 1)])
+    got = [r[1] for r in rows]
+    assert got[0] == np.inf and np.isnan(got[1]) and np.isnan(got[2]) and got[3] == np.inf and got[4] == 5e-324
+    # sum(bigint) overflow -> NUMERIC_VALUE_OUT_OF_RANGE (M/type/BigintOperators.java:47-57)
+    big = np.array([2**62, 2**62, 1], dtype=np.int64)
+    with pytest.raises(pkg.TgpuError) as e:
+        run_agg(pkg, ctx, [pkg.Page(pkg.Block(pkg.BIGINT, np.zeros(3, dtype=np.int64)), pkg.Block(pkg.BIGINT, big))], [pkg.BIGINT], [0], [(pkg.SUM_BIGINT, 1)])
+    assert e.value.code == -2
+    neg = np.array([-(2**62), -(2**62), -5, 7], dtype=np.int64)
+    rows = run_agg(pkg, ctx, [pkg.Page(pkg.Block(pkg.BIGINT, np.zeros(4, dtype=np.int64)), pkg.Block(pkg.BIGINT, neg))], [pkg.BIGINT], [0], [(pkg.SUM_BIGINT, 1)])
+    assert rows[0][1] == int(neg.sum())
+
+
+def test_hash_aggregation_partial_final(pkg, ctx, oracle):
+    rng = np.random.default_rng(13)
+    n = 30_000
+    pages = []
+    for _ in range(3):
+        pages.append(pkg.Page(rand_block(pkg, rng, pkg.VARCHAR, n, 0.02, (0, 300)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.1),
+                              rand_block(pkg, rng, pkg.BIGINT, n, 0.1, (-10**6, 10**6))))
+    aggs = [(pkg.COUNT_ALL, -1), (pkg.SUM_DOUBLE, 1), (pkg.AVG_DOUBLE, 1), (pkg.SUM_BIGINT, 2), (pkg.AVG_BIGINT, 2), (pkg.COUNT_COLUMN, 2)]
+    single = run_agg(pkg, ctx, pages, [pkg.VARCHAR], [0], aggs)
+    # two partial operators over disjoint page sets, one final
+    partial_rows = []
+    fp = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.VARCHAR], [0], aggs, step=pkg.PARTIAL)
+    partial_pages = []
+    for chunk in (pages[:1], pages[1:]):
+        op = fp.createOperator()
+        partial_pages.extend(pkg.to_pages(op, chunk))
+        op.close()
+    # intermediate layout: key, then count | (count,sum) per aggregate
+    final_aggs = [(pkg.COUNT_ALL, 1), (pkg.SUM_DOUBLE, 2), (pkg.AVG_DOUBLE, 4), (pkg.SUM_BIGINT, 6), (pkg.AVG_BIGINT, 8), (pkg.COUNT_COLUMN, 10)]
+    final = run_agg(pkg, ctx, partial_pages, [pkg.VARCHAR], [0], final_aggs, step=pkg.FINAL)
+    a = {r[0]: r[1:] for r in single}
+    b = {r[0]: r[1:] for r in final}
+    assert a.keys() == b.keys()
+    for k in a:
+        assert a[k][0] == b[k][0] and a[k][3] == b[k][3] and a[k][5] == b[k][5]
+        # sums cross the partial/final boundary as rounded doubles (LongDoubleState), so <= 1 ULP per partial
+        assert ulp_diff([a[k][1], a[k][2], a[k][4]], [b[k][1], b[k][2], b[k][4]]).max() <= 2
+
+
+def test_global_aggregation_and_default_output(pkg, ctx):
+    f = pkg.HashAggregationOperatorFactory(ctx, 0, [], [], [(pkg.COUNT_ALL, -1), (pkg.SUM_DOUBLE, 0)], produce_default_output=True)
+    op = f.createOperator()
+    out = pkg.to_pages(op, [])
+    assert [p.rows() for p in out] == [[(0, None)]]
+    op = f.createOperator()
+    out = pkg.to_pages(op, [pkg.Page(pkg.Block(pkg.DOUBLE, [1.5, None, 2.5]))])
+    assert out[0].rows() == [(3, 4.0)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hash join
+# ---------------------------------------------------------------------------------------------------------------------
+def run_join(pkg, ctx, build_pages, probe_pages, types_b, types_p, key_b, key_p, hash_b=-1, hash_p=-1, join_type=0, out_b=None, out_p=None):
+    out_b = list(range(len(types_b))) if out_b is None else out_b
+    bf = pkg.HashBuilderOperatorFactory(ctx, 1, types_b, out_b, key_b, precomputed_hash_channel=hash_b)
+    jf = pkg.LookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, types_p, key_p, probe_hash_channel=hash_p, probe_output_channels=out_p, join_type=join_type)
+    build = bf.createOperator()
+    probe = jf.createOperator()
+    assert probe.isBlocked() and not probe.needsInput()  # waits on the lookup source future (LookupJoinOperator.java:235-243)
+    for p in build_pages:
+        assert build.needsInput()
+        build.addInput(p)
+    build.finish()
+    assert not probe.isBlocked()
+    out = pkg.to_pages(probe, probe_pages)
+    stats = bf.lookup_source_factory.stats()
+    probe.close()
+    jf.noMoreOperators()
+    assert build.isFinished()
+    build.close()
+    rows = []
+    for p in out:
+        rows.extend(p.rows())
+    return rows, stats
+
+
+@pytest.mark.parametrize("probe_hash,build_hash", [(False, False), (True, True), (True, False)])
+def test_hash_join_inner_golden(pkg, ctx, oracle, probe_hash, build_hash):
+    # T/operator/TestHashJoinOperator.java:164-199
+    types = [pkg.VARCHAR, pkg.BIGINT, pkg.BIGINT]
+    b = blocks_of(pkg, types, sequence_page(types, 10, 20, 30, 40))
+    p = blocks_of(pkg, types, sequence_page(types, 1000, 0, 1000, 2000))
+    tb, tp = list(types), list(types)
+    if build_hash:
+        b.append(pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, b[0])])))
+        tb.append(pkg.BIGINT)
+    if probe_hash:
+        p.append(pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, p[0])])))
+        tp.append(pkg.BIGINT)
+    rows, stats = run_join(pkg, ctx, [pkg.Page(*b)], [pkg.Page(*p)], tb, tp, [0], [0], hash_b=3 if build_hash else -1, hash_p=3 if probe_hash else -1,
+                           out_b=[0, 1, 2], out_p=[0, 1, 2])
+    assert [list(r) for r in rows] == GOLD["hash_join"]["testInnerJoin"]["expect_rows"]
+    assert stats["positions"] == 10 and stats["link_count"] == 0
+
+
+@pytest.mark.parametrize("name", ["testInnerJoinWithNullProbe", "testInnerJoinWithNullBuild", "testInnerJoinWithNullOnBothSides"])
+def test_hash_join_nulls_golden(pkg, ctx, oracle, name):
+    case = GOLD["hash_join"][name]
+    rows, _ = run_join(pkg, ctx, [pkg.Page(pkg.Block(pkg.VARCHAR, case["build"]))], [pkg.Page(pkg.Block(pkg.VARCHAR, case["probe"]))],
+                       [pkg.VARCHAR], [pkg.VARCHAR], [0], [0])
+    assert sorted(list(r) for r in rows) == sorted(case["expect_rows"])
+
+
+def test_hash_join_probe_outer_golden(pkg, ctx):
+    types = [pkg.VARCHAR, pkg.BIGINT, pkg.BIGINT]
+    b = blocks_of(pkg, types, sequence_page(types, 10, 20, 30, 40))
+    p = blocks_of(pkg, types, sequence_page(types, 15, 20, 1020, 2020))
+    rows, _ = run_join(pkg, ctx, [pkg.Page(*b)], [pkg.Page(*p)], types, types, [0], [0], join_type=pkg.PROBE_OUTER)
+    assert len(rows) == 15
+    for i, r in enumerate(rows):
+        want = (str(20 + i), 1020 + i, 2020 + i) + ((str(20 + i), 30 + i, 40 + i) if i < 10 else (None, None, None))
+        assert r == want
+
+
+@pytest.mark.parametrize("types,domains", [
+    (["BIGINT"], [(0, 2000)]),
+    (["INTEGER"], [(0, 300)]),
+    (["VARCHAR"], [(0, 400)]),
+    (["BIGINT", "VARCHAR"], [(0, 40), (0, 40)]),
+    (["DOUBLE"], [(0, 500)]),
+])
+def test_hash_join_random_vs_oracle(pkg, ctx, oracle, types, domains):
+    """duplicates on both sides, nulls, several build pages: the (probe, build) pair list must equal the Java order
+    (probe ascending, matches newest build position first)."""
+    rng = np.random.default_rng(abs(hash(tuple(types))) % 2**32)
+    tids = [getattr(pkg, t) for t in types]
+    nk = len(tids)
+    build_pages, bcols = [], [[] for _ in tids]
+    for n in (700, 1, 1500):
+        blocks = [rand_block(pkg, rng, t, n, 0.03, d) for t, d in zip(tids, domains)]
+        payload = pkg.Block(pkg.BIGINT, rng.integers(0, 10**9, n).astype(np.int64))
+        build_pages.append(pkg.Page(*(blocks + [payload])))
+    probe_blocks = [rand_block(pkg, rng, t, 5000, 0.03, d) for t, d in zip(tids, domains)]
+    probe_pay = pkg.Block(pkg.BIGINT, np.arange(5000, dtype=np.int64))
+    rows, stats = run_join(pkg, ctx, build_pages, [pkg.Page(*(probe_blocks + [probe_pay]))], tids + [pkg.BIGINT], tids + [pkg.BIGINT],
+                           list(range(nk)), list(range(nk)), out_b=[nk], out_p=[nk])
+    # oracle over the concatenated build side
+    cat = []
+    for c in range(nk + 1):
+        vals = []
+        for pg in build_pages:
+            vals.extend(pg.getBlock(c).to_list())
+        cat.append(pkg.Block((tids + [pkg.BIGINT])[c], vals))
+    ph = oracle.PagesHash([ocol(oracle, b) for b in cat[:nk]])
+    op, ob = ph.probe([ocol(oracle, b) for b in probe_blocks])
+    want = [(int(i), int(cat[nk].values[j])) for i, j in zip(op, ob)]
+    assert rows == want
+    assert stats["link_count"] == ph.link_count
+
+
+def test_hash_join_empty_sides(pkg, ctx):
+    rows, stats = run_join(pkg, ctx, [], [pkg.Page(pkg.Block(pkg.BIGINT, np.arange(10, dtype=np.int64)))], [pkg.BIGINT], [pkg.BIGINT], [0], [0])
+    assert rows == [] and stats["positions"] == 0
+    rows, _ = run_join(pkg, ctx, [], [pkg.Page(pkg.Block(pkg.BIGINT, np.arange(3, dtype=np.int64)))], [pkg.BIGINT], [pkg.BIGINT], [0], [0], join_type=pkg.PROBE_OUTER)
+    assert rows == [(0, None), (1, None), (2, None)]
+    rows, _ = run_join(pkg, ctx, [pkg.Page(pkg.Block(pkg.BIGINT, np.arange(3, dtype=np.int64)))], [], [pkg.BIGINT], [pkg.BIGINT], [0], [0])
+    assert rows == []
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# filter + project
+# ---------------------------------------------------------------------------------------------------------------------
+def run_fp(pkg, ctx, pages, types, filt, projs):
+    f = pkg.FilterAndProjectOperatorFactory(ctx, 0, types, filt, projs)
+    op = f.createOperator()
+    out = pkg.to_pages(op, pages)
+    op.close()
+    return f, out
+
+
+def oracle_fp(pkg, oracle, factory, page):
+    prog = factory.program
+    cols = [ocol(oracle, b) for b in page.blocks]
+    pos = oracle.filter_positions(prog.nodes, prog.filter_root, bytes(prog.pool), cols) if prog.filter_root >= 0 else np.arange(page.position_count, dtype=np.int32)
+    outs = []
+    for r in prog.projection_roots:
+        if prog.nodes[r]["kind"] == 0:  # identity projection
+            vals = page.getBlock(prog.nodes[r]["op"]).flatten().to_list()
+            outs.append([vals[i] for i in pos])
+        else:
+            v, nl = oracle.project(prog.nodes, r, bytes(prog.pool), cols, pos)
+            t = prog.nodes[r]["type"]
+            conv = float if t == pkg.DOUBLE else (bool if t == pkg.BOOLEAN else int)
+            outs.append([None if nl[i] else conv(v[i]) for i in range(len(pos))])
+    return pos, outs
+
+
+def test_filter_project_cfg2_shape(pkg, ctx, oracle):
+    # BASELINE config 2 at test size: col0 > 899 (10 %), project col1 * col2, input order preserved
+    rng = np.random.default_rng(42)
+    n = 300_000
+    cols = [rng.integers(0, 1000, n), rng.integers(0, 2**20, n), rng.integers(0, 2**20, n)]
+    page = pkg.Page(*[pkg.Block(pkg.BIGINT, c.astype(np.int64)) for c in cols])
+    f = pkg.field
+    fac, out = run_fp(pkg, ctx, [page], [pkg.BIGINT] * 3, f(0, pkg.BIGINT) > 899, [f(1, pkg.BIGINT) * f(2, pkg.BIGINT), f(0, pkg.BIGINT)])
+    pos, want = oracle_fp(pkg, oracle, fac, page)
+    assert len(out) == 1 and out[0].position_count == len(pos)
+    assert np.array_equal(out[0].getBlock(0).values, np.array(want[0], dtype=np.int64))
+    assert np.array_equal(out[0].getBlock(1).values, cols[0][pos])
+
+
+def test_filter_project_null_protocol_and_short_circuit(pkg, ctx, oracle):
+    rng = np.random.default_rng(7)
+    n = 20_000
+    T = [pkg.BIGINT, pkg.BIGINT, pkg.DOUBLE, pkg.DATE, pkg.BOOLEAN, pkg.VARCHAR, pkg.INTEGER]
+    doms = [(-50, 50), (-3, 4), None, (9000, 9100), None, (0, 5), (-100, 100)]
+    page = pkg.Page(*[rand_block(pkg, rng, t, n, 0.15, d) for t, d in zip(T, doms)])
+    f, c = pkg.field, pkg.constant
+    a, b, d, dt, bo, s, i = (f(k, t) for k, t in enumerate(T))
+    cases = [
+        (pkg.and_(a > 0, b.ne(0)), [a / b, a % b, a + b, a - b, -a]),
+        (pkg.or_(a < -10, pkg.and_(bo, dt <= 9050)), [d * (c(1.0, pkg.DOUBLE) - d), d / c(0.0, pkg.DOUBLE), pkg.cast(a, pkg.DOUBLE) + d]),
+        (pkg.or_(pkg.is_null(a), s.eq("k3")), [pkg.coalesce(a, b, c(7, pkg.BIGINT)), pkg.if_(bo, a, b), i * i + i, pkg.cast(i, pkg.BIGINT) * a]),
+        (pkg.between(a, -5, b), [pkg.not_(bo), a.eq(b), d < c(0.5, pkg.DOUBLE), s < c("k2", pkg.VARCHAR), s, dt]),
+        (pkg.and_(pkg.or_(b.eq(0), (a / b) > 1), pkg.not_(pkg.is_null(d))), [a]),   # division guarded by the short circuit
+        (None, [a + c(1, pkg.BIGINT), s, pkg.and_(bo, pkg.is_null(a)), c(None, pkg.BIGINT) + a]),
+        (c(None, pkg.BOOLEAN), [a]),
+    ]
+    for filt, projs in cases:
+        fac, out = run_fp(pkg, ctx, [page], T, filt, projs)
+        pos, want = oracle_fp(pkg, oracle, fac, page)
+        if len(pos) == 0:
+            assert out == []
+            continue
+        got = out[0]
+        assert got.position_count == len(pos)
+        for k in range(len(projs)):
+            g = got.getBlock(k).to_list()
+            w = want[k]
+            if projs[k].type == pkg.DOUBLE:
+                gi = [None if x is None else np.float64(x).view(np.int64) for x in g]
+                wi = [None if x is None else np.float64(x).view(np.int64) for x in w]
+                nan_ok = all((x is None) == (y is None) and (x == y or (np.isnan(np.int64(x).view(np.float64)) and np.isnan(np.int64(y).view(np.float64))))
+                             for x, y in zip(gi, wi) if not (x is None and y is None))
+                assert nan_ok, k
+            else:
+                assert g == w, k
+
+
+def test_filter_project_errors_only_on_selected_rows(pkg, ctx, oracle):
+    # multiplyExact overflow is raised only for rows the filter selects (PageProcessor.java:120-136)
+    a = np.array([1, 2**62, 3, 2**62], dtype=np.int64)
+    sel = np.array([1, 0, 1, 0], dtype=np.int64)
+    page = pkg.Page(pkg.Block(pkg.BIGINT, a), pkg.Block(pkg.BIGINT, sel))
+    f = pkg.field
+    fac, out = run_fp(pkg, ctx, [page], [pkg.BIGINT] * 2, f(1, pkg.BIGINT).eq(1), [f(0, pkg.BIGINT) * 4])
+    assert out[0].getBlock(0).to_list() == [4, 12]
+    with pytest.raises(pkg.TgpuError) as e:
+        run_fp(pkg, ctx, [page], [pkg.BIGINT] * 2, f(1, pkg.BIGINT).eq(0), [f(0, pkg.BIGINT) * 4])
+    assert e.value.code == -2
+    with pytest.raises(oracle.OracleError) as oe:
+        prog = pkg.expressions.FlatProgram(f(1, pkg.BIGINT).eq(0), [f(0, pkg.BIGINT) * 4])
+        cols = [ocol(oracle, b) for b in page.blocks]
+        oracle.project(prog.nodes, prog.projection_roots[0], b"", cols, oracle.filter_positions(prog.nodes, prog.filter_root, b"", cols))
+    assert oe.value.code == -2
+    with pytest.raises(pkg.TgpuError) as e:
+        run_fp(pkg, ctx, [page], [pkg.BIGINT] * 2, (f(0, pkg.BIGINT) / (f(1, pkg.BIGINT) - 1)) > 0, [])
+    assert e.value.code == -7
+
+
+def test_filter_project_select_all_none_and_encodings(pkg, ctx):
+    f = pkg.field
+    blk = pkg.Block(pkg.BIGINT, np.arange(1000, dtype=np.int64))
+    dic = pkg.DictionaryBlock(pkg.Block(pkg.VARCHAR, ["x", "y", None]), np.arange(1000, dtype=np.int32) % 3)
+    page = pkg.Page(blk, dic)
+    _, out = run_fp(pkg, ctx, [page], [pkg.BIGINT, pkg.VARCHAR], f(0, pkg.BIGINT) >= 0, [f(1, pkg.VARCHAR), f(0, pkg.BIGINT) + 1])
+    assert out[0].position_count == 1000 and out[0].getBlock(0).to_list()[:4] == ["x", "y", None, "x"]
+    _, out = run_fp(pkg, ctx, [page], [pkg.BIGINT, pkg.VARCHAR], f(0, pkg.BIGINT) < 0, [f(0, pkg.BIGINT)])
+    assert out == []
+    _, out = run_fp(pkg, ctx, [page, pkg.Page(pkg.Block(pkg.BIGINT, []), pkg.Block(pkg.VARCHAR, []))], [pkg.BIGINT, pkg.VARCHAR], f(1, pkg.VARCHAR).eq("y"), [])
+    assert len(out) == 1 and out[0].position_count == 333 and out[0].getChannelCount() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# K10 partition
+# ---------------------------------------------------------------------------------------------------------------------
+def test_partition_page_vs_oracle(pkg, ctx, oracle):
+    rng = np.random.default_rng(3)
+    n = 40_000
+    blocks = [rand_block(pkg, rng, pkg.BIGINT, n, 0.02, (0, 10**6)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.02, (0, 50)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.1)]
+    page = pkg.Page(*blocks)
+    for parts in (1, 2, 8, 7):
+        counts, out = ctx.partition_page(page, [0, 1], parts)
+        host = out.to_host()
+        out.release()
+        raw = oracle.hash_rows([ocol(oracle, blocks[0]), ocol(oracle, blocks[1])])
+        pid = oracle.partition_remote(raw, parts)
+        order = np.argsort(pid, kind="stable")
+        assert list(counts) == [int((pid == p).sum()) for p in range(parts)]
+        rows = page.rows()
+        assert host.rows() == [rows[i] for i in order]
