@@ -252,10 +252,21 @@ def test_hash_aggregation_partial_final(pkg, ctx, oracle):
     a = {r[0]: r[1:] for r in single}
     b = {r[0]: r[1:] for r in final}
     assert a.keys() == b.keys()
+    # per-group sum of |v|: the partial sums cross the partial/final boundary as ROUNDED doubles (LongDoubleState), so the
+    # two-level result may differ from the single-level exact sum by eps * sum|v| (one rounding per partial, with cancellation)
+    abs_sum = {}
+    for pg in pages:
+        ks, ds, ls = pg.getBlock(0).to_list(), pg.getBlock(1).to_list(), pg.getBlock(2).to_list()
+        for k, d, l in zip(ks, ds, ls):
+            e = abs_sum.setdefault(k, [0.0, 0.0])
+            e[0] += abs(d) if d is not None else 0.0
+            e[1] += abs(l) if l is not None else 0.0
+    eps = np.finfo(np.float64).eps
     for k in a:
-        assert a[k][0] == b[k][0] and a[k][3] == b[k][3] and a[k][5] == b[k][5]
-        # sums cross the partial/final boundary as rounded doubles (LongDoubleState), so <= 1 ULP per partial
-        assert ulp_diff([a[k][1], a[k][2], a[k][4]], [b[k][1], b[k][2], b[k][4]]).max() <= 2
+        assert a[k][0] == b[k][0] and a[k][3] == b[k][3] and a[k][5] == b[k][5]   # counts and bigint sums: exact
+        assert abs(a[k][1] - b[k][1]) <= 2 * eps * abs_sum[k][0]
+        assert abs(a[k][2] - b[k][2]) <= 2 * eps * abs_sum[k][0] / max(a[k][5], 1) + abs(a[k][2]) * eps
+        assert abs(a[k][4] - b[k][4]) <= 2 * eps * abs_sum[k][1] / max(a[k][5], 1) + abs(a[k][4]) * eps
 
 
 def test_global_aggregation_and_default_output(pkg, ctx):
