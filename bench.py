@@ -1,0 +1,489 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the operator hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload at N=1 (BASELINE.json configs[3], the one the metric is quoted on): the TPCH-SF100 Q3 operator pipeline on
+synthetic, seeded, device-resident TPCH-shaped columns --
+    customer : FilterAndProject(mktsegment = 'BUILDING')                      -> HashBuilder(custkey)
+    orders   : FilterAndProject(orderdate < 1995-03-15) -> LookupJoin(custkey) -> HashBuilder(orderkey)
+    lineitem : FilterAndProject(shipdate > 1995-03-15, ep*(1-disc))           -> LookupJoin(orderkey)
+               -> HashAggregation(orderkey, orderdate, shippriority; sum(revenue))
+A "step" is one pass of that whole pipeline (both builds + both probes + filters + the final aggregation).
+`value` = lineitem rows entering the lineitem join probe / step time (probe rows/s of the whole job, inputs resident in HBM).
+The same JSON line carries `q1` (BASELINE configs[2]: SF100 Q1 filter/project + hash aggregation, input rows/s) and `cfg2`
+(configs[1]: 100 M-row BIGINT filter+project), a `roofline` object for the dominant kernel (HIP-event timed, algorithmic bytes
+per DESIGN.md) and a `cpu_baseline` object (the C oracle = a row-at-a-time port of the Java operators, 1 core, bounded sample).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+SEED = 42
+M64 = (1 << 64) - 1
+
+
+def s64(x):
+    x &= M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+def lsr(z, k):
+    return (z >> k) & ((1 << (64 - k)) - 1)
+
+
+def splitmix64(x):
+    """counter-based generator: identical on CPU and GPU, int64 wrap-around arithmetic"""
+    z = x + s64(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * s64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * s64(0x94D049BB133111EB)
+    return z ^ lsr(z, 31)
+
+
+def rnd(col, idx, mod):
+    """uniform integer in [0, mod) for (column id, row index tensor)"""
+    z = splitmix64(idx ^ s64(SEED ^ ((col * 0x9E3779B97F4A7C15) & M64)))
+    return lsr(z, 1) % mod
+
+
+D_1995_03_15 = 9204
+SEGMENTS = [b"AUTOMOBILE", b"BUILDING", b"FURNITURE", b"HOUSEHOLD", b"MACHINERY"]
+
+
+def varchar_from_ids(ids, table, dev):
+    lens = torch.tensor([len(s) for s in table], dtype=torch.int64, device=dev)
+    width = max(len(s) for s in table)
+    tab = torch.zeros((len(table), width), dtype=torch.uint8, device=dev)
+    for i, s in enumerate(table):
+        tab[i, : len(s)] = torch.tensor(list(s), dtype=torch.uint8)
+    rl = lens[ids]
+    offsets = torch.zeros(ids.numel() + 1, dtype=torch.int32, device=dev)
+    offsets[1:] = torch.cumsum(rl, 0).to(torch.int32)
+    row = torch.repeat_interleave(torch.arange(ids.numel(), device=dev), rl)
+    pos = torch.arange(row.numel(), device=dev) - offsets[:-1].to(torch.int64)[row]
+    data = tab[ids[row], pos].contiguous()
+    return data, offsets
+
+
+def gen_q3(dev, sf, rank=0):
+    base = rank * 1_000_003
+    n_c = int(150_000 * sf)
+    n_o = int(1_500_000 * sf)
+    t = {}
+    ci = torch.arange(n_c, device=dev, dtype=torch.int64)
+    t["c_custkey"] = ci + 1
+    t["c_seg_bytes"], t["c_seg_off"] = varchar_from_ids(rnd(1, ci + base, 5), SEGMENTS, dev)
+    oi = torch.arange(n_o, device=dev, dtype=torch.int64)
+    t["o_orderkey"] = (oi // 8) * 32 + (oi % 8) + 1
+    t["o_custkey"] = rnd(2, oi + base, n_c) + 1
+    t["o_orderdate"] = (8035 + rnd(3, oi + base, 2406)).to(torch.int32)
+    t["o_shippriority"] = torch.zeros(n_o, dtype=torch.int32, device=dev)
+    cnt = 1 + rnd(4, oi + base, 7)
+    lo = torch.repeat_interleave(oi, cnt)
+    li = torch.arange(lo.numel(), device=dev, dtype=torch.int64)
+    t["l_orderkey"] = t["o_orderkey"][lo]
+    t["l_shipdate"] = (t["o_orderdate"][lo].to(torch.int64) + 1 + rnd(5, li + base, 121)).to(torch.int32)
+    qty = (1 + rnd(6, li + base, 50)).to(torch.float64)
+    t["l_extendedprice"] = qty * ((90000 + rnd(7, li + base, 120001)).to(torch.float64) / 100.0)
+    t["l_discount"] = rnd(8, li + base, 11).to(torch.float64) / 100.0
+    del lo, li, qty, cnt
+    return t
+
+
+def gen_q1(dev, n, rank=0):
+    base = rank * 1_000_003
+    i = torch.arange(n, device=dev, dtype=torch.int64)
+    r = rnd(11, i + base, 10000)
+    rf = torch.where(r < 2460, 65, torch.where(r < 7535, 78, 82)).to(torch.uint8)      # A / N / R
+    ls = torch.where((r >= 2525) & (r < 7535), 79, 70).to(torch.uint8)                 # O / F
+    t = {"returnflag": rf, "linestatus": ls, "off": torch.arange(n + 1, device=dev, dtype=torch.int32)}
+    qty = (1 + rnd(12, i + base, 50)).to(torch.float64)
+    t["quantity"] = qty
+    t["extendedprice"] = qty * ((90000 + rnd(13, i + base, 120001)).to(torch.float64) / 100.0)
+    t["discount"] = rnd(14, i + base, 11).to(torch.float64) / 100.0
+    t["tax"] = rnd(15, i + base, 9).to(torch.float64) / 100.0
+    t["shipdate"] = (8036 + rnd(16, i + base, 2526)).to(torch.int32)
+    return t
+
+
+class Bench:
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", device_id=self.dev)
+            self.dist = dist
+        else:
+            self.dist = None
+        self.pkg = importlib.import_module("presto-1_amd")
+        self.entry = importlib.import_module("__graft_entry__")
+        self.ctx = self.pkg.Context(self.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+    # -- helpers ------------------------------------------------------------------------------------------------------
+    def dblock(self, type_id, values, offsets=None):
+        n = values.numel() if offsets is None else offsets.numel() - 1
+        return self.pkg.DeviceBlock(type_id, n, values, None, offsets)
+
+    def barrier_sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        self.ctx.profile_reset()
+        self.barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        self.barrier_sync()
+        dt = time.perf_counter() - t0
+        if self.dist is not None:
+            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt / steps, self.ctx.profile()
+
+    def drive(self, op, page):
+        """one page through one operator (Driver.processInternal for a single hop); returns device output pages"""
+        outs = []
+        assert op.needsInput()
+        op.addInput(page)
+        o = op.getOutput()
+        if o is not None:
+            outs.append(o)
+        return outs
+
+    def finish(self, op):
+        outs = []
+        op.finish()
+        while not op.isFinished():
+            o = op.getOutput()
+            if o is not None:
+                outs.append(o)
+            elif op.isBlocked():
+                break
+        return outs
+
+    # -- Q3 -----------------------------------------------------------------------------------------------------------
+    def setup_q3(self, sf):
+        p = self.pkg
+        self.q3 = gen_q3(self.dev, sf, self.rank)
+        pp = self.entry.bench_page_processors(p)
+        B, D, DT, V, I = p.BIGINT, p.DOUBLE, p.DATE, p.VARCHAR, p.INTEGER
+        self.q3_fac = {
+            "cust_fp": p.FilterAndProjectOperatorFactory(self.ctx, 0, *pp["q3_customer"]),
+            "ord_fp": p.FilterAndProjectOperatorFactory(self.ctx, 1, *pp["q3_orders"]),
+            "li_fp": p.FilterAndProjectOperatorFactory(self.ctx, 2, *pp["q3_lineitem"]),
+        }
+        t = self.q3
+        self.q3_pages = {
+            "customer": p.Page(self.dblock(B, t["c_custkey"]), self.dblock(V, t["c_seg_bytes"], t["c_seg_off"])),
+            "orders": p.Page(self.dblock(B, t["o_orderkey"]), self.dblock(B, t["o_custkey"]), self.dblock(DT, t["o_orderdate"]), self.dblock(I, t["o_shippriority"])),
+            "lineitem": p.Page(self.dblock(B, t["l_orderkey"]), self.dblock(D, t["l_extendedprice"]), self.dblock(D, t["l_discount"]), self.dblock(DT, t["l_shipdate"])),
+        }
+        self.q3_stats = {}
+
+    def step_q3(self):
+        p, ctx, f, pages = self.pkg, self.ctx, self.q3_fac, self.q3_pages
+        B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
+        st = self.q3_stats
+        # customer: filter -> build
+        cb = p.HashBuilderOperatorFactory(ctx, 10, [B], [], [0])
+        cbuild = cb.createOperator()
+        op = f["cust_fp"].createOperator()
+        for o in self.drive(op, pages["customer"]):
+            st["customer_build_rows"] = o.position_count
+            cbuild.addInput(o.as_device_page())
+            o.release()
+        cbuild.finish()
+        # orders: filter -> probe customer -> build on orderkey (output orderdate, shippriority)
+        oj = p.LookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, [B, B, DT, I], [1], probe_output_channels=[0, 2, 3])
+        ob = p.HashBuilderOperatorFactory(ctx, 12, [B, DT, I], [1, 2], [0])
+        obuild = ob.createOperator()
+        ojoin = oj.createOperator()
+        op = f["ord_fp"].createOperator()
+        for o in self.drive(op, pages["orders"]):
+            st["orders_probe_rows"] = o.position_count
+            for j in self.drive(ojoin, o.as_device_page()):
+                st["orders_build_rows"] = j.position_count
+                obuild.addInput(j.as_device_page())
+                j.release()
+            o.release()
+        obuild.finish()
+        ojoin.close()
+        # lineitem: filter/project -> probe orders -> aggregate
+        lj = p.LookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, [B, D], [0], probe_output_channels=[0, 1])
+        agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
+        ljoin = lj.createOperator()
+        aop = agg.createOperator()
+        op = f["li_fp"].createOperator()
+        for o in self.drive(op, pages["lineitem"]):
+            st["lineitem_probe_rows"] = o.position_count
+            for j in self.drive(ljoin, o.as_device_page()):
+                st["lineitem_join_rows"] = j.position_count
+                aop.addInput(j.as_device_page())
+                j.release()
+            o.release()
+        outs = self.finish(aop)
+        st["groups"] = sum(o.position_count for o in outs)
+        self.q3_result = outs
+        ljoin.close()
+        cbuild.close()
+        obuild.close()
+        aop.close()
+
+    def check_q3(self):
+        """size-independent checks at full size, computed independently with torch on the same device data"""
+        t = self.q3
+        cust_ok = torch.zeros(t["c_custkey"].numel() + 2, dtype=torch.bool, device=self.dev)
+        seg = t["c_seg_bytes"][t["c_seg_off"][:-1].to(torch.int64)]                       # first byte: 'B' only for BUILDING
+        cust_ok[t["c_custkey"]] = seg == ord("B")
+        o_ok = (t["o_orderdate"] < D_1995_03_15) & cust_ok[t["o_custkey"]]
+        ok_by_key = torch.zeros(int(t["o_orderkey"].max().item()) + 2, dtype=torch.bool, device=self.dev)
+        ok_by_key[t["o_orderkey"]] = o_ok
+        l_probe = t["l_shipdate"] > D_1995_03_15
+        l_ok = l_probe & ok_by_key[t["l_orderkey"]]
+        rev = (t["l_extendedprice"] * (1.0 - t["l_discount"]))[l_ok]
+        want = {
+            "customer_build_rows": int((seg == ord("B")).sum().item()),
+            "orders_probe_rows": int((t["o_orderdate"] < D_1995_03_15).sum().item()),
+            "orders_build_rows": int(o_ok.sum().item()),
+            "lineitem_probe_rows": int(l_probe.sum().item()),
+            "lineitem_join_rows": int(l_ok.sum().item()),
+            "groups": int(torch.unique(t["l_orderkey"][l_ok]).numel()),
+        }
+        got = {k: self.q3_stats.get(k) for k in want}
+        ok = got == want
+        # checksum of checksums: the sum over all groups of sum(revenue) (exact per group on the GPU) vs torch's float64 sum
+        total = 0.0
+        for o in self.q3_result:
+            host = o.to_host()
+            total += float(np.sum(host.getBlock(3).values))
+        ref = float(rev.sum().item())
+        rel = abs(total - ref) / max(abs(ref), 1.0)
+        return {"counts_match": ok, "got": got, "want": want, "revenue_rel_err": rel, "ok": bool(ok and rel < 1e-9)}
+
+    # -- Q1 -----------------------------------------------------------------------------------------------------------
+    def setup_q1(self, n):
+        p = self.pkg
+        t = self.q1 = gen_q1(self.dev, n, self.rank)
+        pp = self.entry.bench_page_processors(p)
+        V, D, DT = p.VARCHAR, p.DOUBLE, p.DATE
+        self.q1_fp = p.FilterAndProjectOperatorFactory(self.ctx, 20, *pp["q1"])
+        self.q1_page = p.Page(self.dblock(V, t["returnflag"], t["off"]), self.dblock(V, t["linestatus"], t["off"]), self.dblock(D, t["quantity"]),
+                              self.dblock(D, t["extendedprice"]), self.dblock(D, t["discount"]), self.dblock(D, t["tax"]), self.dblock(DT, t["shipdate"]))
+        # HandTpchQuery1.java:109-130: sum(qty), sum(price), sum(disc_price), sum(charge), avg(qty), avg(price), avg(disc), count(*)
+        aggs = [(p.SUM_DOUBLE, 2), (p.SUM_DOUBLE, 3), (p.SUM_DOUBLE, 5), (p.SUM_DOUBLE, 6), (p.AVG_DOUBLE, 2), (p.AVG_DOUBLE, 3), (p.AVG_DOUBLE, 4), (p.COUNT_ALL, -1)]
+        self.q1_agg = p.HashAggregationOperatorFactory(self.ctx, 21, [V, V], [0, 1], aggs, expected_groups=16)
+
+    def step_q1(self):
+        op = self.q1_fp.createOperator()
+        aop = self.q1_agg.createOperator()
+        for o in self.drive(op, self.q1_page):
+            self.q1_rows_after_filter = o.position_count
+            aop.addInput(o.as_device_page())
+            o.release()
+        outs = self.finish(aop)
+        self.q1_result = [o.to_host().rows() for o in outs]
+        aop.close()
+
+    def check_q1(self):
+        t = self.q1
+        sel = t["shipdate"] <= 10471
+        rows = [r for pg in self.q1_result for r in pg]
+        ok = len(rows) == 4
+        want = {}
+        for rf, ls in ((65, 70), (78, 70), (78, 79), (82, 70)):
+            m = sel & (t["returnflag"] == rf) & (t["linestatus"] == ls)
+            q, e, d, x = t["quantity"][m], t["extendedprice"][m], t["discount"][m], t["tax"][m]
+            want[(chr(rf), chr(ls))] = (float(q.sum()), float(e.sum()), float((e * (1 - d)).sum()), float((e * (1 - d) * (1 + x)).sum()), int(m.sum()))
+        worst = 0.0
+        for r in rows:
+            w = want.get((r[0], r[1]))
+            if w is None:
+                ok = False
+                continue
+            ok = ok and r[9] == w[4]
+            for g, v in zip(r[2:6], w[:4]):
+                worst = max(worst, abs(g - v) / max(abs(v), 1.0))
+        # first-seen group order must equal the order in which the four combos first appear among the selected rows
+        first = {}
+        idx = torch.nonzero(sel)[:4096, 0]
+        for i in idx.tolist():
+            k = (chr(int(t["returnflag"][i])), chr(int(t["linestatus"][i])))
+            first.setdefault(k, len(first))
+            if len(first) == 4:
+                break
+        order_ok = [(r[0], r[1]) for r in rows] == sorted(first, key=first.get) if len(first) == 4 else True
+        return {"groups": len(rows), "sum_rel_err_vs_torch": worst, "group_order_ok": bool(order_ok), "ok": bool(ok and order_ok and worst < 1e-9)}
+
+    # -- cfg2 ---------------------------------------------------------------------------------------------------------
+    def setup_cfg2(self, n):
+        p = self.pkg
+        i = torch.arange(n, device=self.dev, dtype=torch.int64)
+        self.c2 = [rnd(21, i, 1000), rnd(22, i, 1 << 20), rnd(23, i, 1 << 20)]
+        self.c2_fp = p.FilterAndProjectOperatorFactory(self.ctx, 30, *self.entry.bench_page_processors(p)["cfg2"])
+        self.c2_page = p.Page(*[self.dblock(p.BIGINT, c) for c in self.c2])
+
+    def step_cfg2(self):
+        op = self.c2_fp.createOperator()
+        outs = self.drive(op, self.c2_page)
+        self.c2_out = outs
+
+    def check_cfg2(self):
+        o = self.c2_out[0]
+        want = (self.c2[1] * self.c2[2])[self.c2[0] > 899]
+        host = o.to_host().getBlock(0).values
+        return {"rows": int(want.numel()), "ok": bool(np.array_equal(host, want.cpu().numpy()))}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (row-at-a-time C port of the Java operators) on a bounded sample of the Q3 workload, 1 core
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(bench, sample_sf):
+    from oracle import oracle
+    t = gen_q3(bench.dev, sample_sf, 0)
+    h = {k: v.cpu().numpy() for k, v in t.items()}
+    del t
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    seg_first = h["c_seg_bytes"][h["c_seg_off"][:-1]]
+    ck = h["c_custkey"][seg_first == ord("B")]
+    cust = oracle.PagesHash([oracle.Col(oracle.BIGINT, ck)])
+    om = h["o_orderdate"] < D_1995_03_15
+    o_key, o_cust = h["o_orderkey"][om], h["o_custkey"][om]
+    op, ob = cust.probe([oracle.Col(oracle.BIGINT, o_cust)])
+    okeys = o_key[op]
+    orders = oracle.PagesHash([oracle.Col(oracle.BIGINT, okeys)])
+    lm = h["l_shipdate"] > D_1995_03_15
+    lk = h["l_orderkey"][lm]
+    rev = (h["l_extendedprice"] * (1.0 - h["l_discount"]))[lm]
+    lp, lb = orders.probe([oracle.Col(oracle.BIGINT, lk)])
+    g = oracle.BigintGroupByHash(1 << 16)
+    gids = g.get_group_ids(oracle.Col(oracle.BIGINT, lk[lp]))
+    oracle.agg_double_sum(gids, rev[lp], g.group_count)
+    dt = time.perf_counter() - t0
+    return {"value": float(len(lk) / dt), "unit": "probe rows/s", "cores": 1, "kind": "port",
+            "sample": f"same Q3 pipeline at SF{sample_sf:g} ({len(lk)} lineitem probe rows, {len(okeys)} build rows): C oracle = row-at-a-time port of "
+                      f"PagesHash/JoinHash/BigintGroupByHash/DoubleSum, numpy filters, 1 thread, {dt:.1f} s; reference Java operators not runnable: no JVM"}
+
+
+def dominant(profile, rows_by_kernel, bytes_per_row):
+    best = None
+    for name, st in profile.items():
+        if name not in bytes_per_row or st["count"] == 0:
+            continue
+        if best is None or st["total_ms"] > profile[best]["total_ms"]:
+            best = name
+    if best is None:
+        return None
+    st = profile[best]
+    avg_ms = st["total_ms"] / st["count"]
+    alg_bytes = bytes_per_row[best] * rows_by_kernel[best]
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "avg_launch_ms": avg_ms, "launches": st["count"], "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_per_row": bytes_per_row[best], "rows_per_launch": rows_by_kernel[best]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sf", type=float, default=100.0, help="TPCH scale factor per GPU")
+    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2 (default: all at N=1, q3 only at N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-sf", type=float, default=4.0)
+    args = ap.parse_args()
+    b = Bench(args)
+    assert b.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={b.world}"
+    only = set(args.only.split(",")) if args.only else ({"q3", "q1", "cfg2"} if b.world == 1 else {"q3"})
+    b.ctx.profile_enable(True)
+    out = {}
+    extra = {}
+
+    # ---- Q3 (headline) ----
+    b.setup_q3(args.sf)
+    step_s, prof = b.timed(b.step_q3, args.steps, args.warmup)
+    st = dict(b.q3_stats)
+    probe_rows = st["lineitem_probe_rows"]
+    total_probe = probe_rows
+    if b.dist is not None:
+        tt = torch.tensor([probe_rows], device=b.dev, dtype=torch.int64)
+        b.dist.all_reduce(tt)
+        total_probe = int(tt.item())
+    q3_check = b.check_q3()
+    # per-kernel algorithmic bytes per row (DESIGN.md "kernels and their rooflines")
+    bytes_per_row = {"join_probe_count": 40.0, "join_gather": 0.0, "filter_project_emit": 0.0, "gbh_insert": 0.0}
+    rows_by = {"join_probe_count": 0}
+    # the probe kernel runs twice per step (orders probe + lineitem probe): rows per launch = average over the two launches
+    rows_by["join_probe_count"] = (st["lineitem_probe_rows"] + st["orders_probe_rows"]) / 2.0
+    roof = dominant(prof, rows_by, {"join_probe_count": 40.0})
+    out.update({
+        "metric": "probe_rows_per_sec", "value": total_probe / step_s, "unit": "rows/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
+        "config": {"workload": "tpch_q3_hash_join_build_probe_agg (BASELINE configs[3])", "scale_factor_per_gpu": args.sf, "seed": SEED,
+                   "lineitem_rows": int(b.q3["l_orderkey"].numel()), "orders_rows": int(b.q3["o_orderkey"].numel()), "customer_rows": int(b.q3["c_custkey"].numel()),
+                   "lineitem_probe_rows": probe_rows, "orders_build_rows": st["orders_build_rows"], "join_output_rows": st["lineitem_join_rows"],
+                   "groups": st["groups"], "parallelism": f"shard{b.world}"},
+        "roofline": roof, "checks": {"q3": q3_check},
+    })
+    extra["q3_kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+    b.q3_result = None
+    del b.q3, b.q3_pages
+    torch.cuda.empty_cache()
+
+    if "q1" in only:
+        n = int(6_000_379.02 * args.sf)
+        b.setup_q1(n)
+        s1, p1 = b.timed(b.step_q1, args.steps, args.warmup)
+        out["q1"] = {"metric": "input_rows_per_sec", "value": n / s1, "unit": "rows/s", "ms_per_step": s1 * 1e3, "rows": n,
+                     "rows_after_filter": b.q1_rows_after_filter, "workload": "tpch_q1_filter_project_hash_aggregation (BASELINE configs[2])",
+                     "algorithmic_bytes_per_row": 46.0, "achieved_gbps_whole_step": 46.0 * n / s1 / 1e9, "frac_of_8TBps": 46.0 * n / s1 / 8e12,
+                     "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])}}
+        out["checks"]["q1"] = b.check_q1()
+        del b.q1, b.q1_page
+        b.q1_result = None
+        torch.cuda.empty_cache()
+
+    if "cfg2" in only:
+        n2 = int(1_000_000 * args.sf)
+        b.setup_cfg2(n2)
+        s2, p2 = b.timed(b.step_cfg2, args.steps, args.warmup)
+        out["cfg2"] = {"metric": "input_rows_per_sec", "value": n2 / s2, "unit": "rows/s", "ms_per_step": s2 * 1e3, "rows": n2,
+                       "workload": "bigint_filter_project_sel10 (BASELINE configs[1])", "algorithmic_bytes_per_row": 10.4,
+                       "achieved_gbps_whole_step": 10.4 * n2 / s2 / 1e9, "frac_of_8TBps": 10.4 * n2 / s2 / 8e12,
+                       "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p2.items(), key=lambda kv: -kv[1]["total_ms"])}}
+        out["checks"]["cfg2"] = b.check_cfg2()
+        del b.c2, b.c2_page
+        b.c2_out = None
+        torch.cuda.empty_cache()
+
+    if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(b, args.cpu_sample_sf)
+    out.update(extra)
+    if b.rank == 0:
+        print(json.dumps(out))
+    if b.dist is not None:
+        b.dist.barrier()
+        b.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

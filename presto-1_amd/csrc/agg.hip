@@ -2,6 +2,9 @@
 #include "agg.h"
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace tgpu {
 
 namespace {
@@ -96,6 +99,122 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
             case TGPU_AGG_AVG_DOUBLE: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input)[r]); break;
             case TGPU_AGG_AVG_BIGINT: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], (double)((const long long *)a.input)[r]); break;
             default: break;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Low-cardinality path (TPCH Q1: 4 groups x 8 aggregates over 600 M rows).  With a handful of groups every lane of the
+// chip would hammer the same few accumulators, so the accumulators are privatised PER LANE in LDS:
+//     slot(g, a, lane) -> { hi, lo } double-double running sum (two-sum: the pair carries ~106 bits) + uint32 count
+// laid out [g][a][256 lanes] so a wave's access is 64 consecutive 8-byte words (conflict-free, no atomics, and the order
+// in which a lane adds its rows is fixed -> deterministic).  At the end of the block the 256 lane partials of each (g, a)
+// are folded with double-double adds and lane 0 of each wave adds the (hi, lo) pair EXACTLY into the global limb
+// accumulator, so both paths feed the same state and the final rounding is still the exact sum's.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LowCardPlan {
+    int32_t n_aggs;
+    int32_t n_wide;                 // aggregates with a 16-byte state (double sums, bigint sums)
+    int32_t wide_slot[kMaxAggs];    // index among the wide states or -1
+    int32_t per_group_bytes;
+    int32_t n_groups;
+};
+
+__device__ __forceinline__ void dd_add(double &hi, double &lo, double h2, double l2)
+{
+    const double s = hi + h2;
+    const double bb = s - hi;
+    double e = (hi - (s - bb)) + (h2 - bb);
+    e += lo + l2;
+    hi = s + e;
+    lo = e - (hi - s);
+}
+
+__global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCardPlan plan, const int32_t *__restrict__ gids, int64_t n)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int total_words = plan.n_groups * plan.per_group_bytes / 4;
+    for (int i = tid; i < total_words; i += kBlock) ((unsigned int *)lds)[i] = 0u;
+    __syncthreads();
+    const int wide_bytes = plan.n_wide * 2 * kBlock * 8;  // per group: hi[n_wide][256], lo[n_wide][256], then cnt[n_aggs][256]
+
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + tid; r < n; r += (int64_t)gridDim.x * kBlock) {
+        const int g = gids ? gids[r] : 0;
+        unsigned char *gb = lds + (size_t)g * plan.per_group_bytes;
+        double *hi_base = (double *)gb;
+        double *lo_base = (double *)(gb + plan.n_wide * kBlock * 8);
+        unsigned int *cnt_base = (unsigned int *)(gb + wide_bytes);
+        for (int k = 0; k < args.n_aggs; k++) {
+            const AggView &a = args.a[k];
+            if (a.mask && ((a.mask_nulls && a.mask_nulls[r]) || !a.mask[r])) continue;
+            if (a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[r]) continue;
+            cnt_base[k * kBlock + tid] += 1u;
+            const int w = plan.wide_slot[k];
+            if (w < 0) continue;
+            if (a.function == TGPU_AGG_SUM_BIGINT) {
+                unsigned long long *lo64 = (unsigned long long *)&hi_base[w * kBlock + tid];
+                long long *hi64 = (long long *)&lo_base[w * kBlock + tid];
+                const long long v = ((const long long *)a.input)[r];
+                const unsigned long long old = *lo64, nw = old + (unsigned long long)v;
+                *lo64 = nw;
+                *hi64 += (v < 0 ? -1 : 0) + (nw < old ? 1 : 0);
+                continue;
+            }
+            const double v = a.function == TGPU_AGG_AVG_BIGINT ? (double)((const long long *)a.input)[r] : ((const double *)a.input)[r];
+            if (!(fabs(v) <= 1.7976931348623157e308)) {  // NaN / +-inf: flagged globally, not summed
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+                atomicOr(&a.special[g], (bits & 0xfffffffffffffULL) ? 1u : ((bits >> 63) ? 4u : 2u));
+                continue;
+            }
+            double hi = hi_base[w * kBlock + tid];
+            const double s = hi + v;
+            const double bb = s - hi;
+            const double err = (hi - (s - bb)) + (v - bb);
+            hi_base[w * kBlock + tid] = s;
+            lo_base[w * kBlock + tid] += err;
+        }
+    }
+    __syncthreads();
+    // fold the lane partials: one wave-level tree per (group, aggregate), then one exact global add per wave
+    const int lane = tid & 63;
+    for (int g = 0; g < plan.n_groups; g++) {
+        unsigned char *gb = lds + (size_t)g * plan.per_group_bytes;
+        double *hi_base = (double *)gb;
+        double *lo_base = (double *)(gb + plan.n_wide * kBlock * 8);
+        unsigned int *cnt_base = (unsigned int *)(gb + wide_bytes);
+        for (int k = 0; k < args.n_aggs; k++) {
+            const AggView &a = args.a[k];
+            unsigned long long c = cnt_base[k * kBlock + tid];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+            const bool any = __shfl(c, 0, 64) != 0;
+            if (!any) continue;
+            if (lane == 0) atomicAdd((unsigned long long *)&a.counts[g], c);
+            const int w = plan.wide_slot[k];
+            if (w < 0) continue;
+            if (a.function == TGPU_AGG_SUM_BIGINT) {
+                const unsigned long long lo64 = *(unsigned long long *)&hi_base[w * kBlock + tid];
+                const long long hi64 = *(long long *)&lo_base[w * kBlock + tid];
+                if (lo64 || hi64) {
+                    const unsigned long long old = atomicAdd(&a.i128[g * 2], lo64);
+                    const unsigned long long carry = (old + lo64) < old ? 1ULL : 0ULL;
+                    const unsigned long long add_hi = (unsigned long long)hi64 + carry;
+                    if (add_hi) atomicAdd(&a.i128[g * 2 + 1], add_hi);
+                }
+                continue;
+            }
+            double hi = hi_base[w * kBlock + tid], lo = lo_base[w * kBlock + tid];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double h2 = __shfl_down(hi, d, 64), l2 = __shfl_down(lo, d, 64);
+                dd_add(hi, lo, h2, l2);
+            }
+            if (lane == 0) {
+                kulisch_add(&a.limbs[g * kLimbs], &a.special[g], hi);
+                kulisch_add(&a.limbs[g * kLimbs], &a.special[g], lo);
             }
         }
     }
@@ -318,6 +437,28 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
         a.special = st.special ? st.special->as<unsigned int>() : nullptr;
         a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+    }
+    // low-cardinality path: lane-private LDS accumulators when all groups x states fit in one CU's LDS
+    LowCardPlan plan{};
+    plan.n_aggs = args.n_aggs;
+    for (int k = 0; k < args.n_aggs; k++) plan.wide_slot[k] = is_count(args.a[k].function) ? -1 : plan.n_wide++;
+    plan.per_group_bytes = plan.n_wide * 2 * kBlock * 8 + plan.n_aggs * kBlock * 4;
+    const int64_t groups = group_count > 0 ? group_count : 1;
+    const int64_t lds_bytes = groups * plan.per_group_bytes;
+    const bool lowcard_enabled = getenv("TGPU_DISABLE_LOWCARD") == nullptr;
+    if (lowcard_enabled && lds_bytes <= 160 * 1024 && n >= 4096) {
+        plan.n_groups = (int32_t)groups;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)agg_lowcard_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const int per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / lds_bytes));
+        int64_t blocks = std::min<int64_t>((int64_t)ctx_->cu_count() * per_cu, ceil_div(n, kBlock));
+        ProfileScope ps(ctx_, "agg_accumulate_lowcard");
+        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, plan, gids, n);
+        check_launch("agg_accumulate_lowcard");
+        return;
     }
     ProfileScope ps(ctx_, "agg_accumulate");
     agg_accumulate_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, gids, n);

@@ -521,3 +521,33 @@ def test_partition_page_vs_oracle(pkg, ctx, oracle):
         assert list(counts) == [int((pid == p).sum()) for p in range(parts)]
         rows = page.rows()
         assert host.rows() == [rows[i] for i in order]
+
+
+def test_lowcard_and_general_accumulators_agree_bitwise(pkg, oracle, monkeypatch):
+    """the lane-private LDS path (few groups) and the global-atomics path feed the same exact accumulators: identical bits"""
+    rng = np.random.default_rng(21)
+    n = 300_000
+    keys = rng.integers(0, 4, n).astype(np.int64)
+    page = pkg.Page(pkg.Block(pkg.BIGINT, keys), rand_block(pkg, rng, pkg.DOUBLE, n, 0.05), rand_block(pkg, rng, pkg.BIGINT, n, 0.05, (-10**12, 10**12)),
+                    pkg.Block(pkg.BOOLEAN, rng.integers(0, 2, n).astype(np.uint8)))
+    aggs = [(pkg.SUM_DOUBLE, 1), (pkg.AVG_DOUBLE, 1, 3), (pkg.SUM_BIGINT, 2), (pkg.AVG_BIGINT, 2), (pkg.COUNT_COLUMN, 1), (pkg.COUNT_ALL, -1, 3)]
+    results = []
+    for disable in (False, True):
+        if disable:
+            monkeypatch.setenv("TGPU_DISABLE_LOWCARD", "1")
+        c = pkg.Context(0)
+        c.profile_enable(True)
+        results.append(run_agg(pkg, c, [page], [pkg.BIGINT], [0], aggs))
+        prof = c.profile()
+        assert ("agg_accumulate_lowcard" in prof) == (not disable)
+        c.close()
+    a, b = results
+    assert len(a) == 4 and [r[0] for r in a] == [r[0] for r in b]
+    for ra, rb in zip(a, b):
+        assert ra[3] == rb[3] and ra[5] == rb[5] and ra[6] == rb[6]
+        assert ulp_diff([ra[1], ra[2], ra[4]], [rb[1], rb[2], rb[4]]).max() == 0
+    # and both equal the exact oracle
+    o = oracle.BigintGroupByHash(8)
+    gids = o.get_group_ids(oracle.Col(pkg.BIGINT, keys))
+    _, exact = oracle.agg_double_sum_exact(gids, page.getBlock(1).values, 4, nulls=page.getBlock(1).nulls)
+    assert ulp_diff([r[1] for r in a], exact).max() == 0
