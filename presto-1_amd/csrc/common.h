@@ -124,7 +124,19 @@ public:
 
     int cu_count() const { return cu_count_; }
 
+    // C-ABI handle accounting: the context outlives every factory / operator / output page created from it, whatever the
+    // order in which the caller destroys its handles (tgpu_context_destroy defers until the last handle is gone)
+    void retain_handle() { handles_++; }
+    bool release_handle() { return --handles_ == 0 && destroy_requested_; }
+    bool request_destroy()
+    {
+        destroy_requested_ = true;
+        return handles_ == 0;
+    }
+
 private:
+    int handles_ = 0;
+    bool destroy_requested_ = false;
     int device_;
     hipStream_t stream_;
     bool own_stream_ = false;

@@ -1,0 +1,54 @@
+// device_join.h -- probe-side device code shared by the AOT join kernels and the JIT-fused filter+project+probe kernels.
+// Self-contained (embedded verbatim into generated sources after device_hash.h).
+#pragma once
+
+// fast path table for a single BIGINT / INTEGER / DATE key: key stored inline, one 16-byte load per probe step
+struct TgSlot16 {
+    long long key;
+    int head;   // build position of the newest row with this key (PagesHash.key[]), -1 = empty
+    int pad;
+};
+
+// Blocked Bloom filter in front of the table: one 64-bit word per key, 4 bits set.  Sized to stay cache resident
+// (16 bits per build key), it answers most probes of keys that are NOT in the build side without touching the table.
+__device__ inline unsigned long long tg_bloom_mask(unsigned long long m)
+{
+    return (1ULL << (m & 63)) | (1ULL << ((m >> 6) & 63)) | (1ULL << ((m >> 12) & 63)) | (1ULL << ((m >> 18) & 63));
+}
+__device__ inline unsigned long long tg_bloom_word(unsigned long long m, unsigned long long word_mask) { return (m >> 24) & word_mask; }
+
+// Pre-filter in front of the table (answers "key certainly not in the build side" without touching the table):
+//   * dense key domains (TPCH keys): an exact direct-address bitmap, one bit per key value in [key_min, key_max] -- its access
+//     pattern follows the probe keys, so clustered probe keys stream through it and small domains stay L2 resident;
+//   * otherwise the blocked Bloom filter above.
+struct TgPrefilter {
+    const unsigned long long *bitmap;   // nullptr = not available
+    long long key_min, key_max;
+    const unsigned long long *bloom;    // nullptr = not available
+    unsigned long long bloom_word_mask;
+};
+
+// head build position of `key`, or -1 (PagesHash.getAddressIndex, M/operator/PagesHash.java:157-169, specialised)
+__device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long mask, const TgPrefilter &pf, long long key)
+{
+    const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(key));
+    if (pf.bitmap) {
+        if (key < pf.key_min || key > pf.key_max) return -1;
+        const unsigned long long d = (unsigned long long)(key - pf.key_min);
+        if (!((pf.bitmap[d >> 6] >> (d & 63)) & 1ULL)) return -1;
+    }
+    else if (pf.bloom) {
+        const unsigned long long *bloom = pf.bloom;
+        const unsigned long long bloom_word_mask = pf.bloom_word_mask;
+        const unsigned long long bits = tg_bloom_mask(m);
+        if ((bloom[tg_bloom_word(m, bloom_word_mask)] & bits) != bits) return -1;
+    }
+    unsigned long long pos = m & mask;
+    for (unsigned long long iter = 0; iter <= mask; iter++) {
+        const TgSlot16 s = slots[pos];
+        if (s.head < 0) return -1;
+        if (s.key == key) return s.head;
+        pos = (pos + 1) & mask;
+    }
+    return -1;
+}

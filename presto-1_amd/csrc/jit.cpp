@@ -15,10 +15,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <fstream>
+#include <functional>
 #include <set>
 #include <sstream>
 
+#include "join.h"
 #include "kernels.h"
 
 namespace tgpu {
@@ -115,11 +118,52 @@ static std::vector<char> code_object_for(const std::string &source)
 struct JitModule {
     hipModule_t mod = nullptr;
     hipFunction_t count = nullptr, emit = nullptr;
+    std::map<std::string, hipFunction_t> fns;
     ~JitModule()
     {
         if (mod) hipModuleUnload(mod);
     }
+    hipFunction_t fn(const char *name)
+    {
+        auto it = fns.find(name);
+        if (it != fns.end()) return it->second;
+        hipFunction_t f = nullptr;
+        if (hipModuleGetFunction(&f, mod, name) != hipSuccess) fail(TGPU_ERR_COMPILER, std::string("generated module lacks ") + name);
+        fns[name] = f;
+        return f;
+    }
 };
+
+static std::shared_ptr<JitModule> load_module(const std::string &source)
+{
+    std::vector<char> code = code_object_for(source);
+    auto m = std::make_shared<JitModule>();
+    hipError_t e = hipModuleLoadData(&m->mod, code.data());
+    if (e != hipSuccess) fail(TGPU_ERR_COMPILER, std::string("hipModuleLoadData failed: ") + hipGetErrorString(e));
+    return m;
+}
+
+// text of a device header shipped next to the library (csrc/), with its #pragma once removed, for embedding in JIT sources
+static std::string device_header(const char *name)
+{
+    const std::string path = resource_dir() + "/csrc/" + name;
+    std::ifstream f(path);
+    if (!f) fail(TGPU_ERR_COMPILER, "cannot read " + path + " (set the resource dir with tgpu_set_resource_dir)");
+    std::stringstream ss;
+    ss << f.rdbuf();
+    std::string t = ss.str();
+    size_t p = t.find("#pragma once");
+    if (p != std::string::npos) t.erase(p, 12);
+    return t;
+}
+
+template <typename Args> static void launch_args(hipFunction_t f, int grid, Args &args, hipStream_t stream)
+{
+    size_t size = sizeof(Args);
+    void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+    HIP_CHECK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream, nullptr, config));
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // code generation
@@ -150,6 +194,10 @@ struct Gen {
     std::ostringstream consts;
     int tmp = 0;
     std::set<int> used_cols;
+    // register-row mode: fixed-width INPUT references read a pre-loaded row struct `R` (fields c<ch>, n<ch>) instead of
+    // memory, so that the kernel can issue the loads of the NEXT tile before it evaluates the current one
+    bool reg_mode = false;
+    std::set<int> reg_cols;
 
     Gen(const std::vector<tgpu_expr_node> &n, const std::string &p, const std::vector<int32_t> &t) : nodes(n), pool(p), in_types(t) {}
 
@@ -206,8 +254,14 @@ struct Gen {
             if (ch < 0 || ch >= (int)in_types.size()) bad("input channel out of range");
             if (ch >= kFpMaxCols) bad("too many input channels");
             if (in_types[ch] != nd.type) bad("input reference type does not match the channel type");
-            used_cols.insert(ch);
             Val r = declare(nd.type, d);
+            if (reg_mode && nd.type != TGPU_VARCHAR) {
+                reg_cols.insert(ch);
+                os << ind(d) << r.n << " = R.n" << ch << " != 0;\n";
+                os << ind(d) << "if (!" << r.n << ") " << r.v << " = R.c" << ch << (nd.type == TGPU_BOOLEAN ? " != 0" : "") << ";\n";
+                return r;
+            }
+            used_cols.insert(ch);
             std::string c = "c" + std::to_string(ch), cn = "cn" + std::to_string(ch), co = "co" + std::to_string(ch);
             os << ind(d) << r.n << " = " << cn << " && " << cn << "[row];\n";
             if (nd.type == TGPU_VARCHAR)
@@ -718,6 +772,425 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
         else out.cols.push_back(k::gather_column(ctx, in.cols[(size_t)p.channel], positions->as<int32_t>(), n_sel, false));
     }
     return true;
+}
+
+// =====================================================================================================================
+// FusedProbeGpu: filter + project + hash-join probe in one kernel
+// =====================================================================================================================
+namespace {
+
+const char *kFjKernels = R"SRC(
+struct FjArgs {
+  FpArgs fp;
+  const TgSlot16* slots;
+  unsigned long long mask;
+  TgPrefilter pf;
+  int* tile_cnt;            // pairs produced by each tile
+  int* tile_src;            // where the tile's pairs start inside its block's private region
+  const int* tile_dst;      // pass 2: exclusive scan of tile_cnt = final output offset of the tile
+  int* pair_probe;          // block-private regions, capacity = rows the block owns
+  int* pair_build;
+  int* out_build;           // pass 2: build positions in final order
+  unsigned long long* counters;
+  long long tiles;
+  long long grid1;          // grid size of pass 1 (defines the region layout)
+  int outer;
+  int pad;
+};
+#define FJ_STRIPES 8
+#define FJ_TILE (FJ_STRIPES * 256)
+
+// rows-capacity offset of block b's private pair region: tiles are dealt round-robin, block b owns ceil((tiles - b) / grid)
+__device__ inline long long fj_region_base(long long b, long long tiles, long long grid) {
+  const long long q = tiles / grid, r = tiles % grid;
+  return (b * q + (b < r ? b : r)) * FJ_TILE;
+}
+
+// pass 1: one lane per row.  Matches are compacted in input order inside the tile (ballot + popcount) and appended to the
+// block's PRIVATE region, so workgroups never communicate; a scan over the per-tile counts (in tile = input order) then
+// gives every tile its final offset and pass 2 moves the pairs there -- probe positions come out ascending exactly as
+// LookupJoinPageBuilder.java:144-153 requires.
+extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
+  const FpArgs& A = J.fp;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ int C[4][FJ_STRIPES];
+  const long long region = fj_region_base(blockIdx.x, J.tiles, gridDim.x);
+  long long local = 0;      // pairs this block has written so far (uniform across the block)
+  unsigned long long selected = 0;
+  // software pipeline: the column values of the NEXT tile are loaded (all stripes in flight) before the current tile is
+  // evaluated, so the streaming loads overlap the pre-filter / table probes of the current tile
+  TgRow cur[FJ_STRIPES], nxt[FJ_STRIPES];
+#pragma unroll
+  for (int s = 0; s < FJ_STRIPES; s++) {
+    const long long row = (long long)blockIdx.x * FJ_TILE + threadIdx.x + s * 256;
+    tg_zero_row(cur[s]);
+    if (blockIdx.x < J.tiles && row < A.n) tg_load_row(A, row, cur[s]);
+  }
+  for (long long tile = blockIdx.x; tile < J.tiles; tile += gridDim.x) {
+    const long long row0 = tile * FJ_TILE + threadIdx.x;
+    {
+      const long long ntile = tile + gridDim.x;
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        const long long row = ntile * FJ_TILE + threadIdx.x + s * 256;
+        tg_zero_row(nxt[s]);
+        if (ntile < J.tiles && row < A.n) tg_load_row(A, row, nxt[s]);
+      }
+    }
+    bool sel[FJ_STRIPES];
+    bool passed[FJ_STRIPES];
+    long long key[FJ_STRIPES];
+    unsigned long long hm[FJ_STRIPES];
+    // phase 1: filter + key from the pre-loaded rows
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) {
+      const long long row = row0 + s * 256;
+      sel[s] = false; passed[s] = false; key[s] = 0; hm[s] = 0;
+      if (row < A.n && tg_filter(A, row, cur[s])) {
+        selected++;
+        passed[s] = true;
+        long long k = 0;
+        const bool kn = tg_key(A, row, cur[s], k);   // JoinProbe.java:87-97: a null probe key never matches
+        sel[s] = !kn;
+        key[s] = k;
+        hm[s] = tg_fmix64((unsigned long long)tg_hash_long(k));
+      }
+    }
+    // phase 2: pre-filter words (exact key bitmap for dense key domains, else the blocked Bloom filter) -- unconditional loads
+    // from always-valid addresses so that all stripes are in flight together
+    bool maybe[FJ_STRIPES];
+    {
+      unsigned long long bw[FJ_STRIPES];
+      unsigned long long bits[FJ_STRIPES];
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        bw[s] = ~0ULL; bits[s] = 0;
+        if (J.pf.bitmap) {
+          const bool in_range = sel[s] && key[s] >= J.pf.key_min && key[s] <= J.pf.key_max;
+          const unsigned long long d = in_range ? (unsigned long long)(key[s] - J.pf.key_min) : 0ULL;
+          bits[s] = in_range ? (1ULL << (d & 63)) : ~0ULL;   // out of range: a mask the word (0) can never satisfy
+          bw[s] = in_range ? J.pf.bitmap[d >> 6] : 0ULL;
+        } else if (J.pf.bloom) {
+          bits[s] = tg_bloom_mask(hm[s]);
+          bw[s] = J.pf.bloom[tg_bloom_word(hm[s], J.pf.bloom_word_mask)];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        maybe[s] = sel[s] && (bw[s] & bits[s]) == bits[s];
+#ifdef FJ_EXP_NOPROBE
+        maybe[s] = false;
+#endif
+      }
+    }
+    // phase 3: first table slot of every survivor (predicated loads, issued back to back), then resolve; only a
+    // collision with another key walks further
+    int head[FJ_STRIPES];
+    bool emit[FJ_STRIPES];
+    unsigned long long b[FJ_STRIPES];
+    {
+      TgSlot16 sl[FJ_STRIPES];
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        sl[s].key = 0; sl[s].head = -1; sl[s].pad = 0;
+        if (maybe[s]) sl[s] = J.slots[hm[s] & J.mask];
+      }
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        head[s] = -1;
+        if (maybe[s] && sl[s].head >= 0) {
+          if (sl[s].key == key[s]) head[s] = sl[s].head;
+          else {
+            unsigned long long pos = ((hm[s] & J.mask) + 1) & J.mask;
+            for (unsigned long long it = 0; it < J.mask; it++) {
+              const TgSlot16 t = J.slots[pos];
+              if (t.head < 0) break;
+              if (t.key == key[s]) { head[s] = t.head; break; }
+              pos = (pos + 1) & J.mask;
+            }
+          }
+        }
+        emit[s] = head[s] >= 0 || (J.outer && passed[s]);   // PROBE_OUTER: every row that passed the filter (LookupJoinOperator.java:354-361)
+        b[s] = __ballot(emit[s]);
+        if (lane == 0) C[w][s] = __popcll(b[s]);
+      }
+    }
+    __syncthreads();
+    long long base = region + local;
+    int tile_total = 0;
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) {
+      int before = 0, total = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) { const int c = C[w2][s]; if (w2 < w) before += c; total += c; }
+      if (emit[s]) {
+        const long long o = base + before + __builtin_amdgcn_mbcnt_hi((unsigned)(b[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b[s], 0u));
+        J.pair_probe[o] = (int)(row0 + s * 256);
+        J.pair_build[o] = head[s];
+      }
+      base += total;
+      tile_total += total;
+    }
+    if (threadIdx.x == 0) { J.tile_cnt[tile] = tile_total; J.tile_src[tile] = (int)local; }
+    local += tile_total;
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) cur[s] = nxt[s];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) selected += __shfl_down(selected, d, 64);
+  if (lane == 0 && selected) atomicAdd(&J.counters[0], selected);
+}
+
+// pass 2: one wave per tile: moves the tile's pairs to their final position and evaluates the probe-side output
+// projections for the matching rows only
+extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
+  const FpArgs& A = J.fp;
+  const int lane = threadIdx.x & 63;
+  const long long waves = (long long)gridDim.x * 4;
+  for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < J.tiles; tile += waves) {
+    const int cnt = J.tile_cnt[tile];
+    if (cnt == 0) continue;
+    const long long src = fj_region_base(tile % J.grid1, J.tiles, J.grid1) + J.tile_src[tile];
+    const long long dst = J.tile_dst[tile];
+    for (int i = lane; i < cnt; i += 64) {
+      const long long row = J.pair_probe[src + i];
+      J.out_build[dst + i] = J.pair_build[src + i];
+      tg_emit_outputs(A, row, dst + i);
+    }
+  }
+}
+)SRC";
+
+}  // namespace
+
+FusedProbeGpu::FusedProbeGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec, int32_t join_channel, std::vector<int32_t> output_channels)
+    : input_types_(std::move(input_types)), output_channels_(std::move(output_channels)), join_channel_(join_channel)
+{
+    TG_CHECK_ARG(spec != nullptr, "page processor spec is null");
+    nodes_.assign(spec->nodes, spec->nodes + spec->node_count);
+    if (spec->string_pool && spec->string_pool_len > 0) pool_.assign(spec->string_pool, spec->string_pool + spec->string_pool_len);
+    filter_root_ = spec->filter_root;
+    proj_roots_.assign(spec->projection_roots, spec->projection_roots + spec->projection_count);
+    TG_CHECK_ARG(join_channel_ >= 0 && join_channel_ < (int)proj_roots_.size(), "join channel out of range");
+    for (int32_t ch : output_channels_) TG_CHECK_ARG(ch >= 0 && ch < (int)proj_roots_.size(), "probe output channel out of range");
+    for (int32_t r : proj_roots_) {
+        TG_CHECK_ARG(r >= 0 && r < (int)nodes_.size(), "projection root out of range");
+        proj_types_.push_back(nodes_[(size_t)r].type);
+    }
+    const int32_t kt = proj_types_[(size_t)join_channel_];
+    supported_ = (kt == TGPU_BIGINT || kt == TGPU_INTEGER || kt == TGPU_DATE) && (int)output_channels_.size() <= kFpMaxProj;
+    for (int32_t ch : output_channels_) supported_ = supported_ && proj_types_[(size_t)ch] != TGPU_VARCHAR;
+    // The fused kernel evaluates the non-key projections lazily (for matching rows only) or not at all (channels the join
+    // drops), whereas FilterAndProjectOperator evaluates every projection on every selected row.  That is only equivalent
+    // when those projections cannot raise: anything with checked integer arithmetic keeps the unfused composition.
+    std::function<bool(int)> can_raise = [&](int idx) -> bool {
+        const tgpu_expr_node &nd = nodes_[(size_t)idx];
+        if (nd.kind == TGPU_EX_CALL) {
+            const bool int_result = nd.type == TGPU_BIGINT || nd.type == TGPU_INTEGER;
+            if (int_result && nd.op >= TGPU_OP_ADD && nd.op <= TGPU_OP_NEGATE) return true;
+            if (nd.op == TGPU_OP_CAST && nd.type == TGPU_INTEGER) return true;
+        }
+        if (nd.kind == TGPU_EX_CALL || nd.kind == TGPU_EX_SPECIAL)
+            for (int k = 0; k < nd.n_args; k++)
+                if (can_raise(nd.args[k])) return true;
+        return false;
+    };
+    for (size_t ch = 0; ch < proj_roots_.size(); ch++)
+        if ((int)ch != join_channel_ && can_raise(proj_roots_[ch])) supported_ = false;
+    if (supported_) generate();
+}
+
+FusedProbeGpu::~FusedProbeGpu() {}
+
+void FusedProbeGpu::generate()
+{
+    auto cols_decl = [&](const Gen &g) {
+        std::ostringstream cols;
+        for (int ch : g.used_cols) {
+            const int32_t t = input_types_[(size_t)ch];
+            const char *T = (t == TGPU_VARCHAR || t == TGPU_BOOLEAN) ? "unsigned char" : ctype(t);
+            cols << "  const " << T << "* c" << ch << " = (const " << T << "*)A.col_values[" << ch << "]; (void)c" << ch << ";\n";
+            cols << "  const unsigned char* cn" << ch << " = A.col_nulls[" << ch << "]; (void)cn" << ch << ";\n";
+            if (t == TGPU_VARCHAR) cols << "  const int* co" << ch << " = A.col_offsets[" << ch << "]; (void)co" << ch << ";\n";
+        }
+        return cols.str();
+    };
+    auto splice = [](std::string t, const std::string &cols) {
+        size_t p = t.find("@COLS@");
+        if (p != std::string::npos) t.replace(p, 6, cols);
+        return t;
+    };
+    const int32_t kt = proj_types_[(size_t)join_channel_];
+
+    // (a) filter + join key in register-row mode: evaluated for every row of pass 1 from pre-loaded column values
+    Gen gr(nodes_, pool_, input_types_);
+    gr.reg_mode = true;
+    std::vector<std::string> reg_bodies;
+    if (filter_root_ >= 0) {
+        Val f = gr.gen(filter_root_, 1);
+        if (f.type != TGPU_BOOLEAN) gr.bad("filter must be boolean");
+        std::ostringstream fb;
+        fb << "__device__ inline bool tg_filter(const FpArgs& A, long long row, const TgRow& R) {\n@COLS@" << gr.os.str() << "  return !" << f.n << " && " << f.v << ";\n}\n";
+        reg_bodies.push_back(fb.str());
+    }
+    else reg_bodies.push_back("__device__ inline bool tg_filter(const FpArgs& A, long long row, const TgRow& R) { return true; }\n");
+    {
+        gr.os.str("");
+        Val v = gr.gen(proj_roots_[(size_t)join_channel_], 1);
+        std::ostringstream f;
+        f << "__device__ inline bool tg_key(const FpArgs& A, long long row, const TgRow& R, long long& key) {\n@COLS@" << gr.os.str() << "  key = (long long)" << v.v
+          << ";\n  return " << v.n << ";\n}\n";
+        reg_bodies.push_back(f.str());
+    }
+    // (b) output projections in memory mode: evaluated lazily in pass 2 for the matching rows only
+    Gen gm(nodes_, pool_, input_types_);
+    gm.tmp = gr.tmp;
+    std::vector<std::string> mem_bodies;
+    std::set<int> outs(output_channels_.begin(), output_channels_.end());
+    for (int ch : outs) {
+        gm.os.str("");
+        Val v = gm.gen(proj_roots_[(size_t)ch], 1);
+        std::ostringstream f;
+        f << "__device__ inline bool tg_p" << ch << "(const FpArgs& A, long long row, " << ctype(proj_types_[(size_t)ch]) << "& out) {\n@COLS@" << gm.os.str()
+          << "  out = " << v.v << ";\n  return " << v.n << ";\n}\n";
+        mem_bodies.push_back(f.str());
+    }
+
+    std::ostringstream src;
+    src << kPrelude << device_header("device_hash.h") << device_header("device_join.h") << gr.consts.str() << gm.consts.str();
+    // the pre-loaded row: one field pair per fixed-width column the filter / key read
+    src << "struct TgRow {\n";
+    for (int ch : gr.reg_cols) {
+        const int32_t t = input_types_[(size_t)ch];
+        src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : ctype(t)) << " c" << ch << "; unsigned char n" << ch << ";\n";
+    }
+    if (gr.reg_cols.empty()) src << "  int unused;\n";
+    src << "};\n__device__ inline void tg_load_row(const FpArgs& A, long long row, TgRow& R) {\n";
+    for (int ch : gr.reg_cols) {
+        const int32_t t = input_types_[(size_t)ch];
+        const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
+        src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = A.col_nulls[" << ch << "] ? A.col_nulls[" << ch << "][row] : 0;\n";
+    }
+    src << "  (void)A; (void)row; (void)R;\n}\n__device__ inline void tg_zero_row(TgRow& R) {\n";
+    for (int ch : gr.reg_cols) src << "  R.c" << ch << " = 0; R.n" << ch << " = 0;\n";
+    src << "  (void)R;\n}\n";
+    const std::string rc = cols_decl(gr), mc = cols_decl(gm);
+    for (auto &b : reg_bodies) src << splice(b, rc);
+    for (auto &b : mem_bodies) src << splice(b, mc);
+    (void)kt;
+    src << "__device__ inline void tg_emit_outputs(const FpArgs& A, long long row, long long o) {\n";
+    for (size_t i = 0; i < output_channels_.size(); i++) {
+        const int ch = output_channels_[i];
+        const int32_t t = proj_types_[(size_t)ch];
+        const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
+        src << "  { " << ctype(t) << " v = 0; const bool n = tg_p" << ch << "(A, row, v); ((" << T << "*)A.out_values[" << i << "])[o] = n ? (" << T << ")0 : (" << T
+            << ")v; A.out_nulls[" << i << "][o] = n ? 1 : 0; }\n";
+    }
+    src << "}\n";
+    // experiment switches for kernel studies (tools/exp_fused.py); never set in production
+    if (const char *exp = getenv("TGPU_FJ_EXP")) src << "#define FJ_EXP_" << exp << " 1\n";
+    src << kFjKernels;
+    source_ = src.str();
+}
+
+void FusedProbeGpu::precompile()
+{
+    if (supported_) (void)code_object_for(source_);
+}
+
+void FusedProbeGpu::ensure_loaded()
+{
+    if (!module_) module_ = load_module(source_);
+}
+
+void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, std::vector<DeviceColumn> &probe_out,
+                            BufferPtr &build_idx, int64_t &count, int64_t &selected_rows)
+{
+    TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
+    TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
+    IntTableView tv;
+    TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
+    ensure_loaded();
+    const int64_t n = in.n;
+    count = 0;
+    selected_rows = 0;
+    probe_out.clear();
+    if (n == 0) return;
+    FjArgs J{};
+    for (size_t i = 0; i < in.cols.size() && i < (size_t)kFpMaxCols; i++) {
+        J.fp.col_values[i] = in.cols[i].values;
+        J.fp.col_nulls[i] = in.cols[i].nulls;
+        J.fp.col_offsets[i] = in.cols[i].offsets;
+    }
+    J.fp.n = n;
+    J.slots = tv.slots;
+    J.mask = tv.mask;
+    J.bitmap = tv.bitmap;
+    J.key_min = tv.key_min;
+    J.key_max = tv.key_max;
+    J.bloom = tv.bloom;
+    J.bloom_word_mask = tv.bloom_word_mask;
+    J.outer = outer ? 1 : 0;
+    J.tiles = ceil_div(n, 8 * 256);
+    TG_CHECK_ARG(J.tiles <= 0x7fffffffLL, "page too large");
+    const int64_t grid1 = std::min<int64_t>(J.tiles, (int64_t)ctx->cu_count() * 8);
+    J.grid1 = grid1;
+    BufferPtr tile_cnt = ctx->alloc((size_t)J.tiles * 4), tile_src = ctx->alloc((size_t)J.tiles * 4), tile_dst = ctx->alloc((size_t)J.tiles * 4);
+    BufferPtr misc = ctx->alloc(32);  // [0] expression error word, [1] rows selected by the filter, [2] total pairs
+    HIP_CHECK(hipMemsetAsync(misc->ptr(), 0xff, 8, ctx->stream()));
+    HIP_CHECK(hipMemsetAsync(misc->as<uint8_t>() + 8, 0, 24, ctx->stream()));
+    J.fp.error = misc->as<unsigned long long>();
+    J.counters = misc->as<unsigned long long>() + 1;
+    J.tile_cnt = tile_cnt->as<int32_t>();
+    J.tile_src = tile_src->as<int32_t>();
+    J.tile_dst = tile_dst->as<int32_t>();
+    // without duplicate build keys a probe row yields at most one pair: the private regions hold tiles x 2048 rows in total
+    const int64_t cap = J.tiles * 8 * 256;
+    BufferPtr pair_probe = ctx->alloc((size_t)cap * 4), pair_build = ctx->alloc((size_t)cap * 4);
+    J.pair_probe = pair_probe->as<int32_t>();
+    J.pair_build = pair_build->as<int32_t>();
+    {
+        ProfileScope ps(ctx, "fused_filter_probe");
+        launch_args(module_->fn("fj_probe"), (int)grid1, J, ctx->stream());
+    }
+    {
+        ProfileScope ps(ctx, "fused_probe_scan");
+        k::exclusive_scan_i32(ctx, J.tile_cnt, tile_dst->as<int32_t>(), J.tiles, (int64_t *)(misc->as<unsigned long long>() + 2));
+    }
+    struct { unsigned long long expr_err, selected, total; } h;
+    ctx->download(&h, misc->ptr(), 24);
+    auto raise = [](unsigned long long e) {
+        const long long row = (long long)(e >> 8);
+        if ((int)(e & 0xff) == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
+        fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
+    };
+    if (h.expr_err != ~0ull) raise(h.expr_err);
+    selected_rows = (int64_t)h.selected;
+    count = (int64_t)h.total;
+    if (count == 0) return;
+    if (count > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "join output of one probe page cannot exceed 2 billion rows");
+    build_idx = ctx->alloc((size_t)count * 4);
+    J.out_build = build_idx->as<int32_t>();
+    for (size_t i = 0; i < output_channels_.size(); i++) {
+        DeviceColumn c;
+        c.type = proj_types_[(size_t)output_channels_[i]];
+        c.n = count;
+        c.values_buf = ctx->alloc((size_t)count * type_width(c.type));
+        c.values = c.values_buf->ptr();
+        c.nulls_buf = ctx->alloc((size_t)count);
+        c.nulls = c.nulls_buf->as<uint8_t>();
+        J.fp.out_values[i] = c.values_buf->ptr();
+        J.fp.out_nulls[i] = c.nulls_buf->as<uint8_t>();
+        probe_out.push_back(c);
+    }
+    {
+        ProfileScope ps(ctx, "fused_probe_emit");
+        int64_t blocks = std::min<int64_t>(ceil_div(J.tiles, 4), (int64_t)ctx->cu_count() * 8);
+        launch_args(module_->fn("fj_emit"), (int)blocks, J, ctx->stream());
+    }
+    unsigned long long e = ctx->read_scalar(misc->as<unsigned long long>());
+    if (e != ~0ull) raise(e);
 }
 
 }  // namespace tgpu

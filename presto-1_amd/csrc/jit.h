@@ -60,6 +60,62 @@ private:
     std::shared_ptr<JitModule> module_;
 };
 
+// ---- operator fusion by codegen ---------------------------------------------------------------------------------------
+// FilterAndProject feeding a LookupJoin probe, compiled into one kernel: filter -> key projection -> Bloom filter -> table
+// probe -> order-preserving compaction of the (probe row, build position) pairs (in-tile ballot compaction into workgroup-
+// private regions, then a scan over the per-tile counts); the probe-side output projections are then evaluated for the
+// matching rows only.  Results are identical to running the two
+// reference operators back to back (M/operator/FilterAndProjectOperator.java + LookupJoinOperator.java).
+struct FjArgs {  // must match the generated struct
+    FpArgs fp;
+    const void *slots;
+    unsigned long long mask;
+    const unsigned long long *bitmap;
+    long long key_min, key_max;
+    const unsigned long long *bloom;
+    unsigned long long bloom_word_mask;
+    int32_t *tile_cnt;
+    int32_t *tile_src;
+    const int32_t *tile_dst;
+    int32_t *pair_probe;
+    int32_t *pair_build;
+    int32_t *out_build;
+    unsigned long long *counters;   // [0] rows selected by the filter
+    long long tiles;
+    long long grid1;
+    int32_t outer;
+    int32_t pad;
+};
+
+class LookupSourceGpu;
+
+class FusedProbeGpu {
+public:
+    // join_channel / output_channels index the page processor's projections (= the probe page the join would have seen)
+    FusedProbeGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec, int32_t join_channel, std::vector<int32_t> output_channels);
+    ~FusedProbeGpu();
+    void precompile();
+    bool supported() const { return supported_; }   // false -> the operator runs the unfused composition
+    const std::vector<int32_t> &projection_types() const { return proj_types_; }
+    // probes `in` against the lookup source's int-key table; returns the probe-side output columns + build positions
+    void process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, std::vector<DeviceColumn> &probe_out,
+                 BufferPtr &build_idx, int64_t &count, int64_t &selected_rows);
+    const std::string &source() const { return source_; }
+
+private:
+    void generate();
+    void ensure_loaded();
+    std::vector<int32_t> input_types_;
+    std::vector<tgpu_expr_node> nodes_;
+    std::string pool_;
+    int filter_root_;
+    std::vector<int32_t> proj_roots_, proj_types_, output_channels_;
+    int32_t join_channel_;
+    bool supported_ = false;
+    std::string source_;
+    std::shared_ptr<JitModule> module_;
+};
+
 std::string resource_dir();
 void set_resource_dir(const std::string &dir);
 

@@ -30,9 +30,22 @@ private:
     int64_t n_ = 0;
 };
 
+// device view of the int-key fast path table, for the JIT-fused filter+project+probe kernels
+struct IntTableView {
+    const void *slots = nullptr;            // TgSlot16[mask + 1]
+    uint64_t mask = 0;
+    const unsigned long long *bloom = nullptr;
+    unsigned long long bloom_word_mask = 0;
+    const unsigned long long *bitmap = nullptr;   // dense key domain: one bit per key value in [key_min, key_max]
+    long long key_min = 0, key_max = -1;
+    const int32_t *links = nullptr;         // nullptr = no duplicate build keys
+    int32_t key_type = 0;
+};
+
 // The built lookup source: PagesHash + ArrayPositionLinks behind JoinHash (M/operator/JoinHash.java:44-125).
 class LookupSourceGpu {
 public:
+    bool int_table(IntTableView &v) const;
     LookupSourceGpu(Context *ctx, std::shared_ptr<PagesIndexGpu> index, std::vector<int32_t> key_channels, int32_t hash_channel,
                     std::vector<int32_t> output_channels);
     void build();  // PagesHash constructor (M/operator/PagesHash.java:53-125)
@@ -60,6 +73,10 @@ private:
     bool int_key_fast_ = false;  // single BIGINT / INTEGER / DATE key: key stored inline in the slot
     BufferPtr heads_;            // int32[capacity], -1 empty          (PagesHash.key)
     BufferPtr slots16_;          // fast path: {int64 key, int32 head, int32 pad}[capacity]
+    BufferPtr bloom_;            // fast path: blocked Bloom filter over the build keys (sparse key domains)
+    int64_t bloom_words_ = 0;
+    BufferPtr bitmap_;           // fast path: exact bitmap over [key_min_, key_max_] (dense key domains)
+    long long key_min_ = 0, key_max_ = -1;
     BufferPtr tags_;             // uint8[n]                           (PagesHash.positionToHashes)
     BufferPtr links_;            // int32[n] or empty when no duplicates (ArrayPositionLinks)
     std::vector<DeviceColumn> key_cols_;

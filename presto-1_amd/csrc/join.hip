@@ -13,8 +13,12 @@
 #include "join.h"
 #include "kernels.h"
 #include "device_hash.h"
+#include "device_join.h"
 
 #include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace tgpu {
 
@@ -30,11 +34,7 @@ int grid_for(Context *ctx, int64_t n)
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
-struct Slot16 {
-    long long key;
-    int head;
-    int pad;
-};
+using Slot16 = TgSlot16;
 
 // EQUAL operators on non-null cells (S/type/AbstractLongType.java:132-136, DoubleType.java:157-161: NaN != NaN, -0 == +0)
 __device__ __forceinline__ bool rows_equal_nonnull(const KeyCols &a, int64_t ra, const KeyCols &b, int64_t rb)
@@ -95,8 +95,10 @@ __global__ void __launch_bounds__(kBlock) tags_kernel(const int64_t *__restrict_
 
 // counters[0] = rows that joined an existing key (ArrayPositionLinks.FactoryBuilder.size()), counters[1] = error
 __global__ void __launch_bounds__(kBlock) build_insert_kernel(KeyCols keys, const int64_t *__restrict__ hashes, const uint8_t *__restrict__ tags, int64_t n,
-                                                               int *heads, uint64_t mask, int32_t *__restrict__ row_slot, unsigned long long *counters)
+                                                               int *heads, int stride, uint64_t mask, int32_t *__restrict__ row_slot,
+                                                               unsigned long long *counters)
 {
+    // `heads` is either the plain int32 slot array (stride 1) or the head field of the TgSlot16 array (stride 4 words)
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         bool dup = false;
         int32_t slot = -1;
@@ -104,14 +106,15 @@ __global__ void __launch_bounds__(kBlock) build_insert_kernel(KeyCols keys, cons
             const int64_t h = hashes[r];
             uint64_t pos = tg_fmix64((uint64_t)h) & mask;
             for (uint64_t iter = 0; iter <= mask; iter++) {
-                int cur = __hip_atomic_load(&heads[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int *hp = heads + pos * stride;
+                int cur = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == -1) {
-                    int old = atomicCAS(&heads[pos], -1, (int)r);
+                    int old = atomicCAS(hp, -1, (int)r);
                     if (old == -1) { slot = (int32_t)pos; break; }
                     cur = old;
                 }
                 if (tags[cur] == (uint8_t)h && rows_equal_nonnull(keys, cur, keys, r)) {
-                    atomicMax(&heads[pos], (int)r);
+                    atomicMax(hp, (int)r);
                     slot = (int32_t)pos;
                     dup = true;
                     break;
@@ -148,15 +151,61 @@ __global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long 
     }
 }
 
-__global__ void __launch_bounds__(kBlock) pack_slots_kernel(const int *__restrict__ heads, int64_t capacity, ColView key, Slot16 *__restrict__ slots)
+// int-key fast path: empty table = {key 0, head -1}
+__global__ void __launch_bounds__(kBlock) init_slots_kernel(Slot16 *__restrict__ slots, int64_t capacity)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * kBlock) {
-        int h = heads[i];
         Slot16 s;
-        s.head = h;
+        s.key = 0;
+        s.head = -1;
         s.pad = 0;
-        s.key = h >= 0 ? int_key_at(key, h) : 0;
         slots[i] = s;
+    }
+}
+
+// after the insert pass every indexed row publishes its key into its slot (rows sharing a slot share the key) and feeds the
+// key range (minmax[0] = min, minmax[1] = max)
+__global__ void __launch_bounds__(kBlock) publish_keys_kernel(const int32_t *__restrict__ row_slot, int64_t n, ColView key, Slot16 *slots, long long *minmax)
+{
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        const int32_t sl = row_slot[r];
+        if (sl < 0) continue;
+        const long long k = int_key_at(key, r);
+        slots[sl].key = k;
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const long long l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bitmap_build_kernel(const int32_t *__restrict__ row_slot, int64_t n, ColView key, long long key_min,
+                                                               unsigned long long *bitmap)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        if (row_slot[r] < 0) continue;
+        const unsigned long long d = (unsigned long long)(int_key_at(key, r) - key_min);
+        atomicOr(&bitmap[d >> 6], 1ULL << (d & 63));
+    }
+}
+
+// blocked Bloom filter over the build keys of the int-key fast path (device_join.h), for sparse key domains
+__global__ void __launch_bounds__(kBlock) bloom_build_kernel(const int32_t *__restrict__ row_slot, int64_t n, ColView key, unsigned long long *bloom,
+                                                              unsigned long long word_mask)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        if (row_slot[r] < 0) continue;
+        const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(int_key_at(key, r)));
+        atomicOr(&bloom[tg_bloom_word(m, word_mask)], tg_bloom_mask(m));
     }
 }
 
@@ -166,6 +215,7 @@ struct ProbeTable {
     const uint8_t *tags;
     const int32_t *links;
     uint64_t mask;
+    TgPrefilter pf;
 };
 
 // head build position of the probe row's key, or -1 (PagesHash.getAddressIndex)
@@ -174,14 +224,9 @@ __device__ __forceinline__ int find_head(const ProbeTable &t, const KeyCols &bui
 {
     uint64_t pos = tg_fmix64((uint64_t)h) & t.mask;
     if (FAST) {
-        const long long key = int_key_at(probe.c[0], r);
-        for (uint64_t iter = 0; iter <= t.mask; iter++) {
-            const Slot16 s = t.slots[pos];
-            if (s.head < 0) return -1;
-            if (s.key == key) return s.head;
-            pos = (pos + 1) & t.mask;
-        }
-        return -1;
+        // the slot position comes from the key's own hash (== the raw hash channel when that is H5 of the key)
+        (void)pos;
+        return tg_find_head_int(t.slots, t.mask, t.pf, int_key_at(probe.c[0], r));
     }
     for (uint64_t iter = 0; iter <= t.mask; iter++) {
         const int b = t.heads[pos];
@@ -365,7 +410,8 @@ std::vector<int32_t> LookupSourceGpu::key_types() const
 
 int64_t LookupSourceGpu::estimated_size() const
 {
-    return index_->estimated_size() + capacity_ * (int_key_fast_ ? 16 : 4) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0);
+    return index_->estimated_size() + capacity_ * (int_key_fast_ ? 16 : 4) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0) +
+           (bitmap_ ? (int64_t)bitmap_->bytes() : 0) + (bloom_ ? bloom_words_ * 8 : 0);
 }
 
 void LookupSourceGpu::build()
@@ -373,23 +419,36 @@ void LookupSourceGpu::build()
     n_ = index_->position_count();
     key_cols_.clear();
     for (int32_t ch : key_channels_) key_cols_.push_back(index_->column(ch));
-    // table size: the reference uses arraySize(n, 0.75) (PagesHash.java:63); any power of two >= n / 0.75 gives the same results
-    capacity_ = 1024;
-    while ((double)capacity_ * 0.75 < (double)n_) capacity_ <<= 1;
-    if (capacity_ > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "hash table size cannot exceed 2 billion slots");
-    heads_ = ctx_->alloc((size_t)capacity_ * 4);
-    k::fill_i32(ctx_, heads_->as<int32_t>(), -1, capacity_);
     int_key_fast_ = key_cols_.size() == 1 && (key_cols_[0].type == TGPU_BIGINT || key_cols_[0].type == TGPU_INTEGER || key_cols_[0].type == TGPU_DATE);
+    // table size: the reference uses arraySize(n, 0.75) (PagesHash.java:63); the layout is unobservable, so the int-key fast
+    // path runs at load <= 0.5 (HBM is plentiful and almost every probe then resolves in its first slot)
+    const double max_load = int_key_fast_ ? 0.5 : 0.75;
+    capacity_ = 1024;
+    while ((double)capacity_ * max_load < (double)n_) capacity_ <<= 1;
+    if (capacity_ > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "hash table size cannot exceed 2 billion slots");
     link_count_ = 0;
     links_.reset();
-    if (n_ == 0) {
-        if (int_key_fast_) {
-            slots16_ = ctx_->alloc((size_t)capacity_ * 16);
-            pack_slots_kernel<<<grid_for(ctx_, capacity_), kBlock, 0, ctx_->stream()>>>(heads_->as<int>(), capacity_, ColView{}, slots16_->as<Slot16>());
-            check_launch("pack_slots");
-        }
-        return;
+    bitmap_.reset();
+    bloom_.reset();
+    heads_.reset();
+    slots16_.reset();
+    key_min_ = 0;
+    key_max_ = -1;
+    int *heads = nullptr;
+    int stride = 1;
+    if (int_key_fast_) {
+        slots16_ = ctx_->alloc((size_t)capacity_ * 16);
+        init_slots_kernel<<<grid_for(ctx_, capacity_), kBlock, 0, ctx_->stream()>>>(slots16_->as<Slot16>(), capacity_);
+        check_launch("init_slots");
+        heads = &slots16_->as<Slot16>()->head;
+        stride = 4;
     }
+    else {
+        heads_ = ctx_->alloc((size_t)capacity_ * 4);
+        k::fill_i32(ctx_, heads_->as<int32_t>(), -1, capacity_);
+        heads = heads_->as<int>();
+    }
+    if (n_ == 0) return;
     std::vector<const DeviceColumn *> kp;
     for (auto &c : key_cols_) kp.push_back(&c);
     const KeyCols keys = key_cols_of(kp);
@@ -397,7 +456,10 @@ void LookupSourceGpu::build()
     BufferPtr own_hashes;
     const int64_t *hashes;
     DeviceColumn hash_col;
-    if (hash_channel_ >= 0) {  // precomputed $hashvalue channel: JoinCompiler.java:405-428
+    // int-key fast path: slot positions always come from the key's own H5 hash, so that probes (and the JIT-fused probe
+    // kernels) can derive them from the key alone; a precomputed $hashvalue channel equals that hash by construction
+    // (HashGenerationOptimizer.java:866-888)
+    if (hash_channel_ >= 0 && !int_key_fast_) {  // precomputed $hashvalue channel: JoinCompiler.java:405-428
         hash_col = index_->column(hash_channel_);
         TG_CHECK_ARG(hash_col.type == TGPU_BIGINT, "hash channel must be BIGINT");
         hashes = (const int64_t *)hash_col.values;
@@ -414,7 +476,7 @@ void LookupSourceGpu::build()
     {
         ProfileScope ps(ctx_, "join_build_insert");
         tags_kernel<<<g, kBlock, 0, ctx_->stream()>>>(hashes, n_, tags_->as<uint8_t>());
-        build_insert_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys, hashes, tags_->as<uint8_t>(), n_, heads_->as<int>(), (uint64_t)capacity_ - 1,
+        build_insert_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys, hashes, tags_->as<uint8_t>(), n_, heads, stride, (uint64_t)capacity_ - 1,
                                                              row_slot->as<int32_t>(), counters->as<unsigned long long>());
         check_launch("build_insert");
     }
@@ -437,11 +499,52 @@ void LookupSourceGpu::build()
         check_launch("links");
     }
     if (int_key_fast_) {
-        ProfileScope ps(ctx_, "join_build_pack");
-        slots16_ = ctx_->alloc((size_t)capacity_ * 16);
-        pack_slots_kernel<<<grid_for(ctx_, capacity_), kBlock, 0, ctx_->stream()>>>(heads_->as<int>(), capacity_, keys.c[0], slots16_->as<Slot16>());
-        check_launch("pack_slots");
+        ProfileScope ps(ctx_, "join_build_prefilter");
+        BufferPtr mm = ctx_->alloc(16);
+        const long long init[2] = {0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1};
+        ctx_->upload(mm->ptr(), init, 16);
+        publish_keys_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], slots16_->as<Slot16>(), mm->as<long long>());
+        check_launch("publish_keys");
+        long long host_mm[2];
+        ctx_->download(host_mm, mm->ptr(), 16);
+        key_min_ = host_mm[0];
+        key_max_ = host_mm[1];
+        // pre-filter: exact bitmap when the key domain is dense enough, else a blocked Bloom filter (16 bits per build row)
+        const bool has_keys = key_max_ >= key_min_;
+        const unsigned long long range = has_keys ? (unsigned long long)key_max_ - (unsigned long long)key_min_ + 1ULL : 0ULL;
+        // dense: at most 4096 candidate key values per build row and a bitmap of at most 2 GiB
+        const bool dense = has_keys && range != 0 && range <= (1ULL << 34) && range / 4096ULL <= (unsigned long long)std::max<int64_t>(n_, 1) &&
+                           getenv("TGPU_DISABLE_BITMAP") == nullptr;
+        if (dense) {
+            const int64_t words = (int64_t)((range + 63) / 64);
+            bitmap_ = ctx_->alloc_zero((size_t)words * 8);
+            bitmap_build_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], key_min_, bitmap_->as<unsigned long long>());
+            check_launch("bitmap_build");
+        }
+        else if (has_keys) {
+            int64_t words = 1024;
+            while (words * 64 < n_ * 16) words <<= 1;
+            bloom_words_ = words;
+            bloom_ = ctx_->alloc_zero((size_t)words * 8);
+            bloom_build_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], bloom_->as<unsigned long long>(), (unsigned long long)words - 1);
+            check_launch("bloom_build");
+        }
     }
+}
+
+bool LookupSourceGpu::int_table(IntTableView &v) const
+{
+    if (!int_key_fast_ || !slots16_) return false;
+    v.slots = slots16_->ptr();
+    v.mask = (uint64_t)capacity_ - 1;
+    v.bloom = bloom_ ? bloom_->as<unsigned long long>() : nullptr;
+    v.bloom_word_mask = bloom_ ? (unsigned long long)bloom_words_ - 1 : 0;
+    v.bitmap = bitmap_ ? bitmap_->as<unsigned long long>() : nullptr;
+    v.key_min = key_min_;
+    v.key_max = key_max_;
+    v.links = links_ ? links_->as<int32_t>() : nullptr;
+    v.key_type = key_cols_.empty() ? index_->types()[(size_t)key_channels_[0]] : key_cols_[0].type;
+    return true;
 }
 
 void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys, const int64_t *probe_hashes, int64_t n, bool probe_outer,
@@ -470,11 +573,16 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
         probe_hashes = own_hashes->as<int64_t>();
     }
     ProbeTable t{};
-    t.heads = heads_->as<int>();
+    t.heads = heads_ ? heads_->as<int>() : nullptr;
     t.slots = slots16_ ? slots16_->as<Slot16>() : nullptr;
     t.tags = tags_ ? tags_->as<uint8_t>() : nullptr;
     t.links = links_ ? links_->as<int32_t>() : nullptr;
     t.mask = (uint64_t)capacity_ - 1;
+    t.pf.bitmap = bitmap_ ? bitmap_->as<unsigned long long>() : nullptr;
+    t.pf.key_min = key_min_;
+    t.pf.key_max = key_max_;
+    t.pf.bloom = bloom_ ? bloom_->as<unsigned long long>() : nullptr;
+    t.pf.bloom_word_mask = bloom_ ? (unsigned long long)bloom_words_ - 1 : 0;
     BufferPtr heads = ctx_->alloc((size_t)n * 4), counts = ctx_->alloc((size_t)n * 4), offsets = ctx_->alloc((size_t)n * 4), total = ctx_->alloc(8);
     const int g = grid_for(ctx_, n);
     {

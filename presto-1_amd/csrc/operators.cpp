@@ -4,6 +4,8 @@
 
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace tgpu {
 
 // =====================================================================================================================
@@ -269,6 +271,33 @@ std::unique_ptr<Operator> HashBuilderOperatorFactory::create_operator()
     return std::make_unique<HashBuilderOperator>(ctx_, operator_id_, cfg_, bridge_);
 }
 
+// PageJoiner.processProbe + LookupJoinPageBuilder.build for one probe page (M/operator/LookupJoinOperator.java:299-347,
+// LookupJoinPageBuilder.java:101-131): probe columns by probe index, then the build side's output columns.
+// Returns false when the page produces no output row.
+static bool probe_page(Context *ctx, LookupSourceGpu &source, const DevicePage &in, const LookupJoinConfig &cfg, DevicePage &out)
+{
+    TG_CHECK_ARG(in.cols.size() == cfg.probe_types.size(), "probe page channel count differs from the operator's types");
+    if (in.n == 0) return false;
+    std::vector<const DeviceColumn *> keys;
+    for (int32_t ch : cfg.probe_join_channels) keys.push_back(&in.cols[(size_t)ch]);
+    const int64_t *hashes = nullptr;
+    if (cfg.probe_hash_channel >= 0) {
+        TG_CHECK_ARG(in.cols[(size_t)cfg.probe_hash_channel].type == TGPU_BIGINT, "probe hash channel must be BIGINT");
+        hashes = (const int64_t *)in.cols[(size_t)cfg.probe_hash_channel].values;
+    }
+    const bool outer = cfg.join_type == TGPU_JOIN_PROBE_OUTER;
+    BufferPtr probe_idx, build_idx;
+    int64_t count = 0;
+    source.probe(keys, hashes, in.n, outer, probe_idx, build_idx, count);
+    if (count == 0) return false;  // no output page for this probe page (:276-283 pageBuilder.isEmpty)
+    out.n = count;
+    ProfileScope ps(ctx, "join_gather");
+    for (int32_t ch : cfg.probe_output_channels) out.cols.push_back(k::gather_column(ctx, in.cols[(size_t)ch], probe_idx->as<int32_t>(), count, false));
+    const int nb = (int)source.output_channels().size();
+    for (int i = 0; i < nb; i++) out.cols.push_back(source.gather_build(i, build_idx->as<int32_t>(), count, outer));
+    return true;
+}
+
 // =====================================================================================================================
 // LookupJoinOperator / PageJoiner (M/operator/LookupJoinOperator.java:208-378)
 // =====================================================================================================================
@@ -292,29 +321,8 @@ public:
         std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
         DevicePage in = ingest_page(ctx_, page);
-        TG_CHECK_ARG(in.cols.size() == cfg_.probe_types.size(), "probe page channel count differs from the operator's types");
-        if (in.n == 0) return;
-        std::vector<const DeviceColumn *> keys;
-        for (int32_t ch : cfg_.probe_join_channels) keys.push_back(&in.cols[(size_t)ch]);
-        const int64_t *hashes = nullptr;
-        if (cfg_.probe_hash_channel >= 0) {
-            TG_CHECK_ARG(in.cols[(size_t)cfg_.probe_hash_channel].type == TGPU_BIGINT, "probe hash channel must be BIGINT");
-            hashes = (const int64_t *)in.cols[(size_t)cfg_.probe_hash_channel].values;
-        }
-        const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER;
-        BufferPtr probe_idx, build_idx;
-        int64_t count = 0;
-        source->probe(keys, hashes, in.n, outer, probe_idx, build_idx, count);
-        if (count == 0) return;  // no output page for this probe page (:276-283 pageBuilder.isEmpty)
-        // LookupJoinPageBuilder.build (M/operator/LookupJoinPageBuilder.java:101-131): probe columns by probe index,
-        // then the build side's output columns
         DevicePage out;
-        out.n = count;
-        ProfileScope ps(ctx_, "join_gather");
-        for (int32_t ch : cfg_.probe_output_channels) out.cols.push_back(k::gather_column(ctx_, in.cols[(size_t)ch], probe_idx->as<int32_t>(), count, false));
-        const int nb = (int)source->output_channels().size();
-        for (int i = 0; i < nb; i++) out.cols.push_back(source->gather_build(i, build_idx->as<int32_t>(), count, outer));
-        pending_ = wrap(std::move(out));
+        if (probe_page(ctx_, *source, in, cfg_, out)) pending_ = wrap(std::move(out));
     }
 
     std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
@@ -360,6 +368,113 @@ std::unique_ptr<Operator> LookupJoinOperatorFactory::create_operator()
 }
 
 void LookupJoinOperatorFactory::no_more_operators()
+{
+    closed_ = true;
+    bridge_->no_more_probes();
+}
+
+// =====================================================================================================================
+// FilterAndProject fused into the probe
+// =====================================================================================================================
+class FusedFilterProjectJoinOperator : public Operator {
+public:
+    FusedFilterProjectJoinOperator(Context *ctx, int32_t id, const LookupJoinConfig &cfg, std::shared_ptr<LookupSourceFactory> bridge,
+                                   std::shared_ptr<PageProcessorGpu> processor, std::shared_ptr<FusedProbeGpu> fused)
+        : Operator(ctx, id), cfg_(cfg), bridge_(std::move(bridge)), processor_(std::move(processor)), fused_(std::move(fused))
+    {
+        bridge_->probe_created();
+    }
+    ~FusedFilterProjectJoinOperator() override { close(); }
+
+    bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
+    bool needs_input() override { return !finishing_ && !pending_ && !is_blocked(); }
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        TG_CHECK_STATE(!pending_, "Operator still has pending output");
+        std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
+        TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
+        DevicePage in = ingest_page(ctx_, page);
+        if (in.n == 0) return;
+        const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER;
+        IntTableView tv;
+        const bool fused_ok = fused_->supported() && cfg_.probe_join_channels.size() == 1 && source->int_table(tv) && tv.links == nullptr &&
+                              tv.key_type == fused_->projection_types()[(size_t)cfg_.probe_join_channels[0]] && getenv("TGPU_DISABLE_FUSION") == nullptr;
+        if (fused_ok) {
+            std::vector<DeviceColumn> probe_out;
+            BufferPtr build_idx;
+            int64_t count = 0, selected = 0;
+            fused_->process(ctx_, in, *source, outer, probe_out, build_idx, count, selected);
+            probe_rows_ += selected;
+            if (count == 0) return;
+            DevicePage out;
+            out.n = count;
+            out.cols = std::move(probe_out);
+            ProfileScope ps(ctx_, "join_gather");
+            const int nb = (int)source->output_channels().size();
+            for (int i = 0; i < nb; i++) out.cols.push_back(source->gather_build(i, build_idx->as<int32_t>(), count, outer));
+            pending_ = wrap(std::move(out));
+            return;
+        }
+        // unfused composition: FilterAndProject, then the probe
+        DevicePage mid, out;
+        if (!processor_->process(ctx_, in, mid)) return;
+        probe_rows_ += mid.n;
+        if (probe_page(ctx_, *source, mid, cfg_, out)) pending_ = wrap(std::move(out));
+    }
+
+    std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
+    void finish() override { finishing_ = true; }
+    bool is_finished() override
+    {
+        bool done = finishing_ && !pending_;
+        if (done) close();
+        return done;
+    }
+    int64_t memory_bytes() override { return pending_ ? pending_->page.size_in_bytes() : 0; }
+    int64_t probe_rows() const { return probe_rows_; }
+    void close() override
+    {
+        if (!closed_) {
+            closed_ = true;
+            bridge_->probe_closed();
+        }
+    }
+
+private:
+    LookupJoinConfig cfg_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    std::shared_ptr<PageProcessorGpu> processor_;
+    std::shared_ptr<FusedProbeGpu> fused_;
+    std::unique_ptr<OutputPage> pending_;
+    int64_t probe_rows_ = 0;
+    bool finishing_ = false, closed_ = false;
+};
+
+FusedFilterProjectJoinOperatorFactory::FusedFilterProjectJoinOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types,
+                                                                             const tgpu_page_processor_spec *spec, LookupJoinConfig cfg,
+                                                                             std::shared_ptr<LookupSourceFactory> bridge)
+    : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg)), bridge_(std::move(bridge))
+{
+    processor_ = std::make_shared<PageProcessorGpu>(input_types, spec);
+    cfg_.probe_types = processor_->output_types();
+    const int nt = (int)cfg_.probe_types.size();
+    TG_CHECK_ARG(!cfg_.probe_join_channels.empty(), "hash join needs at least one join channel");
+    for (int32_t ch : cfg_.probe_join_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe join channel out of range");
+    for (int32_t ch : cfg_.probe_output_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe output channel out of range");
+    TG_CHECK_ARG(cfg_.probe_hash_channel < nt, "probe hash channel out of range");
+    TG_CHECK_ARG(cfg_.join_type == TGPU_JOIN_INNER || cfg_.join_type == TGPU_JOIN_PROBE_OUTER, "only INNER and PROBE_OUTER joins are supported");
+    fused_ = std::make_shared<FusedProbeGpu>(input_types, spec, cfg_.probe_join_channels[0], cfg_.probe_output_channels);
+}
+
+std::unique_ptr<Operator> FusedFilterProjectJoinOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<FusedFilterProjectJoinOperator>(ctx_, operator_id_, cfg_, bridge_, processor_, fused_);
+}
+
+void FusedFilterProjectJoinOperatorFactory::no_more_operators()
 {
     closed_ = true;
     bridge_->no_more_probes();

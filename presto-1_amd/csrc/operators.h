@@ -136,6 +136,24 @@ private:
     std::shared_ptr<LookupSourceFactory> bridge_;
 };
 
+// ---- FilterAndProject fused into the LookupJoin probe (operator fusion by codegen, jit.h FusedProbeGpu).  The pair behaves
+// exactly like FilterAndProjectOperator feeding LookupJoinOperator; `cfg` addresses the page processor's projections. ----
+class FusedFilterProjectJoinOperatorFactory : public OperatorFactory {
+public:
+    FusedFilterProjectJoinOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec,
+                                          LookupJoinConfig cfg, std::shared_ptr<LookupSourceFactory> bridge);
+    std::unique_ptr<Operator> create_operator() override;
+    void no_more_operators() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    LookupJoinConfig cfg_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    std::shared_ptr<PageProcessorGpu> processor_;
+    std::shared_ptr<FusedProbeGpu> fused_;
+};
+
 }  // namespace tgpu
 
 struct tgpu_context {
@@ -143,12 +161,15 @@ struct tgpu_context {
 };
 struct tgpu_operator_factory {
     std::unique_ptr<tgpu::OperatorFactory> f;
+    tgpu::Context *ctx = nullptr;
 };
 struct tgpu_operator {
     std::unique_ptr<tgpu::Operator> op;
+    tgpu::Context *ctx = nullptr;
 };
 struct tgpu_lookup_source_factory {
     std::shared_ptr<tgpu::LookupSourceFactory> bridge;
+    tgpu::Context *ctx = nullptr;
 };
 struct tgpu_group_by_hash {
     tgpu::Context *ctx;

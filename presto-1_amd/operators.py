@@ -228,6 +228,34 @@ class LookupJoinOperatorFactory(OperatorFactory):
         self._bridge = lookup_source_factory
 
 
+class FilterProjectLookupJoinOperatorFactory(OperatorFactory):
+    """FilterAndProjectOperator fused into the LookupJoin probe (one generated kernel); same results as the two reference
+    operators back to back.  probe_join_channels / probe_output_channels index the page processor's projections."""
+
+    def __init__(self, ctx: Context, operator_id, lookup_source_factory: LookupSourceFactory, input_types, filter_expr, projections,
+                 probe_join_channels, probe_hash_channel=-1, probe_output_channels=None, join_type=INNER):
+        if probe_output_channels is None:
+            probe_output_channels = list(range(len(projections)))
+        self.program = FlatProgram(filter_expr, projections)
+        spec, keep = self.program.to_c()
+        t, nt = _i32(input_types)
+        jc, nj = _i32(probe_join_channels)
+        oc, no = _i32(probe_output_channels)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_filter_project_lookup_join_factory_create(ctx.handle, operator_id, lookup_source_factory.handle, nt, t, C.byref(spec),
+                                                                             nj, jc, probe_hash_channel, no, oc, join_type, C.byref(h)))
+        super().__init__(h, keep)
+        self._bridge = lookup_source_factory
+
+
+def precompile_fused_probe(input_types, filter_expr, projections, join_channel, probe_output_channels):
+    prog = FlatProgram(filter_expr, projections)
+    spec, keep = prog.to_c()
+    t, nt = _i32(input_types)
+    oc, no = _i32(probe_output_channels)
+    _lib.check(_lib.lib().tgpu_precompile_fused_probe(nt, t, C.byref(spec), join_channel, no, oc))
+
+
 class GroupByHash:
     """GroupByHash.createGroupByHash (M/operator/GroupByHash.java:45-59) over the GPU table."""
 

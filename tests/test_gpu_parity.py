@@ -551,3 +551,93 @@ def test_lowcard_and_general_accumulators_agree_bitwise(pkg, oracle, monkeypatch
     gids = o.get_group_ids(oracle.Col(pkg.BIGINT, keys))
     _, exact = oracle.agg_double_sum_exact(gids, page.getBlock(1).values, 4, nulls=page.getBlock(1).nulls)
     assert ulp_diff([r[1] for r in a], exact).max() == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# operator fusion: FilterAndProject + LookupJoin in one generated kernel == the two reference operators back to back
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("join_type", [0, 1])
+@pytest.mark.parametrize("key_type", ["BIGINT", "INTEGER"])
+def test_fused_filter_project_join_matches_unfused_and_oracle(pkg, oracle, monkeypatch, join_type, key_type):
+    rng = np.random.default_rng(17)
+    kt = getattr(pkg, key_type)
+    nb, n = 20_000, 150_000
+    bkeys = rng.permutation(60_000)[:nb]
+    build = pkg.Page(pkg.Block(kt, bkeys.astype(np.int64 if kt == pkg.BIGINT else np.int32)), pkg.Block(pkg.DOUBLE, rng.standard_normal(nb)),
+                     rand_block(pkg, rng, pkg.VARCHAR, nb, 0.05, (0, 9)))
+    T = [kt, pkg.DOUBLE, pkg.DOUBLE, pkg.DATE]
+    probe = pkg.Page(rand_block(pkg, rng, kt, n, 0.03, (0, 60_000)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.05), rand_block(pkg, rng, pkg.DOUBLE, n, 0.0),
+                     rand_block(pkg, rng, pkg.DATE, n, 0.02, (9000, 9400)))
+    f, c = pkg.field, pkg.constant
+    filt = f(3, pkg.DATE) > 9204
+    projs = [f(0, kt), f(1, pkg.DOUBLE) * (c(1.0, pkg.DOUBLE) - f(2, pkg.DOUBLE)), f(3, pkg.DATE)]
+    results = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("TGPU_DISABLE_FUSION", "1")
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        bf = pkg.HashBuilderOperatorFactory(ctx, 1, [kt, pkg.DOUBLE, pkg.VARCHAR], [1, 2], [0])
+        jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, T, filt, projs, [0], probe_output_channels=[1, 0, 2], join_type=join_type)
+        b = bf.createOperator()
+        b.addInput(build)
+        b.finish()
+        op = jf.createOperator()
+        out = pkg.to_pages(op, [probe, pkg.Page(*[pkg.Block(t, []) for t in T]), probe])
+        results[mode] = [r for p in out for r in p.rows()]
+        prof = ctx.profile()
+        assert ("fused_filter_probe" in prof) == (mode == "fused")
+        op.close(); b.close(); ctx.close()
+    assert results["fused"] == results["unfused"]
+    # oracle composition: filter positions -> projections -> PagesHash probe
+    prog = pkg.expressions.FlatProgram(filt, projs)
+    cols = [ocol(oracle, blk) for blk in probe.blocks]
+    pos = oracle.filter_positions(prog.nodes, prog.filter_root, b"", cols)
+    rev, rev_null = oracle.project(prog.nodes, prog.projection_roots[1], b"", cols, pos)
+    keyblk = probe.getBlock(0)
+    kcol = oracle.Col(kt, keyblk.values[pos], None if keyblk.nulls is None else keyblk.nulls[pos])
+    ph = oracle.PagesHash([ocol(oracle, build.getBlock(0))])
+    opx, obx = ph.probe([kcol], probe_outer=bool(join_type))
+    bl = build.rows()
+    want = []
+    for i, j in zip(opx, obx):
+        r = pos[i]
+        want.append((None if rev_null[i] else float(rev[i]), keyblk.get(int(r)), probe.getBlock(3).get(int(r))) + ((bl[j][1], bl[j][2]) if j >= 0 else (None, None)))
+    assert results["fused"] == want + want
+
+
+def test_fused_join_falls_back_when_projection_can_raise(pkg, ctx):
+    # a checked BIGINT projection must still raise for selected rows that do NOT match (FilterAndProject semantics)
+    build = pkg.Page(pkg.Block(pkg.BIGINT, np.array([1, 2], dtype=np.int64)))
+    probe = pkg.Page(pkg.Block(pkg.BIGINT, np.array([1, 5], dtype=np.int64)), pkg.Block(pkg.BIGINT, np.array([3, 2**62], dtype=np.int64)))
+    f = pkg.field
+    bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT], [], [0])
+    jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, [pkg.BIGINT] * 2, None, [f(0, pkg.BIGINT), f(1, pkg.BIGINT) * 4], [0])
+    b = bf.createOperator()
+    b.addInput(build)
+    b.finish()
+    with pytest.raises(pkg.TgpuError) as e:
+        pkg.to_pages(jf.createOperator(), [probe])
+    assert e.value.code == -2
+
+
+@pytest.mark.parametrize("stride", [1, 10**12])
+def test_join_prefilters_dense_bitmap_and_sparse_bloom(pkg, ctx, oracle, stride):
+    """dense key domains use the exact bitmap pre-filter, sparse ones the Bloom filter: same pairs as the oracle either way"""
+    rng = np.random.default_rng(23)
+    bkeys = (rng.permutation(300_000)[:100_000].astype(np.int64) - 150_000) * stride
+    pkeys = (rng.integers(-200_000, 200_000, 400_000).astype(np.int64)) * stride
+    rows, stats = run_join(pkg, ctx, [pkg.Page(pkg.Block(pkg.BIGINT, bkeys), pkg.Block(pkg.BIGINT, np.arange(len(bkeys), dtype=np.int64)))],
+                           [pkg.Page(pkg.Block(pkg.BIGINT, pkeys))], [pkg.BIGINT] * 2, [pkg.BIGINT], [0], [0], out_b=[1], out_p=[0])
+    op, ob = oracle.PagesHash([oracle.Col(pkg.BIGINT, bkeys)]).probe([oracle.Col(pkg.BIGINT, pkeys)])
+    assert rows == [(int(pkeys[i]), int(j)) for i, j in zip(op, ob)]
+    # and through the fused filter+project+probe kernel
+    f = pkg.field
+    bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT], [0], [0])
+    jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, [pkg.BIGINT], None, [f(0, pkg.BIGINT)], [0])
+    b = bf.createOperator()
+    b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, bkeys)))
+    b.finish()
+    out = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, pkeys))])
+    got = np.concatenate([p.getBlock(0).values for p in out])
+    assert np.array_equal(got, pkeys[op])

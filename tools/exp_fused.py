@@ -1,0 +1,49 @@
+"""Kernel study: time the fused filter+project+probe kernel on the Q3 lineitem shape under experiment switches."""
+import importlib, os, sys, json
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+sf = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
+variants = sys.argv[2].split(",") if len(sys.argv) > 2 else ["BASE", "NOLOOKBACK", "NOPROBE"]
+pkg = importlib.import_module("presto-1_amd")
+entry = importlib.import_module("__graft_entry__")
+dev = torch.device("cuda", 0)
+t = bench.gen_q3(dev, sf)
+B, D, DT, I = pkg.BIGINT, pkg.DOUBLE, pkg.DATE, pkg.INTEGER
+# build side: orders passing both filters (computed with torch, like check_q3)
+cust_ok = torch.zeros(t["c_custkey"].numel() + 2, dtype=torch.bool, device=dev)
+seg = t["c_seg_bytes"][t["c_seg_off"][:-1].to(torch.int64)]
+cust_ok[t["c_custkey"]] = seg == ord("B")
+o_ok = (t["o_orderdate"] < 9204) & cust_ok[t["o_custkey"]]
+bkeys = t["o_orderkey"][o_ok].contiguous()
+print("build rows", bkeys.numel(), "lineitem rows", t["l_orderkey"].numel())
+for v in variants:
+    if v == "BASE":
+        os.environ.pop("TGPU_FJ_EXP", None)
+    else:
+        os.environ["TGPU_FJ_EXP"] = v
+    ctx = pkg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx.profile_enable(True)
+    bf = pkg.HashBuilderOperatorFactory(ctx, 1, [B], [], [0])
+    b = bf.createOperator()
+    b.addInput(pkg.Page(pkg.DeviceBlock(B, bkeys.numel(), bkeys)))
+    b.finish()
+    pp = entry.bench_page_processors(pkg)
+    jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, *pp["q3_lineitem"], [0], probe_output_channels=[0, 1])
+    page = pkg.Page(pkg.DeviceBlock(B, t["l_orderkey"].numel(), t["l_orderkey"]), pkg.DeviceBlock(D, t["l_orderkey"].numel(), t["l_extendedprice"]),
+                    pkg.DeviceBlock(D, t["l_orderkey"].numel(), t["l_discount"]), pkg.DeviceBlock(DT, t["l_orderkey"].numel(), t["l_shipdate"]))
+    for it in range(4):
+        op = jf.createOperator()
+        op.addInput(page)
+        o = op.getOutput()
+        rows = o.position_count if o is not None else 0
+        if o is not None:
+            o.release()
+        op.close()
+        if it == 0:
+            ctx.profile_reset()
+    prof = ctx.profile()
+    print(v, "rows", rows, {k: round(x["total_ms"] / x["count"], 3) for k, x in prof.items() if k.startswith("fused")})
+    b.close()
+    ctx.close()
