@@ -206,6 +206,19 @@ int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_
                                                        int32_t probe_output_channel_count, const int32_t *probe_output_channels,
                                                        int32_t join_type, tgpu_operator_factory **out);
 
+/* FilterAndProjectOperator feeding HashAggregationOperator as one fused pipeline (what LocalExecutionPlanner.visitAggregation,
+ * M/sql/planner/LocalExecutionPlanner.java:1198,2965-3056, would construct over a filter/project source; the shape of
+ * testing/trino-benchmark HandTpchQuery1.java:60-133).  Same results as the two reference operators back to back.  `spec`'s
+ * projections form the aggregation's input page: group_by_channels, hash_channel and the aggregates' input / mask channels
+ * index those projections.  step is SINGLE or PARTIAL. */
+int32_t tgpu_filter_project_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator_id,
+                                                            int32_t input_type_count, const int32_t *input_types,
+                                                            const tgpu_page_processor_spec *spec,
+                                                            int32_t group_by_count, const int32_t *group_by_types, const int32_t *group_by_channels,
+                                                            int32_t hash_channel /* -1 = none */, int32_t step,
+                                                            int32_t agg_count, const tgpu_agg_spec *aggs,
+                                                            int32_t expected_groups, tgpu_operator_factory **out);
+
 /* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory);

@@ -78,6 +78,7 @@ SYMBOLS = {
     "tgpu_lookup_source_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     "tgpu_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
     "tgpu_filter_project_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), P(PageProcessorSpec), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
+    "tgpu_filter_project_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, P(vp)]),
     "tgpu_operator_factory_create_operator": (i32, [vp, P(vp)]),
     "tgpu_operator_factory_no_more_operators": (i32, [vp]),
     "tgpu_operator_factory_destroy": (None, [vp]),
@@ -113,6 +114,7 @@ EXTRA_SYMBOLS = {
     "tgpu_page_processor_source": (i64, [i32, P(i32), P(PageProcessorSpec), cp, i64]),
     "tgpu_group_by_hash_rehash_count": (i32, [vp]),
     "tgpu_precompile_fused_probe": (i32, [i32, P(i32), P(PageProcessorSpec), i32, i32, P(i32)]),
+    "tgpu_precompile_fused_aggregation": (i32, [i32, P(i32), P(PageProcessorSpec), i32, P(AggSpec), i32, P(i32)]),
 }
 
 

@@ -26,6 +26,17 @@ public:
     void add_intermediate(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count);
     // appends the output channels for groups [0, group_count)
     void evaluate(int64_t group_count, std::vector<DeviceColumn> &out);
+    // device state of aggregate k for groups [0, reserve()d): used by the JIT-fused project+accumulate kernels
+    struct DeviceState {
+        int32_t function;
+        long long *counts;
+        long long *limbs;
+        unsigned int *special;
+        unsigned long long *i128;
+    };
+    void reserve(int64_t groups) { ensure(groups > 0 ? groups : 1); }
+    DeviceState device_state(int k) const;
+    const std::vector<tgpu_agg_spec> specs() const;
     int output_channel_count() const;
     int intermediate_channel_count() const;
     int64_t estimated_size() const;

@@ -1,6 +1,7 @@
 // agg.hip -- grouped accumulators (K6) for count / sum / avg.
 #include "agg.h"
 #include "kernels.h"
+#include "device_agg.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -32,45 +33,15 @@ struct AggArgs {
     AggView a[kMaxAggs];
 };
 
-// exact accumulation of one double into the limb array of its group (order independent)
-__device__ __forceinline__ void kulisch_add(long long *limbs, unsigned int *special, double v)
-{
-    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    const unsigned int e = (unsigned int)((bits >> 52) & 0x7ff);
-    unsigned long long m = bits & 0xfffffffffffffULL;
-    const bool neg = (bits >> 63) != 0;
-    if (e == 0x7ff) {
-        atomicOr(special, m ? 1u : (neg ? 4u : 2u));
-        return;
-    }
-    int p = 0;
-    if (e) { m |= 1ULL << 52; p = (int)e - 1; }
-    if (m == 0) return;
-    const int j = p >> 5, s = p & 31;
-    // (m << s) as three 32-bit limbs
-    const unsigned long long lo64 = m << s;                      // low 64 bits
-    const unsigned long long hi64 = s ? (m >> (64 - s)) : 0ULL;  // bits 64..84
-    long long l0 = (long long)(lo64 & 0xffffffffULL), l1 = (long long)(lo64 >> 32), l2 = (long long)hi64;
-    if (neg) { l0 = -l0; l1 = -l1; l2 = -l2; }
-    if (l0) atomicAdd((unsigned long long *)&limbs[j], (unsigned long long)l0);
-    if (l1) atomicAdd((unsigned long long *)&limbs[j + 1], (unsigned long long)l1);
-    if (l2) atomicAdd((unsigned long long *)&limbs[j + 2], (unsigned long long)l2);
-}
-
-__device__ __forceinline__ void i128_add(unsigned long long *acc, long long v)
-{
-    const unsigned long long uv = (unsigned long long)v;
-    const unsigned long long old = atomicAdd(&acc[0], uv);
-    const unsigned long long carry = (old + uv) < old ? 1ULL : 0ULL;
-    const unsigned long long hi_add = (v < 0 ? ~0ULL : 0ULL) + carry;
-    if (hi_add) atomicAdd(&acc[1], hi_add);
-}
+#define kulisch_add tg_kulisch_add
+#define i128_add tg_i128_add
 
 template <bool INTERMEDIATE>
 __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, const int32_t *__restrict__ gids, int64_t n)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         const int64_t g = gids ? gids[r] : 0;
+        if (g < 0) continue;  // row excluded by a filter fused in front of the table
         for (int k = 0; k < args.n_aggs; k++) {
             const AggView &a = args.a[k];
             if (INTERMEDIATE) {
@@ -107,117 +78,48 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Low-cardinality path (TPCH Q1: 4 groups x 8 aggregates over 600 M rows).  With a handful of groups every lane of the
-// chip would hammer the same few accumulators, so the accumulators are privatised PER LANE in LDS:
+// chip would hammer the same few accumulators, so the accumulators are privatised PER LANE in LDS (device_agg.h):
 //     slot(g, a, lane) -> { hi, lo } double-double running sum (two-sum: the pair carries ~106 bits) + uint32 count
 // laid out [g][a][256 lanes] so a wave's access is 64 consecutive 8-byte words (conflict-free, no atomics, and the order
 // in which a lane adds its rows is fixed -> deterministic).  At the end of the block the 256 lane partials of each (g, a)
-// are folded with double-double adds and lane 0 of each wave adds the (hi, lo) pair EXACTLY into the global limb
-// accumulator, so both paths feed the same state and the final rounding is still the exact sum's.
+// are folded with double-double adds and added EXACTLY into the global limb accumulator, so both paths feed the same
+// state and the final rounding is still the exact sum's.
 // ---------------------------------------------------------------------------------------------------------------------
-struct LowCardPlan {
-    int32_t n_aggs;
-    int32_t n_wide;                 // aggregates with a 16-byte state (double sums, bigint sums)
-    int32_t wide_slot[kMaxAggs];    // index among the wide states or -1
-    int32_t per_group_bytes;
-    int32_t n_groups;
+using LowCardPlan = TgLowCardPlan;
+
+struct LowCardStates {
+    TgAggState st[kMaxAggs];
 };
 
-__device__ __forceinline__ void dd_add(double &hi, double &lo, double h2, double l2)
-{
-    const double s = hi + h2;
-    const double bb = s - hi;
-    double e = (hi - (s - bb)) + (h2 - bb);
-    e += lo + l2;
-    hi = s + e;
-    lo = e - (hi - s);
-}
-
-__global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCardPlan plan, const int32_t *__restrict__ gids, int64_t n)
+__global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCardStates states, LowCardPlan plan, const int32_t *__restrict__ gids, int64_t n)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int total_words = plan.n_groups * plan.per_group_bytes / 4;
-    for (int i = tid; i < total_words; i += kBlock) ((unsigned int *)lds)[i] = 0u;
-    __syncthreads();
-    const int wide_bytes = plan.n_wide * 2 * kBlock * 8;  // per group: hi[n_wide][256], lo[n_wide][256], then cnt[n_aggs][256]
-
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + tid; r < n; r += (int64_t)gridDim.x * kBlock) {
+    tg_lc_zero(lds, plan);
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         const int g = gids ? gids[r] : 0;
-        unsigned char *gb = lds + (size_t)g * plan.per_group_bytes;
-        double *hi_base = (double *)gb;
-        double *lo_base = (double *)(gb + plan.n_wide * kBlock * 8);
-        unsigned int *cnt_base = (unsigned int *)(gb + wide_bytes);
+        if (g < 0) continue;
+        double *hi_base = tg_lc_hi(lds, plan, g), *lo_base = tg_lc_lo(lds, plan, g);
+        unsigned int *cnt_base = tg_lc_cnt(lds, plan, g);
         for (int k = 0; k < args.n_aggs; k++) {
             const AggView &a = args.a[k];
             if (a.mask && ((a.mask_nulls && a.mask_nulls[r]) || !a.mask[r])) continue;
             if (a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[r]) continue;
-            cnt_base[k * kBlock + tid] += 1u;
+            cnt_base[k * kBlock + threadIdx.x] += 1u;
             const int w = plan.wide_slot[k];
             if (w < 0) continue;
             if (a.function == TGPU_AGG_SUM_BIGINT) {
-                unsigned long long *lo64 = (unsigned long long *)&hi_base[w * kBlock + tid];
-                long long *hi64 = (long long *)&lo_base[w * kBlock + tid];
-                const long long v = ((const long long *)a.input)[r];
-                const unsigned long long old = *lo64, nw = old + (unsigned long long)v;
-                *lo64 = nw;
-                *hi64 += (v < 0 ? -1 : 0) + (nw < old ? 1 : 0);
+                tg_lc_add_bigint(hi_base, lo_base, w, ((const long long *)a.input)[r]);
                 continue;
             }
             const double v = a.function == TGPU_AGG_AVG_BIGINT ? (double)((const long long *)a.input)[r] : ((const double *)a.input)[r];
             if (!(fabs(v) <= 1.7976931348623157e308)) {  // NaN / +-inf: flagged globally, not summed
-                const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-                atomicOr(&a.special[g], (bits & 0xfffffffffffffULL) ? 1u : ((bits >> 63) ? 4u : 2u));
+                tg_flag_special(&a.special[g], v);
                 continue;
             }
-            double hi = hi_base[w * kBlock + tid];
-            const double s = hi + v;
-            const double bb = s - hi;
-            const double err = (hi - (s - bb)) + (v - bb);
-            hi_base[w * kBlock + tid] = s;
-            lo_base[w * kBlock + tid] += err;
+            tg_lc_add_double(hi_base, lo_base, w, v);
         }
     }
-    __syncthreads();
-    // fold the lane partials: one wave-level tree per (group, aggregate), then one exact global add per wave
-    const int lane = tid & 63;
-    for (int g = 0; g < plan.n_groups; g++) {
-        unsigned char *gb = lds + (size_t)g * plan.per_group_bytes;
-        double *hi_base = (double *)gb;
-        double *lo_base = (double *)(gb + plan.n_wide * kBlock * 8);
-        unsigned int *cnt_base = (unsigned int *)(gb + wide_bytes);
-        for (int k = 0; k < args.n_aggs; k++) {
-            const AggView &a = args.a[k];
-            unsigned long long c = cnt_base[k * kBlock + tid];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
-            const bool any = __shfl(c, 0, 64) != 0;
-            if (!any) continue;
-            if (lane == 0) atomicAdd((unsigned long long *)&a.counts[g], c);
-            const int w = plan.wide_slot[k];
-            if (w < 0) continue;
-            if (a.function == TGPU_AGG_SUM_BIGINT) {
-                const unsigned long long lo64 = *(unsigned long long *)&hi_base[w * kBlock + tid];
-                const long long hi64 = *(long long *)&lo_base[w * kBlock + tid];
-                if (lo64 || hi64) {
-                    const unsigned long long old = atomicAdd(&a.i128[g * 2], lo64);
-                    const unsigned long long carry = (old + lo64) < old ? 1ULL : 0ULL;
-                    const unsigned long long add_hi = (unsigned long long)hi64 + carry;
-                    if (add_hi) atomicAdd(&a.i128[g * 2 + 1], add_hi);
-                }
-                continue;
-            }
-            double hi = hi_base[w * kBlock + tid], lo = lo_base[w * kBlock + tid];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const double h2 = __shfl_down(hi, d, 64), l2 = __shfl_down(lo, d, 64);
-                dd_add(hi, lo, h2, l2);
-            }
-            if (lane == 0) {
-                kulisch_add(&a.limbs[g * kLimbs], &a.special[g], hi);
-                kulisch_add(&a.limbs[g * kLimbs], &a.special[g], lo);
-            }
-        }
-    }
+    tg_lc_fold(lds, plan, states.st);
 }
 
 // limbs -> correctly rounded double (round half to even)
@@ -365,6 +267,25 @@ GroupedAccumulators::GroupedAccumulators(Context *ctx, std::vector<tgpu_agg_spec
     error_ = ctx_->alloc_zero(4);
 }
 
+GroupedAccumulators::DeviceState GroupedAccumulators::device_state(int k) const
+{
+    const State &st = states_[(size_t)k];
+    DeviceState d;
+    d.function = st.spec.function;
+    d.counts = st.counts ? st.counts->as<long long>() : nullptr;
+    d.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
+    d.special = st.special ? st.special->as<unsigned int>() : nullptr;
+    d.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+    return d;
+}
+
+const std::vector<tgpu_agg_spec> GroupedAccumulators::specs() const
+{
+    std::vector<tgpu_agg_spec> v;
+    for (auto &s : states_) v.push_back(s.spec);
+    return v;
+}
+
 int GroupedAccumulators::output_channel_count() const
 {
     return step_ == TGPU_STEP_PARTIAL ? intermediate_channel_count() : (int)states_.size();
@@ -456,7 +377,15 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         const int per_cu = (int)std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / lds_bytes));
         int64_t blocks = std::min<int64_t>((int64_t)ctx_->cu_count() * per_cu, ceil_div(n, kBlock));
         ProfileScope ps(ctx_, "agg_accumulate_lowcard");
-        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, plan, gids, n);
+        LowCardStates states{};
+        for (int k = 0; k < args.n_aggs; k++) {
+            states.st[k].function = args.a[k].function;
+            states.st[k].counts = args.a[k].counts;
+            states.st[k].limbs = args.a[k].limbs;
+            states.st[k].special = args.a[k].special;
+            states.st[k].i128 = args.a[k].i128;
+        }
+        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, states, plan, gids, n);
         check_launch("agg_accumulate_lowcard");
         return;
     }

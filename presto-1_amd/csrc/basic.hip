@@ -128,29 +128,10 @@ void exclusive_scan_i32(Context *ctx, const int32_t *in, int32_t *out, int64_t n
 // ---------------------------------------------------------------------------------------------------------------------
 // K3 raw hash: h = 31*h + (isNull ? 0 : typeHash(cell)), start 0 (M/operator/InterpretedHashGenerator.java:56-70)
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ tg_i64 hash_cell(const ColView &c, int64_t r)
-{
-    if (c.nulls && c.nulls[r]) return 0;
-    switch (c.type) {
-    case TGPU_BIGINT: return tg_hash_long(((const tg_i64 *)c.values)[r]);
-    case TGPU_INTEGER:
-    case TGPU_DATE: return tg_hash_int(((const int *)c.values)[r]);
-    case TGPU_DOUBLE: return tg_hash_double_bits(((const tg_u64 *)c.values)[r]);
-    case TGPU_BOOLEAN: return tg_hash_boolean(((const tg_u8 *)c.values)[r]);
-    case TGPU_VARCHAR: {
-        int a = c.offsets[r], b = c.offsets[r + 1];
-        return (tg_i64)tg_xxh64((const tg_u8 *)c.values + a, b - a);
-    }
-    default: return 0;
-    }
-}
-
 __global__ void __launch_bounds__(kBlock) hash_rows_kernel(KeyCols keys, int64_t n, int64_t *__restrict__ out)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        tg_i64 h = 0;
-        for (int c = 0; c < keys.n; c++) h = tg_combine_hash(h, hash_cell(keys.c[c], r));
-        out[r] = h;
+        out[r] = tg_hash_row(keys, r);
     }
 }
 

@@ -304,6 +304,40 @@ int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_
     });
 }
 
+int32_t tgpu_filter_project_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t input_type_count, const int32_t *input_types,
+                                                            const tgpu_page_processor_spec *spec, int32_t group_by_count, const int32_t *group_by_types,
+                                                            const int32_t *group_by_channels, int32_t hash_channel, int32_t step, int32_t agg_count,
+                                                            const tgpu_agg_spec *aggs, int32_t expected_groups, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out && spec, "null argument");
+        TG_CHECK_ARG(agg_count >= 0 && (agg_count == 0 || aggs != nullptr), "null aggregate array");
+        TG_CHECK_ARG(step == TGPU_STEP_SINGLE || step == TGPU_STEP_PARTIAL, "a fused filter/project feeds a SINGLE or PARTIAL aggregation");
+        HashAggregationConfig cfg;
+        cfg.group_by_types = vec(group_by_types, group_by_count);
+        cfg.group_by_channels = vec(group_by_channels, group_by_count);
+        cfg.hash_channel = hash_channel;
+        cfg.step = step;
+        cfg.aggs.assign(aggs, aggs + agg_count);
+        cfg.expected_groups = expected_groups;
+        if (const char *env = getenv("TGPU_MAX_PARTIAL_AGGREGATION_MEMORY")) cfg.max_partial_memory = atoll(env);
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<FusedFilterProjectAggregationOperatorFactory>(ctx->ctx.get(), operator_id, vec(input_types, input_type_count), spec, std::move(cfg));
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
+int32_t tgpu_precompile_fused_aggregation(int32_t input_type_count, const int32_t *input_types, const tgpu_page_processor_spec *spec, int32_t agg_count,
+                                          const tgpu_agg_spec *aggs, int32_t group_by_count, const int32_t *group_by_channels)
+{
+    return guard([&] {
+        FusedAggGpu f(vec(input_types, input_type_count), spec, std::vector<tgpu_agg_spec>(aggs, aggs + agg_count), vec(group_by_channels, group_by_count));
+        f.precompile();
+    });
+}
+
 // compile-only (no GPU): pre-warm the kernel cache of a fused filter+project+probe pipeline
 int32_t tgpu_precompile_fused_probe(int32_t input_type_count, const int32_t *input_types, const tgpu_page_processor_spec *spec, int32_t join_channel,
                                     int32_t probe_output_channel_count, const int32_t *probe_output_channels)

@@ -203,20 +203,14 @@ struct DevicePage {
     }
 };
 
-// plain struct passed by value to kernels
-struct ColView {
-    const void *values;
-    const uint8_t *nulls;
-    const int32_t *offsets;
-    int32_t type;
-    int32_t pad;
-};
-constexpr int kMaxKeyChannels = 8;
-struct KeyCols {
-    int32_t n;
-    int32_t pad;
-    ColView c[kMaxKeyChannels];
-};
+}  // namespace tgpu
+// plain structs passed by value to kernels (device_cols.h: shared with the JIT-compiled kernels)
+#include "device_hash.h"
+#include "device_cols.h"
+namespace tgpu {
+using ColView = TgColView;
+using KeyCols = TgKeyCols;
+constexpr int kMaxKeyChannels = TG_MAX_KEY_CHANNELS;
 
 inline ColView view_of(const DeviceColumn &c) { return ColView{c.values, c.nulls, c.offsets, c.type, 0}; }
 inline KeyCols key_cols_of(const std::vector<const DeviceColumn *> &cols)

@@ -4,7 +4,22 @@
 
 #include "common.h"
 
+#include <functional>
+
 namespace tgpu {
+
+// one probe/insert launch of a sub-batch, for probe kernels compiled outside groupby.hip (jit.cpp: key-schema specialised,
+// filter fused in front).  Rows are numbered from 0 inside the sub-batch; row0 is the sub-batch's offset in the page.
+struct GbhProbeLaunch {
+    int64_t row0, n;
+    uint64_t *words;
+    uint64_t mask;
+    KeyCols store;
+    int32_t store_groups;
+    int32_t *out;
+    unsigned long long *counters;   // [0] pending rows, [2] table-full error
+};
+using GbhProbeFn = std::function<void(const GbhProbeLaunch &)>;
 
 class GroupByHashGpu {
 public:
@@ -12,7 +27,11 @@ public:
 
     // group id (int32, device) of each of the n rows; new keys get ids in first-seen order.
     // hashes == nullptr -> raw hashes are computed from the keys (InterpretedHashGenerator).
-    void get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids);
+    // row_mask (optional, one byte per row): rows with 0 take no part and get id -1 (a filter fused in front of the table).
+    // inline_hash: with hashes == nullptr, compute the raw hash inside the probe kernel instead of materialising it.
+    // probe: optional external probe/insert kernel (replaces the generic one; it applies its own row filter)
+    void get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
+                       const uint8_t *row_mask = nullptr, bool inline_hash = false, const GbhProbeFn *probe = nullptr);
     // lookup only (GroupByHash.contains): out[i] = group id or -1
     void lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids);
 
@@ -38,7 +57,10 @@ private:
     void ensure_table(int64_t need_groups);
     void ensure_store(int64_t need_groups);
     void ensure_pool(KeyStore &ks, int64_t need_bytes);
-    void process_sub_batch(const KeyCols &batch, const int64_t *hashes, int64_t n, int32_t *out_gids);
+    // returns false when the table overflowed (the caller rebuilds a bigger one and re-runs the rows); *new_groups out
+    bool process_sub_batch(const KeyCols &batch, const int64_t *hashes, const uint8_t *row_mask, int64_t row0, int64_t n, int32_t *out_gids,
+                           const GbhProbeFn *probe, int64_t *new_groups);
+    void rebuild_table(int64_t min_capacity);
     KeyCols store_view() const;
     void advance_java_capacity();
 

@@ -20,7 +20,9 @@
 #include "groupby.h"
 #include "kernels.h"
 #include "device_hash.h"
+#include "device_groupby.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 
@@ -31,100 +33,29 @@ namespace {
 constexpr int kBlock = 256;
 constexpr uint64_t kEmpty = ~0ull;
 
-__device__ __forceinline__ uint64_t make_new(uint32_t tag, uint32_t row) { return (1ull << 62) | ((uint64_t)tag << 32) | row; }
 __device__ __forceinline__ uint64_t make_old(uint32_t tag, uint32_t gid) { return ((uint64_t)tag << 32) | gid; }
 
-// IS NOT DISTINCT FROM per channel (JoinCompiler.java positionNotDistinctFromRow; DoubleType.java:181-192 NaN rule)
-__device__ __forceinline__ bool rows_not_distinct(const KeyCols &a, int64_t ra, const KeyCols &b, int64_t rb)
-{
-    for (int c = 0; c < a.n; c++) {
-        const ColView &x = a.c[c], &y = b.c[c];
-        bool nx = x.nulls && x.nulls[ra], ny = y.nulls && y.nulls[rb];
-        if (nx || ny) {
-            if (nx != ny) return false;
-            continue;
-        }
-        switch (x.type) {
-        case TGPU_BIGINT:
-            if (((const int64_t *)x.values)[ra] != ((const int64_t *)y.values)[rb]) return false;
-            break;
-        case TGPU_INTEGER:
-        case TGPU_DATE:
-            if (((const int32_t *)x.values)[ra] != ((const int32_t *)y.values)[rb]) return false;
-            break;
-        case TGPU_DOUBLE: {
-            double u = ((const double *)x.values)[ra], v = ((const double *)y.values)[rb];
-            if (!((u != u && v != v) || u == v)) return false;
-            break;
-        }
-        case TGPU_BOOLEAN:
-            if ((((const uint8_t *)x.values)[ra] != 0) != (((const uint8_t *)y.values)[rb] != 0)) return false;
-            break;
-        case TGPU_VARCHAR: {
-            int32_t ax = x.offsets[ra], lx = x.offsets[ra + 1] - ax;
-            int32_t ay = y.offsets[rb], ly = y.offsets[rb + 1] - ay;
-            if (lx != ly) return false;
-            const uint8_t *px = (const uint8_t *)x.values + ax, *py = (const uint8_t *)y.values + ay;
-            for (int32_t i = 0; i < lx; i++)
-                if (px[i] != py[i]) return false;
-            break;
-        }
-        default: return false;
-        }
-    }
-    return true;
-}
-
-// Plain (L1/L2 cacheable) load: a stale value is harmless because a slot only ever moves EMPTY -> NEW(row) -> NEW(smaller row)
-// within a kernel and every decision taken on a stale value is re-validated by the CAS / atomicMin that follows
-// (an observed EMPTY is confirmed by CAS; an observed NEW/OLD occupant never changes its key).  Cacheable loads matter for
-// low-cardinality inputs (TPCH Q1: 4 groups), where every lane of the chip reads the same few slots.
-__device__ __forceinline__ uint64_t load_word(const uint64_t *p) { return *p; }
+// generic key accessor for the shared probe protocol (device_groupby.h): run-time typed key columns
+struct GenericKeys {
+    KeyCols batch, store;
+    const int64_t *hashes;
+    __device__ long long hash(long long r) const { return hashes ? hashes[r] : tg_hash_row(batch, r); }
+    __device__ bool eq_store(long long r, int gid) const { return tg_rows_not_distinct(batch, r, store, gid); }
+    __device__ bool eq_row(long long r, long long r2) const { return tg_rows_not_distinct(batch, r, batch, r2); }
+};
 
 // counters: [0] pending rows, [2] error
 template <bool INSERT>
-__global__ void __launch_bounds__(kBlock) gbh_probe_kernel(KeyCols batch, const int64_t *__restrict__ hashes, int64_t n, uint64_t *words,
-                                                            uint64_t mask, KeyCols store, int32_t *__restrict__ out, unsigned long long *counters)
+__global__ void __launch_bounds__(kBlock) gbh_probe_kernel(KeyCols batch, const int64_t *__restrict__ hashes, const uint8_t *__restrict__ row_mask, int64_t n,
+                                                            uint64_t *words, uint64_t mask, KeyCols store, int32_t store_groups,
+                                                            int32_t *__restrict__ out, unsigned long long *counters)
 {
+    // hashes == nullptr: the raw hash is computed from the key cells; row_mask: rows with 0 take no part (out = -1)
+    GenericKeys k{batch, store, hashes};
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        const uint64_t m = tg_fmix64((uint64_t)hashes[r]);
-        uint64_t pos = m & mask;
-        const uint32_t tag = (uint32_t)(m >> 48);
-        int32_t result = -1;
         bool pending = false;
-        for (uint64_t iter = 0; iter <= mask; iter++) {
-            uint64_t w = load_word(&words[pos]);
-            if (w == kEmpty) {
-                if (!INSERT) break;
-                uint64_t old = atomicCAS((unsigned long long *)&words[pos], (unsigned long long)kEmpty, (unsigned long long)make_new(tag, (uint32_t)r));
-                if (old == kEmpty) {
-                    result = -(int32_t)(pos + 2);
-                    pending = true;
-                    break;
-                }
-                w = old;
-            }
-            if ((uint32_t)((w >> 32) & 0xffff) == tag) {
-                if ((w >> 62) == 0) {
-                    uint32_t gid = (uint32_t)w;
-                    if (rows_not_distinct(batch, r, store, gid)) {
-                        result = (int32_t)gid;
-                        break;
-                    }
-                }
-                else if (INSERT) {
-                    uint32_t r2 = (uint32_t)w;
-                    if (r2 == (uint32_t)r || rows_not_distinct(batch, r, batch, r2)) {
-                        if ((uint32_t)r < r2) atomicMin((unsigned long long *)&words[pos], (unsigned long long)make_new(tag, (uint32_t)r));
-                        result = -(int32_t)(pos + 2);
-                        pending = true;
-                        break;
-                    }
-                }
-            }
-            pos = (pos + 1) & mask;
-            if (iter == mask) atomicExch(&counters[2], 1ull);  // table full: cannot happen by construction
-        }
+        int32_t result = -1;
+        if (!row_mask || row_mask[r]) result = tg_gbh_probe<INSERT>(k, r, (unsigned long long *)words, (unsigned long long)mask, store_groups, counters, pending);
         out[r] = result;
         if (INSERT) {
             unsigned long long b = __ballot(pending);
@@ -163,7 +94,7 @@ __global__ void __launch_bounds__(kBlock) gbh_finalize_kernel(KeyCols batch, con
         const int64_t gid = base_gid + rank[r];
         const uint64_t w = words[pos];
         words[pos] = make_old((uint32_t)((w >> 32) & 0xffff), (uint32_t)gid);
-        raw_hash[gid] = hashes[r];
+        raw_hash[gid] = hashes ? hashes[r] : tg_hash_row(batch, r);
         for (int c = 0; c < batch.n; c++) {
             const ColView &s = batch.c[c];
             const ColView &d = store.c[c];
@@ -358,22 +289,29 @@ KeyCols GroupByHashGpu::store_view() const
     return k;
 }
 
-void GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hashes, int64_t n, int32_t *out)
+bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hashes, const uint8_t *row_mask, int64_t row0, int64_t n, int32_t *out,
+                                       const GbhProbeFn *probe, int64_t *new_groups_out)
 {
-    ensure_table(groups_ + n);
+    *new_groups_out = 0;
+    // room for every row of a normal sub-batch to be a new group; larger (optimistic) sub-batches rely on overflow detection
+    ensure_table(groups_ + std::min<int64_t>(n, sub_batch_));
     ensure_store(groups_ > 0 ? groups_ : 1);  // the store view must be addressable for OLD slots
     unsigned long long *ctr = counters_->as<unsigned long long>();
     HIP_CHECK(hipMemsetAsync(ctr, 0, 8 * 8, ctx_->stream()));
     const int g = grid_for(ctx_, n);
-    {
+    if (probe) {
+        GbhProbeLaunch l{row0, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr};
+        (*probe)(l);
+    }
+    else {
         ProfileScope ps(ctx_, "gbh_insert");
-        gbh_probe_kernel<true><<<g, kBlock, 0, ctx_->stream()>>>(batch, hashes, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), out, ctr);
+        gbh_probe_kernel<true><<<g, kBlock, 0, ctx_->stream()>>>(batch, hashes, row_mask, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr);
         check_launch("gbh_insert");
     }
     unsigned long long host_ctr[3];
     ctx_->download(host_ctr, ctr, sizeof(host_ctr));
-    TG_CHECK_STATE(host_ctr[2] == 0, "group-by table overflow");
-    if (host_ctr[0] == 0) return;  // every row hit an existing group
+    if (host_ctr[2] != 0) return false;  // table overflow
+    if (host_ctr[0] == 0) return true;   // every row hit an existing group
 
     BufferPtr flags = ctx_->alloc((size_t)n * 4), rank = ctx_->alloc((size_t)n * 4);
     {
@@ -414,28 +352,62 @@ void GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
         check_launch("gbh_resolve");
     }
     groups_ += new_groups;
+    *new_groups_out = new_groups;
     advance_java_capacity();
+    return true;
 }
 
-void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids)
+// drops every NEW mark of an aborted sub-batch by re-inserting the known groups into a fresh, larger table
+void GroupByHashGpu::rebuild_table(int64_t min_capacity)
+{
+    int64_t want = capacity_ > 0 ? capacity_ : 1024;
+    while (want < min_capacity) want <<= 1;
+    if (want > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "Size of hash table cannot exceed 1 billion entries");
+    BufferPtr nw = ctx_->alloc((size_t)want * 8);
+    k::fill_u64(ctx_, nw->as<uint64_t>(), kEmpty, want);
+    if (groups_ > 0) {
+        gbh_rehash_kernel<<<grid_for(ctx_, groups_), kBlock, 0, ctx_->stream()>>>(raw_hash_->as<int64_t>(), groups_, nw->as<uint64_t>(), (uint64_t)want - 1);
+        check_launch("gbh_rehash");
+    }
+    words_ = nw;
+    capacity_ = want;
+}
+
+void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
+                                   const uint8_t *row_mask, bool inline_hash, const GbhProbeFn *probe)
 {
     TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
     for (size_t i = 0; i < keys.size(); i++) TG_CHECK_ARG(keys[i]->type == types_[i], "group-by key channel type mismatch");
     if (n <= 0) return;
     BufferPtr own_hashes;
-    if (!hashes) {
+    if (!hashes && !inline_hash) {
         own_hashes = ctx_->alloc((size_t)n * 8);
         k::hash_rows(ctx_, key_cols_of(keys), n, own_hashes->as<int64_t>());
         hashes = own_hashes->as<int64_t>();
     }
-    for (int64_t start = 0; start < n; start += sub_batch_) {
-        const int64_t len = std::min(sub_batch_, n - start);
+    // Sub-batching bounds the table growth a single launch can need.  Once a sub-batch created no new group (the steady state
+    // of low-cardinality inputs: TPCH Q1 has 4 groups in 600 M rows) the next one is 8x larger: fewer, longer launches.  Such an
+    // optimistic launch can overflow the table only if it meets tens of millions of new keys; the probe kernel then flags it,
+    // the table is rebuilt twice as large and the rows are re-run in smaller pieces.
+    int64_t sub = sub_batch_;
+    int64_t start = 0;
+    while (start < n) {
+        const int64_t len = std::min(sub, n - start);
         std::vector<DeviceColumn> views;
         views.reserve(keys.size());
         for (auto *c : keys) views.push_back(k::region_of(ctx_, *c, start, len));
         std::vector<const DeviceColumn *> vp;
         for (auto &v : views) vp.push_back(&v);
-        process_sub_batch(key_cols_of(vp), hashes + start, len, out_gids + start);
+        int64_t new_groups = 0;
+        const bool ok = process_sub_batch(key_cols_of(vp), hashes ? hashes + start : nullptr, row_mask ? row_mask + start : nullptr, start, len,
+                                          out_gids + start, probe, &new_groups);
+        if (!ok) {
+            rebuild_table(capacity_ * 2);
+            sub = std::max<int64_t>(std::min(sub_batch_, len / 4), 1);
+            continue;
+        }
+        start += len;
+        sub = new_groups == 0 ? std::min<int64_t>(sub * 8, 1ll << 30) : sub_batch_;
     }
 }
 
@@ -451,8 +423,9 @@ void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const
     }
     ensure_table(groups_);
     ensure_store(groups_ > 0 ? groups_ : 1);
-    gbh_probe_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(key_cols_of(keys), hashes, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
-                                                                              store_view(), out_gids, counters_->as<unsigned long long>());
+    gbh_probe_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(key_cols_of(keys), hashes, nullptr, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
+                                                                              store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out_gids,
+                                                                              counters_->as<unsigned long long>());
     check_launch("gbh_lookup");
 }
 

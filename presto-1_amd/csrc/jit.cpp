@@ -21,6 +21,8 @@
 #include <set>
 #include <sstream>
 
+#include "agg.h"
+#include "groupby.h"
 #include "join.h"
 #include "kernels.h"
 
@@ -103,6 +105,10 @@ static std::vector<char> code_object_for(const std::string &source)
     }
     std::vector<char> code = compile_source(source);
     mkdir((resource_dir() + "/_kcache").c_str(), 0755);
+    if (getenv("TGPU_JIT_DUMP")) {  // keep the generated source next to its code object (kernel studies)
+        std::ofstream f(path.substr(0, path.size() - 6) + ".hip");
+        f << source;
+    }
     const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
     {
         std::ofstream f(tmp, std::ios::binary);
@@ -1191,6 +1197,679 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     }
     unsigned long long e = ctx->read_scalar(misc->as<unsigned long long>());
     if (e != ~0ull) raise(e);
+}
+
+// =====================================================================================================================
+// FusedAggGpu: filter -> row mask; projections + accumulate in one kernel
+// =====================================================================================================================
+namespace {
+
+
+const char *kFaKernels = R"SRC(
+struct FaArgs {
+  FpArgs fp;
+  const int* gids;
+  unsigned char* mask_out;
+  TgAggState st[TG_MAX_AGGS];
+  TgLowCardPlan plan;
+  long long tiles;
+  int lowcard;
+  int pad;
+};
+#define FA_STRIPES 8
+#define FA_TILE (FA_STRIPES * 256)
+
+// pass A: the filter as a row mask (one byte per row) for the group-by table
+extern "C" __global__ void __launch_bounds__(256) fa_mask(FaArgs F) {
+  const FpArgs& A = F.fp;
+  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < A.n; row += (long long)gridDim.x * 256)
+    F.mask_out[row] = tg_filter_mem(A, row) ? 1 : 0;
+}
+
+// pass C: group id + the aggregates' input projections (evaluated in registers from pre-loaded column values, next tile's
+// loads in flight while the current tile accumulates) -> lane-private LDS accumulators (few groups) or exact global atomics
+template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, unsigned char* lds) {
+  const FpArgs& A = F.fp;
+  TgRow cur[FA_STRIPES], nxt[FA_STRIPES];
+  int gcur[FA_STRIPES], gnxt[FA_STRIPES];
+#pragma unroll
+  for (int s = 0; s < FA_STRIPES; s++) {
+    const long long row = (long long)blockIdx.x * FA_TILE + threadIdx.x + s * 256;
+    tg_zero_row(cur[s]);
+    gcur[s] = -1;
+    if (blockIdx.x < F.tiles && row < A.n) { gcur[s] = F.gids ? F.gids[row] : 0; tg_load_row(A, row, cur[s]); }
+  }
+  for (long long tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
+    const long long row0 = tile * FA_TILE + threadIdx.x;
+    const long long ntile = tile + gridDim.x;
+#pragma unroll
+    for (int s = 0; s < FA_STRIPES; s++) {
+      const long long row = ntile * FA_TILE + threadIdx.x + s * 256;
+      tg_zero_row(nxt[s]);
+      gnxt[s] = -1;
+      if (ntile < F.tiles && row < A.n) { gnxt[s] = F.gids ? F.gids[row] : 0; tg_load_row(A, row, nxt[s]); }
+    }
+#pragma unroll
+    for (int s = 0; s < FA_STRIPES; s++) {
+      if (gcur[s] >= 0) {
+        if (LC) tg_accumulate_row_lc(F, A, row0 + s * 256, cur[s], gcur[s], lds);
+        else tg_accumulate_row_gl(F, A, row0 + s * 256, cur[s], gcur[s]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < FA_STRIPES; s++) { cur[s] = nxt[s]; gcur[s] = gnxt[s]; }
+  }
+}
+
+extern "C" __global__ void __launch_bounds__(256) fa_accumulate_lowcard(FaArgs F) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FA_LDS_BYTES];
+  tg_lc_zero(lds, F.plan);
+  fa_accumulate_body<true>(F, lds);
+  tg_lc_fold(lds, F.plan, F.st);
+}
+
+extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F) {
+  fa_accumulate_body<false>(F, (unsigned char*)0);
+}
+)SRC";
+
+// host mirror of the generated FaArgs
+struct FaArgsHost {
+    FpArgs fp;
+    const int32_t *gids;
+    unsigned char *mask_out;
+    struct St {
+        int32_t function;
+        int32_t pad;
+        long long *counts;
+        long long *limbs;
+        unsigned int *special;
+        unsigned long long *i128;
+    } st[16];
+    struct Plan {
+        int32_t n_aggs, n_wide;
+        int32_t wide_slot[16];
+        int32_t per_group_bytes, n_groups;
+    } plan;
+    long long tiles;
+    int32_t lowcard;
+    int32_t pad;
+};
+
+}  // namespace
+
+FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec, std::vector<tgpu_agg_spec> aggs,
+                         std::vector<int32_t> group_by_channels)
+    : input_types_(std::move(input_types)), aggs_(std::move(aggs))
+{
+    TG_CHECK_ARG(spec != nullptr, "page processor spec is null");
+    nodes_.assign(spec->nodes, spec->nodes + spec->node_count);
+    if (spec->string_pool && spec->string_pool_len > 0) pool_.assign(spec->string_pool, spec->string_pool + spec->string_pool_len);
+    filter_root_ = spec->filter_root;
+    proj_roots_.assign(spec->projection_roots, spec->projection_roots + spec->projection_count);
+    for (int32_t r : proj_roots_) {
+        TG_CHECK_ARG(r >= 0 && r < (int)nodes_.size(), "projection root out of range");
+        proj_types_.push_back(nodes_[(size_t)r].type);
+    }
+    TG_CHECK_ARG((int)aggs_.size() <= 16, "at most 16 aggregates");
+    supported_ = true;
+    const int np = (int)proj_roots_.size();
+    for (auto &a : aggs_) {
+        TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_AVG_DOUBLE, "unknown aggregate function");
+        if (a.function != TGPU_AGG_COUNT_ALL) {
+            TG_CHECK_ARG(a.input_channel >= 0 && a.input_channel < np, "aggregate input channel out of range");
+            const int32_t t = proj_types_[(size_t)a.input_channel];
+            const bool want_bigint = a.function == TGPU_AGG_SUM_BIGINT || a.function == TGPU_AGG_AVG_BIGINT;
+            const bool want_double = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE;
+            TG_CHECK_ARG(!(want_bigint && t != TGPU_BIGINT) && !(want_double && t != TGPU_DOUBLE), "aggregate input type mismatch");
+            if (a.function == TGPU_AGG_COUNT_COLUMN && t == TGPU_VARCHAR) supported_ = supported_ && nodes_[(size_t)proj_roots_[(size_t)a.input_channel]].kind == TGPU_EX_INPUT;
+        }
+        if (a.mask_channel >= 0) TG_CHECK_ARG(a.mask_channel < np && proj_types_[(size_t)a.mask_channel] == TGPU_BOOLEAN, "aggregate mask must be a BOOLEAN channel");
+    }
+    // Equivalence with FilterAndProject -> HashAggregation needs every projection that can raise to be evaluated on every
+    // selected row; the fused kernel evaluates exactly the aggregates' inputs on exactly those rows, so any OTHER projection
+    // that can raise (dropped by the aggregation) keeps the unfused composition.
+    std::function<bool(int)> can_raise = [&](int idx) -> bool {
+        const tgpu_expr_node &nd = nodes_[(size_t)idx];
+        if (nd.kind == TGPU_EX_CALL) {
+            const bool int_result = nd.type == TGPU_BIGINT || nd.type == TGPU_INTEGER;
+            if (int_result && nd.op >= TGPU_OP_ADD && nd.op <= TGPU_OP_NEGATE) return true;
+            if (nd.op == TGPU_OP_CAST && nd.type == TGPU_INTEGER) return true;
+        }
+        if (nd.kind == TGPU_EX_CALL || nd.kind == TGPU_EX_SPECIAL)
+            for (int k = 0; k < nd.n_args; k++)
+                if (can_raise(nd.args[k])) return true;
+        return false;
+    };
+    std::set<int> used;
+    for (auto &a : aggs_) {
+        if (a.function != TGPU_AGG_COUNT_ALL) used.insert(a.input_channel);
+        if (a.mask_channel >= 0) used.insert(a.mask_channel);
+    }
+    for (int ch = 0; ch < np; ch++)
+        if (can_raise(proj_roots_[(size_t)ch])) {
+            // a masked aggregate would skip evaluating its input on masked-out rows; an unused channel is never evaluated
+            bool always_evaluated = used.count(ch) > 0;
+            for (auto &a : aggs_)
+                if (a.function != TGPU_AGG_COUNT_ALL && a.input_channel == ch && a.mask_channel >= 0) always_evaluated = false;
+            if (!always_evaluated) supported_ = false;
+        }
+    n_wide_ = 0;
+    for (size_t k = 0; k < aggs_.size(); k++) {
+        const bool count_only = aggs_[k].function == TGPU_AGG_COUNT_ALL || aggs_[k].function == TGPU_AGG_COUNT_COLUMN;
+        wide_slot_[k] = count_only ? -1 : n_wide_++;
+    }
+    per_group_bytes_ = n_wide_ * 2 * 256 * 8 + (int)aggs_.size() * 256 * 4;
+    max_groups_ = per_group_bytes_ > 0 ? (160 * 1024 - 64) / per_group_bytes_ : 0;  // 64 B: headroom for the compiler's own LDS use
+    if (aggs_.empty()) supported_ = false;
+    for (int32_t ch : group_by_channels) {
+        TG_CHECK_ARG(ch >= 0 && ch < np, "group-by channel out of range");
+        const int raw = identity_channel(ch);
+        if (raw < 0) supported_ = false;   // computed group-by keys keep the unfused composition
+        key_inputs_.push_back(raw);
+    }
+    if ((int)key_inputs_.size() > kMaxKeyChannels) supported_ = false;
+    if (!supported_) key_inputs_.clear();
+    if (supported_) generate();
+}
+
+FusedAggGpu::~FusedAggGpu() {}
+
+int FusedAggGpu::identity_channel(int ch) const
+{
+    const tgpu_expr_node &nd = nodes_[(size_t)proj_roots_[(size_t)ch]];
+    return nd.kind == TGPU_EX_INPUT ? nd.op : -1;
+}
+
+void FusedAggGpu::generate()
+{
+    auto cols_decl = [&](const Gen &g) {
+        std::ostringstream cols;
+        for (int ch : g.used_cols) {
+            const int32_t t = input_types_[(size_t)ch];
+            const char *T = (t == TGPU_VARCHAR || t == TGPU_BOOLEAN) ? "unsigned char" : ctype(t);
+            cols << "  const " << T << "* c" << ch << " = (const " << T << "*)A.col_values[" << ch << "]; (void)c" << ch << ";\n";
+            cols << "  const unsigned char* cn" << ch << " = A.col_nulls[" << ch << "]; (void)cn" << ch << ";\n";
+            if (t == TGPU_VARCHAR) cols << "  const int* co" << ch << " = A.col_offsets[" << ch << "]; (void)co" << ch << ";\n";
+        }
+        return cols.str();
+    };
+    // (a) the filter in memory mode (pass A)
+    Gen gm(nodes_, pool_, input_types_);
+    std::ostringstream filter_fn;
+    if (filter_root_ >= 0) {
+        Val f = gm.gen(filter_root_, 1);
+        if (f.type != TGPU_BOOLEAN) gm.bad("filter must be boolean");
+        filter_fn << "__device__ inline bool tg_filter_mem(const FpArgs& A, long long row) {\n" << cols_decl(gm) << gm.os.str() << "  return !" << f.n << " && " << f.v << ";\n}\n";
+    }
+    else filter_fn << "__device__ inline bool tg_filter_mem(const FpArgs& A, long long row) { return true; }\n";
+
+    // (b) the aggregates' masks and inputs in register-row mode (pass C).  Phase 1 evaluates every aggregate's (take, value)
+    // pair into registers; the low-cardinality variant then reads ALL the lane's LDS slots, updates them in registers and
+    // writes them back (one LDS round trip per row instead of one per aggregate); the global variant issues the exact atomics.
+    Gen gr(nodes_, pool_, input_types_);
+    gr.reg_mode = true;
+    gr.tmp = gm.tmp;
+    std::ostringstream eval, lc_read, lc_upd, lc_write, gl;
+    for (size_t k = 0; k < aggs_.size(); k++) {
+        const tgpu_agg_spec &a = aggs_[k];
+        const int w = wide_slot_[k];
+        const bool is_dbl = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE || a.function == TGPU_AGG_AVG_BIGINT;
+        const bool is_big = a.function == TGPU_AGG_SUM_BIGINT;
+        eval << "  bool t" << k << " = true; double x" << k << " = 0.0; long long y" << k << " = 0; (void)x" << k << "; (void)y" << k << ";\n  {\n";
+        gr.os.str("");
+        if (a.mask_channel >= 0) {
+            Val m = gr.gen(proj_roots_[(size_t)a.mask_channel], 2);
+            eval << gr.os.str() << "    t" << k << " = !" << m.n << " && " << m.v << ";\n";
+            gr.os.str("");
+        }
+        if (a.function != TGPU_AGG_COUNT_ALL) {
+            eval << "    if (t" << k << ") {\n";
+            Val v = gr.gen(proj_roots_[(size_t)a.input_channel], 3);
+            eval << gr.os.str();
+            gr.os.str("");
+            eval << "      if (" << v.n << ") t" << k << " = false;\n";
+            if (is_dbl) eval << "      else x" << k << " = " << (a.function == TGPU_AGG_AVG_BIGINT ? "(double)" : "") << v.v << ";\n";
+            else if (is_big) eval << "      else y" << k << " = " << v.v << ";\n";
+            eval << "    }\n";
+        }
+        if (is_dbl)  // NaN / +-inf are flagged on the group, not summed (the flags decide the result at evaluation time)
+            eval << "    if (t" << k << " && !(fabs(x" << k << ") <= 1.7976931348623157e308)) { tg_flag_special(&F.st[" << k << "].special[g], x" << k << "); x" << k
+                 << " = 0.0; }\n";
+        eval << "  }\n";
+        // low-cardinality: lane-private slots
+        lc_read << "  unsigned int c" << k << " = cnt_base[" << k << " * 256 + threadIdx.x];\n";
+        lc_upd << "  c" << k << " += t" << k << " ? 1u : 0u;\n";
+        lc_write << "  cnt_base[" << k << " * 256 + threadIdx.x] = c" << k << ";\n";
+        if (is_dbl) {
+            lc_read << "  double h" << k << " = hi_base[" << w << " * 256 + threadIdx.x], l" << k << " = lo_base[" << w << " * 256 + threadIdx.x];\n";
+            lc_upd << "  { const double v_ = t" << k << " ? x" << k << " : 0.0; const double s_ = h" << k << " + v_; const double bb_ = s_ - h" << k << "; l" << k
+                   << " += (h" << k << " - (s_ - bb_)) + (v_ - bb_); h" << k << " = s_; }\n";
+            lc_write << "  hi_base[" << w << " * 256 + threadIdx.x] = h" << k << "; lo_base[" << w << " * 256 + threadIdx.x] = l" << k << ";\n";
+        }
+        else if (is_big) {
+            lc_read << "  unsigned long long bl" << k << " = ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x]; long long bh" << k << " = ((long long*)lo_base)[" << w
+                    << " * 256 + threadIdx.x];\n";
+            lc_upd << "  { const long long v_ = t" << k << " ? y" << k << " : 0; const unsigned long long n_ = bl" << k << " + (unsigned long long)v_; bh" << k
+                   << " += (v_ < 0 ? -1 : 0) + (n_ < bl" << k << " ? 1 : 0); bl" << k << " = n_; }\n";
+            lc_write << "  ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x] = bl" << k << "; ((long long*)lo_base)[" << w << " * 256 + threadIdx.x] = bh" << k << ";\n";
+        }
+        // global: exact atomics per row
+        gl << "  if (t" << k << ") {\n    atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], 1ULL);\n";
+        if (is_dbl) gl << "    tg_kulisch_add(&F.st[" << k << "].limbs[(size_t)g * TG_LIMBS], &F.st[" << k << "].special[g], x" << k << ");\n";
+        else if (is_big) gl << "    tg_i128_add(&F.st[" << k << "].i128[(size_t)g * 2], y" << k << ");\n";
+        gl << "  }\n";
+    }
+
+    std::ostringstream src;
+    src << kPrelude;
+    if (const char *exp = getenv("TGPU_FG_EXP")) src << "#define FG_EXP_" << exp << " 1\n";  // kernel-study switch, never set in production
+    src << device_header("device_hash.h") << device_header("device_agg.h") << gm.consts.str() << gr.consts.str();
+    src << "#define FA_LDS_BYTES " << std::max(64, max_groups_ * per_group_bytes_) << "\n";
+    src << "struct TgRow {\n";
+    for (int ch : gr.reg_cols) {
+        const int32_t t = input_types_[(size_t)ch];
+        src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : ctype(t)) << " c" << ch << "; unsigned char n" << ch << ";\n";
+    }
+    if (gr.reg_cols.empty()) src << "  int unused;\n";
+    src << "};\n__device__ inline void tg_load_row(const FpArgs& A, long long row, TgRow& R) {\n";
+    for (int ch : gr.reg_cols) {
+        const int32_t t = input_types_[(size_t)ch];
+        const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
+        src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = A.col_nulls[" << ch << "] ? A.col_nulls[" << ch << "][row] : 0;\n";
+    }
+    src << "  (void)A; (void)row; (void)R;\n}\n__device__ inline void tg_zero_row(TgRow& R) {\n";
+    for (int ch : gr.reg_cols) src << "  R.c" << ch << " = 0; R.n" << ch << " = 0;\n";
+    src << "  (void)R;\n}\n";
+    src << filter_fn.str();
+    if (!key_inputs_.empty()) {
+        // key accessor generated for this key schema (the GPU counterpart of JoinCompiler's hashRow / positionNotDistinctFromRow)
+        src << device_header("device_cols.h") << device_header("device_groupby.h");
+        src << "struct FgArgs {\n  FpArgs fp;\n  TgKeyCols store;\n  unsigned long long* words;\n  unsigned long long mask;\n  int* out;\n  unsigned long long* counters;\n"
+               "  long long row0;\n  long long n;\n  int store_groups;\n  int pad;\n};\n";
+        auto cell = [&](int i, const std::string &row, const std::string &pfx) {
+            // declares <pfx>n (null flag) and the cell's value variables for key column i of the raw input at `row`
+            const int ch = key_inputs_[(size_t)i];
+            const int32_t t = input_types_[(size_t)ch];
+            std::ostringstream o;
+            o << "    const bool " << pfx << "n = A.col_nulls[" << ch << "] && A.col_nulls[" << ch << "][" << row << "];\n";
+            if (t == TGPU_VARCHAR)
+                o << "    const int " << pfx << "a = A.col_offsets[" << ch << "][" << row << "]; const int " << pfx << "l = A.col_offsets[" << ch << "][" << row << " + 1] - " << pfx
+                  << "a; const unsigned char* " << pfx << "p = (const unsigned char*)A.col_values[" << ch << "] + " << pfx << "a;\n";
+            else {
+                const char *T = t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t));
+                o << "    const " << T << " " << pfx << "v = ((const " << T << "*)A.col_values[" << ch << "])[" << row << "];\n";
+            }
+            return o.str();
+        };
+        auto eq = [&](int i, const std::string &x, const std::string &y) {
+            // value equality of two non-null cells (DOUBLE compared as IS NOT DISTINCT: NaN == NaN, -0 == +0)
+            const int32_t t = input_types_[(size_t)key_inputs_[(size_t)i]];
+            std::ostringstream o;
+            if (t == TGPU_VARCHAR)
+                o << "    { if (" << x << "l != " << y << "l) return false; for (int j_ = 0; j_ < " << x << "l; j_++) if (" << x << "p[j_] != " << y << "p[j_]) return false; }\n";
+            else if (t == TGPU_DOUBLE)
+                o << "    { const double u_ = __longlong_as_double((long long)" << x << "v), w_ = __longlong_as_double((long long)" << y << "v); if (!((u_ != u_ && w_ != w_) || u_ == w_)) return false; }\n";
+            else if (t == TGPU_BOOLEAN) o << "    if ((" << x << "v != 0) != (" << y << "v != 0)) return false;\n";
+            else o << "    if (" << x << "v != " << y << "v) return false;\n";
+            return o.str();
+        };
+        src << "struct SpecKeys {\n  const FpArgs& A; const TgKeyCols& S; long long row0;\n";
+        src << "  __device__ long long hash(long long r) const {\n    const long long row = row0 + r; tg_i64 h = 0;\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int32_t t = input_types_[(size_t)key_inputs_[i]];
+            src << "   {\n" << cell((int)i, "row", "x") << "    tg_i64 c = 0;\n    if (!xn) c = ";
+            switch (t) {
+            case TGPU_BIGINT: src << "tg_hash_long(xv)"; break;
+            case TGPU_INTEGER: case TGPU_DATE: src << "tg_hash_int(xv)"; break;
+            case TGPU_DOUBLE: src << "tg_hash_double_bits(xv)"; break;
+            case TGPU_BOOLEAN: src << "tg_hash_boolean(xv)"; break;
+            default: src << "(tg_i64)tg_xxh64(xp, xl)"; break;
+            }
+            src << ";\n    h = tg_combine_hash(h, c);\n   }\n";
+        }
+        src << "    return h;\n  }\n";
+        src << "  __device__ bool eq_store(long long r, int g) const {\n    const long long row = row0 + r;\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int32_t t = input_types_[(size_t)key_inputs_[i]];
+            src << "   {\n" << cell((int)i, "row", "x");
+            src << "    const bool yn = S.c[" << i << "].nulls && S.c[" << i << "].nulls[g];\n";
+            if (t == TGPU_VARCHAR)
+                src << "    const int ya = S.c[" << i << "].offsets[g]; const int yl = S.c[" << i << "].offsets[g + 1] - ya; const unsigned char* yp = (const unsigned char*)S.c[" << i << "].values + ya;\n";
+            else {
+                const char *T = t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t));
+                src << "    const " << T << " yv = ((const " << T << "*)S.c[" << i << "].values)[g];\n";
+            }
+            src << "    if (xn || yn) { if (xn != yn) return false; } else\n" << eq((int)i, "x", "y") << "   }\n";
+        }
+        src << "    return true;\n  }\n";
+        src << "  __device__ bool eq_row(long long r, long long r2) const {\n    const long long row = row0 + r, row2 = row0 + r2;\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            src << "   {\n" << cell((int)i, "row", "x") << cell((int)i, "row2", "y");
+            src << "    if (xn || yn) { if (xn != yn) return false; } else\n" << eq((int)i, "x", "y") << "   }\n";
+        }
+        src << "    return true;\n  }\n};\n";
+        // block-local copy of the first groups' keys in LDS (few groups = TPCH Q1): a row is compared against those records
+        // (LDS broadcast reads) before it ever touches the table.  Record per (group, key column): 32 bytes =
+        // data[16] (fixed-width value / first 16 varchar bytes) | len int | null byte | long byte (varchar longer than 16 bytes)
+        src << "#define FG_LDS_GROUPS 16\n#define FG_NKEYS " << key_inputs_.size() << "\n";
+        src << "__device__ inline void fg_build_records(const TgKeyCols& S, int groups, unsigned char* rec) {\n"
+               "  for (int idx = threadIdx.x; idx < groups * FG_NKEYS; idx += 256) {\n    const int g = idx / FG_NKEYS, i = idx % FG_NKEYS;\n"
+               "    unsigned char* r = rec + (size_t)idx * 32;\n    const TgColView& c = S.c[i];\n"
+               "    const bool nl = c.nulls && c.nulls[g];\n    r[20] = nl ? 1 : 0; r[21] = 0; *(int*)(r + 16) = 0;\n"
+               "    for (int j = 0; j < 16; j++) r[j] = 0;\n    if (nl) continue;\n"
+               "    if (c.type == 6) {\n      const int a = c.offsets[g], l = c.offsets[g + 1] - a;\n      *(int*)(r + 16) = l;\n      if (l > 16) r[21] = 1;\n"
+               "      else for (int j = 0; j < l; j++) r[j] = ((const unsigned char*)c.values)[a + j];\n    }\n"
+               "    else if (c.type == 1 || c.type == 4) *(unsigned long long*)r = ((const unsigned long long*)c.values)[g];\n"
+               "    else if (c.type == 2 || c.type == 3) *(long long*)r = (long long)((const int*)c.values)[g];\n"
+               "    else *(unsigned long long*)r = ((const unsigned char*)c.values)[g] != 0 ? 1ULL : 0ULL;\n  }\n  __syncthreads();\n}\n";
+        // pre-loaded key cells of one row (phase A: null flags, fixed-width values, varchar offset/length; phase B: the first
+        // varchar byte), so that the loads of all the stripes of a tile are in flight together
+        src << "struct TgKeyRow {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int32_t t = input_types_[(size_t)key_inputs_[i]];
+            if (t == TGPU_VARCHAR) src << "  int a" << i << ", l" << i << "; unsigned char n" << i << ", b" << i << ";\n";
+            else src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t))) << " v" << i << "; unsigned char n" << i << ";\n";
+        }
+        src << "};\n__device__ inline void fg_load_key_a(const FpArgs& A, long long row, TgKeyRow& K) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int ch = key_inputs_[i];
+            const int32_t t = input_types_[(size_t)ch];
+            src << "  K.n" << i << " = A.col_nulls[" << ch << "] ? A.col_nulls[" << ch << "][row] : 0;\n";
+            if (t == TGPU_VARCHAR)
+                src << "  K.a" << i << " = A.col_offsets[" << ch << "][row]; K.l" << i << " = A.col_offsets[" << ch << "][row + 1] - K.a" << i << "; K.b" << i << " = 0;\n";
+            else {
+                const char *T = t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t));
+                src << "  K.v" << i << " = ((const " << T << "*)A.col_values[" << ch << "])[row];\n";
+            }
+        }
+        src << "}\n__device__ inline void fg_zero_key(TgKeyRow& K) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int32_t t = input_types_[(size_t)key_inputs_[i]];
+            if (t == TGPU_VARCHAR) src << "  K.a" << i << " = 0; K.l" << i << " = 0; K.n" << i << " = 1; K.b" << i << " = 0;\n";
+            else src << "  K.v" << i << " = 0; K.n" << i << " = 1;\n";
+        }
+        src << "}\n__device__ inline void fg_load_key_b(const FpArgs& A, TgKeyRow& K) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int ch = key_inputs_[i];
+            if (input_types_[(size_t)ch] == TGPU_VARCHAR)
+                src << "  if (!K.n" << i << " && K.l" << i << " > 0) K.b" << i << " = ((const unsigned char*)A.col_values[" << ch << "])[K.a" << i << "];\n";
+        }
+        src << "  (void)A; (void)K;\n}\n";
+        // row vs LDS record: 1 equal, 0 different, -1 cannot decide here (long varchar: the table path decides)
+        src << "__device__ inline int fg_eq_record(const FpArgs& A, const TgKeyRow& K, const unsigned char* rec, int g) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int ch = key_inputs_[i];
+            const int32_t t = input_types_[(size_t)ch];
+            src << "  {\n    const unsigned char* r = rec + ((size_t)g * FG_NKEYS + " << i << ") * 32;\n";
+            src << "    const bool xn = K.n" << i << " != 0, yn = r[20] != 0;\n    if (xn || yn) { if (xn != yn) return 0; } else {\n";
+            if (t == TGPU_VARCHAR) {
+                src << "      if (K.l" << i << " != *(const int*)(r + 16)) return 0;\n      if (r[21]) return -1;\n      if (K.l" << i << " > 0 && K.b" << i << " != r[0]) return 0;\n"
+                    << "      for (int j_ = 1; j_ < K.l" << i << "; j_++) if (((const unsigned char*)A.col_values[" << ch << "])[K.a" << i << " + j_] != r[j_]) return 0;\n";
+            }
+            else if (t == TGPU_DOUBLE)
+                src << "      { const double u_ = __longlong_as_double((long long)K.v" << i << "), w_ = __longlong_as_double(*(const long long*)r); if (!((u_ != u_ && w_ != w_) || u_ == w_)) return 0; }\n";
+            else if (t == TGPU_BOOLEAN) src << "      if ((K.v" << i << " != 0) != (*(const unsigned long long*)r != 0)) return 0;\n";
+            else src << "      if ((long long)K.v" << i << " != *(const long long*)r) return 0;\n";
+            src << "    }\n  }\n";
+        }
+        src << "  (void)A;\n  return 1;\n}\n";
+        // the first FG_REG_GROUPS records additionally live in registers (loaded once per block): comparing a row against them
+        // is pure VALU work, no LDS round trip per row.  d = first 8 data bytes of the record.
+        src << "#define FG_REG_GROUPS 4\nstruct TgRecReg {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) src << "  unsigned long long d" << i << "; int l" << i << "; unsigned char n" << i << ", g" << i << ";\n";
+        src << "};\n__device__ inline void fg_load_recreg(const unsigned char* rec, int g, TgRecReg& R) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++)
+            src << "  { const unsigned char* r = rec + ((size_t)g * FG_NKEYS + " << i << ") * 32; R.d" << i << " = *(const unsigned long long*)r; R.l" << i
+                << " = *(const int*)(r + 16); R.n" << i << " = r[20]; R.g" << i << " = r[21]; }\n";
+        src << "}\n// 1 equal, 0 different, -1 undecided here (varchar longer than 8 bytes: the LDS / table path decides)\n"
+               "__device__ inline int fg_eq_recreg(const FpArgs& A, const TgKeyRow& K, const TgRecReg& R) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++) {
+            const int ch = key_inputs_[i];
+            const int32_t t = input_types_[(size_t)ch];
+            src << "  {\n    const bool xn = K.n" << i << " != 0, yn = R.n" << i << " != 0;\n    if (xn || yn) { if (xn != yn) return 0; } else {\n";
+            if (t == TGPU_VARCHAR) {
+                src << "      if (K.l" << i << " != R.l" << i << ") return 0;\n      if (K.l" << i << " > 8) return -1;\n      if (K.l" << i << " > 0 && K.b" << i
+                    << " != (unsigned char)(R.d" << i << " & 0xff)) return 0;\n      for (int j_ = 1; j_ < K.l" << i << "; j_++) if (((const unsigned char*)A.col_values[" << ch
+                    << "])[K.a" << i << " + j_] != (unsigned char)((R.d" << i << " >> (8 * j_)) & 0xff)) return 0;\n";
+            }
+            else if (t == TGPU_DOUBLE)
+                src << "      { const double u_ = __longlong_as_double((long long)K.v" << i << "), w_ = __longlong_as_double((long long)R.d" << i
+                    << "); if (!((u_ != u_ && w_ != w_) || u_ == w_)) return 0; }\n";
+            else if (t == TGPU_BOOLEAN) src << "      if ((K.v" << i << " != 0) != (R.d" << i << " != 0)) return 0;\n";
+            else src << "      if ((long long)K.v" << i << " != (long long)R.d" << i << ") return 0;\n";
+            src << "    }\n  }\n";
+        }
+        src << "  (void)A;\n  return 1;\n}\n";
+        src << R"SRC(
+#define FG_STRIPES 8
+#define FG_TILE (FG_STRIPES * 256)
+// the table path (hashing + probe / insert protocol) is rare once the first groups are cached in LDS: it is kept out of line
+// so that the hot loop stays small enough for the instruction cache
+__device__ __attribute__((noinline)) int fg_table_path(const FgArgs& G, long long r, int store_groups, int* pending_out) {
+  SpecKeys K{G.fp, G.store, G.row0};
+  bool pending = false;
+  const int result = tg_gbh_probe<true>(K, r, G.words, G.mask, store_groups, G.counters, pending);
+  *pending_out = pending ? 1 : 0;
+  return result;
+}
+// pass B: filter + group lookup / insert (protocol: device_groupby.h).  Eight rows per lane per tile, processed in phases so
+// that the loads of all eight rows are in flight together: (A) filter column + key cells, (B) first varchar bytes,
+// (C) compare against the LDS copies of the first groups' keys; only a row that matches none of them touches the table.
+extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
+  const FpArgs& A = G.fp;
+  __shared__ __attribute__((aligned(16))) unsigned char rec[FG_LDS_GROUPS * FG_NKEYS * 32];
+  const int lg = G.store_groups < FG_LDS_GROUPS ? G.store_groups : FG_LDS_GROUPS;
+  fg_build_records(G.store, lg, rec);
+  TgRecReg rr[FG_REG_GROUPS];
+#pragma unroll
+  for (int g = 0; g < FG_REG_GROUPS; g++) fg_load_recreg(rec, g < lg ? g : 0, rr[g]);
+  const int rg = lg < FG_REG_GROUPS ? lg : FG_REG_GROUPS;
+  const long long tiles = (G.n + FG_TILE - 1) / FG_TILE;
+  unsigned long long npending = 0;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long r0 = tile * FG_TILE + threadIdx.x;
+    bool sel[FG_STRIPES];
+    TgKeyRow kr[FG_STRIPES];
+#pragma unroll
+    for (int s = 0; s < FG_STRIPES; s++) {
+      const long long r = r0 + s * 256;
+      fg_zero_key(kr[s]);
+      sel[s] = false;
+#ifdef FG_EXP_NOKEYS
+      if (r < G.n) { sel[s] = tg_filter_mem(A, G.row0 + r); }
+#else
+      if (r < G.n) { sel[s] = tg_filter_mem(A, G.row0 + r); fg_load_key_a(A, G.row0 + r, kr[s]); }
+#endif
+    }
+#ifndef FG_EXP_NOKEYS
+#pragma unroll
+    for (int s = 0; s < FG_STRIPES; s++) if (sel[s]) fg_load_key_b(A, kr[s]);
+#endif
+#pragma unroll
+    for (int s = 0; s < FG_STRIPES; s++) {
+      const long long r = r0 + s * 256;
+      if (r >= G.n) continue;
+      int result = -1;
+      if (sel[s]) {
+        bool undecided = false;
+#ifdef FG_EXP_NOKEYS
+        result = 0;
+#else
+#pragma unroll
+        for (int g = 0; g < FG_REG_GROUPS; g++) {
+          if (g < rg && result < 0) {
+            const int e = fg_eq_recreg(A, kr[s], rr[g]);
+            if (e > 0) result = g;
+            undecided = undecided || e < 0;
+          }
+        }
+        for (int g = (undecided ? 0 : rg); g < lg && result < 0; g++) {
+          const int e = fg_eq_record(A, kr[s], rec, g);
+          if (e > 0) result = g;
+          undecided = undecided || e < 0;
+        }
+#endif
+#ifdef FG_EXP_NOTABLE
+        if (false) {
+#else
+        if (result < 0) {
+#endif
+          // not among the cached groups: the table decides (store_groups 0 skips its own key-store scan unless a long
+          // varchar key left a cached group undecided)
+          int pending = 0;
+          result = fg_table_path(G, r, undecided ? G.store_groups : 0, &pending);
+          npending += (unsigned long long)pending;
+        }
+      }
+      G.out[r] = result;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) npending += __shfl_down(npending, d, 64);
+  if ((threadIdx.x & 63) == 0 && npending) atomicAdd(&G.counters[0], npending);
+}
+)SRC";
+    }
+    src << "struct FaArgs;\n";
+    // forward declare FaArgs fields used by the generated accumulate function: emit the struct first
+    std::string kernels = kFaKernels;
+    const size_t split = kernels.find("#define FA_STRIPES");
+    src << kernels.substr(0, split);
+    src << "__device__ inline void tg_accumulate_row_lc(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g, unsigned char* lds) {\n" << cols_decl(gr)
+        << "  double* hi_base = tg_lc_hi(lds, F.plan, g); double* lo_base = tg_lc_lo(lds, F.plan, g);\n"
+        << "  unsigned int* cnt_base = tg_lc_cnt(lds, F.plan, g);\n  (void)hi_base; (void)lo_base; (void)row;\n"
+        << eval.str() << lc_read.str() << lc_upd.str() << lc_write.str() << "}\n";
+    src << "__device__ inline void tg_accumulate_row_gl(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g) {\n" << cols_decl(gr) << "  (void)row;\n"
+        << eval.str() << gl.str() << "}\n";
+    src << kernels.substr(split);
+    source_ = src.str();
+}
+
+void FusedAggGpu::precompile()
+{
+    if (supported_) (void)code_object_for(source_);
+}
+
+void FusedAggGpu::ensure_loaded()
+{
+    if (!module_) module_ = load_module(source_);
+}
+
+void FusedAggGpu::raise_if_error(Context *ctx, BufferPtr &err)
+{
+    unsigned long long e = ctx->read_scalar(err->as<unsigned long long>());
+    if (e == ~0ull) return;
+    const long long row = (long long)(e >> 8);
+    if ((int)(e & 0xff) == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
+    fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
+}
+
+static void fill_fp_cols(FpArgs &fp, const DevicePage &in)
+{
+    for (size_t i = 0; i < in.cols.size() && i < (size_t)kFpMaxCols; i++) {
+        fp.col_values[i] = in.cols[i].values;
+        fp.col_nulls[i] = in.cols[i].nulls;
+        fp.col_offsets[i] = in.cols[i].offsets;
+    }
+    fp.n = in.n;
+}
+
+void FusedAggGpu::filter_mask(Context *ctx, const DevicePage &in, uint8_t *mask_out)
+{
+    TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
+    ensure_loaded();
+    if (in.n == 0) return;
+    FaArgsHost F{};
+    fill_fp_cols(F.fp, in);
+    BufferPtr err = ctx->alloc(8);
+    HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
+    F.fp.error = err->as<unsigned long long>();
+    F.mask_out = mask_out;
+    {
+        ProfileScope ps(ctx, "fused_filter_mask");
+        int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 16);
+        launch_args(module_->fn("fa_mask"), (int)blocks, F, ctx->stream());
+    }
+    raise_if_error(ctx, err);
+}
+
+namespace {
+struct FgArgsHost {
+    FpArgs fp;
+    KeyCols store;
+    unsigned long long *words;
+    unsigned long long mask;
+    int32_t *out;
+    unsigned long long *counters;
+    long long row0;
+    long long n;
+    int32_t store_groups;
+    int32_t pad;
+};
+}  // namespace
+
+void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProbeLaunch &l)
+{
+    TG_CHECK_STATE(supported_ && !key_inputs_.empty(), "fused group lookup not available for this configuration");
+    ensure_loaded();
+    FgArgsHost G{};
+    fill_fp_cols(G.fp, in);
+    BufferPtr err = ctx->alloc(8);
+    HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
+    G.fp.error = err->as<unsigned long long>();
+    G.store = l.store;
+    G.words = (unsigned long long *)l.words;
+    G.mask = l.mask;
+    G.out = l.out;
+    G.counters = l.counters;
+    G.row0 = l.row0;
+    G.n = l.n;
+    G.store_groups = l.store_groups;
+    {
+        ProfileScope ps(ctx, "fused_filter_group_probe");
+        int64_t blocks = std::min<int64_t>(ceil_div(l.n, 256), (int64_t)ctx->cu_count() * 8);
+        launch_args(module_->fn("fg_probe"), (int)blocks, G, ctx->stream());
+    }
+    raise_if_error(ctx, err);
+}
+
+void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, int64_t groups, GroupedAccumulators &accs)
+{
+    TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
+    ensure_loaded();
+    if (in.n == 0) return;
+    accs.reserve(groups);
+    FaArgsHost F{};
+    fill_fp_cols(F.fp, in);
+    BufferPtr err = ctx->alloc(8);
+    HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
+    F.fp.error = err->as<unsigned long long>();
+    F.gids = gids;
+    for (size_t k = 0; k < aggs_.size(); k++) {
+        GroupedAccumulators::DeviceState d = accs.device_state((int)k);
+        F.st[k].function = d.function;
+        F.st[k].counts = d.counts;
+        F.st[k].limbs = d.limbs;
+        F.st[k].special = d.special;
+        F.st[k].i128 = d.i128;
+    }
+    F.plan.n_aggs = (int32_t)aggs_.size();
+    F.plan.n_wide = n_wide_;
+    for (size_t k = 0; k < aggs_.size(); k++) F.plan.wide_slot[k] = wide_slot_[k];
+    F.plan.per_group_bytes = per_group_bytes_;
+    const int64_t g = groups > 0 ? groups : 1;
+    F.lowcard = (g <= max_groups_ && getenv("TGPU_DISABLE_LOWCARD") == nullptr) ? 1 : 0;
+    F.plan.n_groups = F.lowcard ? (int32_t)g : 0;
+    F.tiles = ceil_div(in.n, 8 * 256);
+    // the LDS array is static (sized for max_groups_), so one block per CU is resident; the 8-stripe software pipeline keeps
+    // ~8 x row-bytes in flight per lane, which is what saturates HBM at 4 waves per CU
+    const int64_t blocks = std::min<int64_t>(F.tiles, (int64_t)ctx->cu_count() * (F.lowcard ? 1 : 4));
+    {
+        ProfileScope ps(ctx, F.lowcard ? "fused_project_accumulate_lowcard" : "fused_project_accumulate");
+        launch_args(module_->fn(F.lowcard ? "fa_accumulate_lowcard" : "fa_accumulate_global"), (int)blocks, F, ctx->stream());
+    }
+    raise_if_error(ctx, err);
 }
 
 }  // namespace tgpu

@@ -116,6 +116,50 @@ private:
     std::shared_ptr<JitModule> module_;
 };
 
+// FilterAndProject feeding a HashAggregation: the filter becomes a row mask in front of the group-by table (no row is
+// materialised), and the projections that feed the aggregates are evaluated in registers inside the accumulate kernel.
+class GroupedAccumulators;
+
+class FusedAggGpu {
+public:
+    // aggs[k].input_channel / mask_channel index the page processor's projections
+    // group_by_channels: projection indexes of the group-by keys (they must be plain column references for the fused path)
+    FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec, std::vector<tgpu_agg_spec> aggs,
+                std::vector<int32_t> group_by_channels = {});
+    // raw input channels of the group-by keys (empty when a key is not a plain column reference)
+    const std::vector<int> &key_inputs() const { return key_inputs_; }
+    // one probe/insert launch of the group-by table with the filter fused in front and key code generated for the key schema
+    void probe_groups(Context *ctx, const DevicePage &in, const struct GbhProbeLaunch &l);
+    ~FusedAggGpu();
+    void precompile();
+    bool supported() const { return supported_; }
+    bool has_filter() const { return filter_root_ >= 0; }
+    // channel of the raw input page behind projection `ch` when that projection is a plain column reference, else -1
+    int identity_channel(int ch) const;
+    const std::vector<int32_t> &projection_types() const { return proj_types_; }
+    // mask[row] = 1 iff the filter selects the row (PageFilter semantics); raises the filter's arithmetic errors
+    void filter_mask(Context *ctx, const DevicePage &in, uint8_t *mask_out);
+    // state[gid[row]] (+)= aggregate inputs of every row with gid >= 0
+    void accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, int64_t groups, GroupedAccumulators &accs);
+
+private:
+    void generate();
+    void ensure_loaded();
+    void raise_if_error(Context *ctx, BufferPtr &err);
+    std::vector<int32_t> input_types_;
+    std::vector<tgpu_expr_node> nodes_;
+    std::string pool_;
+    int filter_root_;
+    std::vector<int32_t> proj_roots_, proj_types_;
+    std::vector<tgpu_agg_spec> aggs_;
+    std::vector<int> key_inputs_;
+    bool supported_ = false;
+    int n_wide_ = 0, per_group_bytes_ = 0, max_groups_ = 0;
+    int wide_slot_[16];
+    std::string source_;
+    std::shared_ptr<JitModule> module_;
+};
+
 std::string resource_dir();
 void set_resource_dir(const std::string &dir);
 

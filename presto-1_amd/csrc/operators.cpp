@@ -78,11 +78,22 @@ public:
     // :381-440 -> InMemoryHashAggregationBuilder.processPage (builder/InMemoryHashAggregationBuilder.java:139-155)
     void add_input(const tgpu_page *page) override
     {
+        begin_input();
+        DevicePage in = ingest_page(ctx_, page);
+        process_page(in);
+    }
+
+protected:
+    void begin_input()
+    {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
         TG_CHECK_STATE(!builder_full(), "Aggregation buffer is full");
         input_processed_ = true;
-        DevicePage in = ingest_page(ctx_, page);
         ensure_builder();
+    }
+
+    void process_page(const DevicePage &in)
+    {
         if (in.n == 0) return;
         const int32_t *gids = nullptr;
         BufferPtr gid_buf;
@@ -106,6 +117,7 @@ public:
         else accs_->add_input(gids, in.n, in, groups);
     }
 
+public:
     // :470-518
     std::unique_ptr<OutputPage> get_output() override
     {
@@ -131,7 +143,7 @@ public:
     bool is_finished() override { return finished_; }
     int64_t memory_bytes() override { return (gbh_ ? gbh_->estimated_size() : 0) + (accs_ ? accs_->estimated_size() : 0); }
 
-private:
+protected:
     void ensure_builder()
     {
         if (builder_) return;
@@ -478,6 +490,67 @@ void FusedFilterProjectJoinOperatorFactory::no_more_operators()
 {
     closed_ = true;
     bridge_->no_more_probes();
+}
+
+// =====================================================================================================================
+// FilterAndProject fused into the hash aggregation: the filter becomes a row mask in front of the group-by table and the
+// aggregates' input projections are evaluated inside the accumulate kernel (jit.h FusedAggGpu); no row is materialised.
+// =====================================================================================================================
+class FusedFilterProjectAggregationOperator : public HashAggregationOperator {
+public:
+    FusedFilterProjectAggregationOperator(Context *ctx, int32_t id, const HashAggregationConfig &cfg, std::shared_ptr<PageProcessorGpu> processor,
+                                          std::shared_ptr<FusedAggGpu> fused)
+        : HashAggregationOperator(ctx, id, cfg), processor_(std::move(processor)), fused_(std::move(fused))
+    {
+    }
+
+    void add_input(const tgpu_page *page) override
+    {
+        begin_input();
+        DevicePage in = ingest_page(ctx_, page);
+        if (in.n == 0) return;
+        const bool fused_ok = fused_->supported() && gbh_ && !fused_->key_inputs().empty() && cfg_.step != TGPU_STEP_FINAL && getenv("TGPU_DISABLE_FUSION") == nullptr;
+        if (!fused_ok) {
+            // unfused composition: FilterAndProject, then the aggregation
+            DevicePage mid;
+            if (processor_->process(ctx_, in, mid)) process_page(mid);
+            return;
+        }
+        // the filter is fused in front of the group-by table (rows it rejects get group id -1), the key code is generated
+        // for the key schema, and the raw hash is computed in the kernel (a $hashvalue channel equals it by construction)
+        std::vector<const DeviceColumn *> keys;
+        for (int raw : fused_->key_inputs()) keys.push_back(&in.cols[(size_t)raw]);
+        BufferPtr gids = ctx_->alloc((size_t)in.n * 4);
+        GbhProbeFn probe = [&](const GbhProbeLaunch &l) { fused_->probe_groups(ctx_, in, l); };
+        gbh_->get_group_ids(keys, nullptr, in.n, gids->as<int32_t>(), nullptr, /*inline_hash=*/true, &probe);
+        fused_->accumulate(ctx_, in, gids->as<int32_t>(), gbh_->group_count(), *accs_);
+    }
+
+private:
+    std::shared_ptr<PageProcessorGpu> processor_;
+    std::shared_ptr<FusedAggGpu> fused_;
+};
+
+FusedFilterProjectAggregationOperatorFactory::FusedFilterProjectAggregationOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types,
+                                                                                           const tgpu_page_processor_spec *spec, HashAggregationConfig cfg)
+    : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg))
+{
+    processor_ = std::make_shared<PageProcessorGpu>(input_types, spec);
+    const std::vector<int32_t> &pt = processor_->output_types();
+    TG_CHECK_ARG(cfg_.group_by_types.size() == cfg_.group_by_channels.size(), "group-by types and channels differ in length");
+    for (size_t i = 0; i < cfg_.group_by_channels.size(); i++) {
+        const int32_t ch = cfg_.group_by_channels[i];
+        TG_CHECK_ARG(ch >= 0 && ch < (int)pt.size() && pt[(size_t)ch] == cfg_.group_by_types[i], "group-by channel / type does not match the projections");
+    }
+    TG_CHECK_ARG(cfg_.hash_channel < (int)pt.size(), "hash channel out of range");
+    TG_CHECK_ARG(cfg_.expected_groups > 0, "expectedGroups must be positive");
+    fused_ = std::make_shared<FusedAggGpu>(input_types, spec, cfg_.aggs, cfg_.group_by_channels);
+}
+
+std::unique_ptr<Operator> FusedFilterProjectAggregationOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<FusedFilterProjectAggregationOperator>(ctx_, operator_id_, cfg_, processor_, fused_);
 }
 
 }  // namespace tgpu

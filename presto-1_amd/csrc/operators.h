@@ -154,6 +154,21 @@ private:
     std::shared_ptr<FusedProbeGpu> fused_;
 };
 
+// ---- FilterAndProject fused into the HashAggregation (jit.h FusedAggGpu); cfg's channels address the projections ----
+class FusedFilterProjectAggregationOperatorFactory : public OperatorFactory {
+public:
+    FusedFilterProjectAggregationOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec,
+                                                 HashAggregationConfig cfg);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    HashAggregationConfig cfg_;
+    std::shared_ptr<PageProcessorGpu> processor_;
+    std::shared_ptr<FusedAggGpu> fused_;
+};
+
 }  // namespace tgpu
 
 struct tgpu_context {

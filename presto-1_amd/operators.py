@@ -248,6 +248,40 @@ class FilterProjectLookupJoinOperatorFactory(OperatorFactory):
         self._bridge = lookup_source_factory
 
 
+def _agg_array(aggs):
+    arr = (_lib.AggSpec * max(1, len(aggs)))()
+    for i, a in enumerate(aggs):
+        arr[i] = _lib.AggSpec(a[0], a[1], a[2] if len(a) > 2 else -1)
+    return arr
+
+
+class FilterProjectHashAggregationOperatorFactory(OperatorFactory):
+    """FilterAndProjectOperator fused into HashAggregationOperator (HandTpchQuery1's pipeline shape): group_by_channels and the
+    aggregates' channels index the page processor's projections; same results as the two reference operators back to back."""
+
+    def __init__(self, ctx: Context, operator_id, input_types, filter_expr, projections, group_by_types, group_by_channels, aggs, step=SINGLE,
+                 hash_channel=-1, expected_groups=10_000):
+        self.program = FlatProgram(filter_expr, projections)
+        spec, keep = self.program.to_c()
+        t, nt = _i32(input_types)
+        gt, ng = _i32(group_by_types)
+        gc, _ = _i32(group_by_channels)
+        arr = _agg_array(aggs)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_filter_project_hash_aggregation_factory_create(ctx.handle, operator_id, nt, t, C.byref(spec), ng, gt, gc, hash_channel, step,
+                                                                                  len(aggs), arr, expected_groups, C.byref(h)))
+        super().__init__(h, keep)
+
+
+def precompile_fused_aggregation(input_types, filter_expr, projections, aggs, group_by_channels=()):
+    prog = FlatProgram(filter_expr, projections)
+    spec, keep = prog.to_c()
+    t, nt = _i32(input_types)
+    arr = _agg_array(aggs)
+    gc, ng = _i32(group_by_channels)
+    _lib.check(_lib.lib().tgpu_precompile_fused_aggregation(nt, t, C.byref(spec), len(aggs), arr, ng, gc))
+
+
 def precompile_fused_probe(input_types, filter_expr, projections, join_channel, probe_output_channels):
     prog = FlatProgram(filter_expr, projections)
     spec, keep = prog.to_c()

@@ -641,3 +641,77 @@ def test_join_prefilters_dense_bitmap_and_sparse_bloom(pkg, ctx, oracle, stride)
     out = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, pkeys))])
     got = np.concatenate([p.getBlock(0).values for p in out])
     assert np.array_equal(got, pkeys[op])
+
+
+@pytest.mark.parametrize("ngroups", [4, 3000])
+def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle, monkeypatch, ngroups):
+    """FilterAndProject fused into HashAggregation (row mask + in-register projections) == the unfused composition == the
+    oracle composition; few groups exercise the lane-private LDS accumulators, many groups the exact global atomics"""
+    rng = np.random.default_rng(29)
+    n = 120_000
+    T = [pkg.VARCHAR, pkg.BIGINT, pkg.DOUBLE, pkg.DOUBLE, pkg.DOUBLE, pkg.DATE, pkg.BOOLEAN, pkg.BIGINT]
+    nf = 0.0 if ngroups == 4 else 0.02
+    keys1 = rand_block(pkg, rng, pkg.VARCHAR, n, nf, (0, 2 if ngroups == 4 else 60))
+    keys2 = rand_block(pkg, rng, pkg.BIGINT, n, nf, (0, 2 if ngroups == 4 else 50))
+    page = pkg.Page(keys1, keys2, rand_block(pkg, rng, pkg.DOUBLE, n, 0.05), rand_block(pkg, rng, pkg.DOUBLE, n, 0.0, (0, 11)),
+                    rand_block(pkg, rng, pkg.DOUBLE, n, 0.03, (0, 9)), rand_block(pkg, rng, pkg.DATE, n, 0.01, (9000, 9400)),
+                    rand_block(pkg, rng, pkg.BOOLEAN, n, 0.1), rand_block(pkg, rng, pkg.BIGINT, n, 0.05, (-10**9, 10**9)))
+    f, c = pkg.field, pkg.constant
+    one = c(1.0, pkg.DOUBLE)
+    filt = f(5, pkg.DATE) <= 9300
+    projs = [f(0, pkg.VARCHAR), f(1, pkg.BIGINT), f(2, pkg.DOUBLE), f(2, pkg.DOUBLE) * (one - f(3, pkg.DOUBLE) / c(100.0, pkg.DOUBLE)),
+             f(2, pkg.DOUBLE) * (one - f(3, pkg.DOUBLE) / c(100.0, pkg.DOUBLE)) * (one + f(4, pkg.DOUBLE) / c(100.0, pkg.DOUBLE)), f(6, pkg.BOOLEAN), f(7, pkg.BIGINT)]
+    aggs = [(pkg.SUM_DOUBLE, 2), (pkg.SUM_DOUBLE, 3), (pkg.AVG_DOUBLE, 4), (pkg.COUNT_ALL, -1), (pkg.SUM_DOUBLE, 3, 5), (pkg.SUM_BIGINT, 6), (pkg.AVG_BIGINT, 6),
+            (pkg.COUNT_COLUMN, 2), (pkg.COUNT_ALL, -1, 5)]
+    results = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("TGPU_DISABLE_FUSION", "1")
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.VARCHAR, pkg.BIGINT], [0, 1], aggs)
+        out = pkg.to_pages(fac.createOperator(), [page, pkg.Page(*[pkg.Block(t, []) for t in T]), page])
+        results[mode] = [r for p in out for r in p.rows()]
+        prof = ctx.profile()
+        assert ("fused_project_accumulate_lowcard" in prof or "fused_project_accumulate" in prof) == (mode == "fused")
+        if mode == "fused":
+            assert ("fused_project_accumulate_lowcard" in prof) == (ngroups == 4)
+        ctx.close()
+    a, b = results["fused"], results["unfused"]
+    assert len(a) == len(b) and [r[:2] for r in a] == [r[:2] for r in b]        # same groups in the same (first-seen) order
+    for ra, rb in zip(a, b):
+        assert ra[5] == rb[5] and ra[7] == rb[7] and ra[9] == rb[9] and ra[10] == rb[10]
+        fa_ = [np.nan if x is None else x for x in (ra[2], ra[3], ra[4], ra[6], ra[8])]
+        fb_ = [np.nan if x is None else x for x in (rb[2], rb[3], rb[4], rb[6], rb[8])]
+        assert ulp_diff(fa_, fb_).max() == 0
+    # oracle composition: filter -> projections -> MultiChannelGroupByHash -> exact sums
+    prog = pkg.expressions.FlatProgram(filt, projs)
+    cols = [ocol(oracle, blk) for blk in page.blocks]
+    pos = oracle.filter_positions(prog.nodes, prog.filter_root, b"", cols)
+    kb = [pkg.Block(pkg.VARCHAR, [keys1.get(int(i)) for i in pos]), pkg.Block(pkg.BIGINT, [keys2.get(int(i)) for i in pos])]
+    og = oracle.MultiChannelGroupByHash([pkg.VARCHAR, pkg.BIGINT], 100)
+    gids = og.get_group_ids([ocol(oracle, x) for x in kb])
+    ng = og.group_count
+    assert ng == len(a)
+    v3, n3 = oracle.project(prog.nodes, prog.projection_roots[3], b"", cols, pos)
+    cnt3, sum3 = oracle.agg_double_sum_exact(gids, v3, ng, nulls=n3)
+    got3 = np.array([np.nan if r[3] is None else r[3] for r in a])
+    want3 = np.where(cnt3 > 0, 2 * sum3, np.nan)   # the page was fed twice: exact doubling
+    assert ulp_diff(got3, want3).max() == 0
+    assert [r[5] for r in a] == list(2 * oracle.agg_count(gids, len(pos), ng))
+
+
+def test_group_by_hash_optimistic_sub_batch_overflow_retry(pkg, oracle, monkeypatch):
+    """after a sub-batch without new groups the next one is 8x larger; if that one floods the table with new keys the probe
+    kernel flags the overflow, the table is rebuilt larger and the rows are re-run -- ids must still equal the Java order"""
+    monkeypatch.setenv("TGPU_GBH_SUBBATCH", "1000")
+    c = pkg.Context(0)
+    rng = np.random.default_rng(31)
+    vals = np.concatenate([np.zeros(2000, dtype=np.int64), rng.permutation(200_000)[:60_000].astype(np.int64) + 1, np.zeros(500, dtype=np.int64)])
+    blk = pkg.Block(pkg.BIGINT, vals)
+    gbh = pkg.GroupByHash(c, [pkg.BIGINT], [0], expected_size=10)
+    o = oracle.BigintGroupByHash(10)
+    assert np.array_equal(gbh.getGroupIds(pkg.Page(blk)), o.get_group_ids(ocol(oracle, blk)))
+    assert gbh.getGroupCount() == o.group_count == 60_001
+    gbh.close()
+    c.close()
