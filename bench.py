@@ -73,17 +73,20 @@ def varchar_from_ids(ids, table, dev):
     return data, offsets
 
 
-def gen_q3(dev, sf, rank=0):
-    base = rank * 1_000_003
+def gen_q3(dev, sf, rank=0, world=1):
+    """rank's input split of a TPCH SF(sf * world) database: its slice of customer and orders (global keys) and the lineitems of
+    those orders.  world == 1 is the plain SF(sf) database."""
     n_c = int(150_000 * sf)
     n_o = int(1_500_000 * sf)
+    base = rank * n_o * 8      # distinct counter ranges per rank
     t = {}
     ci = torch.arange(n_c, device=dev, dtype=torch.int64)
-    t["c_custkey"] = ci + 1
+    t["c_custkey"] = rank * n_c + ci + 1
     t["c_seg_bytes"], t["c_seg_off"] = varchar_from_ids(rnd(1, ci + base, 5), SEGMENTS, dev)
     oi = torch.arange(n_o, device=dev, dtype=torch.int64)
-    t["o_orderkey"] = (oi // 8) * 32 + (oi % 8) + 1
-    t["o_custkey"] = rnd(2, oi + base, n_c) + 1
+    og = rank * n_o + oi
+    t["o_orderkey"] = (og // 8) * 32 + (og % 8) + 1
+    t["o_custkey"] = rnd(2, oi + base, n_c * world) + 1
     t["o_orderdate"] = (8035 + rnd(3, oi + base, 2406)).to(torch.int32)
     t["o_shippriority"] = torch.zeros(n_o, dtype=torch.int32, device=dev)
     cnt = 1 + rnd(4, oi + base, 7)
@@ -119,15 +122,20 @@ class Bench:
         self.args = args
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.local_rank = int(os.environ.get("TGPU_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))   # TGPU_BENCH_DEVICE: rehearsal on one GPU
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device("cuda", self.local_rank)
-        if self.world > 1:
+        self.backend = os.environ.get("TGPU_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of several ranks on one GPU
+        if self.world > 1 or os.environ.get("TGPU_BENCH_FORCE_DIST"):
             import torch.distributed as dist
-            dist.init_process_group("nccl", device_id=self.dev)
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
             self.dist = dist
         else:
             self.dist = None
+        self.coll_dev = self.dev if self.backend == "nccl" else torch.device("cpu")
         self.pkg = importlib.import_module("presto-1_amd")
         self.entry = importlib.import_module("__graft_entry__")
         self.ctx = self.pkg.Context(self.local_rank, stream=torch.cuda.current_stream().cuda_stream)
@@ -153,7 +161,7 @@ class Bench:
         self.barrier_sync()
         dt = time.perf_counter() - t0
         if self.dist is not None:
-            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            tt = torch.tensor([dt], device=self.coll_dev, dtype=torch.float64)
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt / steps, self.ctx.profile()
@@ -182,7 +190,10 @@ class Bench:
     # -- Q3 -----------------------------------------------------------------------------------------------------------
     def setup_q3(self, sf):
         p = self.pkg
-        self.q3 = gen_q3(self.dev, sf, self.rank)
+        self.q3 = gen_q3(self.dev, sf, self.rank, self.world)
+        if self.dist is not None:
+            ex_mod = importlib.import_module("presto-1_amd.exchange")
+            self.exchange = ex_mod.HashExchange(self.dist, self.dev, ex_mod.hip_partitioner(self.ctx, self.dev))
         pp = self.entry.bench_page_processors(p)
         B, D, DT, V, I = p.BIGINT, p.DOUBLE, p.DATE, p.VARCHAR, p.INTEGER
         self.q3_fac = {
@@ -239,6 +250,79 @@ class Bench:
         cbuild.close()
         obuild.close()
         aop.close()
+
+    def step_q3_dist(self):
+        """the same Q3 pipeline as a distributed plan (N ranks = N stages of FIXED_HASH_DISTRIBUTION,
+        M/sql/planner/SystemPartitioningHandle.java:60): every exchange is the K10 partition kernel + an RCCL all-to-all-v.
+        The filter/project runs in the producing fragment, so probes behind an exchange use the plain LookupJoinOperator."""
+        p, ctx, f, pages, ex = self.pkg, self.ctx, self.q3_fac, self.q3_pages, self.exchange
+        B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
+        st = self.q3_stats
+
+        def filtered(fac, page):
+            outs = self.drive(fac.createOperator(), page)
+            return outs[0] if outs else None
+
+        def repartition(out_page, keys):
+            pg = ex.exchange(out_page.as_device_page(), keys)
+            out_page.release()
+            return pg
+
+        # customer: filter -> exchange(custkey) -> build
+        cb = p.HashBuilderOperatorFactory(ctx, 10, [B], [], [0])
+        cbuild = cb.createOperator()
+        cpage = repartition(filtered(f["cust_fp"], pages["customer"]), [0])
+        st["customer_build_rows"] = cpage.position_count
+        cbuild.addInput(cpage)
+        cbuild.finish()
+        # orders: filter -> exchange(custkey) -> probe customers -> exchange(orderkey) -> build
+        opage = repartition(filtered(f["ord_fp"], pages["orders"]), [1])
+        st["orders_probe_rows"] = opage.position_count
+        oj = p.LookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, [B, B, DT, I], [1], probe_output_channels=[0, 2, 3])
+        ojoin = oj.createOperator()
+        joined = self.drive(ojoin, opage)
+        ob = p.HashBuilderOperatorFactory(ctx, 12, [B, DT, I], [1, 2], [0])
+        obuild = ob.createOperator()
+        if joined:
+            bpage = repartition(joined[0], [0])
+            st["orders_build_rows"] = bpage.position_count
+            obuild.addInput(bpage)
+        obuild.finish()
+        ojoin.close()
+        # lineitem: filter/project -> exchange(orderkey) -> probe orders -> aggregate (groups are co-located: no second exchange)
+        lpage = repartition(filtered(f["li_fp"], pages["lineitem"]), [0])
+        st["lineitem_probe_rows"] = lpage.position_count
+        lj = p.LookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, [B, D], [0], probe_output_channels=[0, 1])
+        agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
+        ljoin = lj.createOperator()
+        aop = agg.createOperator()
+        st["lineitem_join_rows"] = 0
+        for j in self.drive(ljoin, lpage):
+            st["lineitem_join_rows"] = j.position_count
+            aop.addInput(j.as_device_page())
+            j.release()
+        outs = self.finish(aop)
+        st["groups"] = sum(o.position_count for o in outs)
+        st["exchange_bytes_sent"] = ex.bytes_sent
+        ex.bytes_sent = 0
+        self.q3_result = outs
+        ljoin.close()
+        cbuild.close()
+        obuild.close()
+        aop.close()
+
+    def check_q3_dist(self):
+        """N > 1: conservation checks across ranks (each rank only sees its own split, so the per-rank torch reference of the
+        single-GPU check does not apply): rows in == rows out of every exchange, revenue total equals the all-reduced reference of
+        the rows that survive both joins -- computed from the exchanged pages' owners via all-reduce of local partial sums."""
+        st = self.q3_stats
+        t = self.q3
+        sent = torch.tensor([int((t["l_shipdate"] > D_1995_03_15).sum().item()), int((t["o_orderdate"] < D_1995_03_15).sum().item())], device=self.coll_dev, dtype=torch.int64)
+        recv = torch.tensor([st["lineitem_probe_rows"], st["orders_probe_rows"]], device=self.coll_dev, dtype=torch.int64)
+        self.dist.all_reduce(sent)
+        self.dist.all_reduce(recv)
+        ok = bool(torch.equal(sent, recv))
+        return {"exchange_rows_conserved": ok, "sent": sent.tolist(), "received": recv.tolist(), "ok": ok}
 
     def check_q3(self):
         """size-independent checks at full size, computed independently with torch on the same device data"""
@@ -408,13 +492,14 @@ def main():
 
     # ---- Q3 (headline) ----
     b.setup_q3(args.sf)
-    step_s, prof = b.timed(b.step_q3, args.steps, args.warmup)
-    q3_check = b.check_q3()
+    distributed = b.dist is not None
+    step_s, prof = b.timed(b.step_q3_dist if distributed else b.step_q3, args.steps, args.warmup)
+    q3_check = b.check_q3_dist() if distributed else b.check_q3()
     st = dict(b.q3_stats)
     probe_rows = st["lineitem_probe_rows"]
     total_probe = probe_rows
     if b.dist is not None:
-        tt = torch.tensor([probe_rows], device=b.dev, dtype=torch.int64)
+        tt = torch.tensor([probe_rows], device=b.coll_dev, dtype=torch.int64)
         b.dist.all_reduce(tt)
         total_probe = int(tt.item())
     # per-kernel algorithmic bytes per row (DESIGN.md "kernels and their rooflines")
@@ -423,14 +508,20 @@ def main():
     n_o, n_l = int(b.q3["o_orderkey"].numel()), int(b.q3["l_orderkey"].numel())
     alg = ((4.0 * n_o + 20.0 * st["orders_probe_rows"] + 8.0 * st["orders_build_rows"]) + (4.0 * n_l + 20.0 * st["lineitem_probe_rows"] + 8.0 * st["lineitem_join_rows"])) / 2.0
     rows_avg = (n_o + n_l) / 2.0
-    roof = dominant(prof, {"fused_filter_probe": rows_avg}, {"fused_filter_probe": alg / rows_avg})
+    if distributed:
+        # behind the exchange the probe is the unfused kernel: key 8 B + one table slot 12 B + head/count out 8 B per probe row
+        rows_avg = (st["orders_probe_rows"] + st["lineitem_probe_rows"]) / 2.0
+        roof = dominant(prof, {"join_probe_count": rows_avg}, {"join_probe_count": 28.0})
+    else:
+        roof = dominant(prof, {"fused_filter_probe": rows_avg}, {"fused_filter_probe": alg / rows_avg})
     out.update({
         "metric": "probe_rows_per_sec", "value": total_probe / step_s, "unit": "rows/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
         "config": {"workload": "tpch_q3_hash_join_build_probe_agg (BASELINE configs[3])", "scale_factor_per_gpu": args.sf, "seed": SEED,
                    "lineitem_rows": int(b.q3["l_orderkey"].numel()), "orders_rows": int(b.q3["o_orderkey"].numel()), "customer_rows": int(b.q3["c_custkey"].numel()),
                    "lineitem_probe_rows": probe_rows, "orders_build_rows": st["orders_build_rows"], "join_output_rows": st["lineitem_join_rows"],
-                   "groups": st["groups"], "parallelism": f"shard{b.world}"},
+                   "groups": st["groups"], "parallelism": f"hash-partitioned x{b.world} (K10 partition + RCCL all-to-all-v)" if distributed else "single GPU",
+                   "exchange_bytes_sent_per_step": st.get("exchange_bytes_sent", 0)},
         "roofline": roof, "checks": {"q3": q3_check},
     })
     extra["q3_kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}

@@ -65,19 +65,24 @@ class HashExchange:
         self.partitioner = partitioner
         self.world = dist.get_world_size()
         self.bytes_sent = 0
+        # rehearsal only (several ranks sharing one GPU over `gloo`): gloo moves host tensors, so stage through the host
+        self.host_staging = dist.get_backend() == "gloo" and torch.device(device).type == "cuda"
+        self.coll_device = torch.device("cpu") if self.host_staging else torch.device(device)
 
     def _a2a(self, send, send_splits, recv_splits):
+        if self.host_staging:
+            send = send.cpu()
         recv = torch.empty(int(sum(recv_splits)), dtype=send.dtype, device=send.device)
-        self.dist.all_to_all_single(recv, send, output_split_sizes=[int(x) for x in recv_splits], input_split_sizes=[int(x) for x in send_splits])
+        self.dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[int(x) for x in recv_splits], input_split_sizes=[int(x) for x in send_splits])
         self.bytes_sent += send.numel() * send.element_size()
-        return recv
+        return recv.to(self.device) if self.host_staging else recv
 
     def exchange(self, page: Page, key_channels):
         """repartition `page` by the hash of `key_channels`; returns the rows this rank owns as a device (or host-tensor) Page"""
         w = self.world
         counts, cols = self.partitioner(page, key_channels, w)
-        send_counts = torch.as_tensor(np.asarray(counts, dtype=np.int64), device=self.device)
-        recv_counts = torch.empty(w, dtype=torch.int64, device=self.device)
+        send_counts = torch.as_tensor(np.asarray(counts, dtype=np.int64), device=self.coll_device)
+        recv_counts = torch.empty(w, dtype=torch.int64, device=self.coll_device)
         self.dist.all_to_all_single(recv_counts, send_counts)
         sc = [int(x) for x in counts]
         rc = [int(x) for x in recv_counts.tolist()]
@@ -85,7 +90,7 @@ class HashExchange:
         blocks, keep = [], []
         row_starts = np.concatenate([[0], np.cumsum(sc)])
         for c in cols:
-            any_nulls = torch.tensor([1 if c["nulls"] is not None else 0], device=self.device)
+            any_nulls = torch.tensor([1 if c["nulls"] is not None else 0], device=self.coll_device)
             self.dist.all_reduce(any_nulls, op=self.dist.ReduceOp.MAX)
             nulls = None
             if int(any_nulls.item()):
@@ -97,8 +102,8 @@ class HashExchange:
                 recv_lens = self._a2a(lens, sc, rc)
                 seg = off[torch.as_tensor(row_starts, device=off.device)]
                 send_bytes = [int(x) for x in (seg[1:] - seg[:-1]).tolist()]
-                sb = torch.as_tensor(np.asarray(send_bytes, dtype=np.int64), device=self.device)
-                rb = torch.empty(w, dtype=torch.int64, device=self.device)
+                sb = torch.as_tensor(np.asarray(send_bytes, dtype=np.int64), device=self.coll_device)
+                rb = torch.empty(w, dtype=torch.int64, device=self.coll_device)
                 self.dist.all_to_all_single(rb, sb)
                 values = self._a2a(c["values"][: sum(send_bytes)], send_bytes, [int(x) for x in rb.tolist()])
                 offsets = torch.zeros(n_out + 1, dtype=torch.int32, device=self.device)

@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): every case goes through the C ABI (include/tgpu.h) and is checked
 against the CPU oracle on the same inputs -- bit-exact for hashes, group ids, join matches and BIGINT results; DOUBLE
 aggregates against the exactly rounded sum (tolerance stated in each test)."""
+import importlib
 import json
 import os
 
@@ -715,3 +716,31 @@ def test_group_by_hash_optimistic_sub_batch_overflow_retry(pkg, oracle, monkeypa
     assert gbh.getGroupCount() == o.group_count == 60_001
     gbh.close()
     c.close()
+
+
+def test_hash_exchange_single_rank_nccl(pkg, ctx, oracle):
+    """the exchange code path on the GPU with RCCL (world size 1 on the single-GPU box): K10 partition kernel -> zero-copy torch
+    views of the library's device buffers -> all_to_all_single -> device page"""
+    import torch
+    import torch.distributed as dist
+    ex_mod = importlib.import_module("presto-1_amd.exchange")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dev = torch.device("cuda", 0)
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        rng = np.random.default_rng(37)
+        n = 50_000
+        blocks = [rand_block(pkg, rng, pkg.BIGINT, n, 0.02, (0, 10**6)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.05, (0, 40)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.1)]
+        page = pkg.Page(*blocks)
+        ex = ex_mod.HashExchange(dist, dev, ex_mod.hip_partitioner(ctx, dev))
+        out = ex.exchange(page, [0])
+        assert out.position_count == n
+        # feed the exchanged device page to an operator: identity filter/project brings it back to the host
+        f = pkg.field
+        fac = pkg.FilterAndProjectOperatorFactory(ctx, 0, [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE], None, [f(0, pkg.BIGINT), f(1, pkg.VARCHAR), f(2, pkg.DOUBLE)])
+        got = pkg.to_pages(fac.createOperator(), [out])
+        assert got[0].rows() == page.rows()   # world size 1: one partition, input order preserved
+    finally:
+        dist.destroy_process_group()
