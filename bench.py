@@ -468,7 +468,15 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
     avg_ms = st["total_ms"] / st["count"]
     alg_bytes = bytes_per_row[best] * rows_by_kernel[best]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected and corrected as documented there)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(best)
+        if pmc:
+            traffic = pmc["traffic_bytes_per_launch_avg"]
+    except (OSError, ValueError, KeyError):
+        traffic = None
+    return {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
             "avg_launch_ms": avg_ms, "launches": st["count"], "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_row": bytes_per_row[best], "rows_per_launch": rows_by_kernel[best]}
 
@@ -481,7 +489,7 @@ def main():
     ap.add_argument("--sf", type=float, default=100.0, help="TPCH scale factor per GPU")
     ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2 (default: all at N=1, q3 only at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-sf", type=float, default=4.0)
+    ap.add_argument("--cpu-sample-sf", type=float, default=60.0, help="scale factor of the bounded sample the CPU baseline runs (~15 s of CPU work)")
     args = ap.parse_args()
     b = Bench(args)
     assert b.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={b.world}"
