@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCa
             const AggView &a = args.a[k];
             if (a.mask && ((a.mask_nulls && a.mask_nulls[r]) || !a.mask[r])) continue;
             if (a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[r]) continue;
-            cnt_base[k * kBlock + threadIdx.x] += 1u;
+            cnt_base[plan.cnt_slot[k] * kBlock + threadIdx.x] += 1u;
             const int w = plan.wide_slot[k];
             if (w < 0) continue;
             if (a.function == TGPU_AGG_SUM_BIGINT) {
@@ -362,8 +362,14 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
     // low-cardinality path: lane-private LDS accumulators when all groups x states fit in one CU's LDS
     LowCardPlan plan{};
     plan.n_aggs = args.n_aggs;
-    for (int k = 0; k < args.n_aggs; k++) plan.wide_slot[k] = is_count(args.a[k].function) ? -1 : plan.n_wide++;
-    plan.per_group_bytes = plan.n_wide * 2 * kBlock * 8 + plan.n_aggs * kBlock * 4;
+    for (int k = 0; k < args.n_aggs; k++) {
+        plan.wide_slot[k] = is_count(args.a[k].function) ? -1 : plan.n_wide++;
+        plan.cnt_slot[k] = k;
+        plan.count_from_rows[k] = 0;
+    }
+    plan.n_cnt = plan.n_aggs;
+    plan.rows_slot = -1;
+    plan.per_group_bytes = plan.n_wide * 2 * kBlock * 8 + plan.n_cnt * kBlock * 4;
     const int64_t groups = group_count > 0 ? group_count : 1;
     const int64_t lds_bytes = groups * plan.per_group_bytes;
     const bool lowcard_enabled = getenv("TGPU_DISABLE_LOWCARD") == nullptr;

@@ -69,11 +69,15 @@ __device__ inline void tg_dd_add(double &hi, double &lo, double h2, double l2)
 }
 
 // ---- low-cardinality path: lane-private accumulators in LDS ---------------------------------------------------------
-// layout per group: hi[n_wide][256] doubles, lo[n_wide][256] doubles, cnt[n_aggs][256] uint32
+// layout per group: hi[n_wide][256] doubles, lo[n_wide][256] doubles, cnt[n_cnt][256] uint32
 struct TgLowCardPlan {
     int n_aggs;
-    int n_wide;                     // aggregates with a 16-byte state (double sums, bigint sums)
-    int wide_slot[TG_MAX_AGGS];     // index among the wide states or -1
+    int n_wide;                       // distinct 16-byte states (double sums, bigint sums); aggregates over the same input share one
+    int wide_slot[TG_MAX_AGGS];       // aggregate -> wide state, or -1
+    int n_cnt;                        // count slots (cnt[n_cnt][256])
+    int cnt_slot[TG_MAX_AGGS];        // aggregate -> count slot
+    int count_from_rows[TG_MAX_AGGS]; // 1: this aggregate's count is the group's row count (slot rows_slot), its own slot is not maintained
+    int rows_slot;                    // count slot holding the number of rows of the group, or -1
     int per_group_bytes;
     int n_groups;
 };
@@ -132,7 +136,7 @@ __device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, co
         unsigned int *cnt_base = tg_lc_cnt(lds, p, g);
         for (int k = 0; k < p.n_aggs; k++) {
             const TgAggState &a = st[k];
-            unsigned long long c = cnt_base[k * TG_AGG_BLOCK + threadIdx.x];
+            unsigned long long c = cnt_base[(p.count_from_rows[k] ? p.rows_slot : p.cnt_slot[k]) * TG_AGG_BLOCK + threadIdx.x];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
             const bool any = __shfl(c, 0, 64) != 0;

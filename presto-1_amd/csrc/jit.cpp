@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <fstream>
 #include <functional>
+#include <tuple>
 #include <set>
 #include <sstream>
 
@@ -832,6 +833,9 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     tg_zero_row(cur[s]);
     if (blockIdx.x < J.tiles && row < A.n) tg_load_row(A, row, cur[s]);
   }
+  // drain the prologue loads here: otherwise their pending state flows into the loop header and the compiler's waitcnt
+  // insertion (vmcnt is in-order) puts vmcnt(<=4) waits inside the tile processing, which also wait for the prefetch
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
   for (long long tile = blockIdx.x; tile < J.tiles; tile += gridDim.x) {
     const long long row0 = tile * FJ_TILE + threadIdx.x;
     {
@@ -1205,6 +1209,14 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
 namespace {
 
 
+// rows per lane and tile in the fused accumulate kernels (register rows: 2 x stripes x row dwords live across the LDS phase)
+static int fa_stripes()
+{
+    const char *e = getenv("TGPU_FA_STRIPES");
+    const int v = e ? atoi(e) : 6;
+    return v >= 1 && v <= 8 ? v : 6;
+}
+
 const char *kFaKernels = R"SRC(
 struct FaArgs {
   FpArgs fp;
@@ -1216,7 +1228,7 @@ struct FaArgs {
   int lowcard;
   int pad;
 };
-#define FA_STRIPES 8
+#define FA_STRIPES @FA_STRIPES@
 #define FA_TILE (FA_STRIPES * 256)
 
 // pass A: the filter as a row mask (one byte per row) for the group-by table
@@ -1239,6 +1251,9 @@ template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, un
     gcur[s] = -1;
     if (blockIdx.x < F.tiles && row < A.n) { gcur[s] = F.gids ? F.gids[row] : 0; tg_load_row(A, row, cur[s]); }
   }
+  // drain the prologue loads here: otherwise their pending state flows into the loop header and the compiler's waitcnt
+  // insertion (vmcnt is in-order) puts vmcnt(<=4) waits inside the tile processing, which also wait for the prefetch
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
   for (long long tile = blockIdx.x; tile < F.tiles; tile += gridDim.x) {
     const long long row0 = tile * FA_TILE + threadIdx.x;
     const long long ntile = tile + gridDim.x;
@@ -1249,6 +1264,9 @@ template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, un
       gnxt[s] = -1;
       if (ntile < F.tiles && row < A.n) { gnxt[s] = F.gids ? F.gids[row] : 0; tg_load_row(A, row, nxt[s]); }
     }
+    // keep the prefetch loads up here (issued before the LDS phase, landing while it runs): without the fence the scheduler
+    // sinks them next to their first use to save registers, which serialises HBM latency with the accumulation
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < FA_STRIPES; s++) {
       if (gcur[s] >= 0) {
@@ -1289,6 +1307,10 @@ struct FaArgsHost {
     struct Plan {
         int32_t n_aggs, n_wide;
         int32_t wide_slot[16];
+        int32_t n_cnt;
+        int32_t cnt_slot[16];
+        int32_t count_from_rows[16];
+        int32_t rows_slot;
         int32_t per_group_bytes, n_groups;
     } plan;
     long long tiles;
@@ -1354,12 +1376,57 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
                 if (a.function != TGPU_AGG_COUNT_ALL && a.input_channel == ch && a.mask_channel >= 0) always_evaluated = false;
             if (!always_evaluated) supported_ = false;
         }
+    // state sharing: aggregates over the same (input expression, mask) share their lane-private partials -- sum(x) and avg(x)
+    // need one (hi, lo) pair and one count between them (they still own separate global states)
     n_wide_ = 0;
+    n_cnt_ = 0;
+    std::map<std::tuple<int, int, int>, int> wide_of, cnt_of;
+    std::function<void(int, std::set<int> &)> inputs_of = [&](int idx, std::set<int> &out) {
+        const tgpu_expr_node &nd = nodes_[(size_t)idx];
+        if (nd.kind == TGPU_EX_INPUT) out.insert(nd.op);
+        if (nd.kind == TGPU_EX_CALL || nd.kind == TGPU_EX_SPECIAL)
+            for (int k = 0; k < nd.n_args; k++) inputs_of(nd.args[k], out);
+    };
+    std::function<bool(int)> never_null_given_inputs = [&](int idx) -> bool {
+        // true when the expression is null only if one of its input columns is (no null literal, no IF / COALESCE subtleties)
+        const tgpu_expr_node &nd = nodes_[(size_t)idx];
+        if (nd.kind == TGPU_EX_INPUT) return true;
+        if (nd.kind == TGPU_EX_CONST) return !nd.is_null;
+        if (nd.kind == TGPU_EX_SPECIAL) return false;
+        for (int k = 0; k < nd.n_args; k++)
+            if (!never_null_given_inputs(nd.args[k])) return false;
+        return true;
+    };
     for (size_t k = 0; k < aggs_.size(); k++) {
-        const bool count_only = aggs_[k].function == TGPU_AGG_COUNT_ALL || aggs_[k].function == TGPU_AGG_COUNT_COLUMN;
-        wide_slot_[k] = count_only ? -1 : n_wide_++;
+        const tgpu_agg_spec &a = aggs_[k];
+        const bool count_only = a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN;
+        const int in_root = a.function == TGPU_AGG_COUNT_ALL ? -1 : proj_roots_[(size_t)a.input_channel];
+        const int mask_root = a.mask_channel >= 0 ? proj_roots_[(size_t)a.mask_channel] : -1;
+        const int kind = a.function == TGPU_AGG_SUM_BIGINT ? 1 : (a.function == TGPU_AGG_AVG_BIGINT ? 2 : 0);
+        if (count_only) wide_slot_[k] = -1;
+        else {
+            auto key = std::make_tuple(in_root, mask_root, kind);
+            auto it = wide_of.find(key);
+            if (it == wide_of.end()) it = wide_of.emplace(key, n_wide_++).first;
+            wide_slot_[k] = it->second;
+        }
+        auto ckey = std::make_tuple(in_root, mask_root, 0);
+        auto ct = cnt_of.find(ckey);
+        if (ct == cnt_of.end()) {
+            ct = cnt_of.emplace(ckey, n_cnt_++).first;
+            std::set<int> ins;
+            bool simple = true;
+            if (in_root >= 0) {
+                inputs_of(in_root, ins);
+                simple = never_null_given_inputs(in_root);
+            }
+            cnt_inputs_.push_back(simple ? std::vector<int>(ins.begin(), ins.end()) : std::vector<int>{-1});
+            cnt_masked_.push_back(mask_root >= 0);
+        }
+        cnt_slot_[k] = ct->second;
     }
-    per_group_bytes_ = n_wide_ * 2 * 256 * 8 + (int)aggs_.size() * 256 * 4;
+    rows_slot_ = n_cnt_;   // one extra count slot: rows of the group
+    per_group_bytes_ = n_wide_ * 2 * 256 * 8 + (n_cnt_ + 1) * 256 * 4;
     max_groups_ = per_group_bytes_ > 0 ? (160 * 1024 - 64) / per_group_bytes_ : 0;  // 64 B: headroom for the compiler's own LDS use
     if (aggs_.empty()) supported_ = false;
     for (int32_t ch : group_by_channels) {
@@ -1437,22 +1504,30 @@ void FusedAggGpu::generate()
             eval << "    if (t" << k << " && !(fabs(x" << k << ") <= 1.7976931348623157e308)) { tg_flag_special(&F.st[" << k << "].special[g], x" << k << "); x" << k
                  << " = 0.0; }\n";
         eval << "  }\n";
-        // low-cardinality: lane-private slots
-        lc_read << "  unsigned int c" << k << " = cnt_base[" << k << " * 256 + threadIdx.x];\n";
-        lc_upd << "  c" << k << " += t" << k << " ? 1u : 0u;\n";
-        lc_write << "  cnt_base[" << k << " * 256 + threadIdx.x] = c" << k << ";\n";
-        if (is_dbl) {
-            lc_read << "  double h" << k << " = hi_base[" << w << " * 256 + threadIdx.x], l" << k << " = lo_base[" << w << " * 256 + threadIdx.x];\n";
-            lc_upd << "  { const double v_ = t" << k << " ? x" << k << " : 0.0; const double s_ = h" << k << " + v_; const double bb_ = s_ - h" << k << "; l" << k
-                   << " += (h" << k << " - (s_ - bb_)) + (v_ - bb_); h" << k << " = s_; }\n";
-            lc_write << "  hi_base[" << w << " * 256 + threadIdx.x] = h" << k << "; lo_base[" << w << " * 256 + threadIdx.x] = l" << k << ";\n";
+        // low-cardinality: lane-private slots.  Shared states are updated once (by the first aggregate that owns them).
+        const int cs = cnt_slot_[k];
+        bool first_cnt = true, first_wide = true;
+        for (size_t j = 0; j < k; j++) {
+            if (cnt_slot_[j] == cs) first_cnt = false;
+            if (w >= 0 && wide_slot_[j] == w) first_wide = false;
         }
-        else if (is_big) {
-            lc_read << "  unsigned long long bl" << k << " = ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x]; long long bh" << k << " = ((long long*)lo_base)[" << w
+        if (first_cnt) {
+            lc_read << "  unsigned int c" << cs << " = 0; if (!F.plan.count_from_rows[" << k << "]) c" << cs << " = cnt_base[" << cs << " * 256 + threadIdx.x];\n";
+            lc_upd << "  c" << cs << " += t" << k << " ? 1u : 0u;\n";
+            lc_write << "  if (!F.plan.count_from_rows[" << k << "]) cnt_base[" << cs << " * 256 + threadIdx.x] = c" << cs << ";\n";
+        }
+        if (is_dbl && first_wide) {
+            lc_read << "  double h" << w << " = hi_base[" << w << " * 256 + threadIdx.x], l" << w << " = lo_base[" << w << " * 256 + threadIdx.x];\n";
+            lc_upd << "  { const double v_ = t" << k << " ? x" << k << " : 0.0; const double s_ = h" << w << " + v_; const double bb_ = s_ - h" << w << "; l" << w
+                   << " += (h" << w << " - (s_ - bb_)) + (v_ - bb_); h" << w << " = s_; }\n";
+            lc_write << "  hi_base[" << w << " * 256 + threadIdx.x] = h" << w << "; lo_base[" << w << " * 256 + threadIdx.x] = l" << w << ";\n";
+        }
+        else if (is_big && first_wide) {
+            lc_read << "  unsigned long long bl" << w << " = ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x]; long long bh" << w << " = ((long long*)lo_base)[" << w
                     << " * 256 + threadIdx.x];\n";
-            lc_upd << "  { const long long v_ = t" << k << " ? y" << k << " : 0; const unsigned long long n_ = bl" << k << " + (unsigned long long)v_; bh" << k
-                   << " += (v_ < 0 ? -1 : 0) + (n_ < bl" << k << " ? 1 : 0); bl" << k << " = n_; }\n";
-            lc_write << "  ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x] = bl" << k << "; ((long long*)lo_base)[" << w << " * 256 + threadIdx.x] = bh" << k << ";\n";
+            lc_upd << "  { const long long v_ = t" << k << " ? y" << k << " : 0; const unsigned long long n_ = bl" << w << " + (unsigned long long)v_; bh" << w
+                   << " += (v_ < 0 ? -1 : 0) + (n_ < bl" << w << " ? 1 : 0); bl" << w << " = n_; }\n";
+            lc_write << "  ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x] = bl" << w << "; ((long long*)lo_base)[" << w << " * 256 + threadIdx.x] = bh" << w << ";\n";
         }
         // global: exact atomics per row
         gl << "  if (t" << k << ") {\n    atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], 1ULL);\n";
@@ -1622,25 +1697,26 @@ void FusedAggGpu::generate()
         for (size_t i = 0; i < key_inputs_.size(); i++)
             src << "  { const unsigned char* r = rec + ((size_t)g * FG_NKEYS + " << i << ") * 32; R.d" << i << " = *(const unsigned long long*)r; R.l" << i
                 << " = *(const int*)(r + 16); R.n" << i << " = r[20]; R.g" << i << " = r[21]; }\n";
-        src << "}\n// 1 equal, 0 different, -1 undecided here (varchar longer than 8 bytes: the LDS / table path decides)\n"
-               "__device__ inline int fg_eq_recreg(const FpArgs& A, const TgKeyRow& K, const TgRecReg& R) {\n";
+        // branch-free: eq = the row's key equals the record for sure; maybe = it could (a varchar longer than one byte whose
+        // length and first byte match: the byte-wise LDS comparison decides).  Pure predicate arithmetic, no control flow.
+        src << "}\n__device__ inline void fg_eq_recreg(const TgKeyRow& K, const TgRecReg& R, bool& eq, bool& maybe) {\n  eq = true; maybe = false;\n";
         for (size_t i = 0; i < key_inputs_.size(); i++) {
-            const int ch = key_inputs_[i];
-            const int32_t t = input_types_[(size_t)ch];
-            src << "  {\n    const bool xn = K.n" << i << " != 0, yn = R.n" << i << " != 0;\n    if (xn || yn) { if (xn != yn) return 0; } else {\n";
+            const int32_t t = input_types_[(size_t)key_inputs_[i]];
+            src << "  {\n    const bool xn = K.n" << i << " != 0, yn = R.n" << i << " != 0;\n";
             if (t == TGPU_VARCHAR) {
-                src << "      if (K.l" << i << " != R.l" << i << ") return 0;\n      if (K.l" << i << " > 8) return -1;\n      if (K.l" << i << " > 0 && K.b" << i
-                    << " != (unsigned char)(R.d" << i << " & 0xff)) return 0;\n      for (int j_ = 1; j_ < K.l" << i << "; j_++) if (((const unsigned char*)A.col_values[" << ch
-                    << "])[K.a" << i << " + j_] != (unsigned char)((R.d" << i << " >> (8 * j_)) & 0xff)) return 0;\n";
+                src << "    const bool same_head = K.l" << i << " == R.l" << i << " && (K.l" << i << " == 0 || K.b" << i << " == (unsigned char)(R.d" << i << " & 0xff));\n"
+                    << "    const bool sure = (xn && yn) || (!xn && !yn && same_head && K.l" << i << " <= 1);\n"
+                    << "    const bool open = !xn && !yn && same_head && K.l" << i << " > 1;\n"
+                    << "    eq = eq && (sure || open); maybe = maybe || open;\n";
             }
             else if (t == TGPU_DOUBLE)
-                src << "      { const double u_ = __longlong_as_double((long long)K.v" << i << "), w_ = __longlong_as_double((long long)R.d" << i
-                    << "); if (!((u_ != u_ && w_ != w_) || u_ == w_)) return 0; }\n";
-            else if (t == TGPU_BOOLEAN) src << "      if ((K.v" << i << " != 0) != (R.d" << i << " != 0)) return 0;\n";
-            else src << "      if ((long long)K.v" << i << " != (long long)R.d" << i << ") return 0;\n";
-            src << "    }\n  }\n";
+                src << "    const double u_ = __longlong_as_double((long long)K.v" << i << "), w_ = __longlong_as_double((long long)R.d" << i << ");\n"
+                    << "    eq = eq && ((xn && yn) || (!xn && !yn && ((u_ != u_ && w_ != w_) || u_ == w_)));\n";
+            else if (t == TGPU_BOOLEAN) src << "    eq = eq && ((xn && yn) || (!xn && !yn && ((K.v" << i << " != 0) == (R.d" << i << " != 0))));\n";
+            else src << "    eq = eq && ((xn && yn) || (!xn && !yn && (long long)K.v" << i << " == (long long)R.d" << i << "));\n";
+            src << "  }\n";
         }
-        src << "  (void)A;\n  return 1;\n}\n";
+        src << "  maybe = maybe && eq;\n  eq = eq && !maybe;\n}\n";
         src << R"SRC(
 #define FG_STRIPES 8
 #define FG_TILE (FG_STRIPES * 256)
@@ -1697,13 +1773,13 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
         result = 0;
 #else
 #pragma unroll
-        for (int g = 0; g < FG_REG_GROUPS; g++) {
-          if (g < rg && result < 0) {
-            const int e = fg_eq_recreg(A, kr[s], rr[g]);
-            if (e > 0) result = g;
-            undecided = undecided || e < 0;
-          }
+        for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {   // descending: the lowest matching group id wins the select chain
+          bool eq, maybe;
+          fg_eq_recreg(kr[s], rr[g], eq, maybe);
+          result = (g < rg && eq) ? g : result;
+          undecided = undecided || (g < rg && maybe);
         }
+        if (undecided) result = -1;   // a longer varchar key must be compared byte-wise: redo from group 0 below
         for (int g = (undecided ? 0 : rg); g < lg && result < 0; g++) {
           const int e = fg_eq_record(A, kr[s], rec, g);
           if (e > 0) result = g;
@@ -1739,10 +1815,14 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     src << "__device__ inline void tg_accumulate_row_lc(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g, unsigned char* lds) {\n" << cols_decl(gr)
         << "  double* hi_base = tg_lc_hi(lds, F.plan, g); double* lo_base = tg_lc_lo(lds, F.plan, g);\n"
         << "  unsigned int* cnt_base = tg_lc_cnt(lds, F.plan, g);\n  (void)hi_base; (void)lo_base; (void)row;\n"
-        << eval.str() << lc_read.str() << lc_upd.str() << lc_write.str() << "}\n";
+        << eval.str() << lc_read.str() << "  unsigned int rows_ = cnt_base[F.plan.rows_slot * 256 + threadIdx.x];\n" << lc_upd.str() << "  rows_ += 1u;\n" << lc_write.str()
+        << "  cnt_base[F.plan.rows_slot * 256 + threadIdx.x] = rows_;\n}\n";
     src << "__device__ inline void tg_accumulate_row_gl(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g) {\n" << cols_decl(gr) << "  (void)row;\n"
         << eval.str() << gl.str() << "}\n";
-    src << kernels.substr(split);
+    std::string tail = kernels.substr(split);
+    const std::string tag = "@FA_STRIPES@";
+    tail.replace(tail.find(tag), tag.size(), std::to_string(fa_stripes()));
+    src << tail;
     source_ = src.str();
 }
 
@@ -1856,12 +1936,23 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     }
     F.plan.n_aggs = (int32_t)aggs_.size();
     F.plan.n_wide = n_wide_;
-    for (size_t k = 0; k < aggs_.size(); k++) F.plan.wide_slot[k] = wide_slot_[k];
+    F.plan.n_cnt = n_cnt_ + 1;
+    F.plan.rows_slot = rows_slot_;
+    for (size_t k = 0; k < aggs_.size(); k++) {
+        F.plan.wide_slot[k] = wide_slot_[k];
+        F.plan.cnt_slot[k] = cnt_slot_[k];
+        // the aggregate counts every row of its group when it has no mask and none of the columns its input reads has nulls
+        // in this page: its count is then the group's row count (one shared LDS counter instead of one per aggregate)
+        const int cs = cnt_slot_[k];
+        bool from_rows = !cnt_masked_[(size_t)cs];
+        for (int ch : cnt_inputs_[(size_t)cs]) from_rows = from_rows && ch >= 0 && in.cols[(size_t)ch].nulls == nullptr;
+        F.plan.count_from_rows[k] = from_rows ? 1 : 0;
+    }
     F.plan.per_group_bytes = per_group_bytes_;
     const int64_t g = groups > 0 ? groups : 1;
     F.lowcard = (g <= max_groups_ && getenv("TGPU_DISABLE_LOWCARD") == nullptr) ? 1 : 0;
     F.plan.n_groups = F.lowcard ? (int32_t)g : 0;
-    F.tiles = ceil_div(in.n, 8 * 256);
+    F.tiles = ceil_div(in.n, fa_stripes() * 256);
     // the LDS array is static (sized for max_groups_), so one block per CU is resident; the 8-stripe software pipeline keeps
     // ~8 x row-bytes in flight per lane, which is what saturates HBM at 4 waves per CU
     const int64_t blocks = std::min<int64_t>(F.tiles, (int64_t)ctx->cu_count() * (F.lowcard ? 1 : 4));

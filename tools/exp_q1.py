@@ -17,9 +17,11 @@ page = pkg.Page(db(V, t["returnflag"], t["off"]), db(V, t["linestatus"], t["off"
                 db(D, t["tax"]), db(DT, t["shipdate"]))
 pp = entry.bench_page_processors(pkg)
 for v in variants:
-    if v == "BASE":
-        os.environ.pop("TGPU_FG_EXP", None)
-    else:
+    os.environ.pop("TGPU_FG_EXP", None)
+    if "=" in v:  # NAME=VALUE: an environment switch of the library
+        k, val = v.split("=", 1)
+        os.environ[k] = val
+    elif v != "BASE":
         os.environ["TGPU_FG_EXP"] = v
     ctx = pkg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     ctx.profile_enable(True)
