@@ -75,6 +75,7 @@ private:
     int64_t raw_hash_cap_ = 0;
     int32_t java_capacity_, java_max_fill_, java_rehashes_ = 0;
     int64_t sub_batch_;
+    int64_t next_sub_ = 0;   // size of the next sub-batch (ramps up, see get_group_ids)
     BufferPtr counters_;  // [0] pending rows, [1] new groups (scan total), [2] error flag, [3] scratch total
 };
 

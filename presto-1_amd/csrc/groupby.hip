@@ -389,7 +389,11 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
     // of low-cardinality inputs: TPCH Q1 has 4 groups in 600 M rows) the next one is 8x larger: fewer, longer launches.  Such an
     // optimistic launch can overflow the table only if it meets tens of millions of new keys; the probe kernel then flags it,
     // the table is rebuilt twice as large and the rows are re-run in smaller pieces.
-    int64_t sub = sub_batch_;
+    // The very first launches ramp up from a small piece (2^18 rows): while the table is empty every row takes the insert path
+    // and, with few distinct keys, they all contend for the same slots; once the first groups exist the probe kernels answer
+    // from their cached copies.  next_sub_ persists across pages.
+    if (next_sub_ <= 0) next_sub_ = std::min<int64_t>(sub_batch_, 1ll << 18);
+    int64_t sub = next_sub_;
     int64_t start = 0;
     while (start < n) {
         const int64_t len = std::min(sub, n - start);
@@ -407,7 +411,9 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             continue;
         }
         start += len;
-        sub = new_groups == 0 ? std::min<int64_t>(sub * 8, 1ll << 30) : sub_batch_;
+        if (new_groups == 0) sub = std::min<int64_t>(sub * 8, 1ll << 30);
+        else sub = sub < sub_batch_ ? std::min<int64_t>(sub * 8, sub_batch_) : sub_batch_;
+        next_sub_ = sub;
     }
 }
 

@@ -97,6 +97,11 @@ static std::string cache_path(const std::string &source)
 static std::vector<char> code_object_for(const std::string &source)
 {
     const std::string path = cache_path(source);
+    if (getenv("TGPU_JIT_DUMP")) {  // keep the generated source next to its code object (kernel studies)
+        mkdir((resource_dir() + "/_kcache").c_str(), 0755);
+        std::ofstream f(path.substr(0, path.size() - 6) + ".hip");
+        f << source;
+    }
     {
         std::ifstream f(path, std::ios::binary);
         if (f) {
@@ -106,10 +111,6 @@ static std::vector<char> code_object_for(const std::string &source)
     }
     std::vector<char> code = compile_source(source);
     mkdir((resource_dir() + "/_kcache").c_str(), 0755);
-    if (getenv("TGPU_JIT_DUMP")) {  // keep the generated source next to its code object (kernel studies)
-        std::ofstream f(path.substr(0, path.size() - 6) + ".hip");
-        f << source;
-    }
     const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
     {
         std::ofstream f(tmp, std::ios::binary);
@@ -1213,8 +1214,8 @@ namespace {
 static int fa_stripes()
 {
     const char *e = getenv("TGPU_FA_STRIPES");
-    const int v = e ? atoi(e) : 6;
-    return v >= 1 && v <= 8 ? v : 6;
+    const int v = e ? atoi(e) : 8;
+    return v >= 1 && v <= 8 ? v : 8;
 }
 
 const char *kFaKernels = R"SRC(
@@ -1456,7 +1457,7 @@ void FusedAggGpu::generate()
             const int32_t t = input_types_[(size_t)ch];
             const char *T = (t == TGPU_VARCHAR || t == TGPU_BOOLEAN) ? "unsigned char" : ctype(t);
             cols << "  const " << T << "* c" << ch << " = (const " << T << "*)A.col_values[" << ch << "]; (void)c" << ch << ";\n";
-            cols << "  const unsigned char* cn" << ch << " = A.col_nulls[" << ch << "]; (void)cn" << ch << ";\n";
+            cols << "  const unsigned char* cn" << ch << " = FA_NO_NULLS ? (const unsigned char*)0 : A.col_nulls[" << ch << "]; (void)cn" << ch << ";\n";
             if (t == TGPU_VARCHAR) cols << "  const int* co" << ch << " = A.col_offsets[" << ch << "]; (void)co" << ch << ";\n";
         }
         return cols.str();
@@ -1477,7 +1478,7 @@ void FusedAggGpu::generate()
     Gen gr(nodes_, pool_, input_types_);
     gr.reg_mode = true;
     gr.tmp = gm.tmp;
-    std::ostringstream eval, lc_read, lc_upd, lc_write, gl;
+    std::ostringstream eval, lc_read, lc_upd, lc_write, gl, nf_any, nf_slow, nf_clear;
     for (size_t k = 0; k < aggs_.size(); k++) {
         const tgpu_agg_spec &a = aggs_[k];
         const int w = wide_slot_[k];
@@ -1500,10 +1501,13 @@ void FusedAggGpu::generate()
             else if (is_big) eval << "      else y" << k << " = " << v.v << ";\n";
             eval << "    }\n";
         }
-        if (is_dbl)  // NaN / +-inf are flagged on the group, not summed (the flags decide the result at evaluation time)
-            eval << "    if (t" << k << " && !(fabs(x" << k << ") <= 1.7976931348623157e308)) { tg_flag_special(&F.st[" << k << "].special[g], x" << k << "); x" << k
-                 << " = 0.0; }\n";
         eval << "  }\n";
+        if (is_dbl) {  // NaN / +-inf are flagged on the group, not summed (the flags decide the result at evaluation time)
+            eval << "  const bool nf" << k << " = t" << k << " && !(fabs(x" << k << ") <= 1.7976931348623157e308);\n";
+            nf_any << (nf_any.str().empty() ? "" : " || ") << "nf" << k;
+            nf_slow << "    if (nf" << k << ") tg_flag_special(&F.st[" << k << "].special[g], x" << k << ");\n";
+            nf_clear << "  x" << k << " = nf" << k << " ? 0.0 : x" << k << ";\n";
+        }
         // low-cardinality: lane-private slots.  Shared states are updated once (by the first aggregate that owns them).
         const int cs = cnt_slot_[k];
         bool first_cnt = true, first_wide = true;
@@ -1512,9 +1516,12 @@ void FusedAggGpu::generate()
             if (w >= 0 && wide_slot_[j] == w) first_wide = false;
         }
         if (first_cnt) {
-            lc_read << "  unsigned int c" << cs << " = 0; if (!F.plan.count_from_rows[" << k << "]) c" << cs << " = cnt_base[" << cs << " * 256 + threadIdx.x];\n";
+            // without nulls in the page the count of an unmasked aggregate over a never-null expression IS the row count: static
+            const bool static_rows = !cnt_masked_[(size_t)cs] && !(cnt_inputs_[(size_t)cs].size() == 1 && cnt_inputs_[(size_t)cs][0] < 0);
+            const std::string cfr = "(FA_NO_NULLS ? " + std::string(static_rows ? "1" : "0") + " : F.plan.count_from_rows[" + std::to_string(k) + "])";
+            lc_read << "  unsigned int c" << cs << " = 0; if (!" << cfr << ") c" << cs << " = cnt_base[" << cs << " * 256 + threadIdx.x];\n";
             lc_upd << "  c" << cs << " += t" << k << " ? 1u : 0u;\n";
-            lc_write << "  if (!F.plan.count_from_rows[" << k << "]) cnt_base[" << cs << " * 256 + threadIdx.x] = c" << cs << ";\n";
+            lc_write << "  if (!" << cfr << ") cnt_base[" << cs << " * 256 + threadIdx.x] = c" << cs << ";\n";
         }
         if (is_dbl && first_wide) {
             lc_read << "  double h" << w << " = hi_base[" << w << " * 256 + threadIdx.x], l" << w << " = lo_base[" << w << " * 256 + threadIdx.x];\n";
@@ -1536,11 +1543,17 @@ void FusedAggGpu::generate()
         gl << "  }\n";
     }
 
+    // non-finite inputs are rare: one branch per row guards the per-aggregate flag updates, the values are cleared by selects
+    std::string eval_all = eval.str();
+    if (!nf_any.str().empty()) eval_all += "  if (" + nf_any.str() + ") {\n" + nf_slow.str() + "  }\n" + nf_clear.str();
+
     std::ostringstream src;
     src << kPrelude;
     if (const char *exp = getenv("TGPU_FG_EXP")) src << "#define FG_EXP_" << exp << " 1\n";  // kernel-study switch, never set in production
     src << device_header("device_hash.h") << device_header("device_agg.h") << gm.consts.str() << gr.consts.str();
     src << "#define FA_LDS_BYTES " << std::max(64, max_groups_ * per_group_bytes_) << "\n";
+    // FA_NO_NULLS 1: the specialisation for pages without null vectors (null loads and per-aggregate count slots fold away)
+    src << "#ifndef FA_NO_NULLS\n#define FA_NO_NULLS 0\n#endif\n";
     src << "struct TgRow {\n";
     for (int ch : gr.reg_cols) {
         const int32_t t = input_types_[(size_t)ch];
@@ -1551,7 +1564,7 @@ void FusedAggGpu::generate()
     for (int ch : gr.reg_cols) {
         const int32_t t = input_types_[(size_t)ch];
         const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
-        src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = A.col_nulls[" << ch << "] ? A.col_nulls[" << ch << "][row] : 0;\n";
+        src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? A.col_nulls[" << ch << "][row] : 0;\n";
     }
     src << "  (void)A; (void)row; (void)R;\n}\n__device__ inline void tg_zero_row(TgRow& R) {\n";
     for (int ch : gr.reg_cols) src << "  R.c" << ch << " = 0; R.n" << ch << " = 0;\n";
@@ -1561,13 +1574,13 @@ void FusedAggGpu::generate()
         // key accessor generated for this key schema (the GPU counterpart of JoinCompiler's hashRow / positionNotDistinctFromRow)
         src << device_header("device_cols.h") << device_header("device_groupby.h");
         src << "struct FgArgs {\n  FpArgs fp;\n  TgKeyCols store;\n  unsigned long long* words;\n  unsigned long long mask;\n  int* out;\n  unsigned long long* counters;\n"
-               "  long long row0;\n  long long n;\n  int store_groups;\n  int pad;\n};\n";
+               "  long long row0;\n  long long n;\n  int store_groups;\n  int pad;\n  const FgArgs* self;\n};\n";
         auto cell = [&](int i, const std::string &row, const std::string &pfx) {
             // declares <pfx>n (null flag) and the cell's value variables for key column i of the raw input at `row`
             const int ch = key_inputs_[(size_t)i];
             const int32_t t = input_types_[(size_t)ch];
             std::ostringstream o;
-            o << "    const bool " << pfx << "n = A.col_nulls[" << ch << "] && A.col_nulls[" << ch << "][" << row << "];\n";
+            o << "    const bool " << pfx << "n = !FA_NO_NULLS && A.col_nulls[" << ch << "] && A.col_nulls[" << ch << "][" << row << "];\n";
             if (t == TGPU_VARCHAR)
                 o << "    const int " << pfx << "a = A.col_offsets[" << ch << "][" << row << "]; const int " << pfx << "l = A.col_offsets[" << ch << "][" << row << " + 1] - " << pfx
                   << "a; const unsigned char* " << pfx << "p = (const unsigned char*)A.col_values[" << ch << "] + " << pfx << "a;\n";
@@ -1643,25 +1656,29 @@ void FusedAggGpu::generate()
         src << "struct TgKeyRow {\n";
         for (size_t i = 0; i < key_inputs_.size(); i++) {
             const int32_t t = input_types_[(size_t)key_inputs_[i]];
-            if (t == TGPU_VARCHAR) src << "  int a" << i << ", l" << i << "; unsigned char n" << i << ", b" << i << ";\n";
+            if (t == TGPU_VARCHAR) src << "  int a" << i << ", e" << i << ", l" << i << "; unsigned char n" << i << ", b" << i << ";\n";
             else src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t))) << " v" << i << "; unsigned char n" << i << ";\n";
         }
+        // phase A is loads only (no arithmetic on the loaded values): the loads of all stripes stay in flight together
         src << "};\n__device__ inline void fg_load_key_a(const FpArgs& A, long long row, TgKeyRow& K) {\n";
         for (size_t i = 0; i < key_inputs_.size(); i++) {
             const int ch = key_inputs_[i];
             const int32_t t = input_types_[(size_t)ch];
-            src << "  K.n" << i << " = A.col_nulls[" << ch << "] ? A.col_nulls[" << ch << "][row] : 0;\n";
+            src << "  K.n" << i << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? A.col_nulls[" << ch << "][row] : 0;\n";
             if (t == TGPU_VARCHAR)
-                src << "  K.a" << i << " = A.col_offsets[" << ch << "][row]; K.l" << i << " = A.col_offsets[" << ch << "][row + 1] - K.a" << i << "; K.b" << i << " = 0;\n";
+                src << "  K.a" << i << " = A.col_offsets[" << ch << "][row]; K.e" << i << " = A.col_offsets[" << ch << "][row + 1];\n";
             else {
                 const char *T = t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t));
                 src << "  K.v" << i << " = ((const " << T << "*)A.col_values[" << ch << "])[row];\n";
             }
         }
-        src << "}\n__device__ inline void fg_zero_key(TgKeyRow& K) {\n";
+        src << "}\n__device__ inline void fg_key_lengths(TgKeyRow& K) {\n";
+        for (size_t i = 0; i < key_inputs_.size(); i++)
+            if (input_types_[(size_t)key_inputs_[i]] == TGPU_VARCHAR) src << "  K.l" << i << " = K.e" << i << " - K.a" << i << ";\n";
+        src << "  (void)K;\n}\n__device__ inline void fg_zero_key(TgKeyRow& K) {\n";
         for (size_t i = 0; i < key_inputs_.size(); i++) {
             const int32_t t = input_types_[(size_t)key_inputs_[i]];
-            if (t == TGPU_VARCHAR) src << "  K.a" << i << " = 0; K.l" << i << " = 0; K.n" << i << " = 1; K.b" << i << " = 0;\n";
+            if (t == TGPU_VARCHAR) src << "  K.a" << i << " = 0; K.e" << i << " = 0; K.l" << i << " = 0; K.n" << i << " = 1; K.b" << i << " = 0;\n";
             else src << "  K.v" << i << " = 0; K.n" << i << " = 1;\n";
         }
         src << "}\n__device__ inline void fg_load_key_b(const FpArgs& A, TgKeyRow& K) {\n";
@@ -1689,45 +1706,128 @@ void FusedAggGpu::generate()
             src << "    }\n  }\n";
         }
         src << "  (void)A;\n  return 1;\n}\n";
-        // the first FG_REG_GROUPS records additionally live in registers (loaded once per block): comparing a row against them
-        // is pure VALU work, no LDS round trip per row.  d = first 8 data bytes of the record.
-        src << "#define FG_REG_GROUPS 4\nstruct TgRecReg {\n";
-        for (size_t i = 0; i < key_inputs_.size(); i++) src << "  unsigned long long d" << i << "; int l" << i << "; unsigned char n" << i << ", g" << i << ";\n";
-        src << "};\n__device__ inline void fg_load_recreg(const unsigned char* rec, int g, TgRecReg& R) {\n";
-        for (size_t i = 0; i < key_inputs_.size(); i++)
-            src << "  { const unsigned char* r = rec + ((size_t)g * FG_NKEYS + " << i << ") * 32; R.d" << i << " = *(const unsigned long long*)r; R.l" << i
-                << " = *(const int*)(r + 16); R.n" << i << " = r[20]; R.g" << i << " = r[21]; }\n";
-        // branch-free: eq = the row's key equals the record for sure; maybe = it could (a varchar longer than one byte whose
-        // length and first byte match: the byte-wise LDS comparison decides).  Pure predicate arithmetic, no control flow.
-        src << "}\n__device__ inline void fg_eq_recreg(const TgKeyRow& K, const TgRecReg& R, bool& eq, bool& maybe) {\n  eq = true; maybe = false;\n";
-        for (size_t i = 0; i < key_inputs_.size(); i++) {
-            const int32_t t = input_types_[(size_t)key_inputs_[i]];
-            src << "  {\n    const bool xn = K.n" << i << " != 0, yn = R.n" << i << " != 0;\n";
-            if (t == TGPU_VARCHAR) {
-                src << "    const bool same_head = K.l" << i << " == R.l" << i << " && (K.l" << i << " == 0 || K.b" << i << " == (unsigned char)(R.d" << i << " & 0xff));\n"
-                    << "    const bool sure = (xn && yn) || (!xn && !yn && same_head && K.l" << i << " <= 1);\n"
-                    << "    const bool open = !xn && !yn && same_head && K.l" << i << " > 1;\n"
-                    << "    eq = eq && (sure || open); maybe = maybe || open;\n";
+        // The first FG_REG_GROUPS records additionally live in registers as SIGNATURES: 32-bit words [null mask | one word per
+        // INTEGER / DATE / BOOLEAN key | two per BIGINT / DOUBLE key (DOUBLE canonicalised: one NaN, -0 -> +0) | one per VARCHAR
+        // key = min(length, 2^24-1) << 8 | first byte], compared two words at a time.  Equal signatures decide the row unless it
+        // has a varchar key longer than one byte ("open": the byte-wise LDS comparison decides).  A record that cannot be
+        // summarised (varchar longer than 16 bytes) gets a signature no row can produce for it... its first byte is 0 in the
+        // record, so at worst the row comes out "open" and the byte-wise path sends it to the table.
+        {
+            int nw = 1;
+            for (size_t i = 0; i < key_inputs_.size(); i++) {
+                const int32_t t = input_types_[(size_t)key_inputs_[i]];
+                nw += (t == TGPU_BIGINT || t == TGPU_DOUBLE) ? 2 : 1;
             }
-            else if (t == TGPU_DOUBLE)
-                src << "    const double u_ = __longlong_as_double((long long)K.v" << i << "), w_ = __longlong_as_double((long long)R.d" << i << ");\n"
-                    << "    eq = eq && ((xn && yn) || (!xn && !yn && ((u_ != u_ && w_ != w_) || u_ == w_)));\n";
-            else if (t == TGPU_BOOLEAN) src << "    eq = eq && ((xn && yn) || (!xn && !yn && ((K.v" << i << " != 0) == (R.d" << i << " != 0))));\n";
-            else src << "    eq = eq && ((xn && yn) || (!xn && !yn && (long long)K.v" << i << " == (long long)R.d" << i << "));\n";
-            src << "  }\n";
+            const int nw64 = (nw + 1) / 2;
+            src << "#define FG_REG_GROUPS 4\n#define FG_SIG_WORDS " << nw64 << "\nstruct TgRecReg { unsigned long long s[FG_SIG_WORDS]; };\n";
+            src << "__device__ inline unsigned long long fg_canon_double(unsigned long long bits) {\n  const double u = __longlong_as_double((long long)bits);\n"
+                   "  return u != u ? 0x7ff8000000000000ULL : (u == 0.0 ? 0ULL : bits);\n}\n";
+            auto pack = [&](const std::vector<std::string> &w, const std::string &dst) {
+                std::ostringstream o;
+                for (int j = 0; j < nw64; j++) {
+                    o << "  " << dst << "[" << j << "] = (unsigned long long)(" << w[(size_t)(2 * j)] << ")";
+                    if (2 * j + 1 < (int)w.size()) o << " | ((unsigned long long)(" << w[(size_t)(2 * j + 1)] << ") << 32)";
+                    o << ";\n";
+                }
+                return o.str();
+            };
+            // signature of a row
+            src << "__device__ inline void fg_row_sig(const TgKeyRow& K, unsigned long long* sig, bool& open) {\n  open = false;\n  unsigned int nm = 0;\n";
+            std::vector<std::string> w{"nm"};
+            for (size_t i = 0; i < key_inputs_.size(); i++) {
+                const int32_t t = input_types_[(size_t)key_inputs_[i]];
+                const std::string I = std::to_string(i);
+                src << "  const bool n" << I << " = K.n" << I << " != 0; nm |= n" << I << " ? " << (1u << i) << "u : 0u;\n";
+                if (t == TGPU_VARCHAR) {
+                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (((unsigned int)(K.l" << I << " < 0xffffff ? K.l" << I << " : 0xffffff) << 8) | (unsigned int)K.b" << I << ");\n"
+                        << "  open = open || (!n" << I << " && K.l" << I << " > 1);\n";
+                    w.push_back("w" + I);
+                }
+                else if (t == TGPU_BIGINT || t == TGPU_DOUBLE) {
+                    src << "  const unsigned long long q" << I << " = n" << I << " ? 0ULL : " << (t == TGPU_DOUBLE ? "fg_canon_double((unsigned long long)K.v" + I + ")" : "(unsigned long long)K.v" + I) << ";\n";
+                    w.push_back("(unsigned int)q" + I);
+                    w.push_back("(unsigned int)(q" + I + " >> 32)");
+                }
+                else if (t == TGPU_BOOLEAN) {
+                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (K.v" << I << " != 0 ? 1u : 0u);\n";
+                    w.push_back("w" + I);
+                }
+                else {
+                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (unsigned int)K.v" << I << ";\n";
+                    w.push_back("w" + I);
+                }
+            }
+            src << pack(w, "sig") << "}\n";
+            // signature of a cached group (from its LDS record)
+            src << "__device__ inline void fg_load_recreg(const unsigned char* rec, int g, TgRecReg& R) {\n  unsigned int nm = 0;\n";
+            w.assign(1, "nm");
+            for (size_t i = 0; i < key_inputs_.size(); i++) {
+                const int32_t t = input_types_[(size_t)key_inputs_[i]];
+                const std::string I = std::to_string(i);
+                src << "  const unsigned char* r" << I << " = rec + ((size_t)g * FG_NKEYS + " << I << ") * 32;\n  const bool n" << I << " = r" << I << "[20] != 0; nm |= n" << I << " ? "
+                    << (1u << i) << "u : 0u;\n";
+                if (t == TGPU_VARCHAR) {
+                    src << "  const int l" << I << " = *(const int*)(r" << I << " + 16);\n  const unsigned int w" << I << " = n" << I << " ? 0u : (((unsigned int)(l" << I << " < 0xffffff ? l" << I
+                        << " : 0xffffff) << 8) | (l" << I << " > 0 ? (unsigned int)r" << I << "[0] : 0u));\n";
+                    w.push_back("w" + I);
+                }
+                else if (t == TGPU_BIGINT || t == TGPU_DOUBLE) {
+                    src << "  const unsigned long long q" << I << " = n" << I << " ? 0ULL : " << (t == TGPU_DOUBLE ? "fg_canon_double(*(const unsigned long long*)r" + I + ")" : "*(const unsigned long long*)r" + I) << ";\n";
+                    w.push_back("(unsigned int)q" + I);
+                    w.push_back("(unsigned int)(q" + I + " >> 32)");
+                }
+                else if (t == TGPU_BOOLEAN) {
+                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (*(const unsigned long long*)r" << I << " != 0 ? 1u : 0u);\n";
+                    w.push_back("w" + I);
+                }
+                else {
+                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (unsigned int)*(const unsigned long long*)r" << I << ";\n";
+                    w.push_back("w" + I);
+                }
+            }
+            src << pack(w, "R.s") << "}\n";
         }
-        src << "  maybe = maybe && eq;\n  eq = eq && !maybe;\n}\n";
+        // (c) the filter in register-row mode for the group probe: its fixed-width input columns are loaded in phase A
+        {
+            Gen gf(nodes_, pool_, input_types_);
+            gf.reg_mode = true;
+            gf.tmp = gr.tmp + 1000;
+            std::ostringstream body;
+            if (filter_root_ >= 0) {
+                Val f = gf.gen(filter_root_, 1);
+                body << cols_decl(gf) << gf.os.str() << "  return !" << f.n << " && " << f.v << ";\n";
+            }
+            else body << "  return true;\n";
+            src << gf.consts.str() << "struct TgFRow {\n";
+            for (int ch : gf.reg_cols) {
+                const int32_t t = input_types_[(size_t)ch];
+                src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : ctype(t)) << " c" << ch << "; unsigned char n" << ch << ";\n";
+            }
+            if (gf.reg_cols.empty()) src << "  int unused;\n";
+            src << "};\n__device__ inline void tg_load_frow(const FpArgs& A, long long row, TgFRow& R) {\n";
+            for (int ch : gf.reg_cols) {
+                const int32_t t = input_types_[(size_t)ch];
+                const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
+                src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? A.col_nulls[" << ch << "][row] : 0;\n";
+            }
+            src << "  (void)A; (void)row; (void)R;\n}\n__device__ inline void tg_zero_frow(TgFRow& R) {\n";
+            for (int ch : gf.reg_cols) src << "  R.c" << ch << " = 0; R.n" << ch << " = 0;\n";
+            src << "  (void)R;\n}\n__device__ inline bool tg_filter_f(const FpArgs& A, long long row, const TgFRow& R) {\n" << body.str() << "}\n";
+        }
         src << R"SRC(
 #define FG_STRIPES 8
 #define FG_TILE (FG_STRIPES * 256)
 // the table path (hashing + probe / insert protocol) is rare once the first groups are cached in LDS: it is kept out of line
 // so that the hot loop stays small enough for the instruction cache
-__device__ __attribute__((noinline)) int fg_table_path(const FgArgs& G, long long r, int store_groups, int* pending_out) {
+// It reads its arguments from the copy of the kernel arguments in global memory (G.self): taking the address of the by-value
+// kernel parameter instead would make the compiler spill the whole argument block to scratch and turn every column access
+// of the hot loop into scratch + flat loads.  Returns the group result in the low word, the "pending" flag in bit 32.
+__device__ __attribute__((noinline)) long long fg_table_path(const FgArgs* Gm, long long r, int store_groups) {
+  const FgArgs& G = *Gm;
   SpecKeys K{G.fp, G.store, G.row0};
   bool pending = false;
   const int result = tg_gbh_probe<true>(K, r, G.words, G.mask, store_groups, G.counters, pending);
-  *pending_out = pending ? 1 : 0;
-  return result;
+  return (long long)(unsigned int)result | (pending ? (1LL << 32) : 0LL);
 }
 // pass B: filter + group lookup / insert (protocol: device_groupby.h).  Eight rows per lane per tile, processed in phases so
 // that the loads of all eight rows are in flight together: (A) filter column + key cells, (B) first varchar bytes,
@@ -1747,16 +1847,24 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     const long long r0 = tile * FG_TILE + threadIdx.x;
     bool sel[FG_STRIPES];
     TgKeyRow kr[FG_STRIPES];
+    {
+      TgFRow fr[FG_STRIPES];
 #pragma unroll
-    for (int s = 0; s < FG_STRIPES; s++) {
-      const long long r = r0 + s * 256;
-      fg_zero_key(kr[s]);
-      sel[s] = false;
-#ifdef FG_EXP_NOKEYS
-      if (r < G.n) { sel[s] = tg_filter_mem(A, G.row0 + r); }
-#else
-      if (r < G.n) { sel[s] = tg_filter_mem(A, G.row0 + r); fg_load_key_a(A, G.row0 + r, kr[s]); }
+      for (int s = 0; s < FG_STRIPES; s++) {   // phase A: loads only, unconditional (rows past the end re-read the last row)
+        const long long r = r0 + s * 256;
+        const long long rc = G.row0 + (r < G.n ? r : G.n - 1);
+        fg_zero_key(kr[s]);
+        tg_load_frow(A, rc, fr[s]);
+#ifndef FG_EXP_NOKEYS
+        fg_load_key_a(A, rc, kr[s]);
 #endif
+      }
+#pragma unroll
+      for (int s = 0; s < FG_STRIPES; s++) {
+        const long long r = r0 + s * 256;
+        sel[s] = r < G.n && tg_filter_f(A, G.row0 + r, fr[s]);
+        fg_key_lengths(kr[s]);
+      }
     }
 #ifndef FG_EXP_NOKEYS
 #pragma unroll
@@ -1772,13 +1880,17 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
 #ifdef FG_EXP_NOKEYS
         result = 0;
 #else
+        unsigned long long sig[FG_SIG_WORDS];
+        bool open;
+        fg_row_sig(kr[s], sig, open);
 #pragma unroll
-        for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {   // descending: the lowest matching group id wins the select chain
-          bool eq, maybe;
-          fg_eq_recreg(kr[s], rr[g], eq, maybe);
-          result = (g < rg && eq) ? g : result;
-          undecided = undecided || (g < rg && maybe);
+        for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {   // distinct groups have distinct keys: at most one signature matches
+          bool same = g < rg;
+#pragma unroll
+          for (int j = 0; j < FG_SIG_WORDS; j++) same = same && sig[j] == rr[g].s[j];
+          result = same ? g : result;
         }
+        undecided = open && result >= 0;
         if (undecided) result = -1;   // a longer varchar key must be compared byte-wise: redo from group 0 below
         for (int g = (undecided ? 0 : rg); g < lg && result < 0; g++) {
           const int e = fg_eq_record(A, kr[s], rec, g);
@@ -1793,9 +1905,9 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
 #endif
           // not among the cached groups: the table decides (store_groups 0 skips its own key-store scan unless a long
           // varchar key left a cached group undecided)
-          int pending = 0;
-          result = fg_table_path(G, r, undecided ? G.store_groups : 0, &pending);
-          npending += (unsigned long long)pending;
+          const long long tp = fg_table_path(G.self, r, undecided ? G.store_groups : 0);
+          result = (int)(unsigned int)(tp & 0xffffffffLL);
+          npending += (unsigned long long)(tp >> 32);
         }
       }
       G.out[r] = result;
@@ -1815,10 +1927,10 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     src << "__device__ inline void tg_accumulate_row_lc(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g, unsigned char* lds) {\n" << cols_decl(gr)
         << "  double* hi_base = tg_lc_hi(lds, F.plan, g); double* lo_base = tg_lc_lo(lds, F.plan, g);\n"
         << "  unsigned int* cnt_base = tg_lc_cnt(lds, F.plan, g);\n  (void)hi_base; (void)lo_base; (void)row;\n"
-        << eval.str() << lc_read.str() << "  unsigned int rows_ = cnt_base[F.plan.rows_slot * 256 + threadIdx.x];\n" << lc_upd.str() << "  rows_ += 1u;\n" << lc_write.str()
-        << "  cnt_base[F.plan.rows_slot * 256 + threadIdx.x] = rows_;\n}\n";
+        << eval_all << lc_read.str() << "  unsigned int rows_ = cnt_base[" << rows_slot_ << " * 256 + threadIdx.x];\n" << lc_upd.str() << "  rows_ += 1u;\n" << lc_write.str()
+        << "  cnt_base[" << rows_slot_ << " * 256 + threadIdx.x] = rows_;\n}\n";
     src << "__device__ inline void tg_accumulate_row_gl(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g) {\n" << cols_decl(gr) << "  (void)row;\n"
-        << eval.str() << gl.str() << "}\n";
+        << eval_all << gl.str() << "}\n";
     std::string tail = kernels.substr(split);
     const std::string tag = "@FA_STRIPES@";
     tail.replace(tail.find(tag), tag.size(), std::to_string(fa_stripes()));
@@ -1826,14 +1938,31 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     source_ = src.str();
 }
 
+// the specialisation for pages without null vectors: same source, FA_NO_NULLS 1
+static std::string no_nulls_source(const std::string &src) { return "#define FA_NO_NULLS 1\n" + src; }
+
 void FusedAggGpu::precompile()
 {
-    if (supported_) (void)code_object_for(source_);
+    if (!supported_) return;
+    (void)code_object_for(source_);
+    (void)code_object_for(no_nulls_source(source_));
 }
 
 void FusedAggGpu::ensure_loaded()
 {
     if (!module_) module_ = load_module(source_);
+}
+
+JitModule *FusedAggGpu::module_for(const DevicePage &in)
+{
+    bool nulls = false;
+    for (const DeviceColumn &c : in.cols) nulls = nulls || c.nulls != nullptr;
+    if (nulls) {
+        ensure_loaded();
+        return module_.get();
+    }
+    if (!module_nn_) module_nn_ = load_module(no_nulls_source(source_));
+    return module_nn_.get();
 }
 
 void FusedAggGpu::raise_if_error(Context *ctx, BufferPtr &err)
@@ -1858,7 +1987,7 @@ static void fill_fp_cols(FpArgs &fp, const DevicePage &in)
 void FusedAggGpu::filter_mask(Context *ctx, const DevicePage &in, uint8_t *mask_out)
 {
     TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
-    ensure_loaded();
+    JitModule *module = module_for(in);
     if (in.n == 0) return;
     FaArgsHost F{};
     fill_fp_cols(F.fp, in);
@@ -1869,7 +1998,7 @@ void FusedAggGpu::filter_mask(Context *ctx, const DevicePage &in, uint8_t *mask_
     {
         ProfileScope ps(ctx, "fused_filter_mask");
         int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 16);
-        launch_args(module_->fn("fa_mask"), (int)blocks, F, ctx->stream());
+        launch_args(module->fn("fa_mask"), (int)blocks, F, ctx->stream());
     }
     raise_if_error(ctx, err);
 }
@@ -1886,13 +2015,14 @@ struct FgArgsHost {
     long long n;
     int32_t store_groups;
     int32_t pad;
+    const void *self;   // device copy of this block (read by the out-of-line table path)
 };
 }  // namespace
 
 void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProbeLaunch &l)
 {
     TG_CHECK_STATE(supported_ && !key_inputs_.empty(), "fused group lookup not available for this configuration");
-    ensure_loaded();
+    JitModule *module = module_for(in);
     FgArgsHost G{};
     fill_fp_cols(G.fp, in);
     BufferPtr err = ctx->alloc(8);
@@ -1906,10 +2036,13 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     G.row0 = l.row0;
     G.n = l.n;
     G.store_groups = l.store_groups;
+    BufferPtr self = ctx->alloc(sizeof(FgArgsHost));
+    G.self = self->ptr();
+    ctx->upload(self->ptr(), &G, sizeof(FgArgsHost));
     {
         ProfileScope ps(ctx, "fused_filter_group_probe");
         int64_t blocks = std::min<int64_t>(ceil_div(l.n, 256), (int64_t)ctx->cu_count() * 8);
-        launch_args(module_->fn("fg_probe"), (int)blocks, G, ctx->stream());
+        launch_args(module->fn("fg_probe"), (int)blocks, G, ctx->stream());
     }
     raise_if_error(ctx, err);
 }
@@ -1917,7 +2050,7 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
 void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, int64_t groups, GroupedAccumulators &accs)
 {
     TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
-    ensure_loaded();
+    JitModule *module = module_for(in);
     if (in.n == 0) return;
     accs.reserve(groups);
     FaArgsHost F{};
@@ -1958,7 +2091,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     const int64_t blocks = std::min<int64_t>(F.tiles, (int64_t)ctx->cu_count() * (F.lowcard ? 1 : 4));
     {
         ProfileScope ps(ctx, F.lowcard ? "fused_project_accumulate_lowcard" : "fused_project_accumulate");
-        launch_args(module_->fn(F.lowcard ? "fa_accumulate_lowcard" : "fa_accumulate_global"), (int)blocks, F, ctx->stream());
+        launch_args(module->fn(F.lowcard ? "fa_accumulate_lowcard" : "fa_accumulate_global"), (int)blocks, F, ctx->stream());
     }
     raise_if_error(ctx, err);
 }

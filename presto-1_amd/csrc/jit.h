@@ -145,6 +145,7 @@ public:
 private:
     void generate();
     void ensure_loaded();
+    struct JitModule *module_for(const DevicePage &in);   // the no-nulls specialisation when no column of the page has a null vector
     void raise_if_error(Context *ctx, BufferPtr &err);
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
@@ -159,7 +160,7 @@ private:
     std::vector<std::vector<int>> cnt_inputs_;   // per count slot: the raw input channels its (mask, input) expressions read
     std::vector<bool> cnt_masked_;
     std::string source_;
-    std::shared_ptr<JitModule> module_;
+    std::shared_ptr<JitModule> module_, module_nn_;
 };
 
 std::string resource_dir();
