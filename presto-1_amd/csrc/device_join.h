@@ -28,22 +28,30 @@ struct TgPrefilter {
     unsigned long long bloom_word_mask;
 };
 
+// Slot of a key in the int-key table: Fibonacci hashing, the top log2(capacity) bits of key * 2^64 / phi (one 64-bit multiply
+// per probe instead of the four of the reference's hash + a finaliser; the table layout is not observable, only build
+// positions are).  mask = capacity - 1, capacity a power of two >= 1024.
+__device__ inline unsigned long long tg_slot_of(long long key, unsigned long long mask)
+{
+    return ((unsigned long long)key * 0x9E3779B97F4A7C15ULL) >> (64 - __popcll(mask));
+}
+
 // head build position of `key`, or -1 (PagesHash.getAddressIndex, M/operator/PagesHash.java:157-169, specialised)
 __device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long mask, const TgPrefilter &pf, long long key)
 {
-    const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(key));
     if (pf.bitmap) {
         if (key < pf.key_min || key > pf.key_max) return -1;
         const unsigned long long d = (unsigned long long)(key - pf.key_min);
         if (!((pf.bitmap[d >> 6] >> (d & 63)) & 1ULL)) return -1;
     }
     else if (pf.bloom) {
+        const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(key));
         const unsigned long long *bloom = pf.bloom;
         const unsigned long long bloom_word_mask = pf.bloom_word_mask;
         const unsigned long long bits = tg_bloom_mask(m);
         if ((bloom[tg_bloom_word(m, bloom_word_mask)] & bits) != bits) return -1;
     }
-    unsigned long long pos = m & mask;
+    unsigned long long pos = tg_slot_of(key, mask);
     for (unsigned long long iter = 0; iter <= mask; iter++) {
         const TgSlot16 s = slots[pos];
         if (s.head < 0) return -1;

@@ -189,6 +189,8 @@ GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool ha
     const char *env = getenv("TGPU_GBH_SUBBATCH");
     sub_batch_ = env ? atoll(env) : (1ll << 24);
     if (sub_batch_ < 1) sub_batch_ = 1;
+    // first sub-batch: small when few groups are expected (see get_group_ids), a full one when the planner expects many
+    next_sub_ = std::min<int64_t>(sub_batch_, std::max<int64_t>(1ll << 18, (int64_t)expected_size * 16));
     counters_ = ctx_->alloc_zero(8 * 8);
 }
 
@@ -389,10 +391,9 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
     // of low-cardinality inputs: TPCH Q1 has 4 groups in 600 M rows) the next one is 8x larger: fewer, longer launches.  Such an
     // optimistic launch can overflow the table only if it meets tens of millions of new keys; the probe kernel then flags it,
     // the table is rebuilt twice as large and the rows are re-run in smaller pieces.
-    // The very first launches ramp up from a small piece (2^18 rows): while the table is empty every row takes the insert path
-    // and, with few distinct keys, they all contend for the same slots; once the first groups exist the probe kernels answer
-    // from their cached copies.  next_sub_ persists across pages.
-    if (next_sub_ <= 0) next_sub_ = std::min<int64_t>(sub_batch_, 1ll << 18);
+    // With few expected groups the very first launches ramp up from a small piece (2^18 rows): while the table is empty every
+    // row takes the insert path and, with few distinct keys, they all contend for the same slots; once the first groups exist
+    // the probe kernels answer from their cached copies.  next_sub_ persists across pages.
     int64_t sub = next_sub_;
     int64_t start = 0;
     while (start < n) {

@@ -131,8 +131,23 @@ struct JitModule {
     {
         if (mod) hipModuleUnload(mod);
     }
+    std::mutex mu;   // modules are shared between operators (load_module), possibly on different driver threads
+    std::map<std::string, int> resident;
+    // workgroups of 256 threads of `name` that fit on one CU (registers / LDS): the grid of a persistent kernel
+    int blocks_per_cu(const char *name)
+    {
+        hipFunction_t f = fn(name);
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = resident.find(name);
+        if (it != resident.end()) return it->second;
+        int nb = 0;
+        if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 256, 0) != hipSuccess || nb < 1) nb = 1;
+        resident[name] = nb;
+        return nb;
+    }
     hipFunction_t fn(const char *name)
     {
+        std::lock_guard<std::mutex> lk(mu);
         auto it = fns.find(name);
         if (it != fns.end()) return it->second;
         hipFunction_t f = nullptr;
@@ -142,12 +157,24 @@ struct JitModule {
     }
 };
 
+// Loaded modules are shared process-wide per device, keyed by their source: operator factories are created per query, the
+// kernels they generate repeat (the counterpart of the reference's compiled-class caches, M/sql/gen/PageFunctionCompiler.java
+// :101-139 and JoinCompiler.java:89-107).
 static std::shared_ptr<JitModule> load_module(const std::string &source)
 {
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<JitModule>> loaded;
+    int device = 0;
+    HIP_CHECK(hipGetDevice(&device));
+    const std::string key = std::to_string(device) + ":" + std::to_string(source.size()) + ":" + cache_path(source);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = loaded.find(key);
+    if (it != loaded.end()) return it->second;
     std::vector<char> code = code_object_for(source);
     auto m = std::make_shared<JitModule>();
     hipError_t e = hipModuleLoadData(&m->mod, code.data());
     if (e != hipSuccess) fail(TGPU_ERR_COMPILER, std::string("hipModuleLoadData failed: ") + hipGetErrorString(e));
+    loaded[key] = m;
     return m;
 }
 
@@ -681,17 +708,9 @@ void PageProcessorGpu::ensure_loaded(Context *ctx)
 {
     (void)ctx;
     if (module_) return;
-    std::vector<char> code = code_object_for(source_);
-    auto m = std::make_shared<JitModule>();
-    hipError_t e = hipModuleLoadData(&m->mod, code.data());
-    if (e != hipSuccess) fail(TGPU_ERR_COMPILER, std::string("hipModuleLoadData failed: ") + hipGetErrorString(e));
-    if (filter_root_ >= 0) {
-        e = hipModuleGetFunction(&m->count, m->mod, "fp_count");
-        if (e != hipSuccess) fail(TGPU_ERR_COMPILER, "generated module lacks fp_count");
-    }
-    e = hipModuleGetFunction(&m->emit, m->mod, "fp_emit");
-    if (e != hipSuccess) fail(TGPU_ERR_COMPILER, "generated module lacks fp_emit");
-    module_ = m;
+    module_ = load_module(source_);
+    if (filter_root_ >= 0) fn_count_ = module_->fn("fp_count");
+    fn_emit_ = module_->fn("fp_emit");
 }
 
 static void launch(hipFunction_t f, int grid, FpArgs &args, hipStream_t stream)
@@ -743,7 +762,7 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
         args.tile_counts = tile_counts->as<int32_t>();
         {
             ProfileScope ps(ctx, "filter_count");
-            launch(module_->count, (int)tiles, args, ctx->stream());
+            launch(fn_count_, (int)tiles, args, ctx->stream());
         }
         k::exclusive_scan_i32(ctx, tile_counts->as<int32_t>(), tile_offsets->as<int32_t>(), tiles, total->as<int64_t>());
         n_sel = ctx->read_scalar(total->as<int64_t>());
@@ -770,7 +789,7 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
     }
     if (has_filter || computed_count_ > 0) {
         ProfileScope ps(ctx, has_filter ? "filter_project_emit" : "project_emit");
-        launch(module_->emit, (int)tiles, args, ctx->stream());
+        launch(fn_emit_, (int)tiles, args, ctx->stream());
     }
     if (computed_count_ > 0) check_error();
     out.n = n_sel;
@@ -786,6 +805,14 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
 // FusedProbeGpu: filter + project + hash-join probe in one kernel
 // =====================================================================================================================
 namespace {
+
+// rows per lane and tile in the fused probe kernel
+static int fj_stripes()
+{
+    const char *e = getenv("TGPU_FJ_STRIPES");
+    const int v = e ? atoi(e) : 4;   // 4: ~110 VGPRs = 4 workgroups per CU; the kernel is VALU-issue bound, not latency bound
+    return v >= 1 && v <= 8 ? v : 4;
+}
 
 const char *kFjKernels = R"SRC(
 struct FjArgs {
@@ -805,7 +832,7 @@ struct FjArgs {
   int outer;
   int pad;
 };
-#define FJ_STRIPES 8
+#define FJ_STRIPES @FJ_STRIPES@
 #define FJ_TILE (FJ_STRIPES * 256)
 
 // rows-capacity offset of block b's private pair region: tiles are dealt round-robin, block b owns ceil((tiles - b) / grid)
@@ -818,135 +845,177 @@ __device__ inline long long fj_region_base(long long b, long long tiles, long lo
 // block's PRIVATE region, so workgroups never communicate; a scan over the per-tile counts (in tile = input order) then
 // gives every tile its final offset and pass 2 moves the pairs there -- probe positions come out ascending exactly as
 // LookupJoinPageBuilder.java:144-153 requires.
+//
+// A probe is a chain of three dependent loads (row -> pre-filter word -> table slot).  The loop is software-pipelined over
+// the block's tiles so that the three kinds of load of one iteration belong to three different tiles and are issued back to
+// back: iteration `it` issues the row loads of tile it, the pre-filter loads of tile it-1, the slot loads of tile it-2 and
+// compacts / writes the pairs of tile it-3, whose slots arrived during the previous iteration.  One memory round trip per
+// iteration instead of three (vmcnt is in-order on CDNA: a wait for a dependent load would also wait for every prefetch
+// issued before it, so "prefetch, then probe" inside one iteration cannot overlap).
 extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   const FpArgs& A = J.fp;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __shared__ int C[4][FJ_STRIPES];
+  __shared__ int C[2][4];   // pairs of each wave, double-buffered by tile parity (one barrier per tile)
   const long long region = fj_region_base(blockIdx.x, J.tiles, gridDim.x);
   long long local = 0;      // pairs this block has written so far (uniform across the block)
   unsigned long long selected = 0;
-  // software pipeline: the column values of the NEXT tile are loaded (all stripes in flight) before the current tile is
-  // evaluated, so the streaming loads overlap the pre-filter / table probes of the current tile
-  TgRow cur[FJ_STRIPES], nxt[FJ_STRIPES];
+  // Row layout of a tile: wave w owns the contiguous rows [w * 64 * FJ_STRIPES, (w + 1) * 64 * FJ_STRIPES) of the tile and its
+  // lane reads row s * 64 + lane of them in stripe s (512 contiguous bytes per wave and load).  Input order inside the tile is
+  // then (wave, stripe, lane): the compaction needs the other waves' TOTALS only, everything else is wave-local scalar work.
+  // Rows are 32-bit here (a page has fewer than 2^31 positions).
+  const unsigned int n_rows = (unsigned int)A.n;
+  const unsigned int wave_row = (unsigned int)w * (64u * FJ_STRIPES) + (unsigned int)lane;
+  const long long my_tiles = J.tiles > (long long)blockIdx.x ? (J.tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  TgRow rw[FJ_STRIPES];                                                                                            // stage A -> B
+  long long pkey[FJ_STRIPES]; unsigned int psidx[FJ_STRIPES]; unsigned long long pbits[FJ_STRIPES], pbw[FJ_STRIPES];   // B -> C
+  unsigned char pfl[FJ_STRIPES];                                                                                   // 1 = probe, 2 = passed the filter
+  long long skey[FJ_STRIPES]; unsigned int ssidx[FJ_STRIPES]; unsigned char sfl[FJ_STRIPES]; TgSlot16 ssl[FJ_STRIPES]; // C -> D
 #pragma unroll
   for (int s = 0; s < FJ_STRIPES; s++) {
-    const long long row = (long long)blockIdx.x * FJ_TILE + threadIdx.x + s * 256;
-    tg_zero_row(cur[s]);
-    if (blockIdx.x < J.tiles && row < A.n) tg_load_row(A, row, cur[s]);
+    tg_zero_row(rw[s]);
+    pkey[s] = 0; psidx[s] = 0; pbits[s] = 0; pbw[s] = 0; pfl[s] = 0;
+    skey[s] = 0; ssidx[s] = 0; sfl[s] = 0; ssl[s].key = 0; ssl[s].head = -1; ssl[s].pad = 0;
   }
-  // drain the prologue loads here: otherwise their pending state flows into the loop header and the compiler's waitcnt
-  // insertion (vmcnt is in-order) puts vmcnt(<=4) waits inside the tile processing, which also wait for the prefetch
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
-  for (long long tile = blockIdx.x; tile < J.tiles; tile += gridDim.x) {
-    const long long row0 = tile * FJ_TILE + threadIdx.x;
-    {
-      const long long ntile = tile + gridDim.x;
-#pragma unroll
-      for (int s = 0; s < FJ_STRIPES; s++) {
-        const long long row = ntile * FJ_TILE + threadIdx.x + s * 256;
-        tg_zero_row(nxt[s]);
-        if (ntile < J.tiles && row < A.n) tg_load_row(A, row, nxt[s]);
-      }
-    }
-    bool sel[FJ_STRIPES];
-    bool passed[FJ_STRIPES];
-    long long key[FJ_STRIPES];
-    unsigned long long hm[FJ_STRIPES];
-    // phase 1: filter + key from the pre-loaded rows
-#pragma unroll
-    for (int s = 0; s < FJ_STRIPES; s++) {
-      const long long row = row0 + s * 256;
-      sel[s] = false; passed[s] = false; key[s] = 0; hm[s] = 0;
-      if (row < A.n && tg_filter(A, row, cur[s])) {
-        selected++;
-        passed[s] = true;
-        long long k = 0;
-        const bool kn = tg_key(A, row, cur[s], k);   // JoinProbe.java:87-97: a null probe key never matches
-        sel[s] = !kn;
-        key[s] = k;
-        hm[s] = tg_fmix64((unsigned long long)tg_hash_long(k));
-      }
-    }
-    // phase 2: pre-filter words (exact key bitmap for dense key domains, else the blocked Bloom filter) -- unconditional loads
-    // from always-valid addresses so that all stripes are in flight together
-    bool maybe[FJ_STRIPES];
-    {
-      unsigned long long bw[FJ_STRIPES];
-      unsigned long long bits[FJ_STRIPES];
-#pragma unroll
-      for (int s = 0; s < FJ_STRIPES; s++) {
-        bw[s] = ~0ULL; bits[s] = 0;
-        if (J.pf.bitmap) {
-          const bool in_range = sel[s] && key[s] >= J.pf.key_min && key[s] <= J.pf.key_max;
-          const unsigned long long d = in_range ? (unsigned long long)(key[s] - J.pf.key_min) : 0ULL;
-          bits[s] = in_range ? (1ULL << (d & 63)) : ~0ULL;   // out of range: a mask the word (0) can never satisfy
-          bw[s] = in_range ? J.pf.bitmap[d >> 6] : 0ULL;
-        } else if (J.pf.bloom) {
-          bits[s] = tg_bloom_mask(hm[s]);
-          bw[s] = J.pf.bloom[tg_bloom_word(hm[s], J.pf.bloom_word_mask)];
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < FJ_STRIPES; s++) {
-        maybe[s] = sel[s] && (bw[s] & bits[s]) == bits[s];
-#ifdef FJ_EXP_NOPROBE
-        maybe[s] = false;
-#endif
-      }
-    }
-    // phase 3: first table slot of every survivor (predicated loads, issued back to back), then resolve; only a
-    // collision with another key walks further
+  for (long long it = 0; it < my_tiles + 3; it++) {
+    const long long jD = it - 3, jC = it - 2, jB = it - 1, jA = it;
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): everything the previous iteration issued (consumed right below anyway)
+    // stage D, part 1: resolve tile jD from the slots loaded by the previous iteration; only a collision with another key
+    // walks further
     int head[FJ_STRIPES];
     bool emit[FJ_STRIPES];
-    unsigned long long b[FJ_STRIPES];
-    {
-      TgSlot16 sl[FJ_STRIPES];
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) { head[s] = -1; emit[s] = false; }
+    if (jD >= 0) {
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
-        sl[s].key = 0; sl[s].head = -1; sl[s].pad = 0;
-        if (maybe[s]) sl[s] = J.slots[hm[s] & J.mask];
-      }
-#pragma unroll
-      for (int s = 0; s < FJ_STRIPES; s++) {
-        head[s] = -1;
-        if (maybe[s] && sl[s].head >= 0) {
-          if (sl[s].key == key[s]) head[s] = sl[s].head;
+        if ((sfl[s] & 1) && ssl[s].head >= 0) {
+          if (ssl[s].key == skey[s]) head[s] = ssl[s].head;
           else {
-            unsigned long long pos = ((hm[s] & J.mask) + 1) & J.mask;
-            for (unsigned long long it = 0; it < J.mask; it++) {
+            unsigned long long pos = ((unsigned long long)ssidx[s] + 1) & J.mask;
+            for (unsigned long long k = 0; k < J.mask; k++) {
               const TgSlot16 t = J.slots[pos];
               if (t.head < 0) break;
-              if (t.key == key[s]) { head[s] = t.head; break; }
+              if (t.key == skey[s]) { head[s] = t.head; break; }
               pos = (pos + 1) & J.mask;
             }
           }
         }
-        emit[s] = head[s] >= 0 || (J.outer && passed[s]);   // PROBE_OUTER: every row that passed the filter (LookupJoinOperator.java:354-361)
-        b[s] = __ballot(emit[s]);
-        if (lane == 0) C[w][s] = __popcll(b[s]);
+        emit[s] = head[s] >= 0 || (J.outer && (sfl[s] & 2));   // PROBE_OUTER: every row that passed the filter (LookupJoinOperator.java:354-361)
       }
     }
-    __syncthreads();
-    long long base = region + local;
-    int tile_total = 0;
+    // stage C: tile jC -- pre-filter verdicts; the survivors' first table slot is loaded below (lanes without a survivor read
+    // slot 0: always-valid addresses, no branches around the loads)
+    const bool doC = jC >= 0 && jC < my_tiles, doB = jB >= 0 && jB < my_tiles, doA = jA < my_tiles;
+    unsigned int cidx[FJ_STRIPES];
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) cidx[s] = 0;
+    if (doC) {
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        bool maybe = (pfl[s] & 1) && (pbw[s] & pbits[s]) == pbits[s];
+#ifdef FJ_EXP_NOPROBE
+        maybe = false;
+#endif
+        skey[s] = pkey[s]; ssidx[s] = psidx[s];
+        sfl[s] = (unsigned char)((maybe ? 1 : 0) | (pfl[s] & 2));
+        cidx[s] = maybe ? psidx[s] : 0u;
+      }
+    }
+    // stage B: tile jB -- filter + key from the rows loaded by the previous iteration; the pre-filter word (exact key bitmap
+    // for dense key domains, else the blocked Bloom filter) is loaded below, again from an always-valid address
+    unsigned long long bidx[FJ_STRIPES];
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) bidx[s] = 0;
+    if (doB) {
+      const unsigned int row0 = (unsigned int)(((long long)blockIdx.x + jB * gridDim.x) * FJ_TILE) + wave_row;
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        const unsigned int row = row0 + s * 64;
+        bool sel = false, passed = false;
+        long long key = 0;
+        if (row < n_rows && tg_filter(A, row, rw[s])) {
+          selected++;
+          passed = true;
+          const bool kn = tg_key(A, row, rw[s], key);   // JoinProbe.java:87-97: a null probe key never matches
+          sel = !kn;
+        }
+        unsigned long long bits = 0;
+        bidx[s] = 0;
+#if FJ_PF == 1
+        {
+          // out-of-range keys read word 0 with a full mask: a false "maybe" at worst (the slot's key comparison is exact)
+          const bool in_range = sel && key >= J.pf.key_min && key <= J.pf.key_max;
+          const unsigned long long d = in_range ? (unsigned long long)(key - J.pf.key_min) : 0ULL;
+          bits = in_range ? (1ULL << (d & 63)) : ~0ULL;
+          bidx[s] = d >> 6;
+        }
+#elif FJ_PF == 2
+        {
+          const unsigned long long hm = tg_fmix64((unsigned long long)tg_hash_long(key));
+          bits = tg_bloom_mask(hm);
+          bidx[s] = tg_bloom_word(hm, J.pf.bloom_word_mask);
+        }
+#endif
+        pkey[s] = key; psidx[s] = (unsigned int)tg_slot_of(key, J.mask); pbits[s] = bits;
+        pfl[s] = (unsigned char)((sel ? 1 : 0) | (passed ? 2 : 0));
+      }
+    }
+    // Every value loaded by the previous iteration has been consumed above; now issue this iteration's loads back to back:
+    // slots of tile jC, pre-filter words of tile jB, rows of tile jA.  They are unconditional (always-valid addresses: slot 0
+    // / word 0 / the page's last row when a stage is idle or a row is past the end): a branch around a load makes the
+    // compiler's in-order wait-count bookkeeping conservative and serialises the three groups.
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < FJ_STRIPES; s++) ssl[s] = J.slots[cidx[s]];
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) {
-      int before = 0, total = 0;
-#pragma unroll
-      for (int w2 = 0; w2 < 4; w2++) { const int c = C[w2][s]; if (w2 < w) before += c; total += c; }
-      if (emit[s]) {
-        const long long o = base + before + __builtin_amdgcn_mbcnt_hi((unsigned)(b[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b[s], 0u));
-        J.pair_probe[o] = (int)(row0 + s * 256);
-        J.pair_build[o] = head[s];
-      }
-      base += total;
-      tile_total += total;
+#if FJ_PF == 1
+      pbw[s] = J.pf.bitmap[bidx[s]];
+#elif FJ_PF == 2
+      pbw[s] = J.pf.bloom[bidx[s]];
+#else
+      pbw[s] = ~0ULL;
+#endif
     }
-    if (threadIdx.x == 0) { J.tile_cnt[tile] = tile_total; J.tile_src[tile] = (int)local; }
-    local += tile_total;
+    {
+      const unsigned int row0 = (unsigned int)(((long long)blockIdx.x + (doA ? jA : 0) * gridDim.x) * FJ_TILE) + wave_row;
 #pragma unroll
-    for (int s = 0; s < FJ_STRIPES; s++) cur[s] = nxt[s];
-    __syncthreads();
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        const unsigned int row = row0 + s * 64;
+        tg_load_row(A, row < n_rows ? row : n_rows - 1, rw[s]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // stage D, part 2: compact the pairs of tile jD in input order and append them to the block's region
+    if (jD >= 0) {
+      const long long tile = (long long)blockIdx.x + jD * gridDim.x;
+      const unsigned int row0 = (unsigned int)(tile * FJ_TILE) + wave_row;
+      unsigned long long b[FJ_STRIPES];
+      int wave_total = 0;
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        b[s] = __ballot(emit[s]);
+        wave_total += __popcll(b[s]);
+      }
+      int* Cw = C[jD & 1];
+      if (lane == 0) Cw[w] = wave_total;
+      __syncthreads();
+      int before = 0, tile_total = 0;
+#pragma unroll
+      for (int w2 = 0; w2 < 4; w2++) { const int c = Cw[w2]; if (w2 < w) before += c; tile_total += c; }
+      long long o = region + local + before;
+#pragma unroll
+      for (int s = 0; s < FJ_STRIPES; s++) {
+        if (emit[s]) {
+          const long long at = o + __builtin_amdgcn_mbcnt_hi((unsigned)(b[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b[s], 0u));
+          J.pair_probe[at] = (int)(row0 + s * 64);
+          J.pair_build[at] = head[s];
+        }
+        o += __popcll(b[s]);
+      }
+      if (threadIdx.x == 0) { J.tile_cnt[tile] = tile_total; J.tile_src[tile] = (int)local; }
+      local += tile_total;
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) selected += __shfl_down(selected, d, 64);
@@ -1101,18 +1170,28 @@ void FusedProbeGpu::generate()
     src << "}\n";
     // experiment switches for kernel studies (tools/exp_fused.py); never set in production
     if (const char *exp = getenv("TGPU_FJ_EXP")) src << "#define FJ_EXP_" << exp << " 1\n";
-    src << kFjKernels;
+    {
+        std::string kernels = kFjKernels;
+        const std::string tag = "@FJ_STRIPES@";
+        kernels.replace(kernels.find(tag), tag.size(), std::to_string(fj_stripes()));
+        src << kernels;
+    }
     source_ = src.str();
 }
 
+// one specialisation per pre-filter kind of the lookup source (0 none, 1 exact key bitmap, 2 blocked Bloom filter)
+static std::string prefilter_source(const std::string &src, int kind) { return "#define FJ_PF " + std::to_string(kind) + "\n" + src; }
+
 void FusedProbeGpu::precompile()
 {
-    if (supported_) (void)code_object_for(source_);
+    if (!supported_) return;
+    for (int kind = 0; kind < 3; kind++) (void)code_object_for(prefilter_source(source_, kind));
 }
 
-void FusedProbeGpu::ensure_loaded()
+JitModule *FusedProbeGpu::module_for(int kind)
 {
-    if (!module_) module_ = load_module(source_);
+    if (!modules_[kind]) modules_[kind] = load_module(prefilter_source(source_, kind));
+    return modules_[kind].get();
 }
 
 void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, std::vector<DeviceColumn> &probe_out,
@@ -1122,7 +1201,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
     IntTableView tv;
     TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
-    ensure_loaded();
+    JitModule *module = module_for(tv.bitmap ? 1 : (tv.bloom ? 2 : 0));
     const int64_t n = in.n;
     count = 0;
     selected_rows = 0;
@@ -1143,9 +1222,11 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.bloom = tv.bloom;
     J.bloom_word_mask = tv.bloom_word_mask;
     J.outer = outer ? 1 : 0;
-    J.tiles = ceil_div(n, 8 * 256);
-    TG_CHECK_ARG(J.tiles <= 0x7fffffffLL, "page too large");
-    const int64_t grid1 = std::min<int64_t>(J.tiles, (int64_t)ctx->cu_count() * 8);
+    const int64_t tile_rows = (int64_t)fj_stripes() * 256;
+    J.tiles = ceil_div(n, tile_rows);
+    TG_CHECK_ARG(n <= 0x7fffffffLL && J.tiles <= 0x7fffffffLL, "page too large");
+    // persistent workgroups: exactly as many as are resident at once (a second round of workgroups would only add a tail)
+    const int64_t grid1 = std::min<int64_t>(J.tiles, (int64_t)ctx->cu_count() * module->blocks_per_cu("fj_probe"));
     J.grid1 = grid1;
     BufferPtr tile_cnt = ctx->alloc((size_t)J.tiles * 4), tile_src = ctx->alloc((size_t)J.tiles * 4), tile_dst = ctx->alloc((size_t)J.tiles * 4);
     BufferPtr misc = ctx->alloc(32);  // [0] expression error word, [1] rows selected by the filter, [2] total pairs
@@ -1157,13 +1238,13 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.tile_src = tile_src->as<int32_t>();
     J.tile_dst = tile_dst->as<int32_t>();
     // without duplicate build keys a probe row yields at most one pair: the private regions hold tiles x 2048 rows in total
-    const int64_t cap = J.tiles * 8 * 256;
+    const int64_t cap = J.tiles * tile_rows;
     BufferPtr pair_probe = ctx->alloc((size_t)cap * 4), pair_build = ctx->alloc((size_t)cap * 4);
     J.pair_probe = pair_probe->as<int32_t>();
     J.pair_build = pair_build->as<int32_t>();
     {
         ProfileScope ps(ctx, "fused_filter_probe");
-        launch_args(module_->fn("fj_probe"), (int)grid1, J, ctx->stream());
+        launch_args(module->fn("fj_probe"), (int)grid1, J, ctx->stream());
     }
     {
         ProfileScope ps(ctx, "fused_probe_scan");
@@ -1198,7 +1279,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     {
         ProfileScope ps(ctx, "fused_probe_emit");
         int64_t blocks = std::min<int64_t>(ceil_div(J.tiles, 4), (int64_t)ctx->cu_count() * 8);
-        launch_args(module_->fn("fj_emit"), (int)blocks, J, ctx->stream());
+        launch_args(module->fn("fj_emit"), (int)blocks, J, ctx->stream());
     }
     unsigned long long e = ctx->read_scalar(misc->as<unsigned long long>());
     if (e != ~0ull) raise(e);

@@ -58,6 +58,7 @@ private:
     int computed_count_ = 0;
     std::string source_;
     std::shared_ptr<JitModule> module_;
+    hipFunction_t fn_count_ = nullptr, fn_emit_ = nullptr;
 };
 
 // ---- operator fusion by codegen ---------------------------------------------------------------------------------------
@@ -104,7 +105,7 @@ public:
 
 private:
     void generate();
-    void ensure_loaded();
+    struct JitModule *module_for(int prefilter_kind);
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
     std::string pool_;
@@ -113,7 +114,7 @@ private:
     int32_t join_channel_;
     bool supported_ = false;
     std::string source_;
-    std::shared_ptr<JitModule> module_;
+    std::shared_ptr<JitModule> modules_[3];
 };
 
 // FilterAndProject feeding a HashAggregation: the filter becomes a row mask in front of the group-by table (no row is

@@ -129,6 +129,61 @@ __global__ void __launch_bounds__(kBlock) build_insert_kernel(KeyCols keys, cons
     }
 }
 
+// int-key fast path: insert + key publication + key range in one pass.  The row that claims an empty slot (CAS on head) also
+// stores the key into it; rows that meet an occupied slot compare against the KEY COLUMN at the slot's current head (the
+// slot's key field may not be visible yet inside this kernel), and a row with the same key raises the head to the newest
+// position (PagesHash.java:104-119 keeps the last inserted position as the head of the key's chain).
+// counters[0] = rows that joined an existing key, counters[1] = error; minmax[0] / [1] = smallest / largest indexed key
+__global__ void __launch_bounds__(kBlock) build_insert_int_kernel(ColView key, int64_t n, Slot16 *slots, uint64_t mask, int32_t *__restrict__ row_slot,
+                                                                   unsigned long long *counters, long long *minmax)
+{
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        bool dup = false;
+        int32_t slot = -1;
+        if (!(key.nulls && key.nulls[r])) {  // PagesHash.java:94-96: rows with a null key are not indexed
+            const long long k = int_key_at(key, r);
+            lo = k < lo ? k : lo;
+            hi = k > hi ? k : hi;
+            uint64_t pos = tg_slot_of(k, mask);
+            for (uint64_t iter = 0; iter <= mask; iter++) {
+                int *hp = &slots[pos].head;
+                int cur = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == -1) {
+                    const int old = atomicCAS(hp, -1, (int)r);
+                    if (old == -1) {
+                        slots[pos].key = k;
+                        slot = (int32_t)pos;
+                        break;
+                    }
+                    cur = old;
+                }
+                if (int_key_at(key, cur) == k) {
+                    atomicMax(hp, (int)r);
+                    slot = (int32_t)pos;
+                    dup = true;
+                    break;
+                }
+                pos = (pos + 1) & mask;
+                if (iter == mask) atomicExch(&counters[1], 1ull);
+            }
+        }
+        row_slot[r] = slot;
+        const unsigned long long b = __ballot(dup);
+        if (dup && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const long long l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) sort_keys_kernel(const int32_t *__restrict__ row_slot, int64_t n, unsigned long long *__restrict__ keys)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
@@ -160,31 +215,6 @@ __global__ void __launch_bounds__(kBlock) init_slots_kernel(Slot16 *__restrict__
         s.head = -1;
         s.pad = 0;
         slots[i] = s;
-    }
-}
-
-// after the insert pass every indexed row publishes its key into its slot (rows sharing a slot share the key) and feeds the
-// key range (minmax[0] = min, minmax[1] = max)
-__global__ void __launch_bounds__(kBlock) publish_keys_kernel(const int32_t *__restrict__ row_slot, int64_t n, ColView key, Slot16 *slots, long long *minmax)
-{
-    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        const int32_t sl = row_slot[r];
-        if (sl < 0) continue;
-        const long long k = int_key_at(key, r);
-        slots[sl].key = k;
-        lo = k < lo ? k : lo;
-        hi = k > hi ? k : hi;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const long long l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-        atomicMin(&minmax[0], lo);
-        atomicMax(&minmax[1], hi);
     }
 }
 
@@ -222,12 +252,8 @@ struct ProbeTable {
 template <bool FAST>
 __device__ __forceinline__ int find_head(const ProbeTable &t, const KeyCols &build, const KeyCols &probe, int64_t r, int64_t h)
 {
+    if (FAST) return tg_find_head_int(t.slots, t.mask, t.pf, int_key_at(probe.c[0], r));   // slot position from the key alone
     uint64_t pos = tg_fmix64((uint64_t)h) & t.mask;
-    if (FAST) {
-        // the slot position comes from the key's own hash (== the raw hash channel when that is H5 of the key)
-        (void)pos;
-        return tg_find_head_int(t.slots, t.mask, t.pf, int_key_at(probe.c[0], r));
-    }
     for (uint64_t iter = 0; iter <= t.mask; iter++) {
         const int b = t.heads[pos];
         if (b < 0) return -1;
@@ -243,7 +269,7 @@ __global__ void __launch_bounds__(kBlock) probe_count_kernel(ProbeTable t, KeyCo
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         int head = -1;
-        if (!row_has_null(probe, r)) head = find_head<FAST>(t, build, probe, r, hashes[r]);  // JoinProbe.java:87-97
+        if (!row_has_null(probe, r)) head = find_head<FAST>(t, build, probe, r, FAST ? 0 : hashes[r]);  // JoinProbe.java:87-97
         int32_t c = 0;
         if (head >= 0) {
             c = 1;
@@ -428,6 +454,7 @@ void LookupSourceGpu::build()
     if (capacity_ > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "hash table size cannot exceed 2 billion slots");
     link_count_ = 0;
     links_.reset();
+    tags_.reset();
     bitmap_.reset();
     bloom_.reset();
     heads_.reset();
@@ -453,35 +480,44 @@ void LookupSourceGpu::build()
     for (auto &c : key_cols_) kp.push_back(&c);
     const KeyCols keys = key_cols_of(kp);
 
-    BufferPtr own_hashes;
-    const int64_t *hashes;
-    DeviceColumn hash_col;
-    // int-key fast path: slot positions always come from the key's own H5 hash, so that probes (and the JIT-fused probe
-    // kernels) can derive them from the key alone; a precomputed $hashvalue channel equals that hash by construction
-    // (HashGenerationOptimizer.java:866-888)
-    if (hash_channel_ >= 0 && !int_key_fast_) {  // precomputed $hashvalue channel: JoinCompiler.java:405-428
-        hash_col = index_->column(hash_channel_);
-        TG_CHECK_ARG(hash_col.type == TGPU_BIGINT, "hash channel must be BIGINT");
-        hashes = (const int64_t *)hash_col.values;
+    BufferPtr row_slot = ctx_->alloc((size_t)n_ * 4);
+    BufferPtr counters = ctx_->alloc(32);   // [0] duplicate rows, [1] error, [2] smallest key, [3] largest key
+    {
+        const long long init[4] = {0, 0, 0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1};
+        ctx_->upload(counters->ptr(), init, 32);
+    }
+    const int g = grid_for(ctx_, n_);
+    if (int_key_fast_) {
+        // slot positions come from the key alone (tg_slot_of), so that probes -- and the JIT-fused probe kernels -- need no hash
+        // channel; no row hashes, tags or separate key publication pass on this path
+        ProfileScope ps(ctx_, "join_build_insert");
+        build_insert_int_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, slots16_->as<Slot16>(), (uint64_t)capacity_ - 1, row_slot->as<int32_t>(),
+                                                                 counters->as<unsigned long long>(), counters->as<long long>() + 2);
+        check_launch("build_insert_int");
     }
     else {
-        own_hashes = ctx_->alloc((size_t)n_ * 8);
-        k::hash_rows(ctx_, keys, n_, own_hashes->as<int64_t>());
-        hashes = own_hashes->as<int64_t>();
-    }
-    tags_ = ctx_->alloc((size_t)n_);
-    BufferPtr row_slot = ctx_->alloc((size_t)n_ * 4);
-    BufferPtr counters = ctx_->alloc_zero(16);
-    const int g = grid_for(ctx_, n_);
-    {
+        BufferPtr own_hashes;
+        const int64_t *hashes;
+        DeviceColumn hash_col;
+        if (hash_channel_ >= 0) {  // precomputed $hashvalue channel: JoinCompiler.java:405-428
+            hash_col = index_->column(hash_channel_);
+            TG_CHECK_ARG(hash_col.type == TGPU_BIGINT, "hash channel must be BIGINT");
+            hashes = (const int64_t *)hash_col.values;
+        }
+        else {
+            own_hashes = ctx_->alloc((size_t)n_ * 8);
+            k::hash_rows(ctx_, keys, n_, own_hashes->as<int64_t>());
+            hashes = own_hashes->as<int64_t>();
+        }
+        tags_ = ctx_->alloc((size_t)n_);
         ProfileScope ps(ctx_, "join_build_insert");
         tags_kernel<<<g, kBlock, 0, ctx_->stream()>>>(hashes, n_, tags_->as<uint8_t>());
         build_insert_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys, hashes, tags_->as<uint8_t>(), n_, heads, stride, (uint64_t)capacity_ - 1,
                                                              row_slot->as<int32_t>(), counters->as<unsigned long long>());
         check_launch("build_insert");
     }
-    unsigned long long host_ctr[2];
-    ctx_->download(host_ctr, counters->ptr(), 16);
+    unsigned long long host_ctr[4];
+    ctx_->download(host_ctr, counters->ptr(), 32);
     TG_CHECK_STATE(host_ctr[1] == 0, "join table overflow");
     link_count_ = (int64_t)host_ctr[0];
     if (link_count_ > 0) {
@@ -500,15 +536,8 @@ void LookupSourceGpu::build()
     }
     if (int_key_fast_) {
         ProfileScope ps(ctx_, "join_build_prefilter");
-        BufferPtr mm = ctx_->alloc(16);
-        const long long init[2] = {0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1};
-        ctx_->upload(mm->ptr(), init, 16);
-        publish_keys_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], slots16_->as<Slot16>(), mm->as<long long>());
-        check_launch("publish_keys");
-        long long host_mm[2];
-        ctx_->download(host_mm, mm->ptr(), 16);
-        key_min_ = host_mm[0];
-        key_max_ = host_mm[1];
+        key_min_ = (long long)host_ctr[2];
+        key_max_ = (long long)host_ctr[3];
         // pre-filter: exact bitmap when the key domain is dense enough, else a blocked Bloom filter (16 bits per build row)
         const bool has_keys = key_max_ >= key_min_;
         const unsigned long long range = has_keys ? (unsigned long long)key_max_ - (unsigned long long)key_min_ + 1ULL : 0ULL;
@@ -567,7 +596,7 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
     for (auto &c : key_cols_) kp.push_back(&c);
     const KeyCols build = key_cols_.empty() ? KeyCols{} : key_cols_of(kp);
     BufferPtr own_hashes;
-    if (!probe_hashes) {  // hashRow: JoinCompiler.java:449-477
+    if (!probe_hashes && !int_key_fast_) {  // hashRow: JoinCompiler.java:449-477 (the int-key table derives its slots from the key)
         own_hashes = ctx_->alloc((size_t)n * 8);
         k::hash_rows(ctx_, probe, n, own_hashes->as<int64_t>());
         probe_hashes = own_hashes->as<int64_t>();

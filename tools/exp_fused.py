@@ -19,9 +19,11 @@ o_ok = (t["o_orderdate"] < 9204) & cust_ok[t["o_custkey"]]
 bkeys = t["o_orderkey"][o_ok].contiguous()
 print("build rows", bkeys.numel(), "lineitem rows", t["l_orderkey"].numel())
 for v in variants:
-    if v == "BASE":
-        os.environ.pop("TGPU_FJ_EXP", None)
-    else:
+    os.environ.pop("TGPU_FJ_EXP", None)
+    if "=" in v:  # NAME=VALUE: an environment switch of the library
+        k_, val_ = v.split("=", 1)
+        os.environ[k_] = val_
+    elif v != "BASE":
         os.environ["TGPU_FJ_EXP"] = v
     ctx = pkg.Context(0, stream=torch.cuda.current_stream().cuda_stream)
     ctx.profile_enable(True)
