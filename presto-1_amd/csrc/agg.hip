@@ -122,52 +122,64 @@ __global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCa
     tg_lc_fold(lds, plan, states.st);
 }
 
-// limbs -> correctly rounded double (round half to even)
+// limbs -> correctly rounded double (round half to even).  One pass over the limbs with O(1) state: the carry-normalised
+// number is a string of 32-bit digits whose sign is only known after the top limb, so the pass tracks, for the number AND for
+// its two's complement, the highest non-zero digit seen so far together with the two digits below it and whether anything
+// further down is non-zero -- 96 bits around the leading one are all the rounding needs (53 + guard + sticky).
+struct KulischWindow {
+    int top;                  // index of the highest non-zero digit, -1 = none
+    unsigned int w0, w1, w2;  // digits top, top - 1, top - 2
+    bool sticky;              // a digit below top - 2 is non-zero
+    unsigned int p1, p2;      // the last two digits seen
+    bool below;               // a digit older than p2 is non-zero
+    __device__ void init() { top = -1; w0 = w1 = w2 = 0; sticky = false; p1 = p2 = 0; below = false; }
+    __device__ void push(int i, unsigned int digit)
+    {
+        if (digit) { top = i; w0 = digit; w1 = p1; w2 = p2; sticky = below; }
+        below = below || p2 != 0;
+        p2 = p1;
+        p1 = digit;
+    }
+};
+
 __device__ double kulisch_round(const long long *limbs, unsigned int special)
 {
     if (special) {
         if ((special & 1u) || ((special & 2u) && (special & 4u))) return __longlong_as_double(0x7ff8000000000000LL);
         return (special & 2u) ? __longlong_as_double(0x7ff0000000000000LL) : __longlong_as_double((long long)0xfff0000000000000ULL);
     }
-    unsigned int d[kLimbs];
+    KulischWindow pos, negw;
+    pos.init();
+    negw.init();
     long long carry = 0;
+    unsigned int negc = 1;   // carry of the "+ 1" of the two's complement: alive while every lower digit was zero
     for (int i = 0; i < kLimbs; i++) {
-        long long v = limbs[i] + carry;
-        d[i] = (unsigned int)(v & 0xffffffffLL);
+        const long long v = limbs[i] + carry;
+        const unsigned int digit = (unsigned int)(v & 0xffffffffLL);
         carry = v >> 32;
+        pos.push(i, digit);
+        const unsigned int nd = ~digit + negc;
+        negc = (negc && digit == 0) ? 1u : 0u;
+        negw.push(i, nd);
     }
-    bool neg = carry < 0;
-    if (neg) {  // two's complement negate
-        unsigned long long c = 1;
-        for (int i = 0; i < kLimbs; i++) {
-            unsigned long long v = (unsigned long long)(~d[i]) + c;
-            d[i] = (unsigned int)v;
-            c = v >> 32;
-        }
-    }
-    int top = -1;
-    for (int i = kLimbs - 1; i >= 0; i--)
-        if (d[i]) { top = i; break; }
-    if (top < 0) return 0.0;
-    const int t = top * 32 + (31 - __clz((int)d[top]));  // index of the highest set bit
-    auto bit_at = [&](int b) -> unsigned long long { return b < 0 ? 0ULL : (unsigned long long)((d[b >> 5] >> (b & 31)) & 1u); };
+    const bool neg = carry < 0;
+    const KulischWindow &w = neg ? negw : pos;
+    if (w.top < 0) return 0.0;
+    const int hb = 31 - __clz((int)w.w0);
+    const int t = w.top * 32 + hb;  // index of the highest set bit
     unsigned long long bits;
     if (t <= 52) {
         // denormal or the smallest normals: exactly representable, the integer IS the bit pattern
-        bits = ((unsigned long long)d[1] << 32) | d[0];
+        bits = w.top == 1 ? (((unsigned long long)w.w0 << 32) | w.w1) : (unsigned long long)w.w0;
     }
     else {
-        unsigned long long mant = 0;
-        for (int b = t; b >= t - 52; b--) mant = (mant << 1) | bit_at(b);
-        const unsigned long long guard = bit_at(t - 53);
-        bool sticky = false;
-        const int q = t - 54;  // highest bit that only contributes to the sticky flag
-        if (q >= 0) {
-            const int li = q >> 5, lb = q & 31;
-            const unsigned int msk = lb == 31 ? 0xffffffffu : ((1u << (lb + 1)) - 1u);
-            sticky = (d[li] & msk) != 0;
-            for (int i = li - 1; i >= 0 && !sticky; i--) sticky = d[i] != 0;
-        }
+        // window = digits top .. top-2, bit (64 + hb) is the leading one; t >= 53 so the 54 bits below it are inside the window
+        const unsigned __int128 win = ((unsigned __int128)w.w0 << 64) | ((unsigned __int128)w.w1 << 32) | (unsigned __int128)w.w2;
+        const int gpos = 64 + hb - 53;   // position of the guard bit (>= 11)
+        unsigned long long mant = (unsigned long long)(win >> (gpos + 1));   // 53 bits including the leading one
+        const bool guard = (unsigned long long)(win >> gpos) & 1ULL;
+        bool sticky = w.sticky || (win & (((unsigned __int128)1 << gpos) - 1)) != 0;
+        // digits below the window exist only when top >= 3; when top < 2 the missing digits are zero (w1 / w2 were pushed as 0)
         long long e = (long long)t - 51;
         if (guard && (sticky || (mant & 1ULL))) {
             mant++;

@@ -52,14 +52,33 @@ __global__ void __launch_bounds__(kBlock) gbh_probe_kernel(KeyCols batch, const 
 {
     // hashes == nullptr: the raw hash is computed from the key cells; row_mask: rows with 0 take no part (out = -1)
     GenericKeys k{batch, store, hashes};
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = base + threadIdx.x;
+        const bool active = r < n && (!row_mask || row_mask[r]);
+        // Runs of equal keys in adjacent rows (inputs clustered by key, e.g. the lineitems of one order) would hammer one table
+        // slot from neighbouring lanes: only the first row of a run inside the wave goes to the table, the others copy its
+        // answer (same group, or the same pending slot -- whose first row is the leader's or an earlier one anyway).
+        const long long h = active ? k.hash(r) : 0;
+        const long long h_prev = __shfl_up(h, 1, 64);
+        const int active_prev = __shfl_up(active ? 1 : 0, 1, 64);
+        const bool follower = active && lane > 0 && active_prev && h == h_prev && k.eq_row(r, r - 1);
+        const unsigned long long leaders = __ballot(active && !follower);
         bool pending = false;
         int32_t result = -1;
-        if (!row_mask || row_mask[r]) result = tg_gbh_probe<INSERT>(k, r, (unsigned long long *)words, (unsigned long long)mask, store_groups, counters, pending);
-        out[r] = result;
+        if (active && !follower) result = tg_gbh_probe<INSERT>(k, r, (unsigned long long *)words, (unsigned long long)mask, store_groups, counters, pending);
+        const unsigned long long at_or_below = leaders & ((2ULL << lane) - 1ULL);
+        const int src = at_or_below ? 63 - __clzll((long long)at_or_below) : lane;
+        const int32_t lead_result = __shfl(result, src, 64);
+        const int lead_pending = __shfl(pending ? 1 : 0, src, 64);
+        if (follower) {
+            result = lead_result;
+            pending = lead_pending != 0;
+        }
+        if (r < n) out[r] = result;
         if (INSERT) {
             unsigned long long b = __ballot(pending);
-            if (pending && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+            if (pending && lane == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
         }
     }
 }

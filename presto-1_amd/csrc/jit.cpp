@@ -858,7 +858,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   __shared__ int C[2][4];   // pairs of each wave, double-buffered by tile parity (one barrier per tile)
   const long long region = fj_region_base(blockIdx.x, J.tiles, gridDim.x);
   long long local = 0;      // pairs this block has written so far (uniform across the block)
-  unsigned long long selected = 0;
+  unsigned int selected = 0;   // per lane: rows that passed the filter (a lane sees fewer than 2^31 rows)
   // Row layout of a tile: wave w owns the contiguous rows [w * 64 * FJ_STRIPES, (w + 1) * 64 * FJ_STRIPES) of the tile and its
   // lane reads row s * 64 + lane of them in stripe s (512 contiguous bytes per wave and load).  Input order inside the tile is
   // then (wave, stripe, lane): the compaction needs the other waves' TOTALS only, everything else is wave-local scalar work.
@@ -867,8 +867,16 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   const unsigned int wave_row = (unsigned int)w * (64u * FJ_STRIPES) + (unsigned int)lane;
   const long long my_tiles = J.tiles > (long long)blockIdx.x ? (J.tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
   TgRow rw[FJ_STRIPES];                                                                                            // stage A -> B
-  long long pkey[FJ_STRIPES]; unsigned int psidx[FJ_STRIPES]; unsigned long long pbits[FJ_STRIPES], pbw[FJ_STRIPES];   // B -> C
+  long long pkey[FJ_STRIPES]; unsigned int psidx[FJ_STRIPES]; unsigned long long pbw[FJ_STRIPES];                      // B -> C
+#if FJ_PF == 2
+  unsigned long long pbits[FJ_STRIPES];     // Bloom mask of the key
+#else
+  unsigned int pbits[FJ_STRIPES];           // bit of the key inside its bitmap word
+#endif
   unsigned char pfl[FJ_STRIPES];                                                                                   // 1 = probe, 2 = passed the filter
+#if FJ_PF == 1
+  const unsigned long long key_range = (unsigned long long)J.pf.key_max - (unsigned long long)J.pf.key_min;
+#endif
   long long skey[FJ_STRIPES]; unsigned int ssidx[FJ_STRIPES]; unsigned char sfl[FJ_STRIPES]; TgSlot16 ssl[FJ_STRIPES]; // C -> D
 #pragma unroll
   for (int s = 0; s < FJ_STRIPES; s++) {
@@ -912,7 +920,13 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     if (doC) {
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
+#if FJ_PF == 2
         bool maybe = (pfl[s] & 1) && (pbw[s] & pbits[s]) == pbits[s];
+#elif FJ_PF == 1
+        bool maybe = (pfl[s] & 1) && ((unsigned int)(pbw[s] >> pbits[s]) & 1u);
+#else
+        bool maybe = (pfl[s] & 1) != 0;
+#endif
 #ifdef FJ_EXP_NOPROBE
         maybe = false;
 #endif
@@ -939,24 +953,25 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
           const bool kn = tg_key(A, row, rw[s], key);   // JoinProbe.java:87-97: a null probe key never matches
           sel = !kn;
         }
-        unsigned long long bits = 0;
         bidx[s] = 0;
 #if FJ_PF == 1
         {
-          // out-of-range keys read word 0 with a full mask: a false "maybe" at worst (the slot's key comparison is exact)
-          const bool in_range = sel && key >= J.pf.key_min && key <= J.pf.key_max;
-          const unsigned long long d = in_range ? (unsigned long long)(key - J.pf.key_min) : 0ULL;
-          bits = in_range ? (1ULL << (d & 63)) : ~0ULL;
-          bidx[s] = d >> 6;
+          // key in [key_min, key_max] <=> (key - key_min) mod 2^64 <= key_max - key_min; a key outside cannot match: no probe
+          const unsigned long long d = (unsigned long long)key - (unsigned long long)J.pf.key_min;
+          sel = sel && d <= key_range;
+          pbits[s] = (unsigned int)d & 63u;
+          bidx[s] = sel ? (d >> 6) : 0ULL;
         }
 #elif FJ_PF == 2
         {
           const unsigned long long hm = tg_fmix64((unsigned long long)tg_hash_long(key));
-          bits = tg_bloom_mask(hm);
+          pbits[s] = tg_bloom_mask(hm);
           bidx[s] = tg_bloom_word(hm, J.pf.bloom_word_mask);
         }
+#else
+        pbits[s] = 0;
 #endif
-        pkey[s] = key; psidx[s] = (unsigned int)tg_slot_of(key, J.mask); pbits[s] = bits;
+        pkey[s] = key; psidx[s] = (unsigned int)tg_slot_of(key, J.mask);
         pfl[s] = (unsigned char)((sel ? 1 : 0) | (passed ? 2 : 0));
       }
     }
@@ -979,10 +994,17 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     }
     {
       const unsigned int row0 = (unsigned int)(((long long)blockIdx.x + (doA ? jA : 0) * gridDim.x) * FJ_TILE) + wave_row;
+      const unsigned int tile_row0 = (unsigned int)(((long long)blockIdx.x + (doA ? jA : 0) * gridDim.x) * FJ_TILE);
+      if (tile_row0 + FJ_TILE <= n_rows) {   // interior tile: one address per column, the stripes are constant offsets from it
 #pragma unroll
-      for (int s = 0; s < FJ_STRIPES; s++) {
-        const unsigned int row = row0 + s * 64;
-        tg_load_row(A, row < n_rows ? row : n_rows - 1, rw[s]);
+        for (int s = 0; s < FJ_STRIPES; s++) tg_load_row(A, row0 + s * 64, rw[s]);
+      }
+      else {
+#pragma unroll
+        for (int s = 0; s < FJ_STRIPES; s++) {
+          const unsigned int row = row0 + s * 64;
+          tg_load_row(A, row < n_rows ? row : n_rows - 1, rw[s]);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1003,23 +1025,26 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       int before = 0, tile_total = 0;
 #pragma unroll
       for (int w2 = 0; w2 < 4; w2++) { const int c = Cw[w2]; if (w2 < w) before += c; tile_total += c; }
-      long long o = region + local + before;
+      int* pp = J.pair_probe + (region + local);   // uniform bases, 32-bit lane offsets
+      int* pb = J.pair_build + (region + local);
+      unsigned int o = (unsigned int)before;
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
         if (emit[s]) {
-          const long long at = o + __builtin_amdgcn_mbcnt_hi((unsigned)(b[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b[s], 0u));
-          J.pair_probe[at] = (int)(row0 + s * 64);
-          J.pair_build[at] = head[s];
+          const unsigned int at = o + __builtin_amdgcn_mbcnt_hi((unsigned)(b[s] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b[s], 0u));
+          pp[at] = (int)(row0 + s * 64);
+          pb[at] = head[s];
         }
-        o += __popcll(b[s]);
+        o += (unsigned int)__popcll(b[s]);
       }
       if (threadIdx.x == 0) { J.tile_cnt[tile] = tile_total; J.tile_src[tile] = (int)local; }
       local += tile_total;
     }
   }
+  unsigned long long selected_wave = selected;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) selected += __shfl_down(selected, d, 64);
-  if (lane == 0 && selected) atomicAdd(&J.counters[0], selected);
+  for (int d = 32; d >= 1; d >>= 1) selected_wave += __shfl_down(selected_wave, d, 64);
+  if (lane == 0 && selected_wave) atomicAdd(&J.counters[0], selected_wave);
 }
 
 // pass 2: one wave per tile: moves the tile's pairs to their final position and evaluates the probe-side output
@@ -1091,7 +1116,7 @@ void FusedProbeGpu::generate()
             const int32_t t = input_types_[(size_t)ch];
             const char *T = (t == TGPU_VARCHAR || t == TGPU_BOOLEAN) ? "unsigned char" : ctype(t);
             cols << "  const " << T << "* c" << ch << " = (const " << T << "*)A.col_values[" << ch << "]; (void)c" << ch << ";\n";
-            cols << "  const unsigned char* cn" << ch << " = A.col_nulls[" << ch << "]; (void)cn" << ch << ";\n";
+            cols << "  const unsigned char* cn" << ch << " = FJ_NO_NULLS ? (const unsigned char*)0 : A.col_nulls[" << ch << "]; (void)cn" << ch << ";\n";
             if (t == TGPU_VARCHAR) cols << "  const int* co" << ch << " = A.col_offsets[" << ch << "]; (void)co" << ch << ";\n";
         }
         return cols.str();
@@ -1150,7 +1175,7 @@ void FusedProbeGpu::generate()
     for (int ch : gr.reg_cols) {
         const int32_t t = input_types_[(size_t)ch];
         const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
-        src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = A.col_nulls[" << ch << "] ? A.col_nulls[" << ch << "][row] : 0;\n";
+        src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = (!FJ_NO_NULLS && A.col_nulls[" << ch << "]) ? A.col_nulls[" << ch << "][row] : 0;\n";
     }
     src << "  (void)A; (void)row; (void)R;\n}\n__device__ inline void tg_zero_row(TgRow& R) {\n";
     for (int ch : gr.reg_cols) src << "  R.c" << ch << " = 0; R.n" << ch << " = 0;\n";
@@ -1180,18 +1205,23 @@ void FusedProbeGpu::generate()
 }
 
 // one specialisation per pre-filter kind of the lookup source (0 none, 1 exact key bitmap, 2 blocked Bloom filter)
-static std::string prefilter_source(const std::string &src, int kind) { return "#define FJ_PF " + std::to_string(kind) + "\n" + src; }
+// x pages with / without null vectors (FJ_NO_NULLS: the null loads and tests fold away)
+static std::string prefilter_source(const std::string &src, int variant)
+{
+    return "#define FJ_PF " + std::to_string(variant % 3) + "\n#define FJ_NO_NULLS " + std::to_string(variant / 3) + "\n" + src;
+}
 
 void FusedProbeGpu::precompile()
 {
     if (!supported_) return;
-    for (int kind = 0; kind < 3; kind++) (void)code_object_for(prefilter_source(source_, kind));
+    for (int variant = 0; variant < 6; variant++) (void)code_object_for(prefilter_source(source_, variant));
 }
 
-JitModule *FusedProbeGpu::module_for(int kind)
+JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls)
 {
-    if (!modules_[kind]) modules_[kind] = load_module(prefilter_source(source_, kind));
-    return modules_[kind].get();
+    const int variant = kind + (no_nulls ? 3 : 0);
+    if (!modules_[variant]) modules_[variant] = load_module(prefilter_source(source_, variant));
+    return modules_[variant].get();
 }
 
 void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, std::vector<DeviceColumn> &probe_out,
@@ -1201,7 +1231,9 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
     IntTableView tv;
     TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
-    JitModule *module = module_for(tv.bitmap ? 1 : (tv.bloom ? 2 : 0));
+    bool any_nulls = false;
+    for (const DeviceColumn &c : in.cols) any_nulls = any_nulls || c.nulls != nullptr;
+    JitModule *module = module_for(tv.bitmap ? 1 : (tv.bloom ? 2 : 0), !any_nulls);
     const int64_t n = in.n;
     count = 0;
     selected_rows = 0;

@@ -105,7 +105,7 @@ public:
 
 private:
     void generate();
-    struct JitModule *module_for(int prefilter_kind);
+    struct JitModule *module_for(int prefilter_kind, bool no_nulls);
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
     std::string pool_;
@@ -114,7 +114,7 @@ private:
     int32_t join_channel_;
     bool supported_ = false;
     std::string source_;
-    std::shared_ptr<JitModule> modules_[3];
+    std::shared_ptr<JitModule> modules_[6];
 };
 
 // FilterAndProject feeding a HashAggregation: the filter becomes a row mask in front of the group-by table (no row is

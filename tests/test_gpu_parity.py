@@ -644,6 +644,35 @@ def test_join_prefilters_dense_bitmap_and_sparse_bloom(pkg, ctx, oracle, stride)
     assert np.array_equal(got, pkeys[op])
 
 
+@pytest.mark.parametrize("layout", ["clustered", "spread", "duplicates"])
+def test_join_int_table_key_layouts(pkg, ctx, oracle, layout):
+    """int-key table under key sets that stress its slot hash (runs of consecutive keys far apart, the TPCH orderkey pattern,
+    duplicate build keys): the pairs equal the oracle's in all cases"""
+    rng = np.random.default_rng(31)
+    if layout == "clustered":      # two runs of consecutive keys at the ends of a 2e9-wide domain
+        bkeys = np.concatenate([np.arange(200_000), 2_000_000_000 + np.arange(200_000)]).astype(np.int64)
+    elif layout == "spread":       # TPCH-like: 8 consecutive keys, then a gap
+        og = np.sort(rng.permutation(1_000_000)[:200_000])
+        bkeys = ((og // 8) * 32 + og % 8 + 1).astype(np.int64)
+    else:                          # duplicates on the build side: position links
+        bkeys = rng.integers(0, 50_000, 200_000).astype(np.int64)
+    pkeys = np.concatenate([rng.choice(bkeys, 150_000), rng.integers(-10, int(bkeys.max()) + 10, 150_000)]).astype(np.int64)
+    rows, stats = run_join(pkg, ctx, [pkg.Page(pkg.Block(pkg.BIGINT, bkeys), pkg.Block(pkg.BIGINT, np.arange(len(bkeys), dtype=np.int64)))],
+                           [pkg.Page(pkg.Block(pkg.BIGINT, pkeys))], [pkg.BIGINT] * 2, [pkg.BIGINT], [0], [0], out_b=[1], out_p=[0])
+    op, ob = oracle.PagesHash([oracle.Col(pkg.BIGINT, bkeys)]).probe([oracle.Col(pkg.BIGINT, pkeys)])
+    assert rows == [(int(pkeys[i]), int(j)) for i, j in zip(op, ob)]
+    if layout != "duplicates":     # and through the fused filter+project+probe kernel (no duplicate build keys there)
+        f = pkg.field
+        bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT], [0], [0])
+        jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, [pkg.BIGINT], None, [f(0, pkg.BIGINT)], [0])
+        b = bf.createOperator()
+        b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, bkeys)))
+        b.finish()
+        out = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, pkeys))])
+        got = np.concatenate([p.getBlock(0).values for p in out])
+        assert np.array_equal(got, pkeys[op])
+
+
 @pytest.mark.parametrize("ngroups", [4, 3000])
 def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle, monkeypatch, ngroups):
     """FilterAndProject fused into HashAggregation (row mask + in-register projections) == the unfused composition == the
