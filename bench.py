@@ -252,6 +252,87 @@ class Bench:
         aop.close()
 
     def step_q3_dist(self):
+        """Q3 as the distributed plan Trino's optimizer picks for these inputs (N ranks, one per GPU):
+          * customer (small after its filter) is the REPLICATED build side of a broadcast join (join_distribution_type
+            BROADCAST, M/sql/planner/optimizations/AddExchanges.java: replicated build -> FIXED_BROADCAST_DISTRIBUTION): one
+            all-gather of the filtered keys over xGMI, every rank builds the full customer table;
+          * orders and lineitem are partitioned on orderkey by their connector (the tpch connector exposes that partitioning,
+            P/trino-tpch TpchNodePartitioningProvider), so orders |x| customer and lineitem |x| orders are co-located: the same
+            fused filter+probe operators as on one GPU, no exchange of the big probe sides;
+          * the aggregation is PARTIAL per rank, then a FIXED_HASH_DISTRIBUTION exchange on the group keys (K10 partition kernel
+            + RCCL all-to-all-v) feeds the FINAL HashAggregationOperator (HashAggregationOperator.java Step.PARTIAL / FINAL).
+        TGPU_BENCH_PLAN=repartition runs the plan with hash-repartitioned join inputs instead (step_q3_dist_repartition)."""
+        p, ctx, f, pages, ex = self.pkg, self.ctx, self.q3_fac, self.q3_pages, self.exchange
+        B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
+        st = self.q3_stats
+        ex_mod = importlib.import_module("presto-1_amd.exchange")
+        # customer: filter -> broadcast -> build on every rank
+        cb = p.HashBuilderOperatorFactory(ctx, 10, [B], [], [0])
+        cbuild = cb.createOperator()
+        outs = self.drive(f["cust_fp"].createOperator(), pages["customer"])
+        local = outs[0].as_device_page() if outs else p.Page(self.dblock(B, torch.zeros(0, dtype=torch.int64, device=self.dev)), position_count=0)
+        allc = ex_mod.all_gather_page(self.dist, self.dev, local)
+        st["customer_build_rows"] = allc.position_count
+        st["exchange_bytes_sent"] = local.position_count * 8 * (self.world - 1)
+        if allc.position_count:
+            cbuild.addInput(allc)
+        cbuild.finish()
+        for o in outs:
+            o.release()
+        # orders: filter/project fused into the probe of the replicated customer table -> local build on orderkey
+        pp = self.entry.bench_page_processors(p)
+        oj = p.FilterProjectLookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, *pp["q3_orders"], [1], probe_output_channels=[0, 2, 3])
+        ob = p.HashBuilderOperatorFactory(ctx, 12, [B, DT, I], [1, 2], [0])
+        obuild = ob.createOperator()
+        ojoin = oj.createOperator()
+        st["orders_build_rows"] = 0
+        for j in self.drive(ojoin, pages["orders"]):
+            st["orders_build_rows"] = j.position_count
+            obuild.addInput(j.as_device_page())
+            j.release()
+        obuild.finish()
+        ojoin.close()
+        # lineitem: filter/project fused into the probe of the local orders table -> PARTIAL aggregation
+        lj = p.FilterProjectLookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, *pp["q3_lineitem"], [0], probe_output_channels=[0, 1])
+        pagg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], step=p.PARTIAL, expected_groups=1 << 20)
+        ljoin = lj.createOperator()
+        paop = pagg.createOperator()
+        st["lineitem_join_rows"] = 0
+        for j in self.drive(ljoin, pages["lineitem"]):
+            st["lineitem_join_rows"] = j.position_count
+            paop.addInput(j.as_device_page())
+            j.release()
+        partial = self.finish(paop)
+        # exchange on the group keys -> FINAL aggregation (intermediate channels: count at 3, sum at 4)
+        fagg = p.HashAggregationOperatorFactory(ctx, 15, [B, DT, I], [0, 1, 2], [(p.SUM_DOUBLE, 3)], step=p.FINAL, expected_groups=1 << 20)
+        faop = fagg.createOperator()
+        st["partial_groups"] = 0
+        sent0 = ex.bytes_sent
+        empty = None
+        for o in partial:
+            st["partial_groups"] += o.position_count
+            pg = ex.exchange(o.as_device_page(), [0, 1, 2])
+            o.release()
+            if pg.position_count:
+                faop.addInput(pg)
+        if not partial:   # a rank without groups still takes part in the collectives
+            empty = p.Page(self.dblock(B, torch.zeros(0, dtype=torch.int64, device=self.dev)), self.dblock(DT, torch.zeros(0, dtype=torch.int32, device=self.dev)),
+                           self.dblock(I, torch.zeros(0, dtype=torch.int32, device=self.dev)), self.dblock(B, torch.zeros(0, dtype=torch.int64, device=self.dev)),
+                           self.dblock(D, torch.zeros(0, dtype=torch.float64, device=self.dev)), position_count=0)
+            pg = ex.exchange(empty, [0, 1, 2])
+            if pg.position_count:
+                faop.addInput(pg)
+        st["exchange_bytes_sent"] += ex.bytes_sent - sent0
+        outs = self.finish(faop)
+        st["groups"] = sum(o.position_count for o in outs)
+        self.q3_result = outs
+        ljoin.close()
+        cbuild.close()
+        obuild.close()
+        paop.close()
+        faop.close()
+
+    def step_q3_dist_repartition(self):
         """the same Q3 pipeline as a distributed plan (N ranks = N stages of FIXED_HASH_DISTRIBUTION,
         M/sql/planner/SystemPartitioningHandle.java:60): every exchange is the K10 partition kernel + an RCCL all-to-all-v.
         The filter/project runs in the producing fragment, so probes behind an exchange use the plain LookupJoinOperator."""
@@ -312,6 +393,43 @@ class Bench:
         aop.close()
 
     def check_q3_dist(self):
+        """N > 1, replicated-customer plan: every count and the revenue total against a reference computed independently with torch
+        (each rank evaluates its own split against the all-gathered customer segment flags; totals are all-reduced)."""
+        if os.environ.get("TGPU_BENCH_PLAN") == "repartition":
+            return self.check_q3_dist_repartition()
+        st, t, dist = self.q3_stats, self.q3, self.dist
+        n_c = t["c_custkey"].numel()
+        seg_ok = (t["c_seg_bytes"][t["c_seg_off"][:-1].to(torch.int64)] == ord("B")).to(torch.uint8)
+        send = seg_ok.to(self.coll_dev)
+        parts = [torch.empty(n_c, dtype=torch.uint8, device=self.coll_dev) for _ in range(self.world)]
+        dist.all_gather(parts, send)
+        cust_ok = torch.cat([torch.zeros(1, dtype=torch.bool, device=self.dev)] + [x.to(self.dev).to(torch.bool) for x in parts])   # indexed by custkey (1-based)
+        o_ok = (t["o_orderdate"] < D_1995_03_15) & cust_ok[t["o_custkey"]]
+        base = int(t["o_orderkey"].min().item())
+        ok_by_key = torch.zeros(int(t["o_orderkey"].max().item()) - base + 2, dtype=torch.bool, device=self.dev)
+        ok_by_key[t["o_orderkey"] - base] = o_ok
+        l_probe = t["l_shipdate"] > D_1995_03_15
+        l_ok = l_probe & ok_by_key[t["l_orderkey"] - base]
+        rev = (t["l_extendedprice"] * (1.0 - t["l_discount"]))[l_ok]
+        local_groups = int(torch.unique(t["l_orderkey"][l_ok]).numel())
+        total = 0.0
+        for o in self.q3_result:
+            total += float(np.sum(o.to_host().getBlock(3).values))
+        want = torch.tensor([float(seg_ok.sum().item()), float(o_ok.sum().item()), float(l_ok.sum().item()), float(local_groups), float(rev.sum().item())],
+                            dtype=torch.float64, device=self.coll_dev)
+        got = torch.tensor([float(st["customer_build_rows"]) / self.world, float(st["orders_build_rows"]), float(st["lineitem_join_rows"]), float(st["groups"]), total],
+                           dtype=torch.float64, device=self.coll_dev)
+        dist.all_reduce(want)
+        dist.all_reduce(got)
+        st["orders_probe_rows"] = int((t["o_orderdate"] < D_1995_03_15).sum().item())
+        st["lineitem_probe_rows"] = int(l_probe.sum().item())
+        counts_ok = bool(torch.equal(want[:4], got[:4]))
+        rel = abs(float(got[4].item()) - float(want[4].item())) / max(abs(float(want[4].item())), 1.0)
+        names = ["customer_build_rows", "orders_build_rows", "lineitem_join_rows", "groups", "revenue"]
+        return {"counts_match": counts_ok, "got": dict(zip(names, got.tolist())), "want": dict(zip(names, want.tolist())), "revenue_rel_err": rel,
+                "partial_groups_local": st.get("partial_groups"), "ok": bool(counts_ok and rel < 1e-9)}
+
+    def check_q3_dist_repartition(self):
         """N > 1: conservation checks across ranks (each rank only sees its own split, so the per-rank torch reference of the
         single-GPU check does not apply): rows in == rows out of every exchange, revenue total equals the all-reduced reference of
         the rows that survive both joins -- computed from the exchanged pages' owners via all-reduce of local partial sums."""
@@ -501,7 +619,9 @@ def main():
     # ---- Q3 (headline) ----
     b.setup_q3(args.sf)
     distributed = b.dist is not None
-    step_s, prof = b.timed(b.step_q3_dist if distributed else b.step_q3, args.steps, args.warmup)
+    repartition = distributed and os.environ.get("TGPU_BENCH_PLAN") == "repartition"
+    step_fn = b.step_q3 if not distributed else (b.step_q3_dist_repartition if repartition else b.step_q3_dist)
+    step_s, prof = b.timed(step_fn, args.steps, args.warmup)
     q3_check = b.check_q3_dist() if distributed else b.check_q3()
     st = dict(b.q3_stats)
     probe_rows = st["lineitem_probe_rows"]
@@ -516,7 +636,7 @@ def main():
     n_o, n_l = int(b.q3["o_orderkey"].numel()), int(b.q3["l_orderkey"].numel())
     alg = ((4.0 * n_o + 20.0 * st["orders_probe_rows"] + 8.0 * st["orders_build_rows"]) + (4.0 * n_l + 20.0 * st["lineitem_probe_rows"] + 8.0 * st["lineitem_join_rows"])) / 2.0
     rows_avg = (n_o + n_l) / 2.0
-    if distributed:
+    if repartition:
         # behind the exchange the probe is the unfused kernel: key 8 B + one table slot 12 B + head/count out 8 B per probe row
         rows_avg = (st["orders_probe_rows"] + st["lineitem_probe_rows"]) / 2.0
         roof = dominant(prof, {"join_probe_count": rows_avg}, {"join_probe_count": 28.0})
@@ -528,7 +648,8 @@ def main():
         "config": {"workload": "tpch_q3_hash_join_build_probe_agg (BASELINE configs[3])", "scale_factor_per_gpu": args.sf, "seed": SEED,
                    "lineitem_rows": int(b.q3["l_orderkey"].numel()), "orders_rows": int(b.q3["o_orderkey"].numel()), "customer_rows": int(b.q3["c_custkey"].numel()),
                    "lineitem_probe_rows": probe_rows, "orders_build_rows": st["orders_build_rows"], "join_output_rows": st["lineitem_join_rows"],
-                   "groups": st["groups"], "parallelism": f"hash-partitioned x{b.world} (K10 partition + RCCL all-to-all-v)" if distributed else "single GPU",
+                   "groups": st["groups"], "parallelism": ("single GPU" if not distributed else f"hash-repartitioned joins x{b.world} (K10 partition + RCCL all-to-all-v)" if repartition else
+                                   f"x{b.world}: customer replicated (RCCL all-gather), orders/lineitem co-partitioned on orderkey, partial->final aggregation over a hash exchange (K10 partition + RCCL all-to-all-v)"),
                    "exchange_bytes_sent_per_step": st.get("exchange_bytes_sent", 0)},
         "roofline": roof, "checks": {"q3": q3_check},
     })

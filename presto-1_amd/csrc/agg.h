@@ -6,6 +6,12 @@
 // limbs held in int64 words, updated with integer atomics), so the result is the correctly rounded exact sum whatever
 // the interleaving of lanes -- deterministic, and equal to the Java left-to-right sum whenever that sum is itself exact.
 // See DESIGN.md "DOUBLE aggregate policy".
+//
+// With MANY groups (more than the lane-private LDS path holds) that state would cost 544 bytes per group and per aggregate,
+// and neighbouring rows of one group would serialise on the same atomics.  Accumulators that allow it then switch to the
+// ORDERED mode instead: the page's rows are sorted by group id (stable radix sort, row order kept inside a group) and one
+// lane per group adds its rows sequentially, in row order, into a plain double per group -- the very order of the
+// reference's per-position loop (AccumulatorCompiler.java:487-566), so the sums are bit-identical to the Java operator's.
 #pragma once
 
 #include "common.h"
@@ -35,6 +41,9 @@ public:
         unsigned long long *i128;
     };
     void reserve(int64_t groups) { ensure(groups > 0 ? groups : 1); }
+    // the JIT-fused accumulate kernels address the exact (limb) state directly: they keep the accumulators out of ORDERED mode
+    void set_allow_ordered(bool on) { allow_ordered_ = on; }
+    bool ordered() const { return mode_ == Mode::ORDERED; }
     DeviceState device_state(int k) const;
     const std::vector<tgpu_agg_spec> specs() const;
     int output_channel_count() const;
@@ -48,9 +57,15 @@ private:
         BufferPtr limbs;    // int64[g][kLimbs]  (double sums)
         BufferPtr special;  // uint32[g] NaN / +-inf flags
         BufferPtr i128;     // uint64[g][2] (bigint sums)
+        BufferPtr dsum;     // double[g]: ORDERED mode running sums (instead of limbs / special)
         int64_t cap = 0;
     };
+    enum class Mode { UNDECIDED, EXACT, ORDERED };
     void ensure(int64_t groups);
+    void decide_mode(int64_t groups, int64_t n);
+    void sort_rows_by_group(const int32_t *gids, int64_t n, int64_t groups, BufferPtr &keys, BufferPtr &rows);
+    Mode mode_ = Mode::UNDECIDED;
+    bool allow_ordered_ = false;
     Context *ctx_;
     std::vector<State> states_;
     int32_t step_;

@@ -3,6 +3,8 @@
 #include "kernels.h"
 #include "device_agg.h"
 
+#include <rocprim/rocprim.hpp>
+
 #include <algorithm>
 #include <cstdlib>
 
@@ -25,6 +27,7 @@ struct AggView {
     long long *limbs;
     unsigned int *special;
     unsigned long long *i128;
+    double *dsum;                // ORDERED mode: plain running sum per group
 };
 
 struct AggArgs {
@@ -75,6 +78,68 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ORDERED mode (many groups): keys[i] = group id + 1 of the i-th row in (group, row) order (0 = row excluded by a filter),
+// rows[i] = its row number.  The lane that owns the first row of a group walks the group's rows in order.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) ordered_keys_kernel(const int32_t *__restrict__ gids, int64_t n, unsigned int *__restrict__ keys, int *__restrict__ rows)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        keys[r] = (unsigned int)(gids[r] + 1);
+        rows[r] = (int)r;
+    }
+}
+
+template <bool INTERMEDIATE>
+__global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const unsigned int *__restrict__ keys, const int *__restrict__ rows, int64_t n,
+                                                              unsigned int *error)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const unsigned int key = keys[i];
+        if (key == 0 || (i > 0 && keys[i - 1] == key)) continue;
+        const int64_t g = (int64_t)key - 1;
+#pragma unroll
+        for (int k = 0; k < kMaxAggs; k++) {   // constant indices into the by-value argument block (no scratch copy)
+            if (k >= args.n_aggs) break;
+            const AggView &a = args.a[k];
+            long long cnt = 0;
+            double s = a.dsum ? a.dsum[g] : 0.0;
+            __int128 big = 0;
+            for (int64_t j = i; j < n && keys[j] == key; j++) {
+                const int64_t r = rows[j];
+                if (INTERMEDIATE) {
+                    // combine(): DoubleSumAggregation.java:48-52, AverageAggregations.java:63-67, CountAggregation.java:46-49
+                    const long long c = ((const long long *)a.input)[r];
+                    if (c == 0) continue;   // empty partial state
+                    cnt += c;
+                    if (a.function == TGPU_AGG_SUM_BIGINT) big += ((const long long *)a.input2)[r];
+                    else if (a.function != TGPU_AGG_COUNT_ALL && a.function != TGPU_AGG_COUNT_COLUMN) s += ((const double *)a.input2)[r];
+                    continue;
+                }
+                if (a.mask && ((a.mask_nulls && a.mask_nulls[r]) || !a.mask[r])) continue;
+                if (a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[r]) continue;
+                cnt++;
+                switch (a.function) {
+                case TGPU_AGG_SUM_BIGINT: big += ((const long long *)a.input)[r]; break;
+                case TGPU_AGG_SUM_DOUBLE:
+                case TGPU_AGG_AVG_DOUBLE: s += ((const double *)a.input)[r]; break;
+                case TGPU_AGG_AVG_BIGINT: s += (double)((const long long *)a.input)[r]; break;
+                default: break;
+                }
+            }
+            if (cnt) a.counts[g] += cnt;
+            if (a.dsum) a.dsum[g] = s;
+            if (a.i128 && big != 0) {
+                const unsigned __int128 cur = ((unsigned __int128)a.i128[g * 2 + 1] << 64) | a.i128[g * 2];
+                const unsigned __int128 nxt = cur + (unsigned __int128)big;
+                a.i128[g * 2] = (unsigned long long)nxt;
+                a.i128[g * 2 + 1] = (unsigned long long)(nxt >> 64);
+            }
+        }
+    }
+    (void)error;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Low-cardinality path (TPCH Q1: 4 groups x 8 aggregates over 600 M rows).  With a handful of groups every lane of the
@@ -199,6 +264,7 @@ struct EvalView {
     const long long *limbs;
     const unsigned int *special;
     const unsigned long long *i128;
+    const double *dsum;   // ORDERED mode
     void *out0;           // final value, or (partial) the count channel
     uint8_t *out0_nulls;
     void *out1;           // partial: the sum channel
@@ -230,7 +296,7 @@ __global__ void __launch_bounds__(kBlock) agg_evaluate_kernel(EvalArgs args, int
             if (hi != expect_hi) atomicOr(error, 1u);  // BigintOperators.add overflow (M/type/BigintOperators.java:47-57)
         }
         else {
-            dsum = kulisch_round(&a.limbs[g * kLimbs], a.special[g]);
+            dsum = a.dsum ? a.dsum[g] : kulisch_round(&a.limbs[g * kLimbs], a.special[g]);
         }
         if (a.partial) {
             ((long long *)a.out0)[g] = cnt;
@@ -316,6 +382,7 @@ int64_t GroupedAccumulators::estimated_size() const
     for (auto &st : states_) {
         s += st.cap * 8;
         if (st.limbs) s += st.cap * (kLimbs * 8 + 4);
+        if (st.dsum) s += st.cap * 8;
         if (st.i128) s += st.cap * 16;
     }
     return s;
@@ -329,8 +396,11 @@ void GroupedAccumulators::ensure(int64_t groups)
         while (cap < groups) cap <<= 1;
         st.counts = grow(ctx_, st.counts, st.cap, cap, 8);
         if (is_double_state(st.spec.function)) {
-            st.limbs = grow(ctx_, st.limbs, st.cap * kLimbs, cap * kLimbs, 8);
-            st.special = grow(ctx_, st.special, st.cap, cap, 4);
+            if (mode_ == Mode::ORDERED) st.dsum = grow(ctx_, st.dsum, st.cap, cap, 8);
+            else {
+                st.limbs = grow(ctx_, st.limbs, st.cap * kLimbs, cap * kLimbs, 8);
+                st.special = grow(ctx_, st.special, st.cap, cap, 4);
+            }
         }
         if (st.spec.function == TGPU_AGG_SUM_BIGINT) st.i128 = grow(ctx_, st.i128, st.cap * 2, cap * 2, 8);
         st.cap = cap;
@@ -343,9 +413,47 @@ static void check_channel(const DevicePage &page, int ch, int32_t want_type, con
     if (want_type) TG_CHECK_ARG(page.cols[ch].type == want_type, std::string(what) + ": unexpected channel type " + type_name(page.cols[ch].type));
 }
 
+// lane-private LDS bytes one group needs on the low-cardinality path (AOT layout: every aggregate has its own slots)
+static int64_t lowcard_bytes_per_group(const std::vector<tgpu_agg_spec> &specs)
+{
+    int64_t wide = 0;
+    for (auto &s : specs) wide += is_count(s.function) ? 0 : 1;
+    return wide * 2 * kBlock * 8 + (int64_t)specs.size() * kBlock * 4;
+}
+
+// The mode is fixed by the first page: ORDERED when it is allowed, the page has group ids and its groups do not fit the
+// low-cardinality LDS path; else EXACT.
+void GroupedAccumulators::decide_mode(int64_t groups, int64_t n)
+{
+    if (mode_ != Mode::UNDECIDED) return;
+    (void)n;
+    const bool many = groups * lowcard_bytes_per_group(specs()) > 160 * 1024;
+    mode_ = (allow_ordered_ && many && getenv("TGPU_DISABLE_ORDERED") == nullptr) ? Mode::ORDERED : Mode::EXACT;
+}
+
+// (group id + 1, row) pairs of the page in (group, row) order: stable LSD radix sort on the bits the group ids use
+void GroupedAccumulators::sort_rows_by_group(const int32_t *gids, int64_t n, int64_t groups, BufferPtr &keys, BufferPtr &rows)
+{
+    BufferPtr keys_in = ctx_->alloc((size_t)n * 4), rows_in = ctx_->alloc((size_t)n * 4);
+    keys = ctx_->alloc((size_t)n * 4);
+    rows = ctx_->alloc((size_t)n * 4);
+    ordered_keys_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(gids, n, keys_in->as<unsigned int>(), rows_in->as<int>());
+    check_launch("ordered_keys");
+    unsigned int end_bit = 1;
+    while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)groups) end_bit++;   // keys are in [0, groups]
+    size_t temp_bytes = 0;
+    HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys_in->as<unsigned int>(), keys->as<unsigned int>(), rows_in->as<int>(), rows->as<int>(), (size_t)n, 0,
+                                        end_bit, ctx_->stream()));
+    BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
+    HIP_CHECK(rocprim::radix_sort_pairs(temp->ptr(), temp_bytes, keys_in->as<unsigned int>(), keys->as<unsigned int>(), rows_in->as<int>(), rows->as<int>(), (size_t)n, 0,
+                                        end_bit, ctx_->stream()));
+}
+
 void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
 {
     if (states_.empty() || n <= 0) return;
+    if (gids) decide_mode(group_count > 0 ? group_count : 1, n);
+    else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
     ensure(group_count > 0 ? group_count : 1);
     AggArgs args{};
     args.n_aggs = (int32_t)states_.size();
@@ -370,6 +478,16 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
         a.special = st.special ? st.special->as<unsigned int>() : nullptr;
         a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+        a.dsum = st.dsum ? st.dsum->as<double>() : nullptr;
+    }
+    if (mode_ == Mode::ORDERED) {
+        TG_CHECK_STATE(gids != nullptr, "ordered accumulation needs group ids");
+        ProfileScope ps(ctx_, "agg_accumulate_ordered");
+        BufferPtr keys, rows;
+        sort_rows_by_group(gids, n, group_count, keys, rows);
+        agg_ordered_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>());
+        check_launch("agg_accumulate_ordered");
+        return;
     }
     // low-cardinality path: lane-private LDS accumulators when all groups x states fit in one CU's LDS
     LowCardPlan plan{};
@@ -415,6 +533,8 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
 void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
 {
     if (states_.empty() || n <= 0) return;
+    if (gids) decide_mode(group_count > 0 ? group_count : 1, n);
+    else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
     ensure(group_count > 0 ? group_count : 1);
     AggArgs args{};
     args.n_aggs = (int32_t)states_.size();
@@ -435,6 +555,16 @@ void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const
         a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
         a.special = st.special ? st.special->as<unsigned int>() : nullptr;
         a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+        a.dsum = st.dsum ? st.dsum->as<double>() : nullptr;
+    }
+    if (mode_ == Mode::ORDERED) {
+        TG_CHECK_STATE(gids != nullptr, "ordered accumulation needs group ids");
+        ProfileScope ps(ctx_, "agg_combine_ordered");
+        BufferPtr keys, rows;
+        sort_rows_by_group(gids, n, group_count, keys, rows);
+        agg_ordered_kernel<true><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>());
+        check_launch("agg_combine_ordered");
+        return;
     }
     ProfileScope ps(ctx_, "agg_combine");
     agg_accumulate_kernel<true><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, gids, n);
@@ -458,6 +588,7 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
         a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
         a.special = st.special ? st.special->as<unsigned int>() : nullptr;
         a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+        a.dsum = st.dsum ? st.dsum->as<double>() : nullptr;
         DeviceColumn c0;
         c0.n = groups;
         c0.values_buf = ctx_->alloc((size_t)alloc_n * 8);

@@ -147,7 +147,11 @@ __global__ void __launch_bounds__(kBlock) any_null_kernel(KeyCols keys, int64_t 
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         uint8_t f = 0;
-        for (int c = 0; c < keys.n; c++) f |= (keys.c[c].nulls && keys.c[c].nulls[r]) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
+            if (c >= keys.n) break;
+            f |= (keys.c[c].nulls && keys.c[c].nulls[r]) ? 1 : 0;
+        }
         out[r] = f;
     }
 }

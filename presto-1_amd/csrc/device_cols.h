@@ -39,15 +39,22 @@ __device__ inline tg_i64 tg_hash_cell(const TgColView &c, long long r)
 // raw hash of the key columns of one row (M/operator/InterpretedHashGenerator.java:56-70)
 __device__ inline tg_i64 tg_hash_row(const TgKeyCols &k, long long r)
 {
+    // full unroll with constant column indices: a run-time index into the by-value column array would move it to scratch
     tg_i64 h = 0;
-    for (int c = 0; c < k.n; c++) h = tg_combine_hash(h, tg_hash_cell(k.c[c], r));
+#pragma unroll
+    for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
+        if (c >= k.n) break;
+        h = tg_combine_hash(h, tg_hash_cell(k.c[c], r));
+    }
     return h;
 }
 
 // IS NOT DISTINCT FROM per channel (JoinCompiler.java positionNotDistinctFromRow; DoubleType.java:181-192 NaN rule)
 __device__ inline bool tg_rows_not_distinct(const TgKeyCols &a, long long ra, const TgKeyCols &b, long long rb)
 {
-    for (int c = 0; c < a.n; c++) {
+#pragma unroll
+    for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
+        if (c >= a.n) break;
         const TgColView &x = a.c[c], &y = b.c[c];
         const bool nx = x.nulls && x.nulls[ra], ny = y.nulls && y.nulls[rb];
         if (nx || ny) {

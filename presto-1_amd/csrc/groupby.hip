@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(kBlock) gbh_finalize_kernel(KeyCols batch, con
         const uint64_t w = words[pos];
         words[pos] = make_old((uint32_t)((w >> 32) & 0xffff), (uint32_t)gid);
         raw_hash[gid] = hashes ? hashes[r] : tg_hash_row(batch, r);
-        for (int c = 0; c < batch.n; c++) {
+#pragma unroll
+        for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
+            if (c >= batch.n) break;
             const ColView &s = batch.c[c];
             const ColView &d = store.c[c];
             const bool isnull = s.nulls && s.nulls[r];

@@ -1313,8 +1313,8 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
         int64_t blocks = std::min<int64_t>(ceil_div(J.tiles, 4), (int64_t)ctx->cu_count() * 8);
         launch_args(module->fn("fj_emit"), (int)blocks, J, ctx->stream());
     }
-    unsigned long long e = ctx->read_scalar(misc->as<unsigned long long>());
-    if (e != ~0ull) raise(e);
+    // no second error read-back: the projections evaluated by pass 2 cannot raise (the constructor keeps anything with checked
+    // integer arithmetic on the unfused path), and pass 1's filter / key errors were raised above
 }
 
 // =====================================================================================================================

@@ -39,7 +39,9 @@ using Slot16 = TgSlot16;
 // EQUAL operators on non-null cells (S/type/AbstractLongType.java:132-136, DoubleType.java:157-161: NaN != NaN, -0 == +0)
 __device__ __forceinline__ bool rows_equal_nonnull(const KeyCols &a, int64_t ra, const KeyCols &b, int64_t rb)
 {
-    for (int c = 0; c < a.n; c++) {
+#pragma unroll
+    for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
+        if (c >= a.n) break;
         const ColView &x = a.c[c], &y = b.c[c];
         switch (x.type) {
         case TGPU_BIGINT:
@@ -72,8 +74,11 @@ __device__ __forceinline__ bool rows_equal_nonnull(const KeyCols &a, int64_t ra,
 
 __device__ __forceinline__ bool row_has_null(const KeyCols &k, int64_t r)
 {
-    for (int c = 0; c < k.n; c++)
+#pragma unroll
+    for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
+        if (c >= k.n) break;
         if (k.c[c].nulls && k.c[c].nulls[r]) return true;
+    }
     return false;
 }
 

@@ -150,8 +150,12 @@ protected:
         if (!cfg_.group_by_types.empty())
             gbh_ = std::make_unique<GroupByHashGpu>(ctx_, cfg_.group_by_types, cfg_.hash_channel >= 0, cfg_.expected_groups);
         accs_ = std::make_unique<GroupedAccumulators>(ctx_, cfg_.aggs, cfg_.step);
+        accs_->set_allow_ordered(allow_ordered_accumulation());
         builder_ = true;
     }
+    // many groups: rows sorted by group id, one lane per group adds them in row order (agg.h); the JIT-fused accumulate kernels
+    // work on the exact state only
+    virtual bool allow_ordered_accumulation() const { return true; }
     void reset_builder()
     {
         gbh_.reset();
@@ -503,6 +507,8 @@ public:
         : HashAggregationOperator(ctx, id, cfg), processor_(std::move(processor)), fused_(std::move(fused))
     {
     }
+
+    bool allow_ordered_accumulation() const override { return false; }
 
     void add_input(const tgpu_page *page) override
     {

@@ -58,6 +58,63 @@ def hip_partitioner(ctx, device):
     return run
 
 
+def page_columns(page: Page, device):
+    """torch views of a device Page's fixed-width columns: [{type, values, nulls|None}] (VARCHAR is not handled here)"""
+    cols = []
+    n = page.position_count
+    for b in page.blocks:
+        if b.type == VARCHAR:
+            raise NotImplementedError("all_gather_page replicates fixed-width columns only")
+        values = b.values if hasattr(b.values, "data_ptr") else device_view(b.values, n, TORCH_DTYPE[b.type], page, device)
+        nulls = None
+        if hasattr(b.nulls, "data_ptr"):
+            nulls = b.nulls
+        elif b.nulls:   # a raw device address (None / 0 = no null vector)
+            nulls = device_view(b.nulls, n, torch.uint8, page, device)
+        cols.append({"type": b.type, "values": values, "nulls": nulls})
+    return cols
+
+
+def all_gather_page(dist, device, page: Page) -> Page:
+    """REPLICATED distribution of a (small) build side: every rank receives the rows of all ranks, concatenated in rank order --
+    the broadcast exchange in front of a replicated join (M/sql/planner/SystemPartitioningHandle.java:59 FIXED_BROADCAST_DISTRIBUTION).
+    One all-gather of the row counts, then one all-gather per column buffer (RCCL over xGMI), padded to the largest rank."""
+    w = dist.get_world_size()
+    host_staging = dist.get_backend() == "gloo" and torch.device(device).type == "cuda"
+    coll = torch.device("cpu") if host_staging else torch.device(device)
+    n = int(page.position_count)
+    counts = [torch.zeros(1, dtype=torch.int64, device=coll) for _ in range(w)]
+    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=coll))
+    counts = [int(c.item()) for c in counts]
+    m = max(max(counts), 1)
+    total = sum(counts)
+
+    def gather(t, dtype):
+        pad = torch.zeros(m, dtype=dtype, device=coll)
+        if n:
+            pad[:n] = t.to(coll) if host_staging else t
+        outs = [torch.empty(m, dtype=dtype, device=coll) for _ in range(w)]
+        dist.all_gather(outs, pad)
+        parts = [outs[r][: counts[r]] for r in range(w)]
+        res = torch.cat(parts) if total else torch.zeros(1, dtype=dtype, device=coll)
+        return res.to(device) if host_staging else res
+
+    cols = page_columns(page, device)
+    blocks, keep = [], []
+    for c in cols:
+        any_nulls = torch.tensor([1 if c["nulls"] is not None else 0], device=coll)
+        dist.all_reduce(any_nulls, op=dist.ReduceOp.MAX)
+        nulls = None
+        if int(any_nulls.item()):
+            nulls = gather(c["nulls"] if c["nulls"] is not None else torch.zeros(n, dtype=torch.uint8, device=device), torch.uint8)
+        values = gather(c["values"], TORCH_DTYPE[c["type"]])
+        blocks.append(DeviceBlock(c["type"], total, values, nulls))
+        keep += [values, nulls]
+    out = Page(*blocks, position_count=total)
+    out._keep = keep
+    return out
+
+
 class HashExchange:
     def __init__(self, dist, device, partitioner):
         self.dist = dist
