@@ -409,7 +409,7 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
         hashes = own_hashes->as<int64_t>();
     }
     // Sub-batching bounds the table growth a single launch can need.  Once a sub-batch created no new group (the steady state
-    // of low-cardinality inputs: TPCH Q1 has 4 groups in 600 M rows) the next one is 8x larger: fewer, longer launches.  Such an
+    // of low-cardinality inputs: TPCH Q1 has 4 groups in 600 M rows) the next one is 64x larger: fewer, longer launches.  Such an
     // optimistic launch can overflow the table only if it meets tens of millions of new keys; the probe kernel then flags it,
     // the table is rebuilt twice as large and the rows are re-run in smaller pieces.
     // With few expected groups the very first launches ramp up from a small piece (2^18 rows): while the table is empty every
@@ -433,7 +433,7 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             continue;
         }
         start += len;
-        if (new_groups == 0) sub = std::min<int64_t>(sub * 8, 1ll << 30);
+        if (new_groups == 0) sub = std::min<int64_t>(sub * 64, 1ll << 30);
         else sub = sub < sub_batch_ ? std::min<int64_t>(sub * 8, sub_batch_) : sub_batch_;
         next_sub_ = sub;
     }

@@ -544,6 +544,7 @@ struct FpArgs {
   int* tile_counts;
   unsigned long long* error;
   long long n;
+  unsigned long long* sel_mask;   // filter verdicts of pass 1, one 64-bit ballot per (tile, stripe, wave)
 };
 // first failing row wins (the reference throws at the first failing position)
 __device__ inline void tg_error(unsigned long long* e, long long row, int code) {
@@ -641,7 +642,11 @@ extern "C" __global__ void __launch_bounds__(256) fp_count(FpArgs A) {
 #pragma unroll
   for (int s = 0; s < TG_STRIPES; s++) {
     long long row = tile_base + s * 256 + threadIdx.x;
-    if (row < A.n && tg_filter(A, row)) cnt++;
+    const bool sel = row < A.n && tg_filter(A, row);
+    if (sel) cnt++;
+    // the verdicts are kept (1 bit per row) so that pass 2 neither re-reads the filter's columns nor re-evaluates it
+    const unsigned long long b = __ballot(sel);
+    if ((threadIdx.x & 63) == 0) A.sel_mask[((long long)blockIdx.x * TG_STRIPES + s) * 4 + (threadIdx.x >> 6)] = b;
   }
   __shared__ int wsum[4];
 #pragma unroll
@@ -664,9 +669,8 @@ extern "C" __global__ void __launch_bounds__(256) fp_emit(FpArgs A) {
   unsigned long long b[TG_STRIPES];
 #pragma unroll
   for (int s = 0; s < TG_STRIPES; s++) {
-    long long row = tile_base + s * 256 + threadIdx.x;
-    sel[s] = row < A.n && tg_filter(A, row);
-    b[s] = __ballot(sel[s]);
+    b[s] = A.sel_mask[((long long)blockIdx.x * TG_STRIPES + s) * 4 + w];   // pass 1's verdicts (wave-uniform load)
+    sel[s] = (b[s] >> lane) & 1ULL;
     if (lane == 0) C[w][s] = __popcll(b[s]);
   }
   __syncthreads();
@@ -753,9 +757,11 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
     };
 
     int64_t n_sel = n;
-    BufferPtr positions, tile_counts, tile_offsets;
+    BufferPtr positions, tile_counts, tile_offsets, sel_mask;
     const bool has_filter = filter_root_ >= 0;
     if (has_filter) {
+        sel_mask = ctx->alloc((size_t)tiles * 4 * 4 * 8);   // TG_STRIPES (4) x 4 waves ballots per tile
+        args.sel_mask = sel_mask->as<unsigned long long>();
         tile_counts = ctx->alloc((size_t)tiles * 4);
         tile_offsets = ctx->alloc((size_t)tiles * 4);
         BufferPtr total = ctx->alloc(8);

@@ -21,6 +21,7 @@ struct FpArgs {  // must match the struct declared in the generated source
     int32_t *tile_counts;
     unsigned long long *error;
     long long n;
+    unsigned long long *sel_mask;
 };
 
 struct JitModule;
