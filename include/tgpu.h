@@ -245,6 +245,11 @@ int32_t tgpu_output_page_block_info(const tgpu_output_page *page, int32_t ch, in
 /* D2H copy of one channel into caller buffers: values (value_bytes), nulls (position_count bytes, may be NULL),
  * offsets ((position_count+1) int32, VARCHAR only) */
 int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, void *values, uint8_t *nulls, int32_t *offsets);
+/* the same for ALL channels at once (arrays indexed by channel, entries as for copy_block): every transfer is queued through
+ * pinned staging and the stream is synchronised once (twice with VARCHAR channels: offsets first, then the bytes) instead of once
+ * per buffer -- what the JNI shim uses to turn a GPU output page into heap blocks (S/Page.java:33-73) */
+int32_t tgpu_output_page_copy_blocks(const tgpu_output_page *page, int32_t channel_count, void *const *values, uint8_t *const *nulls,
+                                     int32_t *const *offsets);
 void tgpu_output_page_release(tgpu_output_page *page);
 
 /* ---- GroupByHash (M/operator/GroupByHash.java:45-99; BigintGroupByHash / MultiChannelGroupByHash semantics) ---- */

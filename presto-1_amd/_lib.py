@@ -95,6 +95,7 @@ SYMBOLS = {
     "tgpu_output_page_as_page": (i32, [vp, P(Page)]),
     "tgpu_output_page_block_info": (i32, [vp, i32, P(i32), P(i64), P(i32)]),
     "tgpu_output_page_copy_block": (i32, [vp, i32, vp, vp, vp]),
+    "tgpu_output_page_copy_blocks": (i32, [vp, i32, vp, vp, vp]),
     "tgpu_output_page_release": (None, [vp]),
     "tgpu_group_by_hash_create": (i32, [vp, i32, P(i32), P(i32), i32, i32, P(vp)]),
     "tgpu_group_by_hash_destroy": (None, [vp]),

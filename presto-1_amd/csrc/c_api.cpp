@@ -513,6 +513,42 @@ int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, vo
     });
 }
 
+int32_t tgpu_output_page_copy_blocks(const tgpu_output_page *page, int32_t channel_count, void *const *values, uint8_t *const *nulls,
+                                     int32_t *const *offsets)
+{
+    return guard([&] {
+        TG_CHECK_ARG(page != nullptr && values != nullptr && nulls != nullptr && offsets != nullptr, "null argument");
+        TG_CHECK_ARG(channel_count == (int)page->page.cols.size(), "channel count differs from the page's");
+        const int64_t n = page->page.n;
+        Context *ctx = page->ctx;
+        std::vector<Context::Transfer> first, second;
+        for (int ch = 0; ch < channel_count; ch++) {
+            const DeviceColumn &c = page->page.cols[(size_t)ch];
+            if (nulls[ch]) {
+                if (c.nulls) first.push_back({nulls[ch], c.nulls, (size_t)n});
+                else memset(nulls[ch], 0, (size_t)n);
+            }
+            if (c.type == TGPU_VARCHAR) {
+                TG_CHECK_ARG(offsets[ch] != nullptr, "offsets buffer required for VARCHAR");
+                first.push_back({offsets[ch], c.offsets, (size_t)(n + 1) * 4});
+            }
+            else if (values[ch] && n > 0) first.push_back({values[ch], c.values, (size_t)n * type_width(c.type)});
+        }
+        ctx->download_batch(first);
+        for (int ch = 0; ch < channel_count; ch++) {
+            const DeviceColumn &c = page->page.cols[(size_t)ch];
+            if (c.type != TGPU_VARCHAR) continue;
+            int32_t *off = offsets[ch];
+            const int32_t base = n > 0 ? off[0] : 0;
+            const int64_t bytes = n > 0 ? (int64_t)off[n] - base : 0;
+            if (bytes && values[ch]) second.push_back({values[ch], (const uint8_t *)c.values + base, (size_t)bytes});
+            for (int64_t i = 0; i <= n; i++) off[i] -= base;
+            if (n == 0) off[0] = 0;
+        }
+        ctx->download_batch(second);
+    });
+}
+
 void tgpu_output_page_release(tgpu_output_page *page)
 {
     if (!page) return;

@@ -106,6 +106,9 @@ public:
     void *pinned(size_t bytes);
     void upload(void *dst, const void *src, size_t bytes);          // async H2D through pinned staging when small
     void download(void *dst, const void *src, size_t bytes);        // D2H + sync
+    // many small D2H copies with ONE synchronisation: staged through pinned memory, then scattered to the destinations
+    struct Transfer { void *dst; const void *src; size_t bytes; };
+    void download_batch(const std::vector<Transfer> &transfers);
     template <typename T> T read_scalar(const T *dptr)
     {
         T v;

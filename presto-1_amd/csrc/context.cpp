@@ -151,6 +151,25 @@ void Context::download(void *dst, const void *src, size_t bytes)
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
+void Context::download_batch(const std::vector<Transfer> &transfers)
+{
+    size_t total = 0;
+    for (auto &t : transfers) total += (t.bytes + 63) / 64 * 64;
+    if (!total) return;
+    uint8_t *stage = static_cast<uint8_t *>(pinned(total));
+    size_t off = 0;
+    for (auto &t : transfers) {
+        if (t.bytes) HIP_CHECK(hipMemcpyAsync(stage + off, t.src, t.bytes, hipMemcpyDeviceToHost, stream_));
+        off += (t.bytes + 63) / 64 * 64;
+    }
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    off = 0;
+    for (auto &t : transfers) {
+        if (t.bytes) memcpy(t.dst, stage + off, t.bytes);
+        off += (t.bytes + 63) / 64 * 64;
+    }
+}
+
 void Context::set_profiling(bool on) { profiling_ = on; }
 
 void Context::profile_reset()

@@ -26,6 +26,9 @@ struct TgPrefilter {
     long long key_min, key_max;
     const unsigned long long *bloom;    // nullptr = not available
     unsigned long long bloom_word_mask;
+    // DIRECT layout (dense key domain without duplicate build keys): no hash table at all -- the bitmap says whether a key is
+    // in the build side and direct[key - key_min] is its build position (only the entries of present keys are defined)
+    const int *direct;
 };
 
 // Slot of a key in the int-key table: Fibonacci hashing, the top log2(capacity) bits of key * 2^64 / phi (one 64-bit multiply
@@ -43,6 +46,7 @@ __device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long
         if (key < pf.key_min || key > pf.key_max) return -1;
         const unsigned long long d = (unsigned long long)(key - pf.key_min);
         if (!((pf.bitmap[d >> 6] >> (d & 63)) & 1ULL)) return -1;
+        if (pf.direct) return pf.direct[d];
     }
     else if (pf.bloom) {
         const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(key));

@@ -880,7 +880,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   unsigned int pbits[FJ_STRIPES];           // bit of the key inside its bitmap word
 #endif
   unsigned char pfl[FJ_STRIPES];                                                                                   // 1 = probe, 2 = passed the filter
-#if FJ_PF == 1
+#if FJ_PF == 1 || FJ_PF == 3
   const unsigned long long key_range = (unsigned long long)J.pf.key_max - (unsigned long long)J.pf.key_min;
 #endif
   long long skey[FJ_STRIPES]; unsigned int ssidx[FJ_STRIPES]; unsigned char sfl[FJ_STRIPES]; TgSlot16 ssl[FJ_STRIPES]; // C -> D
@@ -902,6 +902,9 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     if (jD >= 0) {
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
+#if FJ_PF == 3
+        if (sfl[s] & 1) head[s] = ssl[s].head;   // the bitmap is exact: the key is in the build side, this is its position
+#else
         if ((sfl[s] & 1) && ssl[s].head >= 0) {
           if (ssl[s].key == skey[s]) head[s] = ssl[s].head;
           else {
@@ -914,6 +917,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
             }
           }
         }
+#endif
         emit[s] = head[s] >= 0 || (J.outer && (sfl[s] & 2));   // PROBE_OUTER: every row that passed the filter (LookupJoinOperator.java:354-361)
       }
     }
@@ -928,7 +932,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       for (int s = 0; s < FJ_STRIPES; s++) {
 #if FJ_PF == 2
         bool maybe = (pfl[s] & 1) && (pbw[s] & pbits[s]) == pbits[s];
-#elif FJ_PF == 1
+#elif FJ_PF == 1 || FJ_PF == 3
         bool maybe = (pfl[s] & 1) && ((unsigned int)(pbw[s] >> pbits[s]) & 1u);
 #else
         bool maybe = (pfl[s] & 1) != 0;
@@ -960,7 +964,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
           sel = !kn;
         }
         bidx[s] = 0;
-#if FJ_PF == 1
+#if FJ_PF == 1 || FJ_PF == 3
         {
           // key in [key_min, key_max] <=> (key - key_min) mod 2^64 <= key_max - key_min; a key outside cannot match: no probe
           const unsigned long long d = (unsigned long long)key - (unsigned long long)J.pf.key_min;
@@ -977,7 +981,11 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #else
         pbits[s] = 0;
 #endif
+#if FJ_PF == 3
+        pkey[s] = key; psidx[s] = (unsigned int)((unsigned long long)key - (unsigned long long)J.pf.key_min);   // DIRECT: the slot is the key's offset
+#else
         pkey[s] = key; psidx[s] = (unsigned int)tg_slot_of(key, J.mask);
+#endif
         pfl[s] = (unsigned char)((sel ? 1 : 0) | (passed ? 2 : 0));
       }
     }
@@ -987,10 +995,16 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     // compiler's in-order wait-count bookkeeping conservative and serialises the three groups.
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < FJ_STRIPES; s++) ssl[s] = J.slots[cidx[s]];
+    for (int s = 0; s < FJ_STRIPES; s++) {
+#if FJ_PF == 3
+      ssl[s].head = J.pf.direct[cidx[s]];   // DIRECT layout: the build position itself (entry 0 for lanes without a survivor: unused)
+#else
+      ssl[s] = J.slots[cidx[s]];
+#endif
+    }
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) {
-#if FJ_PF == 1
+#if FJ_PF == 1 || FJ_PF == 3
       pbw[s] = J.pf.bitmap[bidx[s]];
 #elif FJ_PF == 2
       pbw[s] = J.pf.bloom[bidx[s]];
@@ -1210,22 +1224,23 @@ void FusedProbeGpu::generate()
     source_ = src.str();
 }
 
-// one specialisation per pre-filter kind of the lookup source (0 none, 1 exact key bitmap, 2 blocked Bloom filter)
+// one specialisation per layout of the lookup source (0 no pre-filter, 1 exact key bitmap, 2 blocked Bloom filter, 3 DIRECT:
+// bitmap + build position by key offset, no hash table)
 // x pages with / without null vectors (FJ_NO_NULLS: the null loads and tests fold away)
 static std::string prefilter_source(const std::string &src, int variant)
 {
-    return "#define FJ_PF " + std::to_string(variant % 3) + "\n#define FJ_NO_NULLS " + std::to_string(variant / 3) + "\n" + src;
+    return "#define FJ_PF " + std::to_string(variant % 4) + "\n#define FJ_NO_NULLS " + std::to_string(variant / 4) + "\n" + src;
 }
 
 void FusedProbeGpu::precompile()
 {
     if (!supported_) return;
-    for (int variant = 0; variant < 6; variant++) (void)code_object_for(prefilter_source(source_, variant));
+    for (int variant = 0; variant < 8; variant++) (void)code_object_for(prefilter_source(source_, variant));
 }
 
 JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls)
 {
-    const int variant = kind + (no_nulls ? 3 : 0);
+    const int variant = kind + (no_nulls ? 4 : 0);
     if (!modules_[variant]) modules_[variant] = load_module(prefilter_source(source_, variant));
     return modules_[variant].get();
 }
@@ -1239,7 +1254,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
     bool any_nulls = false;
     for (const DeviceColumn &c : in.cols) any_nulls = any_nulls || c.nulls != nullptr;
-    JitModule *module = module_for(tv.bitmap ? 1 : (tv.bloom ? 2 : 0), !any_nulls);
+    JitModule *module = module_for(tv.direct ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls);
     const int64_t n = in.n;
     count = 0;
     selected_rows = 0;
@@ -1259,6 +1274,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.key_max = tv.key_max;
     J.bloom = tv.bloom;
     J.bloom_word_mask = tv.bloom_word_mask;
+    J.direct = tv.direct;
     J.outer = outer ? 1 : 0;
     const int64_t tile_rows = (int64_t)fj_stripes() * 256;
     J.tiles = ceil_div(n, tile_rows);

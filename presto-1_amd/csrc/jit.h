@@ -76,6 +76,7 @@ struct FjArgs {  // must match the generated struct
     long long key_min, key_max;
     const unsigned long long *bloom;
     unsigned long long bloom_word_mask;
+    const int32_t *direct;
     int32_t *tile_cnt;
     int32_t *tile_src;
     const int32_t *tile_dst;
@@ -115,7 +116,7 @@ private:
     int32_t join_channel_;
     bool supported_ = false;
     std::string source_;
-    std::shared_ptr<JitModule> modules_[6];
+    std::shared_ptr<JitModule> modules_[8];
 };
 
 // FilterAndProject feeding a HashAggregation: the filter becomes a row mask in front of the group-by table (no row is

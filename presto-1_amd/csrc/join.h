@@ -38,6 +38,7 @@ struct IntTableView {
     unsigned long long bloom_word_mask = 0;
     const unsigned long long *bitmap = nullptr;   // dense key domain: one bit per key value in [key_min, key_max]
     long long key_min = 0, key_max = -1;
+    const int32_t *direct = nullptr;        // DIRECT layout: build position by key - key_min (slots is then nullptr)
     const int32_t *links = nullptr;         // nullptr = no duplicate build keys
     int32_t key_type = 0;
 };
@@ -65,6 +66,7 @@ public:
     DeviceColumn gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const;
 
 private:
+    bool build_direct(const KeyCols &keys);
     Context *ctx_;
     std::shared_ptr<PagesIndexGpu> index_;
     std::vector<int32_t> key_channels_, output_channels_;
@@ -76,6 +78,7 @@ private:
     BufferPtr bloom_;            // fast path: blocked Bloom filter over the build keys (sparse key domains)
     int64_t bloom_words_ = 0;
     BufferPtr bitmap_;           // fast path: exact bitmap over [key_min_, key_max_] (dense key domains)
+    BufferPtr direct_;           // fast path, DIRECT layout: int32 build position by key - key_min_ (no hash table)
     long long key_min_ = 0, key_max_ = -1;
     BufferPtr tags_;             // uint8[n]                           (PagesHash.positionToHashes)
     BufferPtr links_;            // int32[n] or empty when no duplicates (ArrayPositionLinks)

@@ -98,6 +98,35 @@ __global__ void __launch_bounds__(kBlock) tags_kernel(const int64_t *__restrict_
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) tags[i] = (uint8_t)hashes[i];
 }
 
+// folds the lanes' (lo, hi) into minmax[0] / [1] with ONE pair of atomics per workgroup (wave shuffles, then LDS): thousands of
+// waves hitting the same two words with atomics would serialise for longer than the scan itself
+__device__ __forceinline__ void block_minmax(long long lo, long long hi, long long *minmax)
+{
+    __shared__ long long s_lo[kBlock / 64], s_hi[kBlock / 64];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const long long l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; w++) {
+            lo = s_lo[w] < lo ? s_lo[w] : lo;
+            hi = s_hi[w] > hi ? s_hi[w] : hi;
+        }
+        if (lo <= hi) {
+            atomicMin(&minmax[0], lo);
+            atomicMax(&minmax[1], hi);
+        }
+    }
+}
+
 // counters[0] = rows that joined an existing key (ArrayPositionLinks.FactoryBuilder.size()), counters[1] = error
 __global__ void __launch_bounds__(kBlock) build_insert_kernel(KeyCols keys, const int64_t *__restrict__ hashes, const uint8_t *__restrict__ tags, int64_t n,
                                                                int *heads, int stride, uint64_t mask, int32_t *__restrict__ row_slot,
@@ -177,16 +206,7 @@ __global__ void __launch_bounds__(kBlock) build_insert_int_kernel(ColView key, i
         const unsigned long long b = __ballot(dup);
         if (dup && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const long long l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
-        lo = l2 < lo ? l2 : lo;
-        hi = h2 > hi ? h2 : hi;
-    }
-    if ((threadIdx.x & 63) == 0 && lo <= hi) {
-        atomicMin(&minmax[0], lo);
-        atomicMax(&minmax[1], hi);
-    }
+    block_minmax(lo, hi, minmax);
 }
 
 __global__ void __launch_bounds__(kBlock) sort_keys_kernel(const int32_t *__restrict__ row_slot, int64_t n, unsigned long long *__restrict__ keys)
@@ -208,6 +228,39 @@ __global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long 
             if ((p >> 32) == (k >> 32)) link = (int32_t)(uint32_t)p;
         }
         links[(uint32_t)k] = link;
+    }
+}
+
+// DIRECT layout, step 1: smallest / largest non-null key
+__global__ void __launch_bounds__(kBlock) key_range_kernel(ColView key, int64_t n, long long *minmax)
+{
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        if (key.nulls && key.nulls[r]) continue;
+        const long long k = int_key_at(key, r);
+        lo = k < lo ? k : lo;
+        hi = k > hi ? k : hi;
+    }
+    block_minmax(lo, hi, minmax);
+}
+
+// DIRECT layout, step 2: one pass sets the key's bit in the (zeroed) bitmap and stores the row as the key's build position.
+// A bit that was already set means a repeated build key: counted in counters[0]; the caller then drops this layout (position
+// links need the hash table), so the plain store never has to order two rows of one key.
+__global__ void __launch_bounds__(kBlock) build_direct_kernel(ColView key, int64_t n, long long key_min, unsigned long long *bitmap, int *direct,
+                                                               unsigned long long *counters)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        bool dup = false;
+        if (!(key.nulls && key.nulls[r])) {  // PagesHash.java:94-96: rows with a null key are not indexed
+            const unsigned long long d = (unsigned long long)int_key_at(key, r) - (unsigned long long)key_min;
+            const unsigned long long bit = 1ULL << (d & 63);
+            const unsigned long long old = atomicOr(&bitmap[d >> 6], bit);
+            dup = (old & bit) != 0;
+            direct[d] = (int)r;
+        }
+        const unsigned long long b = __ballot(dup);
+        if (dup && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
     }
 }
 
@@ -441,7 +494,7 @@ std::vector<int32_t> LookupSourceGpu::key_types() const
 
 int64_t LookupSourceGpu::estimated_size() const
 {
-    return index_->estimated_size() + capacity_ * (int_key_fast_ ? 16 : 4) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0) +
+    return index_->estimated_size() + (direct_ ? (int64_t)direct_->bytes() : capacity_ * (int_key_fast_ ? 16 : 4)) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0) +
            (bitmap_ ? (int64_t)bitmap_->bytes() : 0) + (bloom_ ? bloom_words_ * 8 : 0);
 }
 
@@ -458,6 +511,7 @@ void LookupSourceGpu::build()
     while ((double)capacity_ * max_load < (double)n_) capacity_ <<= 1;
     if (capacity_ > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "hash table size cannot exceed 2 billion slots");
     link_count_ = 0;
+    direct_.reset();
     links_.reset();
     tags_.reset();
     bitmap_.reset();
@@ -468,6 +522,11 @@ void LookupSourceGpu::build()
     key_max_ = -1;
     int *heads = nullptr;
     int stride = 1;
+    if (int_key_fast_ && n_ > 0 && getenv("TGPU_DISABLE_DIRECT") == nullptr) {
+        std::vector<const DeviceColumn *> kp0;
+        for (auto &c : key_cols_) kp0.push_back(&c);
+        if (build_direct(key_cols_of(kp0))) return;
+    }
     if (int_key_fast_) {
         slots16_ = ctx_->alloc((size_t)capacity_ * 16);
         init_slots_kernel<<<grid_for(ctx_, capacity_), kBlock, 0, ctx_->stream()>>>(slots16_->as<Slot16>(), capacity_);
@@ -566,10 +625,50 @@ void LookupSourceGpu::build()
     }
 }
 
+// DIRECT layout of the int-key fast path: when the key domain is dense (at least one key value in 64 is present, at most 2^31
+// values) and no build key repeats, the "table" is an exact bitmap over [key_min, key_max] plus the build position of every
+// present key, addressed by key - key_min: the build is one pass of one atomicOr + one store per row (no probing, no key
+// comparison), a probe is a bit test + one 4-byte load, and inputs clustered by key walk both arrays front to back.  Returns
+// false (nothing kept) when the keys do not qualify; the hash table is built then.
+bool LookupSourceGpu::build_direct(const KeyCols &keys)
+{
+    const int g = grid_for(ctx_, n_);
+    BufferPtr mm = ctx_->alloc(16);
+    const long long init[2] = {0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1};
+    ctx_->upload(mm->ptr(), init, 16);
+    long long host_mm[2];
+    {
+        ProfileScope ps(ctx_, "join_build_range");
+        key_range_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, mm->as<long long>());
+        check_launch("key_range");
+    }
+    ctx_->download(host_mm, mm->ptr(), 16);
+    if (host_mm[1] < host_mm[0]) return false;   // only null keys
+    const unsigned long long range = (unsigned long long)host_mm[1] - (unsigned long long)host_mm[0] + 1ULL;
+    if (range == 0 || range > (1ULL << 31) || range / 64ULL > (unsigned long long)n_) return false;
+    const int64_t words = (int64_t)((range + 63) / 64);
+    BufferPtr bitmap = ctx_->alloc_zero((size_t)words * 8);
+    BufferPtr direct = ctx_->alloc((size_t)range * 4);
+    BufferPtr counters = ctx_->alloc_zero(8);
+    {
+        ProfileScope ps(ctx_, "join_build_insert");
+        build_direct_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, host_mm[0], bitmap->as<unsigned long long>(), direct->as<int>(),
+                                                             counters->as<unsigned long long>());
+        check_launch("build_direct");
+    }
+    if (ctx_->read_scalar(counters->as<unsigned long long>()) != 0) return false;   // repeated build keys: position links needed
+    key_min_ = host_mm[0];
+    key_max_ = host_mm[1];
+    bitmap_ = bitmap;
+    direct_ = direct;
+    return true;
+}
+
 bool LookupSourceGpu::int_table(IntTableView &v) const
 {
-    if (!int_key_fast_ || !slots16_) return false;
-    v.slots = slots16_->ptr();
+    if (!int_key_fast_ || (!slots16_ && !direct_)) return false;
+    v.slots = slots16_ ? slots16_->ptr() : nullptr;
+    v.direct = direct_ ? direct_->as<int32_t>() : nullptr;
     v.mask = (uint64_t)capacity_ - 1;
     v.bloom = bloom_ ? bloom_->as<unsigned long long>() : nullptr;
     v.bloom_word_mask = bloom_ ? (unsigned long long)bloom_words_ - 1 : 0;
@@ -617,6 +716,7 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
     t.pf.key_max = key_max_;
     t.pf.bloom = bloom_ ? bloom_->as<unsigned long long>() : nullptr;
     t.pf.bloom_word_mask = bloom_ ? (unsigned long long)bloom_words_ - 1 : 0;
+    t.pf.direct = direct_ ? direct_->as<int>() : nullptr;
     BufferPtr heads = ctx_->alloc((size_t)n * 4), counts = ctx_->alloc((size_t)n * 4), offsets = ctx_->alloc((size_t)n * 4), total = ctx_->alloc(8);
     const int g = grid_for(ctx_, n);
     {

@@ -234,20 +234,30 @@ class OutputPage:
     def to_host(self) -> Page:
         L = _lib.lib()
         n = self.position_count
-        blocks = []
-        for ch in range(self.channel_count):
+        nch = self.channel_count
+        info, bufs = [], []
+        vptr, nptr, optr = (C.c_void_p * max(nch, 1))(), (C.c_void_p * max(nch, 1))(), (C.c_void_p * max(nch, 1))()
+        for ch in range(nch):
             t, vb, mn = C.c_int32(), C.c_int64(), C.c_int32()
             _lib.check(L.tgpu_output_page_block_info(self.handle, ch, C.byref(t), C.byref(vb), C.byref(mn)))
             nulls = np.zeros(max(n, 1), dtype=np.uint8)
             if t.value == VARCHAR:
                 values = np.zeros(max(vb.value, 1), dtype=np.uint8)
                 offsets = np.zeros(n + 1, dtype=np.int32)
-                _lib.check(L.tgpu_output_page_copy_block(self.handle, ch, values.ctypes.data, nulls.ctypes.data, offsets.ctypes.data))
-                blocks.append(Block(VARCHAR, values, nulls[:n] if mn.value else None, offsets))
+                optr[ch] = offsets.ctypes.data
             else:
                 values = np.zeros(max(n, 1), dtype=NP_DTYPE[t.value])
-                _lib.check(L.tgpu_output_page_copy_block(self.handle, ch, values.ctypes.data, nulls.ctypes.data, None))
-                blocks.append(Block(t.value, values[:n], nulls[:n] if mn.value else None))
+                offsets = None
+            vptr[ch], nptr[ch] = values.ctypes.data, nulls.ctypes.data
+            info.append((t.value, mn.value))
+            bufs.append((values, nulls, offsets))
+        _lib.check(L.tgpu_output_page_copy_blocks(self.handle, nch, vptr, nptr, optr))   # one stream synchronisation for the page
+        blocks = []
+        for (t, mn), (values, nulls, offsets) in zip(info, bufs):
+            if t == VARCHAR:
+                blocks.append(Block(VARCHAR, values, nulls[:n] if mn else None, offsets))
+            else:
+                blocks.append(Block(t, values[:n], nulls[:n] if mn else None))
         return Page(*blocks, position_count=n)
 
     def as_device_page(self) -> Page:
