@@ -131,7 +131,7 @@ void exclusive_scan_i32(Context *ctx, const int32_t *in, int32_t *out, int64_t n
 __global__ void __launch_bounds__(kBlock) hash_rows_kernel(KeyCols keys, int64_t n, int64_t *__restrict__ out)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        out[r] = tg_hash_row(keys, r);
+        out[r] = tg_hash_row_u(keys, r);
     }
 }
 

@@ -36,8 +36,60 @@ __device__ inline tg_i64 tg_hash_cell(const TgColView &c, long long r)
     }
 }
 
+// Two flavours of the per-row key functions.  The plain ones index the column array at run time: use them on key sets that live
+// in MEMORY (kernels that take `const TgKeyCols *`; the loads are scalar and the code stays small).  The `_u` ones are fully
+// unrolled over the 8 possible channels with constant indices: use them on key sets passed BY VALUE as kernel parameters (a
+// run-time index would make the compiler copy the whole parameter block to scratch) -- at the price of 8x the code.
 // raw hash of the key columns of one row (M/operator/InterpretedHashGenerator.java:56-70)
 __device__ inline tg_i64 tg_hash_row(const TgKeyCols &k, long long r)
+{
+    tg_i64 h = 0;
+    for (int c = 0; c < k.n; c++) h = tg_combine_hash(h, tg_hash_cell(k.c[c], r));
+    return h;
+}
+
+// IS NOT DISTINCT FROM per channel (JoinCompiler.java positionNotDistinctFromRow; DoubleType.java:181-192 NaN rule)
+__device__ inline bool tg_rows_not_distinct(const TgKeyCols &a, long long ra, const TgKeyCols &b, long long rb)
+{
+    for (int c = 0; c < a.n; c++) {
+        const TgColView &x = a.c[c], &y = b.c[c];
+        const bool nx = x.nulls && x.nulls[ra], ny = y.nulls && y.nulls[rb];
+        if (nx || ny) {
+            if (nx != ny) return false;
+            continue;
+        }
+        switch (x.type) {
+        case 1:
+            if (((const tg_i64 *)x.values)[ra] != ((const tg_i64 *)y.values)[rb]) return false;
+            break;
+        case 2:
+        case 3:
+            if (((const int *)x.values)[ra] != ((const int *)y.values)[rb]) return false;
+            break;
+        case 4: {
+            const double u = ((const double *)x.values)[ra], v = ((const double *)y.values)[rb];
+            if (!((u != u && v != v) || u == v)) return false;
+            break;
+        }
+        case 5:
+            if ((((const tg_u8 *)x.values)[ra] != 0) != (((const tg_u8 *)y.values)[rb] != 0)) return false;
+            break;
+        case 6: {
+            const int ax = x.offsets[ra], lx = x.offsets[ra + 1] - ax;
+            const int ay = y.offsets[rb], ly = y.offsets[rb + 1] - ay;
+            if (lx != ly) return false;
+            const tg_u8 *px = (const tg_u8 *)x.values + ax, *py = (const tg_u8 *)y.values + ay;
+            for (int i = 0; i < lx; i++)
+                if (px[i] != py[i]) return false;
+            break;
+        }
+        default: return false;
+        }
+    }
+    return true;
+}
+// the same for a key set passed BY VALUE as a kernel parameter
+__device__ inline tg_i64 tg_hash_row_u(const TgKeyCols &k, long long r)
 {
     // full unroll with constant column indices: a run-time index into the by-value column array would move it to scratch
     tg_i64 h = 0;
@@ -49,8 +101,8 @@ __device__ inline tg_i64 tg_hash_row(const TgKeyCols &k, long long r)
     return h;
 }
 
-// IS NOT DISTINCT FROM per channel (JoinCompiler.java positionNotDistinctFromRow; DoubleType.java:181-192 NaN rule)
-__device__ inline bool tg_rows_not_distinct(const TgKeyCols &a, long long ra, const TgKeyCols &b, long long rb)
+// the same for key sets passed BY VALUE as kernel parameters; IS NOT DISTINCT FROM per channel (JoinCompiler.java positionNotDistinctFromRow; DoubleType.java:181-192 NaN rule)
+__device__ inline bool tg_rows_not_distinct_u(const TgKeyCols &a, long long ra, const TgKeyCols &b, long long rb)
 {
 #pragma unroll
     for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {

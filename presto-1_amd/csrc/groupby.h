@@ -62,6 +62,7 @@ private:
                            const GbhProbeFn *probe, int64_t *new_groups);
     void rebuild_table(int64_t min_capacity);
     KeyCols store_view() const;
+    BufferPtr device_keys(const KeyCols &k);
     void advance_java_capacity();
 
     Context *ctx_;

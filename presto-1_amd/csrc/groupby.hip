@@ -36,8 +36,11 @@ constexpr uint64_t kEmpty = ~0ull;
 __device__ __forceinline__ uint64_t make_old(uint32_t tag, uint32_t gid) { return ((uint64_t)tag << 32) | gid; }
 
 // generic key accessor for the shared probe protocol (device_groupby.h): run-time typed key columns
+// The key sets live in device MEMORY (uploaded per launch) and are reached through references: run-time column indices are
+// then plain (scalar) loads.  Passed by value as kernel parameters they would be copied to scratch on the first run-time index,
+// or -- fully unrolled instead -- inflate this kernel to 35 k instructions (measured: 0.6 ms for 3 M rows from I-cache misses).
 struct GenericKeys {
-    KeyCols batch, store;
+    const KeyCols &batch, &store;
     const int64_t *hashes;
     __device__ long long hash(long long r) const { return hashes ? hashes[r] : tg_hash_row(batch, r); }
     __device__ bool eq_store(long long r, int gid) const { return tg_rows_not_distinct(batch, r, store, gid); }
@@ -46,13 +49,14 @@ struct GenericKeys {
 
 // counters: [0] pending rows, [2] error
 template <bool INSERT>
-__global__ void __launch_bounds__(kBlock) gbh_probe_kernel(KeyCols batch, const int64_t *__restrict__ hashes, const uint8_t *__restrict__ row_mask, int64_t n,
-                                                            uint64_t *words, uint64_t mask, KeyCols store, int32_t store_groups,
+__global__ void __launch_bounds__(kBlock) gbh_probe_kernel(const KeyCols *batch_p, const int64_t *__restrict__ hashes, const uint8_t *__restrict__ row_mask, int64_t n,
+                                                            uint64_t *words, uint64_t mask, const KeyCols *store_p, int32_t store_groups,
                                                             int32_t *__restrict__ out, unsigned long long *counters)
 {
     // hashes == nullptr: the raw hash is computed from the key cells; row_mask: rows with 0 take no part (out = -1)
-    GenericKeys k{batch, store, hashes};
+    GenericKeys k{*batch_p, *store_p, hashes};
     const int lane = threadIdx.x & 63;
+    unsigned int my_pending = 0;
     for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
         const int64_t r = base + threadIdx.x;
         const bool active = r < n && (!row_mask || row_mask[r]);
@@ -76,9 +80,20 @@ __global__ void __launch_bounds__(kBlock) gbh_probe_kernel(KeyCols batch, const 
             pending = lead_pending != 0;
         }
         if (r < n) out[r] = result;
-        if (INSERT) {
-            unsigned long long b = __ballot(pending);
-            if (pending && lane == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+        if (INSERT && pending) my_pending++;
+    }
+    if (INSERT) {
+        // one atomic per workgroup: tens of thousands of waves adding to the same word would serialise on it
+        __shared__ unsigned int s_pending[kBlock / 64];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) my_pending += __shfl_down(my_pending, d, 64);
+        if (lane == 0) s_pending[threadIdx.x >> 6] = my_pending;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long total = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) total += s_pending[w];
+            if (total) atomicAdd(&counters[0], total);
         }
     }
 }
@@ -102,11 +117,12 @@ struct VarLens {
     int32_t *len[kMaxKeyChannels];
 };
 
-__global__ void __launch_bounds__(kBlock) gbh_finalize_kernel(KeyCols batch, const int64_t *__restrict__ hashes, int64_t n, uint64_t *words,
+__global__ void __launch_bounds__(kBlock) gbh_finalize_kernel(const KeyCols *batch_p, const int64_t *__restrict__ hashes, int64_t n, uint64_t *words,
                                                                const int32_t *__restrict__ out, const int32_t *__restrict__ flags,
-                                                               const int32_t *__restrict__ rank, int64_t base_gid, KeyCols store,
+                                                               const int32_t *__restrict__ rank, int64_t base_gid, const KeyCols *store_p,
                                                                int64_t *__restrict__ raw_hash, VarLens lens)
 {
+    const KeyCols &batch = *batch_p, &store = *store_p;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         if (!flags[r]) continue;
         const uint64_t pos = (uint64_t)(-(out[r] + 2));
@@ -114,9 +130,7 @@ __global__ void __launch_bounds__(kBlock) gbh_finalize_kernel(KeyCols batch, con
         const uint64_t w = words[pos];
         words[pos] = make_old((uint32_t)((w >> 32) & 0xffff), (uint32_t)gid);
         raw_hash[gid] = hashes ? hashes[r] : tg_hash_row(batch, r);
-#pragma unroll
-        for (int c = 0; c < TG_MAX_KEY_CHANNELS; c++) {
-            if (c >= batch.n) break;
+        for (int c = 0; c < batch.n; c++) {
             const ColView &s = batch.c[c];
             const ColView &d = store.c[c];
             const bool isnull = s.nulls && s.nulls[r];
@@ -300,6 +314,14 @@ void GroupByHashGpu::ensure_pool(KeyStore &ks, int64_t need_bytes)
     ks.pool_cap = cap;
 }
 
+// a key set in device memory, for the kernels that index its columns at run time
+BufferPtr GroupByHashGpu::device_keys(const KeyCols &k)
+{
+    BufferPtr b = ctx_->alloc(sizeof(KeyCols));
+    ctx_->upload(b->ptr(), &k, sizeof(KeyCols));
+    return b;
+}
+
 KeyCols GroupByHashGpu::store_view() const
 {
     KeyCols k{};
@@ -328,7 +350,9 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
     }
     else {
         ProfileScope ps(ctx_, "gbh_insert");
-        gbh_probe_kernel<true><<<g, kBlock, 0, ctx_->stream()>>>(batch, hashes, row_mask, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr);
+        BufferPtr dbatch = device_keys(batch), dstore = device_keys(store_view());
+        gbh_probe_kernel<true><<<g, kBlock, 0, ctx_->stream()>>>(dbatch->as<KeyCols>(), hashes, row_mask, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
+                                                                 dstore->as<KeyCols>(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr);
         check_launch("gbh_insert");
     }
     unsigned long long host_ctr[3];
@@ -357,8 +381,9 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
     }
     {
         ProfileScope ps(ctx_, "gbh_finalize");
-        gbh_finalize_kernel<<<g, kBlock, 0, ctx_->stream()>>>(batch, hashes, n, words_->as<uint64_t>(), out, flags->as<int32_t>(), rank->as<int32_t>(),
-                                                             groups_, store_view(), raw_hash_->as<int64_t>(), lens);
+        BufferPtr dbatch = device_keys(batch), dstore = device_keys(store_view());   // the store may have been re-allocated by ensure_store
+        gbh_finalize_kernel<<<g, kBlock, 0, ctx_->stream()>>>(dbatch->as<KeyCols>(), hashes, n, words_->as<uint64_t>(), out, flags->as<int32_t>(), rank->as<int32_t>(),
+                                                             groups_, dstore->as<KeyCols>(), raw_hash_->as<int64_t>(), lens);
         check_launch("gbh_finalize");
         for (size_t c = 0; c < store_.size(); c++) {
             KeyStore &ks = store_[c];
@@ -451,8 +476,9 @@ void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const
     }
     ensure_table(groups_);
     ensure_store(groups_ > 0 ? groups_ : 1);
-    gbh_probe_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(key_cols_of(keys), hashes, nullptr, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
-                                                                              store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out_gids,
+    BufferPtr dbatch = device_keys(key_cols_of(keys)), dstore = device_keys(store_view());
+    gbh_probe_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(dbatch->as<KeyCols>(), hashes, nullptr, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
+                                                                              dstore->as<KeyCols>(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out_gids,
                                                                               counters_->as<unsigned long long>());
     check_launch("gbh_lookup");
 }

@@ -862,5 +862,23 @@ def test_hash_exchange_single_rank_nccl(pkg, ctx, oracle):
         fac = pkg.FilterAndProjectOperatorFactory(ctx, 0, [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE], None, [f(0, pkg.BIGINT), f(1, pkg.VARCHAR), f(2, pkg.DOUBLE)])
         got = pkg.to_pages(fac.createOperator(), [out])
         assert got[0].rows() == page.rows()   # world size 1: one partition, input order preserved
+        # the REPLICATED distribution (all-gather) of an operator's device output page over RCCL, then into a join build
+        keys = rng.permutation(200_000)[:60_000].astype(np.int64)
+        fp = pkg.FilterAndProjectOperatorFactory(ctx, 1, [pkg.BIGINT], None, [f(0, pkg.BIGINT)])
+        op = fp.createOperator()
+        op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, keys)))
+        o = op.getOutput()
+        rep = ex_mod.all_gather_page(dist, dev, o.as_device_page())
+        assert rep.position_count == len(keys)
+        bf = pkg.HashBuilderOperatorFactory(ctx, 2, [pkg.BIGINT], [0], [0])
+        b = bf.createOperator()
+        b.addInput(rep)
+        b.finish()
+        o.release()
+        jf = pkg.LookupJoinOperatorFactory(ctx, 3, bf.lookup_source_factory, [pkg.BIGINT], [0], probe_output_channels=[0])
+        probe = rng.integers(0, 200_000, 100_000).astype(np.int64)
+        joined = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, probe))])
+        want_p, want_b = oracle.PagesHash([oracle.Col(pkg.BIGINT, keys)]).probe([oracle.Col(pkg.BIGINT, probe)])
+        assert [r for pg in joined for r in pg.rows()] == [(int(probe[i]), int(keys[j])) for i, j in zip(want_p, want_b)]
     finally:
         dist.destroy_process_group()
