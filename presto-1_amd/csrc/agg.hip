@@ -324,10 +324,31 @@ int grid_for(Context *ctx, int64_t n)
 bool is_double_state(int32_t f) { return f == TGPU_AGG_SUM_DOUBLE || f == TGPU_AGG_AVG_DOUBLE || f == TGPU_AGG_AVG_BIGINT; }
 bool is_count(int32_t f) { return f == TGPU_AGG_COUNT_ALL || f == TGPU_AGG_COUNT_COLUMN; }
 
-BufferPtr grow(Context *ctx, BufferPtr old, int64_t old_elems, int64_t new_elems, int elem_bytes)
+// the regions a round of state growth has to clear, zeroed by ONE launch (an operator with 8 aggregates grows ~24 arrays: one
+// memset each would cost more in launch gaps than the clearing itself)
+struct ZeroList {
+    static constexpr int kMax = 5 * kMaxAggs;
+    unsigned long long *ptr[kMax];
+    unsigned long long words[kMax];   // 8-byte words
+    int n;
+};
+
+__global__ void __launch_bounds__(kBlock) multi_zero_kernel(ZeroList z)
 {
-    BufferPtr nb = ctx->alloc_zero((size_t)new_elems * elem_bytes);
-    if (old && old_elems) HIP_CHECK(hipMemcpyAsync(nb->ptr(), old->ptr(), (size_t)old_elems * elem_bytes, hipMemcpyDeviceToDevice, ctx->stream()));
+    for (int i = 0; i < z.n; i++)
+        for (unsigned long long w = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; w < z.words[i]; w += (unsigned long long)gridDim.x * kBlock) z.ptr[i][w] = 0ULL;
+}
+
+// new array of new_elems elements: the old contents are carried over, the tail is queued for clearing (sizes are multiples of 8)
+BufferPtr grow(Context *ctx, BufferPtr old, int64_t old_elems, int64_t new_elems, int elem_bytes, ZeroList &zeros)
+{
+    BufferPtr nb = ctx->alloc((size_t)new_elems * elem_bytes);
+    const size_t keep = old ? (size_t)old_elems * elem_bytes : 0;
+    if (keep) HIP_CHECK(hipMemcpyAsync(nb->ptr(), old->ptr(), keep, hipMemcpyDeviceToDevice, ctx->stream()));
+    TG_CHECK_STATE(zeros.n < ZeroList::kMax && keep % 8 == 0 && ((size_t)new_elems * elem_bytes) % 8 == 0, "accumulator growth list");
+    zeros.ptr[zeros.n] = (unsigned long long *)(nb->as<uint8_t>() + keep);
+    zeros.words[zeros.n] = ((size_t)new_elems * elem_bytes - keep) / 8;
+    zeros.n++;
     return nb;
 }
 
@@ -390,20 +411,27 @@ int64_t GroupedAccumulators::estimated_size() const
 
 void GroupedAccumulators::ensure(int64_t groups)
 {
+    ZeroList zeros{};
     for (auto &st : states_) {
         if (groups <= st.cap) continue;
         int64_t cap = st.cap ? st.cap : 256;
         while (cap < groups) cap <<= 1;
-        st.counts = grow(ctx_, st.counts, st.cap, cap, 8);
+        st.counts = grow(ctx_, st.counts, st.cap, cap, 8, zeros);
         if (is_double_state(st.spec.function)) {
-            if (mode_ == Mode::ORDERED) st.dsum = grow(ctx_, st.dsum, st.cap, cap, 8);
+            if (mode_ == Mode::ORDERED) st.dsum = grow(ctx_, st.dsum, st.cap, cap, 8, zeros);
             else {
-                st.limbs = grow(ctx_, st.limbs, st.cap * kLimbs, cap * kLimbs, 8);
-                st.special = grow(ctx_, st.special, st.cap, cap, 4);
+                st.limbs = grow(ctx_, st.limbs, st.cap * kLimbs, cap * kLimbs, 8, zeros);
+                st.special = grow(ctx_, st.special, st.cap, cap, 4, zeros);
             }
         }
-        if (st.spec.function == TGPU_AGG_SUM_BIGINT) st.i128 = grow(ctx_, st.i128, st.cap * 2, cap * 2, 8);
+        if (st.spec.function == TGPU_AGG_SUM_BIGINT) st.i128 = grow(ctx_, st.i128, st.cap * 2, cap * 2, 8, zeros);
         st.cap = cap;
+    }
+    if (zeros.n) {
+        unsigned long long most = 0;
+        for (int i = 0; i < zeros.n; i++) most = std::max(most, zeros.words[i]);
+        multi_zero_kernel<<<grid_for(ctx_, (int64_t)most), kBlock, 0, ctx_->stream()>>>(zeros);
+        check_launch("multi_zero");
     }
 }
 

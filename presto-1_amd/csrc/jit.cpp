@@ -826,9 +826,9 @@ struct FjArgs {
   const TgSlot16* slots;
   unsigned long long mask;
   TgPrefilter pf;
-  int* tile_cnt;            // pairs produced by each tile
-  int* tile_src;            // where the tile's pairs start inside its block's private region
-  const int* tile_dst;      // pass 2: exclusive scan of tile_cnt = final output offset of the tile
+  int* tile_cnt;            // pairs produced by each CHUNK of tiles (see fj_probe)
+  int* tile_src;            // where the chunk's pairs start inside its block's private region
+  const int* tile_dst;      // pass 2: exclusive scan of tile_cnt = final output offset of the chunk
   int* pair_probe;          // block-private regions, capacity = rows the block owns
   int* pair_build;
   int* out_build;           // pass 2: build positions in final order
@@ -836,15 +836,17 @@ struct FjArgs {
   long long tiles;
   long long grid1;          // grid size of pass 1 (defines the region layout)
   int outer;
-  int pad;
+  int chunk_shift;          // a workgroup takes 2^chunk_shift consecutive tiles at a time
 };
 #define FJ_STRIPES @FJ_STRIPES@
 #define FJ_TILE (FJ_STRIPES * 256)
 
-// rows-capacity offset of block b's private pair region: tiles are dealt round-robin, block b owns ceil((tiles - b) / grid)
-__device__ inline long long fj_region_base(long long b, long long tiles, long long grid) {
-  const long long q = tiles / grid, r = tiles % grid;
-  return (b * q + (b < r ? b : r)) * FJ_TILE;
+// rows-capacity offset of block b's private pair region: CHUNKS of 2^chunk_shift consecutive tiles are dealt round-robin, block b
+// owns ceil((chunks - b) / grid) of them
+__device__ inline long long fj_region_base(long long b, long long tiles, long long grid, int chunk_shift) {
+  const long long chunks = (tiles + (1LL << chunk_shift) - 1) >> chunk_shift;
+  const long long q = chunks / grid, r = chunks % grid;
+  return ((b * q + (b < r ? b : r)) << chunk_shift) * FJ_TILE;
 }
 
 // pass 1: one lane per row.  Matches are compacted in input order inside the tile (ballot + popcount) and appended to the
@@ -862,7 +864,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   const FpArgs& A = J.fp;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __shared__ int C[2][4];   // pairs of each wave, double-buffered by tile parity (one barrier per tile)
-  const long long region = fj_region_base(blockIdx.x, J.tiles, gridDim.x);
+  const long long region = fj_region_base(blockIdx.x, J.tiles, gridDim.x, J.chunk_shift);
   long long local = 0;      // pairs this block has written so far (uniform across the block)
   unsigned int selected = 0;   // per lane: rows that passed the filter (a lane sees fewer than 2^31 rows)
   // Row layout of a tile: wave w owns the contiguous rows [w * 64 * FJ_STRIPES, (w + 1) * 64 * FJ_STRIPES) of the tile and its
@@ -871,7 +873,15 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   // Rows are 32-bit here (a page has fewer than 2^31 positions).
   const unsigned int n_rows = (unsigned int)A.n;
   const unsigned int wave_row = (unsigned int)w * (64u * FJ_STRIPES) + (unsigned int)lane;
-  const long long my_tiles = J.tiles > (long long)blockIdx.x ? (J.tiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  // The j-th tile this workgroup processes: chunks of 2^chunk_shift CONSECUTIVE tiles are dealt round-robin to the workgroups, so
+  // the pairs a workgroup produces for one chunk are contiguous in its region AND in the final (input) order: pass 2 then moves
+  // whole chunks (thousands of pairs, every lane busy) instead of single tiles (a handful of pairs per wave).
+  const int csh = J.chunk_shift;
+  const long long cmask = (1LL << csh) - 1;
+  const long long chunks = (J.tiles + cmask) >> csh;
+  const long long my_tiles = chunks > (long long)blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) << csh : 0;   // incl. tiles past the end
+  auto tile_of = [&](long long j) -> long long { return ((((j >> csh) * gridDim.x) + blockIdx.x) << csh) + (j & cmask); };
+  long long chunk_local0 = 0;   // `local` at the start of the chunk being compacted
   TgRow rw[FJ_STRIPES];                                                                                            // stage A -> B
   long long pkey[FJ_STRIPES]; unsigned int psidx[FJ_STRIPES]; unsigned long long pbw[FJ_STRIPES];                      // B -> C
 #if FJ_PF == 2
@@ -899,7 +909,8 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     bool emit[FJ_STRIPES];
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) { head[s] = -1; emit[s] = false; }
-    if (jD >= 0) {
+    const bool doD = jD >= 0 && tile_of(jD) < J.tiles;
+    if (doD) {
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
 #if FJ_PF == 3
@@ -923,7 +934,8 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     }
     // stage C: tile jC -- pre-filter verdicts; the survivors' first table slot is loaded below (lanes without a survivor read
     // slot 0: always-valid addresses, no branches around the loads)
-    const bool doC = jC >= 0 && jC < my_tiles, doB = jB >= 0 && jB < my_tiles, doA = jA < my_tiles;
+    const bool doC = jC >= 0 && jC < my_tiles && tile_of(jC) < J.tiles, doB = jB >= 0 && jB < my_tiles && tile_of(jB) < J.tiles,
+               doA = jA < my_tiles && tile_of(jA) < J.tiles;
     unsigned int cidx[FJ_STRIPES];
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) cidx[s] = 0;
@@ -951,7 +963,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) bidx[s] = 0;
     if (doB) {
-      const unsigned int row0 = (unsigned int)(((long long)blockIdx.x + jB * gridDim.x) * FJ_TILE) + wave_row;
+      const unsigned int row0 = (unsigned int)(tile_of(jB) * FJ_TILE) + wave_row;
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
         const unsigned int row = row0 + s * 64;
@@ -1013,8 +1025,8 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #endif
     }
     {
-      const unsigned int row0 = (unsigned int)(((long long)blockIdx.x + (doA ? jA : 0) * gridDim.x) * FJ_TILE) + wave_row;
-      const unsigned int tile_row0 = (unsigned int)(((long long)blockIdx.x + (doA ? jA : 0) * gridDim.x) * FJ_TILE);
+      const unsigned int row0 = (unsigned int)((doA ? tile_of(jA) : 0LL) * FJ_TILE) + wave_row;
+      const unsigned int tile_row0 = (unsigned int)((doA ? tile_of(jA) : 0LL) * FJ_TILE);
       if (tile_row0 + FJ_TILE <= n_rows) {   // interior tile: one address per column, the stripes are constant offsets from it
 #pragma unroll
         for (int s = 0; s < FJ_STRIPES; s++) tg_load_row(A, row0 + s * 64, rw[s]);
@@ -1029,9 +1041,10 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     }
     __builtin_amdgcn_sched_barrier(0);
     // stage D, part 2: compact the pairs of tile jD in input order and append them to the block's region
-    if (jD >= 0) {
-      const long long tile = (long long)blockIdx.x + jD * gridDim.x;
+    if (doD) {
+      const long long tile = tile_of(jD);
       const unsigned int row0 = (unsigned int)(tile * FJ_TILE) + wave_row;
+      if ((jD & cmask) == 0) chunk_local0 = local;
       unsigned long long b[FJ_STRIPES];
       int wave_total = 0;
 #pragma unroll
@@ -1057,8 +1070,9 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
         }
         o += (unsigned int)__popcll(b[s]);
       }
-      if (threadIdx.x == 0) { J.tile_cnt[tile] = tile_total; J.tile_src[tile] = (int)local; }
       local += tile_total;
+      // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
+      if (threadIdx.x == 0) { J.tile_cnt[tile >> csh] = (int)(local - chunk_local0); J.tile_src[tile >> csh] = (int)chunk_local0; }
     }
   }
   unsigned long long selected_wave = selected;
@@ -1067,18 +1081,17 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   if (lane == 0 && selected_wave) atomicAdd(&J.counters[0], selected_wave);
 }
 
-// pass 2: one wave per tile: moves the tile's pairs to their final position and evaluates the probe-side output
+// pass 2: one workgroup per chunk: moves the chunk's pairs to their final position and evaluates the probe-side output
 // projections for the matching rows only
 extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
   const FpArgs& A = J.fp;
-  const int lane = threadIdx.x & 63;
-  const long long waves = (long long)gridDim.x * 4;
-  for (long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); tile < J.tiles; tile += waves) {
-    const int cnt = J.tile_cnt[tile];
+  const long long chunks = (J.tiles + (1LL << J.chunk_shift) - 1) >> J.chunk_shift;
+  for (long long chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const int cnt = J.tile_cnt[chunk];
     if (cnt == 0) continue;
-    const long long src = fj_region_base(tile % J.grid1, J.tiles, J.grid1) + J.tile_src[tile];
-    const long long dst = J.tile_dst[tile];
-    for (int i = lane; i < cnt; i += 64) {
+    const long long src = fj_region_base(chunk % J.grid1, J.tiles, J.grid1, J.chunk_shift) + J.tile_src[chunk];
+    const long long dst = J.tile_dst[chunk];
+    for (int i = threadIdx.x; i < cnt; i += 256) {
       const long long row = J.pair_probe[src + i];
       J.out_build[dst + i] = J.pair_build[src + i];
       tg_emit_outputs(A, row, dst + i);
@@ -1280,9 +1293,15 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.tiles = ceil_div(n, tile_rows);
     TG_CHECK_ARG(n <= 0x7fffffffLL && J.tiles <= 0x7fffffffLL, "page too large");
     // persistent workgroups: exactly as many as are resident at once (a second round of workgroups would only add a tail)
-    const int64_t grid1 = std::min<int64_t>(J.tiles, (int64_t)ctx->cu_count() * module->blocks_per_cu("fj_probe"));
+    const int64_t resident = (int64_t)ctx->cu_count() * module->blocks_per_cu("fj_probe");
+    // chunks of consecutive tiles per workgroup (fj_probe): up to 64 tiles, but at least ~4 chunks per resident workgroup
+    int chunk_shift = 0;
+    while (chunk_shift < 6 && (J.tiles >> (chunk_shift + 1)) >= 4 * resident) chunk_shift++;
+    J.chunk_shift = chunk_shift;
+    const int64_t chunks = (J.tiles + (1ll << chunk_shift) - 1) >> chunk_shift;
+    const int64_t grid1 = std::min<int64_t>(chunks, resident);
     J.grid1 = grid1;
-    BufferPtr tile_cnt = ctx->alloc((size_t)J.tiles * 4), tile_src = ctx->alloc((size_t)J.tiles * 4), tile_dst = ctx->alloc((size_t)J.tiles * 4);
+    BufferPtr tile_cnt = ctx->alloc((size_t)chunks * 4), tile_src = ctx->alloc((size_t)chunks * 4), tile_dst = ctx->alloc((size_t)chunks * 4);
     BufferPtr misc = ctx->alloc(32);  // [0] expression error word, [1] rows selected by the filter, [2] total pairs
     HIP_CHECK(hipMemsetAsync(misc->ptr(), 0xff, 8, ctx->stream()));
     HIP_CHECK(hipMemsetAsync(misc->as<uint8_t>() + 8, 0, 24, ctx->stream()));
@@ -1292,7 +1311,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.tile_src = tile_src->as<int32_t>();
     J.tile_dst = tile_dst->as<int32_t>();
     // without duplicate build keys a probe row yields at most one pair: the private regions hold tiles x 2048 rows in total
-    const int64_t cap = J.tiles * tile_rows;
+    const int64_t cap = (chunks << chunk_shift) * tile_rows;
     BufferPtr pair_probe = ctx->alloc((size_t)cap * 4), pair_build = ctx->alloc((size_t)cap * 4);
     J.pair_probe = pair_probe->as<int32_t>();
     J.pair_build = pair_build->as<int32_t>();
@@ -1302,7 +1321,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     }
     {
         ProfileScope ps(ctx, "fused_probe_scan");
-        k::exclusive_scan_i32(ctx, J.tile_cnt, tile_dst->as<int32_t>(), J.tiles, (int64_t *)(misc->as<unsigned long long>() + 2));
+        k::exclusive_scan_i32(ctx, J.tile_cnt, tile_dst->as<int32_t>(), chunks, (int64_t *)(misc->as<unsigned long long>() + 2));
     }
     struct { unsigned long long expr_err, selected, total; } h;
     ctx->download(&h, misc->ptr(), 24);
@@ -1332,7 +1351,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     }
     {
         ProfileScope ps(ctx, "fused_probe_emit");
-        int64_t blocks = std::min<int64_t>(ceil_div(J.tiles, 4), (int64_t)ctx->cu_count() * 8);
+        int64_t blocks = std::min<int64_t>(chunks, (int64_t)ctx->cu_count() * 8);
         launch_args(module->fn("fj_emit"), (int)blocks, J, ctx->stream());
     }
     // no second error read-back: the projections evaluated by pass 2 cannot raise (the constructor keeps anything with checked

@@ -87,7 +87,7 @@ struct FjArgs {  // must match the generated struct
     long long tiles;
     long long grid1;
     int32_t outer;
-    int32_t pad;
+    int32_t chunk_shift;
 };
 
 class LookupSourceGpu;

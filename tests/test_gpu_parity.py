@@ -646,6 +646,33 @@ def test_join_prefilters_dense_bitmap_and_sparse_bloom(pkg, ctx, oracle, stride)
     assert np.array_equal(got, pkeys[op])
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 255, 1023, 1024, 1025, 4097, 65_537, 13_000_003])
+def test_fused_filter_probe_tile_and_chunk_boundaries(pkg, ctx, oracle, n):
+    """the software-pipelined fused filter+probe at page sizes around its tile (1024 rows) and chunk boundaries; the largest
+    size makes a workgroup take chunks of several consecutive tiles.  Expected = numpy filter + the oracle's probe."""
+    rng = np.random.default_rng(41 + n % 97)
+    bkeys = rng.permutation(400_000)[:120_000].astype(np.int64) * 3 + 7
+    pkeys = rng.integers(0, 1_300_000, n).astype(np.int64)
+    dates = rng.integers(9000, 9400, n).astype(np.int32)
+    f, c = pkg.field, pkg.constant
+    bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT], [0], [0])
+    b = bf.createOperator()
+    b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, bkeys)))
+    b.finish()
+    jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, [pkg.BIGINT, pkg.DATE], f(1, pkg.DATE) > c(9200, pkg.DATE),
+                                                     [f(0, pkg.BIGINT), f(1, pkg.DATE)], [0], probe_output_channels=[0, 1])
+    out = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, pkeys), pkg.Block(pkg.DATE, dates))])
+    sel = np.nonzero(dates > 9200)[0]
+    op, ob = oracle.PagesHash([oracle.Col(pkg.BIGINT, bkeys)]).probe([oracle.Col(pkg.BIGINT, pkeys[sel])])
+    want_rows = sel[op]
+    got_k = np.concatenate([p.getBlock(0).values for p in out]) if out else np.zeros(0, dtype=np.int64)
+    got_d = np.concatenate([p.getBlock(1).values for p in out]) if out else np.zeros(0, dtype=np.int32)
+    got_b = np.concatenate([p.getBlock(2).values for p in out]) if out else np.zeros(0, dtype=np.int64)
+    assert np.array_equal(got_k, pkeys[want_rows]) and np.array_equal(got_d, dates[want_rows])
+    assert np.array_equal(got_b, bkeys[ob])     # the build side's key column, gathered at the matching build positions
+    b.close()
+
+
 @pytest.mark.parametrize("layout", ["clustered", "spread", "duplicates"])
 def test_join_int_table_key_layouts(pkg, ctx, oracle, layout):
     """int-key table under key sets that stress its slot hash (runs of consecutive keys far apart, the TPCH orderkey pattern,
