@@ -589,7 +589,7 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected and corrected as documented there)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"].get(best)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")))["kernels"].get(best)
         if pmc:
             traffic = pmc["traffic_bytes_per_launch_avg"]
     except (OSError, ValueError, KeyError):

@@ -1296,7 +1296,8 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     const int64_t resident = (int64_t)ctx->cu_count() * module->blocks_per_cu("fj_probe");
     // chunks of consecutive tiles per workgroup (fj_probe): up to 64 tiles, but at least ~4 chunks per resident workgroup
     int chunk_shift = 0;
-    while (chunk_shift < 6 && (J.tiles >> (chunk_shift + 1)) >= 4 * resident) chunk_shift++;
+    const int max_chunk_shift = getenv("TGPU_FJ_CHUNK_SHIFT") ? atoi(getenv("TGPU_FJ_CHUNK_SHIFT")) : 6;
+    while (chunk_shift < max_chunk_shift && (J.tiles >> (chunk_shift + 1)) >= 4 * resident) chunk_shift++;
     J.chunk_shift = chunk_shift;
     const int64_t chunks = (J.tiles + (1ll << chunk_shift) - 1) >> chunk_shift;
     const int64_t grid1 = std::min<int64_t>(chunks, resident);
