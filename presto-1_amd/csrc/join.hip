@@ -250,17 +250,52 @@ __global__ void __launch_bounds__(kBlock) key_range_kernel(ColView key, int64_t 
 __global__ void __launch_bounds__(kBlock) build_direct_kernel(ColView key, int64_t n, long long key_min, unsigned long long *bitmap, int *direct,
                                                                unsigned long long *counters)
 {
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        bool dup = false;
-        if (!(key.nulls && key.nulls[r])) {  // PagesHash.java:94-96: rows with a null key are not indexed
-            const unsigned long long d = (unsigned long long)int_key_at(key, r) - (unsigned long long)key_min;
-            const unsigned long long bit = 1ULL << (d & 63);
-            const unsigned long long old = atomicOr(&bitmap[d >> 6], bit);
-            dup = (old & bit) != 0;
+    // Neighbouring rows often fall into the same bitmap word (build sides clustered by key: consecutive customer keys share one
+    // word, TPCH order keys every other one): the lanes of a contiguous run with the same word OR their bits together first and
+    // only the run's first lane touches memory -- atomics on one cache line serialise in L2.
+    const int lane = threadIdx.x & 63;
+    unsigned int my_dups = 0;
+    for (int64_t base = (int64_t)blockIdx.x * kBlock; base < n; base += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = base + threadIdx.x;
+        const bool active = r < n && !(key.nulls && key.nulls[r]);   // PagesHash.java:94-96: rows with a null key are not indexed
+        unsigned long long d = 0;
+        if (active) {
+            d = (unsigned long long)int_key_at(key, r) - (unsigned long long)key_min;
             direct[d] = (int)r;
         }
-        const unsigned long long b = __ballot(dup);
-        if (dup && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+        const unsigned int word = active ? (unsigned int)(d >> 6) : 0xffffffffu;
+        unsigned long long bits = active ? (1ULL << (d & 63)) : 0ULL;
+        unsigned int rows = active ? 1u : 0u;
+        const unsigned int word_prev = __shfl_up(word, 1, 64);
+        const bool head = lane == 0 || word_prev != word;
+        const unsigned long long heads = __ballot(head);
+        const int run = __popcll(heads & ((2ULL << lane) - 1ULL));   // id of the contiguous run this lane belongs to
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) {   // segmented suffix reduction: the run's first lane ends up with the whole run
+            const unsigned long long b2 = __shfl_down(bits, k, 64);
+            const unsigned int c2 = __shfl_down(rows, k, 64);
+            const int run2 = __shfl_down(run, k, 64);
+            if (lane + k < 64 && run2 == run) {
+                bits |= b2;
+                rows += c2;
+            }
+        }
+        if (head && active) {
+            const unsigned long long old = atomicOr(&bitmap[word], bits);
+            // repeated build keys: a bit that was already set, or two rows of the run with the same bit
+            my_dups += (unsigned int)__popcll(old & bits) + (rows - (unsigned int)__popcll(bits));
+        }
+    }
+    __shared__ unsigned int s_dups[kBlock / 64];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) my_dups += __shfl_down(my_dups, d, 64);
+    if (lane == 0) s_dups[threadIdx.x >> 6] = my_dups;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) total += s_dups[w];
+        if (total) atomicAdd(&counters[0], total);
     }
 }
 
