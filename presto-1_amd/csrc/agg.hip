@@ -650,8 +650,13 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
         agg_evaluate_kernel<<<grid_for(ctx_, groups * args.n_aggs), kBlock, 0, ctx_->stream()>>>(args, groups, error_->as<unsigned int>());
         check_launch("agg_evaluate");
     }
-    unsigned int err = ctx_->read_scalar(error_->as<unsigned int>());
-    if (err) fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "bigint addition overflow");
+    // only sum(bigint) can raise here (its total left int64): without one there is nothing to wait for
+    bool can_raise = false;
+    for (auto &st : states_) can_raise = can_raise || st.spec.function == TGPU_AGG_SUM_BIGINT;
+    if (can_raise) {
+        unsigned int err = ctx_->read_scalar(error_->as<unsigned int>());
+        if (err) fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "bigint addition overflow");
+    }
 }
 
 }  // namespace tgpu

@@ -355,18 +355,28 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
                                                                  dstore->as<KeyCols>(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr);
         check_launch("gbh_insert");
     }
+    // A smallish sub-batch marks and ranks its first-occurrence rows right away, so that ONE read-back brings the pending count,
+    // the number of new groups and the error flag; a big one (the steady state of low-cardinality inputs: no pending rows) first
+    // looks at the counters and only then pays for the two passes over its rows.
+    BufferPtr flags, rank;
+    auto mark_and_rank = [&] {
+        flags = ctx_->alloc((size_t)n * 4);
+        rank = ctx_->alloc((size_t)n * 4);
+        ProfileScope ps(ctx_, "gbh_assign");
+        gbh_mark_kernel<<<g, kBlock, 0, ctx_->stream()>>>(out, n, words_->as<uint64_t>(), flags->as<int32_t>());
+        k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), rank->as<int32_t>(), n, (int64_t *)&ctr[1]);
+    };
+    const bool eager = n <= (1ll << 22);
+    if (eager) mark_and_rank();
     unsigned long long host_ctr[3];
     ctx_->download(host_ctr, ctr, sizeof(host_ctr));
     if (host_ctr[2] != 0) return false;  // table overflow
     if (host_ctr[0] == 0) return true;   // every row hit an existing group
-
-    BufferPtr flags = ctx_->alloc((size_t)n * 4), rank = ctx_->alloc((size_t)n * 4);
-    {
-        ProfileScope ps(ctx_, "gbh_assign");
-        gbh_mark_kernel<<<g, kBlock, 0, ctx_->stream()>>>(out, n, words_->as<uint64_t>(), flags->as<int32_t>());
-        k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), rank->as<int32_t>(), n, (int64_t *)&ctr[1]);
+    int64_t new_groups = (int64_t)host_ctr[1];
+    if (!eager) {
+        mark_and_rank();
+        new_groups = (int64_t)ctx_->read_scalar((const unsigned long long *)&ctr[1]);
     }
-    const int64_t new_groups = (int64_t)ctx_->read_scalar((const unsigned long long *)&ctr[1]);
     TG_CHECK_STATE(new_groups > 0, "pending rows without new groups");
     ensure_store(groups_ + new_groups);
 

@@ -708,9 +708,88 @@ extern "C" __global__ void __launch_bounds__(256) fp_emit(FpArgs A) {
 
 void PageProcessorGpu::precompile() { (void)code_object_for(source_); }
 
+// ---- process-wide cache of the generated objects ----------------------------------------------------------------------
+namespace {
+void put_i32(std::string &k, int32_t v) { k.append(reinterpret_cast<const char *>(&v), 4); }
+void put_i64(std::string &k, int64_t v) { k.append(reinterpret_cast<const char *>(&v), 8); }
+
+// every field the generators read (field by field: the structs' padding is the caller's business), plus the kernel-study
+// environment switches that change the generated source
+std::string spec_key(const char *what, const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec, const std::vector<int32_t> &extra)
+{
+    TG_CHECK_ARG(spec != nullptr, "page processor spec is null");
+    std::string k(what);
+    put_i32(k, (int32_t)input_types.size());
+    for (int32_t t : input_types) put_i32(k, t);
+    put_i32(k, spec->node_count);
+    for (int32_t i = 0; i < spec->node_count; i++) {
+        const tgpu_expr_node &n = spec->nodes[i];
+        put_i32(k, n.kind); put_i32(k, n.type); put_i32(k, n.op); put_i32(k, n.n_args);
+        put_i32(k, n.args[0]); put_i32(k, n.args[1]); put_i32(k, n.args[2]); put_i32(k, n.is_null);
+        put_i64(k, n.ival);
+        k.append(reinterpret_cast<const char *>(&n.dval), 8);
+        put_i32(k, n.slen);
+    }
+    put_i32(k, spec->string_pool_len);
+    if (spec->string_pool && spec->string_pool_len > 0) k.append(spec->string_pool, (size_t)spec->string_pool_len);
+    put_i32(k, spec->filter_root);
+    put_i32(k, spec->projection_count);
+    for (int32_t i = 0; i < spec->projection_count; i++) put_i32(k, spec->projection_roots[i]);
+    put_i32(k, (int32_t)extra.size());
+    for (int32_t v : extra) put_i32(k, v);
+    for (const char *env : {"TGPU_FG_EXP", "TGPU_FJ_EXP", "TGPU_FA_STRIPES", "TGPU_FJ_STRIPES"}) {
+        const char *v = getenv(env);
+        k += '|';
+        if (v) k += v;
+    }
+    return k;
+}
+
+template <typename T, typename Make> std::shared_ptr<T> cached_object(const std::string &key, Make make)
+{
+    static std::mutex mu;
+    static std::map<std::string, std::shared_ptr<T>> objects;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = objects.find(key);
+    if (it != objects.end()) return it->second;
+    std::shared_ptr<T> obj = make();
+    objects[key] = obj;
+    return obj;
+}
+}  // namespace
+
+std::shared_ptr<PageProcessorGpu> PageProcessorGpu::shared(const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec)
+{
+    return cached_object<PageProcessorGpu>(spec_key("pp", input_types, spec, {}), [&] { return std::make_shared<PageProcessorGpu>(input_types, spec); });
+}
+
+std::shared_ptr<FusedProbeGpu> FusedProbeGpu::shared(const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec, int32_t join_channel,
+                                                     const std::vector<int32_t> &output_channels)
+{
+    std::vector<int32_t> extra{join_channel};
+    extra.insert(extra.end(), output_channels.begin(), output_channels.end());
+    return cached_object<FusedProbeGpu>(spec_key("fj", input_types, spec, extra),
+                                        [&] { return std::make_shared<FusedProbeGpu>(input_types, spec, join_channel, output_channels); });
+}
+
+std::shared_ptr<FusedAggGpu> FusedAggGpu::shared(const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec,
+                                                 const std::vector<tgpu_agg_spec> &aggs, const std::vector<int32_t> &group_by_channels)
+{
+    std::vector<int32_t> extra{(int32_t)aggs.size()};
+    for (const tgpu_agg_spec &a : aggs) {
+        extra.push_back(a.function);
+        extra.push_back(a.input_channel);
+        extra.push_back(a.mask_channel);
+    }
+    extra.insert(extra.end(), group_by_channels.begin(), group_by_channels.end());
+    return cached_object<FusedAggGpu>(spec_key("fa", input_types, spec, extra),
+                                      [&] { return std::make_shared<FusedAggGpu>(input_types, spec, aggs, group_by_channels); });
+}
+
 void PageProcessorGpu::ensure_loaded(Context *ctx)
 {
     (void)ctx;
+    std::lock_guard<std::mutex> lk(mu_);
     if (module_) return;
     module_ = load_module(source_);
     if (filter_root_ >= 0) fn_count_ = module_->fn("fp_count");
@@ -1253,6 +1332,7 @@ void FusedProbeGpu::precompile()
 
 JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls)
 {
+    std::lock_guard<std::mutex> lk(mu_);
     const int variant = kind + (no_nulls ? 4 : 0);
     if (!modules_[variant]) modules_[variant] = load_module(prefilter_source(source_, variant));
     return modules_[variant].get();
@@ -2110,6 +2190,7 @@ void FusedAggGpu::ensure_loaded()
 
 JitModule *FusedAggGpu::module_for(const DevicePage &in)
 {
+    std::lock_guard<std::mutex> lk(mu_);
     bool nulls = false;
     for (const DeviceColumn &c : in.cols) nulls = nulls || c.nulls != nullptr;
     if (nulls) {

@@ -31,6 +31,10 @@ class PageProcessorGpu {
 public:
     PageProcessorGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec);
     ~PageProcessorGpu();
+    // Process-wide cache of compiled page processors keyed by (input types, expressions): operator factories are created per
+    // query, their expressions repeat -- the counterpart of the reference's compiled-class cache
+    // (M/sql/gen/PageFunctionCompiler.java:101-139).  The shared objects are immutable apart from their lazily loaded modules.
+    static std::shared_ptr<PageProcessorGpu> shared(const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec);
     // generates the kernel source and compiles it into the on-disk cache; needs no GPU (used by build() to pre-warm)
     void precompile();
     // returns false when no row is selected (no output page); `out` gets one column per projection
@@ -48,6 +52,7 @@ private:
     };
     void generate();
     void ensure_loaded(Context *ctx);
+    std::mutex mu_;
 
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
@@ -97,6 +102,8 @@ public:
     // join_channel / output_channels index the page processor's projections (= the probe page the join would have seen)
     FusedProbeGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec, int32_t join_channel, std::vector<int32_t> output_channels);
     ~FusedProbeGpu();
+    static std::shared_ptr<FusedProbeGpu> shared(const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec, int32_t join_channel,
+                                                 const std::vector<int32_t> &output_channels);   // see PageProcessorGpu::shared
     void precompile();
     bool supported() const { return supported_; }   // false -> the operator runs the unfused composition
     const std::vector<int32_t> &projection_types() const { return proj_types_; }
@@ -108,6 +115,7 @@ public:
 private:
     void generate();
     struct JitModule *module_for(int prefilter_kind, bool no_nulls);
+    std::mutex mu_;
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
     std::string pool_;
@@ -129,6 +137,8 @@ public:
     // group_by_channels: projection indexes of the group-by keys (they must be plain column references for the fused path)
     FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec, std::vector<tgpu_agg_spec> aggs,
                 std::vector<int32_t> group_by_channels = {});
+    static std::shared_ptr<FusedAggGpu> shared(const std::vector<int32_t> &input_types, const tgpu_page_processor_spec *spec,
+                                               const std::vector<tgpu_agg_spec> &aggs, const std::vector<int32_t> &group_by_channels);   // see PageProcessorGpu::shared
     // raw input channels of the group-by keys (empty when a key is not a plain column reference)
     const std::vector<int> &key_inputs() const { return key_inputs_; }
     // one probe/insert launch of the group-by table with the filter fused in front and key code generated for the key schema
@@ -149,6 +159,7 @@ private:
     void generate();
     void ensure_loaded();
     struct JitModule *module_for(const DevicePage &in);   // the no-nulls specialisation when no column of the page has a null vector
+    std::mutex mu_;
     void raise_if_error(Context *ctx, BufferPtr &err);
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;

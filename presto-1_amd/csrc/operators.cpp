@@ -46,7 +46,7 @@ private:
 
 FilterAndProjectOperatorFactory::FilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types,
                                                                  const tgpu_page_processor_spec *spec)
-    : ctx_(ctx), operator_id_(operator_id), processor_(std::make_shared<PageProcessorGpu>(std::move(input_types), spec))
+    : ctx_(ctx), operator_id_(operator_id), processor_(PageProcessorGpu::shared(input_types, spec))
 {
 }
 
@@ -473,7 +473,7 @@ FusedFilterProjectJoinOperatorFactory::FusedFilterProjectJoinOperatorFactory(Con
                                                                              std::shared_ptr<LookupSourceFactory> bridge)
     : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg)), bridge_(std::move(bridge))
 {
-    processor_ = std::make_shared<PageProcessorGpu>(input_types, spec);
+    processor_ = PageProcessorGpu::shared(input_types, spec);
     cfg_.probe_types = processor_->output_types();
     const int nt = (int)cfg_.probe_types.size();
     TG_CHECK_ARG(!cfg_.probe_join_channels.empty(), "hash join needs at least one join channel");
@@ -481,7 +481,7 @@ FusedFilterProjectJoinOperatorFactory::FusedFilterProjectJoinOperatorFactory(Con
     for (int32_t ch : cfg_.probe_output_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe output channel out of range");
     TG_CHECK_ARG(cfg_.probe_hash_channel < nt, "probe hash channel out of range");
     TG_CHECK_ARG(cfg_.join_type == TGPU_JOIN_INNER || cfg_.join_type == TGPU_JOIN_PROBE_OUTER, "only INNER and PROBE_OUTER joins are supported");
-    fused_ = std::make_shared<FusedProbeGpu>(input_types, spec, cfg_.probe_join_channels[0], cfg_.probe_output_channels);
+    fused_ = FusedProbeGpu::shared(input_types, spec, cfg_.probe_join_channels[0], cfg_.probe_output_channels);
 }
 
 std::unique_ptr<Operator> FusedFilterProjectJoinOperatorFactory::create_operator()
@@ -541,7 +541,7 @@ FusedFilterProjectAggregationOperatorFactory::FusedFilterProjectAggregationOpera
                                                                                            const tgpu_page_processor_spec *spec, HashAggregationConfig cfg)
     : ctx_(ctx), operator_id_(operator_id), cfg_(std::move(cfg))
 {
-    processor_ = std::make_shared<PageProcessorGpu>(input_types, spec);
+    processor_ = PageProcessorGpu::shared(input_types, spec);
     const std::vector<int32_t> &pt = processor_->output_types();
     TG_CHECK_ARG(cfg_.group_by_types.size() == cfg_.group_by_channels.size(), "group-by types and channels differ in length");
     for (size_t i = 0; i < cfg_.group_by_channels.size(); i++) {
@@ -550,7 +550,7 @@ FusedFilterProjectAggregationOperatorFactory::FusedFilterProjectAggregationOpera
     }
     TG_CHECK_ARG(cfg_.hash_channel < (int)pt.size(), "hash channel out of range");
     TG_CHECK_ARG(cfg_.expected_groups > 0, "expectedGroups must be positive");
-    fused_ = std::make_shared<FusedAggGpu>(input_types, spec, cfg_.aggs, cfg_.group_by_channels);
+    fused_ = FusedAggGpu::shared(input_types, spec, cfg_.aggs, cfg_.group_by_channels);
 }
 
 std::unique_ptr<Operator> FusedFilterProjectAggregationOperatorFactory::create_operator()
