@@ -392,6 +392,32 @@ class Bench:
         obuild.close()
         aop.close()
 
+    def q3_top10(self, steps, warmup):
+        """the tail of Q3 (q03.sql: ORDER BY revenue DESC, o_orderdate LIMIT 10) as a TopNOperator over the aggregation's output page;
+        timed on its own, not part of `value`.  Checked against torch.topk of the revenue column."""
+        p, ctx = self.pkg, self.ctx
+        B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
+        pages = [o.as_device_page() for o in self.q3_result]
+        rows = sum(pg.position_count for pg in pages)
+        fac = p.TopNOperatorFactory(ctx, 16, [B, DT, I, D], 10, [3, 1], [p.DESC_NULLS_LAST, p.ASC_NULLS_LAST])
+        result = {}
+
+        def step():
+            op = fac.createOperator()
+            for pg in pages:
+                op.addInput(pg)
+            outs = self.finish(op)
+            result["rows"] = [r for o in outs for r in o.to_host().rows()]
+            op.close()
+
+        step_s, prof = self.timed(step, steps, warmup)
+        ex_mod = importlib.import_module("presto-1_amd.exchange")
+        rev = torch.cat([ex_mod.page_columns(pg, self.dev)[3]["values"] for pg in pages])
+        want = torch.topk(rev, min(10, rev.numel())).values.tolist()
+        got = [r[3] for r in result["rows"]]
+        return {"workload": "TopN(10) ORDER BY revenue DESC, o_orderdate over the Q3 groups", "input_rows": rows, "ms_per_step": step_s * 1e3,
+                "rows_per_sec": rows / step_s, "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in prof.items()}, "ok": got == want}
+
     def check_q3_dist(self):
         """N > 1, replicated-customer plan: every count and the revenue total against a reference computed independently with torch
         (each rank evaluates its own split against the all-gathered customer segment flags; totals are all-reduced)."""
@@ -653,6 +679,8 @@ def main():
                    "exchange_bytes_sent_per_step": st.get("exchange_bytes_sent", 0)},
         "roofline": roof, "checks": {"q3": q3_check},
     })
+    if not distributed and b.q3_result:
+        extra["q3_top10"] = b.q3_top10(args.steps, args.warmup)
     extra["q3_kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
     extra["q3_kernel_launch_min_max_ms"] = {k: [v["min_ms"], v["max_ms"], v["count"]] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
     b.q3_result = None

@@ -219,6 +219,18 @@ int32_t tgpu_filter_project_hash_aggregation_factory_create(tgpu_context *ctx, i
                                                             int32_t agg_count, const tgpu_agg_spec *aggs,
                                                             int32_t expected_groups, tgpu_operator_factory **out);
 
+/* TopNOperator.createOperatorFactory (M/operator/TopNOperator.java:47-62; TopNProcessor.java:45-66): the n first rows of the input
+ * in the order of the sort channels (S/connector/SortOrder.java:18-21; row order = SimplePageWithPositionComparator.java:58-79:
+ * nulls placed by the sort order, values by the type's COMPARISON operator, negated for DESC).  Rows that compare equal on every
+ * sort channel come out in input order (the reference's heap leaves their order unspecified).  n == 0: no output, finished at
+ * once (TopNOperator.java:154-156). */
+typedef enum tgpu_sort_order {
+    TGPU_SORT_ASC_NULLS_FIRST = 0, TGPU_SORT_ASC_NULLS_LAST = 1, TGPU_SORT_DESC_NULLS_FIRST = 2, TGPU_SORT_DESC_NULLS_LAST = 3
+} tgpu_sort_order;
+int32_t tgpu_top_n_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int64_t n,
+                                  int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
+                                  tgpu_operator_factory **out);
+
 /* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory);

@@ -395,3 +395,19 @@ def project(flat_nodes, root, pool, cols, positions):
     if rc < 0:
         raise OracleError(rc, err_row.value)
     return out[:n_sel], nulls[:n_sel]
+
+
+# ---- TopN ---------------------------------------------------------------------------------------
+ASC_NULLS_FIRST, ASC_NULLS_LAST, DESC_NULLS_FIRST, DESC_NULLS_LAST = 0, 1, 2, 3
+
+
+def top_n(cols, n, sort_channels, sort_orders):
+    """row numbers of the n first rows in the order of the sort channels (TopNOperator); equal rows keep their input order"""
+    rows = cols[0].n
+    out = np.zeros(max(min(n, rows), 1), dtype=np.int32)
+    sc = np.ascontiguousarray(sort_channels, dtype=np.int32)
+    so = np.ascontiguousarray(sort_orders, dtype=np.int32)
+    L = lib()
+    L.o_top_n.restype = C.c_int32
+    k = L.o_top_n(col_array(cols), rows, int(n), _ptr(sc), _ptr(so), len(sc), _ptr(out))
+    return out[:k]

@@ -1118,3 +1118,73 @@ int32_t o_project(const o_expr_node *nodes, int32_t root, const char *pool, cons
     }
     return O_OK;
 }
+
+/* ================================================================================================================== */
+/* TopN                                                                                                                */
+/* ================================================================================================================== */
+
+/* the type's COMPARISON operator on two non-null cells (Long.compare: S/type/AbstractLongType.java; Integer.compare:
+ * AbstractIntType.java; Double.compare: S/type/DoubleType.java:194-197; Boolean.compare; Slice.compareTo for VARCHAR) */
+static int compare_cells(const o_column *c, int32_t a, int32_t b)
+{
+    switch (c->type) {
+    case O_BIGINT: { int64_t x = ((const int64_t *)c->values)[a], y = ((const int64_t *)c->values)[b]; return x < y ? -1 : (x > y ? 1 : 0); }
+    case O_INTEGER: case O_DATE: { int32_t x = ((const int32_t *)c->values)[a], y = ((const int32_t *)c->values)[b]; return x < y ? -1 : (x > y ? 1 : 0); }
+    case O_BOOLEAN: { int x = ((const uint8_t *)c->values)[a] != 0, y = ((const uint8_t *)c->values)[b] != 0; return x - y; }
+    case O_DOUBLE: {
+        /* Double.compare: numeric order, then -0.0 < 0.0, NaN equal to itself and greater than everything else */
+        double x = ((const double *)c->values)[a], y = ((const double *)c->values)[b];
+        if (x < y) return -1;
+        if (x > y) return 1;
+        int64_t bx, by;
+        if (x != x) bx = 0x7ff8000000000000LL; else memcpy(&bx, &x, 8);
+        if (y != y) by = 0x7ff8000000000000LL; else memcpy(&by, &y, 8);
+        return bx == by ? 0 : (bx < by ? -1 : 1);
+    }
+    case O_VARCHAR: {
+        int32_t oa = c->offsets[a], la = c->offsets[a + 1] - oa, ob = c->offsets[b], lb = c->offsets[b + 1] - ob;
+        const uint8_t *pa = (const uint8_t *)c->values + oa, *pb = (const uint8_t *)c->values + ob;
+        int32_t m = la < lb ? la : lb;
+        int r = memcmp(pa, pb, (size_t)m);
+        if (r) return r < 0 ? -1 : 1;
+        return la < lb ? -1 : (la > lb ? 1 : 0);
+    }
+    default: return 0;
+    }
+}
+
+int32_t o_compare_rows(const o_column *cols, const int32_t *sort_channels, const int32_t *sort_orders, int32_t n_sort, int32_t a, int32_t b)
+{
+    for (int32_t i = 0; i < n_sort; i++) {
+        const o_column *c = &cols[sort_channels[i]];
+        const int asc = sort_orders[i] == 0 || sort_orders[i] == 1, nulls_first = sort_orders[i] == 0 || sort_orders[i] == 2;
+        const int na = c->nulls && c->nulls[a], nb = c->nulls && c->nulls[b];
+        if (na || nb) {   /* TypeOperators.orderNulls */
+            if (na && nb) continue;
+            if (na) return nulls_first ? -1 : 1;
+            return nulls_first ? 1 : -1;
+        }
+        int cmp = compare_cells(c, a, b);
+        if (cmp) return asc ? cmp : -cmp;
+    }
+    return 0;
+}
+
+int32_t o_top_n(const o_column *cols, int32_t rows, int32_t n, const int32_t *sort_channels, const int32_t *sort_orders, int32_t n_sort,
+                int32_t *positions_out)
+{
+    /* row-at-a-time, like the reference's per-row heap insert: a sorted buffer of at most n rows; a new row goes behind every kept
+     * row that does not sort after it (input order among equals) and pushes the last one out */
+    int32_t kept = 0;
+    if (n <= 0) return 0;
+    for (int32_t r = 0; r < rows; r++) {
+        int32_t at = kept;
+        while (at > 0 && o_compare_rows(cols, sort_channels, sort_orders, n_sort, r, positions_out[at - 1]) < 0) at--;
+        if (at >= n) continue;
+        int32_t last = kept < n ? kept : n - 1;
+        for (int32_t j = last; j > at; j--) positions_out[j] = positions_out[j - 1];
+        positions_out[at] = r;
+        if (kept < n) kept++;
+    }
+    return kept;
+}

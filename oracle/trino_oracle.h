@@ -175,4 +175,13 @@ int32_t o_project(const o_expr_node *nodes, int32_t root, const char *pool, cons
 #ifdef __cplusplus
 }
 #endif
+/* ---- TopN: M/operator/TopNOperator.java:47-62, TopNProcessor.java:45-66; row order = SimplePageWithPositionComparator.java:58-79
+ * with the null placement and DESC negation of S/type/TypeOperators.java:578-596.  sort_orders: 0 ASC_NULLS_FIRST, 1 ASC_NULLS_LAST,
+ * 2 DESC_NULLS_FIRST, 3 DESC_NULLS_LAST (S/connector/SortOrder.java:18-21).  Writes the row numbers of the min(n, rows) first rows in
+ * sort order; rows equal on every sort channel keep their input order (the reference's heap leaves that order unspecified).
+ * Returns the number of rows written. */
+int32_t o_compare_rows(const o_column *cols, const int32_t *sort_channels, const int32_t *sort_orders, int32_t n_sort, int32_t a, int32_t b);
+int32_t o_top_n(const o_column *cols, int32_t rows, int32_t n, const int32_t *sort_channels, const int32_t *sort_orders, int32_t n_sort,
+                int32_t *positions_out);
+
 #endif

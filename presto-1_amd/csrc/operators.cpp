@@ -559,4 +559,59 @@ std::unique_ptr<Operator> FusedFilterProjectAggregationOperatorFactory::create_o
     return std::make_unique<FusedFilterProjectAggregationOperator>(ctx_, operator_id_, cfg_, processor_, fused_);
 }
 
+// =====================================================================================================================
+// TopNOperator (M/operator/TopNOperator.java:135-225 over TopNProcessor.java:45-105): consumes pages until finish(), then emits
+// the n first rows in sort order as one page
+// =====================================================================================================================
+class TopNOperator : public Operator {
+public:
+    TopNOperator(Context *ctx, int32_t id, const std::vector<int32_t> &types, int64_t n, const std::vector<int32_t> &sort_channels,
+                 const std::vector<int32_t> &sort_orders)
+        : Operator(ctx, id), n_(n), top_(ctx, types, n, sort_channels, sort_orders)
+    {
+    }
+
+    // :195-199 (n == 0: the operator is finished from the start and never wants input, :154-156)
+    bool needs_input() override { return n_ > 0 && !finishing_; }
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(needs_input(), "Operator is already finishing");
+        DevicePage in = ingest_page(ctx_, page);
+        top_.add_page(in);
+    }
+
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (n_ == 0 || !finishing_ || finished_) return nullptr;
+        finished_ = true;
+        DevicePage out = top_.result();
+        if (out.n == 0) return nullptr;
+        return wrap(std::move(out));
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return n_ == 0 || finished_; }
+    int64_t memory_bytes() override { return top_.estimated_size(); }
+
+private:
+    int64_t n_;
+    TopNGpu top_;
+    bool finishing_ = false, finished_ = false;
+};
+
+TopNOperatorFactory::TopNOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, int64_t n, std::vector<int32_t> sort_channels,
+                                         std::vector<int32_t> sort_orders)
+    : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), sort_channels_(std::move(sort_channels)), sort_orders_(std::move(sort_orders)), n_(n)
+{
+    TopNGpu check(ctx_, types_, n_, sort_channels_, sort_orders_);   // argument validation up front
+    (void)check;
+}
+
+std::unique_ptr<Operator> TopNOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<TopNOperator>(ctx_, operator_id_, types_, n_, sort_channels_, sort_orders_);
+}
+
 }  // namespace tgpu

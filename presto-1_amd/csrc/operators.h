@@ -7,6 +7,7 @@
 #include "groupby.h"
 #include "jit.h"
 #include "join.h"
+#include "topn.h"
 
 namespace tgpu {
 
@@ -167,6 +168,20 @@ private:
     HashAggregationConfig cfg_;
     std::shared_ptr<PageProcessorGpu> processor_;
     std::shared_ptr<FusedAggGpu> fused_;
+};
+
+// ---- TopNOperator (M/operator/TopNOperator.java:47-62,135-225) ----------------------------------------------------------
+class TopNOperatorFactory : public OperatorFactory {
+public:
+    TopNOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, int64_t n, std::vector<int32_t> sort_channels,
+                        std::vector<int32_t> sort_orders);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> types_, sort_channels_, sort_orders_;
+    int64_t n_;
 };
 
 }  // namespace tgpu

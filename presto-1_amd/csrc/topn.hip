@@ -1,0 +1,248 @@
+// topn.hip -- TopN (K11).  A page's n first rows are found without comparison-sorting the page:
+//   1. every row gets a 64-bit ORDER CODE of its first sort key: the key's order-preserving bit pattern (BIGINT / INTEGER / DATE
+//      biased, DOUBLE in Double.compare order, BOOLEAN, VARCHAR = first 8 bytes big-endian), complemented for DESC, shifted
+//      right by one and topped with a null bit placed by the SortOrder -- code(a) < code(b) implies a sorts before b, equal
+//      codes decide nothing;
+//   2. (code, row) pairs are radix sorted (rocPRIM, stable: equal codes keep input order);
+//   3. the rows up to and including every tie with the n-th code are the candidates (binary search on the sorted codes);
+//   4. only the candidates are sorted with the full comparator (rocPRIM merge sort over row numbers: all sort keys, then the row
+//      number, so the order is total and rows that compare equal keep their input order), the first n are gathered.
+// Streaming: each page contributes its winners to a small candidate store; result() runs the same selection over the store.
+#include "topn.h"
+#include "kernels.h"
+#include "device_hash.h"
+#include "device_cols.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+namespace tgpu {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// sort keys in device memory (read through a pointer: run-time column indices are then plain scalar loads)
+struct TopNKeys {
+    TgKeyCols cols;                       // the sort channels, in priority order
+    int order[TG_MAX_KEY_CHANNELS];       // tgpu_sort_order per key
+};
+
+__device__ __forceinline__ bool asc(int order) { return order == TGPU_SORT_ASC_NULLS_FIRST || order == TGPU_SORT_ASC_NULLS_LAST; }
+__device__ __forceinline__ bool nulls_first(int order) { return order == TGPU_SORT_ASC_NULLS_FIRST || order == TGPU_SORT_DESC_NULLS_FIRST; }
+
+// Double.compare order as an unsigned key: -inf < ... < -0.0 < +0.0 < ... < +inf < NaN (all NaNs equal)
+__device__ __forceinline__ unsigned long long double_order_bits(unsigned long long bits)
+{
+    const double v = __longlong_as_double((long long)bits);
+    if (v != v) bits = 0x7ff8000000000000ULL;
+    return (bits >> 63) ? ~bits : (bits | 0x8000000000000000ULL);
+}
+
+// order-preserving 64-bit pattern of a non-null cell (VARCHAR: a prefix)
+__device__ __forceinline__ unsigned long long cell_order_bits(const TgColView &c, long long r)
+{
+    switch (c.type) {
+    case TGPU_BIGINT: return (unsigned long long)((const long long *)c.values)[r] ^ 0x8000000000000000ULL;
+    case TGPU_INTEGER:
+    case TGPU_DATE: return (unsigned long long)(long long)((const int *)c.values)[r] ^ 0x8000000000000000ULL;
+    case TGPU_DOUBLE: return double_order_bits(((const unsigned long long *)c.values)[r]);
+    case TGPU_BOOLEAN: return ((const unsigned char *)c.values)[r] ? 1ULL : 0ULL;
+    case TGPU_VARCHAR: {
+        const int a = c.offsets[r], l = c.offsets[r + 1] - a;
+        const unsigned char *p = (const unsigned char *)c.values + a;
+        unsigned long long v = 0;
+        for (int i = 0; i < 8; i++) v = (v << 8) | (i < l ? (unsigned long long)p[i] : 0ULL);
+        return v;
+    }
+    default: return 0;
+    }
+}
+
+// the type's COMPARISON operator on two non-null cells: <0, 0, >0 (Long.compare / Integer.compare / Double.compare /
+// Boolean.compare / Slice.compareTo = unsigned bytes, then length)
+__device__ __forceinline__ int compare_cells(const TgColView &c, long long a, long long b)
+{
+    if (c.type == TGPU_VARCHAR) {
+        const int oa = c.offsets[a], la = c.offsets[a + 1] - oa, ob = c.offsets[b], lb = c.offsets[b + 1] - ob;
+        const unsigned char *pa = (const unsigned char *)c.values + oa, *pb = (const unsigned char *)c.values + ob;
+        const int m = la < lb ? la : lb;
+        for (int i = 0; i < m; i++)
+            if (pa[i] != pb[i]) return pa[i] < pb[i] ? -1 : 1;
+        return la < lb ? -1 : (la > lb ? 1 : 0);
+    }
+    const unsigned long long x = cell_order_bits(c, a), y = cell_order_bits(c, b);
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+// SimplePageWithPositionComparator.compareTo over the sort keys
+__device__ __forceinline__ int compare_rows(const TopNKeys &k, long long a, long long b)
+{
+    for (int i = 0; i < k.cols.n; i++) {
+        const TgColView &c = k.cols.c[i];
+        const bool na = c.nulls && c.nulls[a], nb = c.nulls && c.nulls[b];
+        if (na || nb) {   // TypeOperators.orderNulls
+            if (na && nb) continue;
+            if (na) return nulls_first(k.order[i]) ? -1 : 1;
+            return nulls_first(k.order[i]) ? 1 : -1;
+        }
+        const int cmp = compare_cells(c, a, b);
+        if (cmp) return asc(k.order[i]) ? cmp : -cmp;
+    }
+    return 0;
+}
+
+__global__ void __launch_bounds__(kBlock) order_codes_kernel(const TopNKeys *kp, int64_t n, unsigned long long *codes, int *rows)
+{
+    const TopNKeys &k = *kp;
+    const TgColView &c = k.cols.c[0];
+    const int order = k.order[0];
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        const bool is_null = c.nulls && c.nulls[r];
+        unsigned long long v = 0;
+        if (!is_null) {
+            v = cell_order_bits(c, r);
+            if (!asc(order)) v = ~v;
+        }
+        // the null bit on top (nulls first: nulls get 0 and values 1), the value's upper 63 bits below it
+        const unsigned long long top = (is_null == nulls_first(order)) ? 0ULL : 1ULL;
+        codes[r] = (top << 63) | (is_null ? 0ULL : (v >> 1));
+        rows[r] = (int)r;
+    }
+}
+
+// count[0] = number of leading entries of the sorted codes that are <= codes[want - 1] (the candidates)
+__global__ void candidate_count_kernel(const unsigned long long *sorted_codes, int64_t n, int64_t want, long long *count)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long cut = sorted_codes[want - 1];
+    int64_t lo = want, hi = n;   // first index in [want, n) whose code is greater than the cut
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted_codes[mid] <= cut) lo = mid + 1;
+        else hi = mid;
+    }
+    count[0] = lo;
+}
+
+struct RowLess {
+    const TopNKeys *k;
+    __device__ bool operator()(const int &a, const int &b) const
+    {
+        const int cmp = compare_rows(*k, a, b);
+        return cmp ? cmp < 0 : a < b;
+    }
+};
+
+int grid_for(Context *ctx, int64_t n)
+{
+    int64_t blocks = ceil_div(n, kBlock);
+    const int64_t cap = (int64_t)ctx->cu_count() * 8;
+    if (blocks > cap) blocks = cap;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+TopNGpu::TopNGpu(Context *ctx, std::vector<int32_t> types, int64_t n, std::vector<int32_t> sort_channels, std::vector<int32_t> sort_orders)
+    : ctx_(ctx), types_(std::move(types)), sort_channels_(std::move(sort_channels)), sort_orders_(std::move(sort_orders)), n_(n), kept_(ctx, types_)
+{
+    TG_CHECK_ARG(n_ >= 0, "n must be positive");
+    TG_CHECK_ARG(!sort_channels_.empty() && sort_channels_.size() == sort_orders_.size(), "sort channels and sort orders differ in length");
+    TG_CHECK_ARG((int)sort_channels_.size() <= kMaxKeyChannels, "at most 8 sort channels");
+    for (size_t i = 0; i < sort_channels_.size(); i++) {
+        TG_CHECK_ARG(sort_channels_[i] >= 0 && sort_channels_[i] < (int)types_.size(), "sort channel out of range");
+        TG_CHECK_ARG(sort_orders_[i] >= TGPU_SORT_ASC_NULLS_FIRST && sort_orders_[i] <= TGPU_SORT_DESC_NULLS_LAST, "unknown sort order");
+    }
+    for (int32_t t : types_) TG_CHECK_ARG(valid_type(t), "unknown type");
+}
+
+BufferPtr TopNGpu::top_positions(const DevicePage &page, int64_t &count)
+{
+    const int64_t n = page.n;
+    const int64_t want = std::min<int64_t>(n_, n);
+    count = want;
+    if (want == 0) return ctx_->alloc(4);
+    TG_CHECK_ARG(n <= 0x7fffffffLL, "page too large");
+    TopNKeys host{};
+    host.cols.n = (int32_t)sort_channels_.size();
+    for (size_t i = 0; i < sort_channels_.size(); i++) {
+        host.cols.c[i] = view_of(page.cols[(size_t)sort_channels_[i]]);
+        host.order[i] = sort_orders_[i];
+    }
+    BufferPtr keys = ctx_->alloc(sizeof(TopNKeys));
+    ctx_->upload(keys->ptr(), &host, sizeof(TopNKeys));
+    BufferPtr codes_in = ctx_->alloc((size_t)n * 8), codes = ctx_->alloc((size_t)n * 8), rows_in = ctx_->alloc((size_t)n * 4), rows = ctx_->alloc((size_t)n * 4);
+    BufferPtr cand = ctx_->alloc(8);
+    {
+        ProfileScope ps(ctx_, "topn_select");
+        order_codes_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(keys->as<TopNKeys>(), n, codes_in->as<unsigned long long>(), rows_in->as<int>());
+        check_launch("order_codes");
+        size_t temp_bytes = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes_in->as<unsigned long long>(), codes->as<unsigned long long>(), rows_in->as<int>(), rows->as<int>(),
+                                            (size_t)n, 0, 64, ctx_->stream()));
+        BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
+        HIP_CHECK(rocprim::radix_sort_pairs(temp->ptr(), temp_bytes, codes_in->as<unsigned long long>(), codes->as<unsigned long long>(), rows_in->as<int>(), rows->as<int>(),
+                                            (size_t)n, 0, 64, ctx_->stream()));
+        candidate_count_kernel<<<1, 64, 0, ctx_->stream()>>>(codes->as<unsigned long long>(), n, want, cand->as<long long>());
+        check_launch("candidate_count");
+    }
+    const int64_t m = ctx_->read_scalar(cand->as<long long>());
+    TG_CHECK_STATE(m >= want && m <= n, "candidate count out of range");
+    // the candidates, ordered by the full comparator
+    BufferPtr sorted = ctx_->alloc((size_t)m * 4);
+    {
+        ProfileScope ps(ctx_, "topn_sort");
+        RowLess less{keys->as<TopNKeys>()};
+        size_t temp_bytes = 0;
+        HIP_CHECK(rocprim::merge_sort(nullptr, temp_bytes, rows->as<int>(), sorted->as<int>(), (size_t)m, less, ctx_->stream()));
+        BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
+        HIP_CHECK(rocprim::merge_sort(temp->ptr(), temp_bytes, rows->as<int>(), sorted->as<int>(), (size_t)m, less, ctx_->stream()));
+    }
+    return sorted;
+}
+
+void TopNGpu::add_page(const DevicePage &page)
+{
+    TG_CHECK_ARG(page.cols.size() == types_.size(), "page channel count does not match the operator's types");
+    for (size_t i = 0; i < types_.size(); i++) TG_CHECK_ARG(page.cols[i].type == types_[i], "page channel type does not match the operator's types");
+    if (page.n == 0 || n_ == 0) return;
+    int64_t count = 0;
+    BufferPtr pos = top_positions(page, count);
+    DevicePage winners;
+    winners.n = count;
+    {
+        ProfileScope ps(ctx_, "topn_gather");
+        for (auto &c : page.cols) winners.cols.push_back(k::gather_column(ctx_, c, pos->as<int32_t>(), count, false));
+    }
+    kept_.add_page(winners);
+    // many small pages: fold the store back to n rows now and then
+    if (kept_.position_count() > std::max<int64_t>(4 * n_, 1 << 16)) {
+        DevicePage folded = result();
+        PagesIndexGpu fresh(ctx_, types_);
+        fresh.add_page(folded);
+        kept_ = std::move(fresh);
+    }
+}
+
+DevicePage TopNGpu::result()
+{
+    DevicePage all;
+    all.n = kept_.position_count();
+    for (size_t i = 0; i < types_.size(); i++) all.cols.push_back(kept_.column((int)i));
+    DevicePage out;
+    int64_t count = 0;
+    if (all.n == 0) {
+        out.n = 0;
+        for (size_t i = 0; i < types_.size(); i++) out.cols.push_back(kept_.column((int)i));
+        return out;
+    }
+    BufferPtr pos = top_positions(all, count);
+    out.n = count;
+    ProfileScope ps(ctx_, "topn_gather");
+    for (auto &c : all.cols) out.cols.push_back(k::gather_column(ctx_, c, pos->as<int32_t>(), count, false));
+    return out;
+}
+
+}  // namespace tgpu

@@ -16,6 +16,8 @@ from .spi import OutputPage, Page
 
 COUNT_ALL, COUNT_COLUMN, SUM_BIGINT, SUM_DOUBLE, AVG_BIGINT, AVG_DOUBLE = 1, 2, 3, 4, 5, 6
 SINGLE, PARTIAL, FINAL = 0, 1, 2
+# S/connector/SortOrder.java:18-21
+ASC_NULLS_FIRST, ASC_NULLS_LAST, DESC_NULLS_FIRST, DESC_NULLS_LAST = 0, 1, 2, 3
 INNER, PROBE_OUTER = 0, 1
 
 
@@ -253,6 +255,19 @@ def _agg_array(aggs):
     for i, a in enumerate(aggs):
         arr[i] = _lib.AggSpec(a[0], a[1], a[2] if len(a) > 2 else -1)
     return arr
+
+
+class TopNOperatorFactory(OperatorFactory):
+    """TopNOperator.createOperatorFactory (M/operator/TopNOperator.java:47-62): the n first rows in the order of the sort channels."""
+
+    def __init__(self, ctx: Context, operator_id, types, n, sort_channels, sort_orders):
+        t, nt = _i32(types)
+        sc, ns = _i32(sort_channels)
+        so, no = _i32(sort_orders)
+        assert ns == no, "sort channels and sort orders differ in length"
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_top_n_factory_create(ctx.handle, operator_id, nt, t, int(n), ns, sc, so, C.byref(h)))
+        super().__init__(h)
 
 
 class FilterProjectHashAggregationOperatorFactory(OperatorFactory):

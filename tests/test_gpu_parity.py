@@ -909,3 +909,54 @@ def test_hash_exchange_single_rank_nccl(pkg, ctx, oracle):
         assert [r for pg in joined for r in pg.rows()] == [(int(probe[i]), int(keys[j])) for i, j in zip(want_p, want_b)]
     finally:
         dist.destroy_process_group()
+
+
+# ---- TopN (M/operator/TopNOperator.java) ---------------------------------------------------------------------------------------
+_TOPN_TYPES = {"BIGINT": 1, "DOUBLE": 4, "VARCHAR": 6}
+_SORT = {"ASC_NULLS_FIRST": 0, "ASC_NULLS_LAST": 1, "DESC_NULLS_FIRST": 2, "DESC_NULLS_LAST": 3}
+
+
+@pytest.mark.parametrize("name", ["testSingleFieldKey", "testMultiFieldKey", "testReverseOrder"])
+def test_top_n_golden(pkg, ctx, name):
+    # T/operator/TestTopNOperator.java:77-165: the literal pages and expectations of the reference's own tests
+    case = GOLD["top_n"][name]
+    types = [_TOPN_TYPES[t] for t in case["types"]]
+    pages = [pkg.Page(*[pkg.Block(t, [r[i] for r in pg]) for i, t in enumerate(types)]) for pg in case["pages"]]
+    fac = pkg.TopNOperatorFactory(ctx, 0, types, case["n"], case["sort_channels"], [_SORT[o] for o in case["sort_orders"]])
+    out = pkg.to_pages(fac.createOperator(), pages)
+    assert [list(r) for p in out for r in p.rows()] == case["expect_rows"]
+
+
+def test_top_n_limit_zero(pkg, ctx):
+    # T/operator/TestTopNOperator.java:167-183
+    fac = pkg.TopNOperatorFactory(ctx, 0, [pkg.BIGINT], 0, [0], [pkg.DESC_NULLS_LAST])
+    op = fac.createOperator()
+    assert op.getOutput() is None and op.isFinished() and not op.needsInput() and op.getOutput() is None
+    op.close()
+
+
+@pytest.mark.parametrize("n_rows,n", [(1, 5), (1000, 1), (5000, 100), (300_000, 10), (300_000, 5000), (6_000, 100_000)])
+def test_top_n_matches_oracle(pkg, ctx, oracle, n_rows, n):
+    """random pages (nulls, NaN / +-0.0 / infinities, few distinct values = many ties, varchar longer than the 8-byte order code)
+    over every sort order and multi-channel sort keys: the rows equal the oracle's, including the input order of equal rows"""
+    rng = np.random.default_rng(53 + n_rows % 89 + n)
+    dbl = rng.integers(-5, 6, n_rows).astype(np.float64) / 4.0
+    special = rng.integers(0, n_rows, max(n_rows // 50, 1))
+    dbl[special] = rng.choice([np.nan, np.inf, -np.inf, -0.0, 0.0], len(special))
+    strs = [None if k % 17 == 0 else "key-prefix-%03d%s" % (k % 40, "x" * (k % 3)) for k in rng.integers(0, 1000, n_rows)]
+    blocks = [pkg.Block(pkg.DOUBLE, dbl, (rng.random(n_rows) < 0.05).astype(np.uint8)), pkg.Block(pkg.VARCHAR, strs),
+              rand_block(pkg, rng, pkg.BIGINT, n_rows, 0.05, (-50, 50)), rand_block(pkg, rng, pkg.DATE, n_rows, 0.0, (9000, 9020)),
+              pkg.Block(pkg.BIGINT, np.arange(n_rows, dtype=np.int64))]
+    types = [pkg.DOUBLE, pkg.VARCHAR, pkg.BIGINT, pkg.DATE, pkg.BIGINT]
+    ocols = [ocol(oracle, b) for b in blocks]
+    # three pages, so that the streaming path (per-page winners + final selection) is exercised
+    cuts = [0, n_rows // 3, n_rows // 2, n_rows]
+    pages = [pkg.Page(*[pkg.Block(t, b.to_list()[a:z]) if t == pkg.VARCHAR else
+                        pkg.Block(t, b.values[a:z], None if b.nulls is None else b.nulls[a:z]) for t, b in zip(types, blocks)]) for a, z in zip(cuts[:-1], cuts[1:]) if z > a]
+    for sort_channels, sort_orders in ([[0], [pkg.DESC_NULLS_LAST]], [[0], [pkg.ASC_NULLS_FIRST]], [[1, 2], [pkg.ASC_NULLS_LAST, pkg.DESC_NULLS_FIRST]],
+                                      [[3, 0, 1], [pkg.DESC_NULLS_FIRST, pkg.ASC_NULLS_LAST, pkg.DESC_NULLS_LAST]]):
+        fac = pkg.TopNOperatorFactory(ctx, 0, types, n, sort_channels, sort_orders)
+        out = pkg.to_pages(fac.createOperator(), pages)
+        got = np.concatenate([p.getBlock(4).values for p in out]) if out else np.zeros(0, dtype=np.int64)
+        want = oracle.top_n(ocols, n, sort_channels, sort_orders)
+        assert np.array_equal(got, want), (sort_channels, sort_orders)

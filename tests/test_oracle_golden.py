@@ -224,3 +224,29 @@ def test_exact_sum_matches_fsum(oracle):
     rng = np.random.default_rng(3)
     v = rng.standard_normal(20000) * 10.0 ** rng.integers(-8, 8, 20000)
     assert oracle.exact_sum(v) == math.fsum(v)
+
+
+TYPE_ID = {"BIGINT": BIGINT, "DOUBLE": DOUBLE, "VARCHAR": VARCHAR, "BOOLEAN": BOOLEAN}
+SORT_ORDER = {"ASC_NULLS_FIRST": 0, "ASC_NULLS_LAST": 1, "DESC_NULLS_FIRST": 2, "DESC_NULLS_LAST": 3}
+
+
+@pytest.mark.parametrize("name", ["testSingleFieldKey", "testMultiFieldKey", "testReverseOrder"])
+def test_top_n_golden(oracle, name):
+    # T/operator/TestTopNOperator.java:77-165: the literal rows and expectations of the reference's own tests
+    case = GOLD["top_n"][name]
+    rows = [r for page in case["pages"] for r in page]
+    types = [TYPE_ID[t] for t in case["types"]]
+    cols = [oracle.Col(t, [r[i] for r in rows]) for i, t in enumerate(types)]
+    pos = oracle.top_n(cols, case["n"], case["sort_channels"], [SORT_ORDER[o] for o in case["sort_orders"]])
+    assert [rows[i] for i in pos] == case["expect_rows"]
+
+
+def test_top_n_null_placement_and_double_order(oracle):
+    # TypeOperators.java:578-596: nulls by the sort order, values by Double.compare (DoubleType.java:194-197: -0.0 < 0.0 < NaN), DESC negates
+    vals = [1.5, None, float("nan"), -0.0, 0.0, float("inf"), float("-inf"), None]
+    col = oracle.Col(DOUBLE, [0.0 if v is None else v for v in vals], np.array([v is None for v in vals], dtype=np.uint8))
+    order = lambda so: list(oracle.top_n([col], len(vals), [0], [so]))
+    assert order(0) == [1, 7, 6, 3, 4, 0, 5, 2]      # ASC_NULLS_FIRST: nulls (input order), -inf, -0.0, 0.0, 1.5, inf, NaN
+    assert order(1) == [6, 3, 4, 0, 5, 2, 1, 7]      # ASC_NULLS_LAST
+    assert order(2) == [1, 7, 2, 5, 0, 4, 3, 6]      # DESC_NULLS_FIRST
+    assert order(3) == [2, 5, 0, 4, 3, 6, 1, 7]      # DESC_NULLS_LAST
