@@ -25,6 +25,7 @@ private:
     std::vector<int32_t> types_, sort_channels_, sort_orders_;
     int64_t n_;
     PagesIndexGpu kept_;   // candidates: the per-page winners, appended page after page
+    bool sorted_ = false;  // the store holds one selection result (at most n rows, in order)
 };
 
 }  // namespace tgpu

@@ -3,8 +3,11 @@
 //      biased, DOUBLE in Double.compare order, BOOLEAN, VARCHAR = first 8 bytes big-endian), complemented for DESC, shifted
 //      right by one and topped with a null bit placed by the SortOrder -- code(a) < code(b) implies a sorts before b, equal
 //      codes decide nothing;
-//   2. (code, row) pairs are radix sorted (rocPRIM, stable: equal codes keep input order);
-//   3. the rows up to and including every tie with the n-th code are the candidates (binary search on the sorted codes);
+//   2. a CUTOFF code that certainly admits the n first rows: the n-th smallest code of a strided sample of 64 K rows (the n-th
+//      smallest of a subset is never below the n-th smallest of the whole); small pages skip this and keep every row;
+//   3. the rows whose code does not exceed the cutoff are the candidates, compacted in input order (flags + scan): about
+//      n x rows / 64 K of them.  If the codes are so coarse that the candidates are still many (few distinct values), they are
+//      radix sorted by code (rocPRIM, stable) and cut at the ties of the n-th code;
 //   4. only the candidates are sorted with the full comparator (rocPRIM merge sort over row numbers: all sort keys, then the row
 //      number, so the order is total and rows that compare equal keep their input order), the first n are gathered.
 // Streaming: each page contributes its winners to a small candidate store; result() runs the same selection over the store.
@@ -126,6 +129,31 @@ __global__ void candidate_count_kernel(const unsigned long long *sorted_codes, i
     count[0] = lo;
 }
 
+// every stride-th code, for the cutoff estimate
+__global__ void __launch_bounds__(kBlock) sample_codes_kernel(const unsigned long long *codes, int64_t n, int64_t stride, int64_t samples, unsigned long long *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < samples; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i * stride;
+        out[i] = codes[r < n ? r : n - 1];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) flag_candidates_kernel(const unsigned long long *codes, int64_t n, const unsigned long long *cutoff, int *flags)
+{
+    const unsigned long long cut = *cutoff;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) flags[r] = codes[r] <= cut ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(kBlock) compact_candidates_kernel(const int *flags, const int *offsets, const unsigned long long *codes, int64_t n, int *rows_out,
+                                                                     unsigned long long *codes_out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock)
+        if (flags[r]) {
+            rows_out[offsets[r]] = (int)r;
+            codes_out[offsets[r]] = codes[r];
+        }
+}
+
 struct RowLess {
     const TopNKeys *k;
     __device__ bool operator()(const int &a, const int &b) const
@@ -173,23 +201,57 @@ BufferPtr TopNGpu::top_positions(const DevicePage &page, int64_t &count)
     }
     BufferPtr keys = ctx_->alloc(sizeof(TopNKeys));
     ctx_->upload(keys->ptr(), &host, sizeof(TopNKeys));
-    BufferPtr codes_in = ctx_->alloc((size_t)n * 8), codes = ctx_->alloc((size_t)n * 8), rows_in = ctx_->alloc((size_t)n * 4), rows = ctx_->alloc((size_t)n * 4);
-    BufferPtr cand = ctx_->alloc(8);
+    constexpr int64_t kSamples = 1 << 16;
+    BufferPtr codes = ctx_->alloc((size_t)n * 8), rows = ctx_->alloc((size_t)n * 4);
+    BufferPtr scalar = ctx_->alloc(16);   // [0] candidate count, [1] cutoff code
+    int64_t m = n;
     {
         ProfileScope ps(ctx_, "topn_select");
-        order_codes_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(keys->as<TopNKeys>(), n, codes_in->as<unsigned long long>(), rows_in->as<int>());
+        order_codes_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(keys->as<TopNKeys>(), n, codes->as<unsigned long long>(), rows->as<int>());
         check_launch("order_codes");
-        size_t temp_bytes = 0;
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes_in->as<unsigned long long>(), codes->as<unsigned long long>(), rows_in->as<int>(), rows->as<int>(),
-                                            (size_t)n, 0, 64, ctx_->stream()));
-        BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
-        HIP_CHECK(rocprim::radix_sort_pairs(temp->ptr(), temp_bytes, codes_in->as<unsigned long long>(), codes->as<unsigned long long>(), rows_in->as<int>(), rows->as<int>(),
-                                            (size_t)n, 0, 64, ctx_->stream()));
-        candidate_count_kernel<<<1, 64, 0, ctx_->stream()>>>(codes->as<unsigned long long>(), n, want, cand->as<long long>());
-        check_launch("candidate_count");
+        if (n > 4 * kSamples && want < kSamples / 2) {
+            // cutoff from a strided sample, then the rows at or below it, in input order
+            const int64_t stride = n / kSamples;
+            BufferPtr sample = ctx_->alloc((size_t)kSamples * 8), sample_sorted = ctx_->alloc((size_t)kSamples * 8);
+            sample_codes_kernel<<<grid_for(ctx_, kSamples), kBlock, 0, ctx_->stream()>>>(codes->as<unsigned long long>(), n, stride, kSamples, sample->as<unsigned long long>());
+            check_launch("sample_codes");
+            size_t temp_bytes = 0;
+            HIP_CHECK(rocprim::radix_sort_keys(nullptr, temp_bytes, sample->as<unsigned long long>(), sample_sorted->as<unsigned long long>(), (size_t)kSamples, 0, 64,
+                                               ctx_->stream()));
+            BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
+            HIP_CHECK(rocprim::radix_sort_keys(temp->ptr(), temp_bytes, sample->as<unsigned long long>(), sample_sorted->as<unsigned long long>(), (size_t)kSamples, 0, 64,
+                                               ctx_->stream()));
+            BufferPtr flags = ctx_->alloc((size_t)n * 4), offsets = ctx_->alloc((size_t)n * 4);
+            flag_candidates_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(codes->as<unsigned long long>(), n, sample_sorted->as<unsigned long long>() + (want - 1),
+                                                                                     flags->as<int>());
+            check_launch("flag_candidates");
+            k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), offsets->as<int32_t>(), n, scalar->as<int64_t>());
+            BufferPtr crow = ctx_->alloc((size_t)n * 4), ccode = ctx_->alloc((size_t)n * 8);
+            compact_candidates_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(flags->as<int>(), offsets->as<int>(), codes->as<unsigned long long>(), n, crow->as<int>(),
+                                                                                        ccode->as<unsigned long long>());
+            check_launch("compact_candidates");
+            m = ctx_->read_scalar(scalar->as<long long>());
+            TG_CHECK_STATE(m >= want && m <= n, "candidate count out of range");
+            rows = crow;
+            codes = ccode;
+        }
+        if (m > std::max<int64_t>(8 * want, 1 << 18)) {
+            // still many candidates (coarse codes): order them by code and keep everything up to the ties of the n-th code
+            BufferPtr codes_sorted = ctx_->alloc((size_t)m * 8), rows_sorted = ctx_->alloc((size_t)m * 4);
+            size_t temp_bytes = 0;
+            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, temp_bytes, codes->as<unsigned long long>(), codes_sorted->as<unsigned long long>(), rows->as<int>(),
+                                                rows_sorted->as<int>(), (size_t)m, 0, 64, ctx_->stream()));
+            BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
+            HIP_CHECK(rocprim::radix_sort_pairs(temp->ptr(), temp_bytes, codes->as<unsigned long long>(), codes_sorted->as<unsigned long long>(), rows->as<int>(),
+                                                rows_sorted->as<int>(), (size_t)m, 0, 64, ctx_->stream()));
+            candidate_count_kernel<<<1, 64, 0, ctx_->stream()>>>(codes_sorted->as<unsigned long long>(), m, want, scalar->as<long long>());
+            check_launch("candidate_count");
+            const int64_t m2 = ctx_->read_scalar(scalar->as<long long>());
+            TG_CHECK_STATE(m2 >= want && m2 <= m, "candidate count out of range");
+            m = m2;
+            rows = rows_sorted;
+        }
     }
-    const int64_t m = ctx_->read_scalar(cand->as<long long>());
-    TG_CHECK_STATE(m >= want && m <= n, "candidate count out of range");
     // the candidates, ordered by the full comparator
     BufferPtr sorted = ctx_->alloc((size_t)m * 4);
     {
@@ -216,6 +278,7 @@ void TopNGpu::add_page(const DevicePage &page)
         ProfileScope ps(ctx_, "topn_gather");
         for (auto &c : page.cols) winners.cols.push_back(k::gather_column(ctx_, c, pos->as<int32_t>(), count, false));
     }
+    sorted_ = kept_.position_count() == 0;   // a single page's winners are already the answer, in order
     kept_.add_page(winners);
     // many small pages: fold the store back to n rows now and then
     if (kept_.position_count() > std::max<int64_t>(4 * n_, 1 << 16)) {
@@ -223,6 +286,7 @@ void TopNGpu::add_page(const DevicePage &page)
         PagesIndexGpu fresh(ctx_, types_);
         fresh.add_page(folded);
         kept_ = std::move(fresh);
+        sorted_ = true;
     }
 }
 
@@ -238,6 +302,7 @@ DevicePage TopNGpu::result()
         for (size_t i = 0; i < types_.size(); i++) out.cols.push_back(kept_.column((int)i));
         return out;
     }
+    if (sorted_) return all;
     BufferPtr pos = top_positions(all, count);
     out.n = count;
     ProfileScope ps(ctx_, "topn_gather");
