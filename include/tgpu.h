@@ -231,6 +231,15 @@ int32_t tgpu_top_n_factory_create(tgpu_context *ctx, int32_t operator_id, int32_
                                   int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
                                   tgpu_operator_factory **out);
 
+/* OrderByOperator.OrderByOperatorFactory (M/operator/OrderByOperator.java:48-131): every input row, in the order of the sort channels
+ * (PagesIndex.sort, M/operator/PagesIndex.java:386-394, with the same row order as TopN above); output_channels selects the channels
+ * of the output page.  Rows that compare equal come out in input order (the reference's quicksort leaves their order unspecified).
+ * The sorted rows are emitted as one page (the reference cuts them into <= 1 MB pages, :270-296). */
+int32_t tgpu_order_by_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types,
+                                     int32_t output_channel_count, const int32_t *output_channels, int32_t expected_positions,
+                                     int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
+                                     tgpu_operator_factory **out);
+
 /* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory);

@@ -1170,9 +1170,36 @@ int32_t o_compare_rows(const o_column *cols, const int32_t *sort_channels, const
     return 0;
 }
 
+/* every row in sort order: bottom-up merge sort, stable (the left run wins ties), what PagesIndex.sort (M/operator/PagesIndex.java
+ * :386-394) computes up to the order of rows that compare equal */
+static void sort_all_rows(const o_column *cols, int32_t rows, const int32_t *sort_channels, const int32_t *sort_orders, int32_t n_sort, int32_t *pos)
+{
+    int32_t *tmp = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1));
+    for (int32_t i = 0; i < rows; i++) pos[i] = i;
+    for (int32_t width = 1; width < rows; width *= 2) {
+        for (int32_t lo = 0; lo < rows; lo += 2 * width) {
+            int32_t mid = lo + width < rows ? lo + width : rows, hi = lo + 2 * width < rows ? lo + 2 * width : rows;
+            int32_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) tmp[k++] = o_compare_rows(cols, sort_channels, sort_orders, n_sort, pos[j], pos[i]) < 0 ? pos[j++] : pos[i++];
+            while (i < mid) tmp[k++] = pos[i++];
+            while (j < hi) tmp[k++] = pos[j++];
+        }
+        memcpy(pos, tmp, sizeof(int32_t) * (size_t)rows);
+    }
+    free(tmp);
+}
+
 int32_t o_top_n(const o_column *cols, int32_t rows, int32_t n, const int32_t *sort_channels, const int32_t *sort_orders, int32_t n_sort,
                 int32_t *positions_out)
 {
+    if (n > 64) {   /* large n (OrderBy: n = rows): sort everything, keep the first n -- the same rows in the same order */
+        int32_t *all = (int32_t *)malloc(sizeof(int32_t) * (size_t)(rows > 0 ? rows : 1));
+        sort_all_rows(cols, rows, sort_channels, sort_orders, n_sort, all);
+        int32_t k = n < rows ? n : rows;
+        memcpy(positions_out, all, sizeof(int32_t) * (size_t)k);
+        free(all);
+        return k;
+    }
     /* row-at-a-time, like the reference's per-row heap insert: a sorted buffer of at most n rows; a new row goes behind every kept
      * row that does not sort after it (input order among equals) and pushes the last one out */
     int32_t kept = 0;

@@ -78,6 +78,7 @@ SYMBOLS = {
     "tgpu_lookup_source_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     "tgpu_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
     "tgpu_top_n_factory_create": (i32, [vp, i32, i32, P(i32), C.c_int64, i32, P(i32), P(i32), P(vp)]),
+    "tgpu_order_by_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, i32, P(i32), P(i32), P(vp)]),
     "tgpu_filter_project_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), P(PageProcessorSpec), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
     "tgpu_filter_project_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, P(vp)]),
     "tgpu_operator_factory_create_operator": (i32, [vp, P(vp)]),

@@ -258,6 +258,23 @@ int32_t tgpu_top_n_factory_create(tgpu_context *ctx, int32_t operator_id, int32_
     });
 }
 
+int32_t tgpu_order_by_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types,
+                                     int32_t output_channel_count, const int32_t *output_channels, int32_t expected_positions,
+                                     int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
+                                     tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out, "null argument");
+        (void)expected_positions;   // a sizing hint of the reference's PagesIndex; the device store grows by doubling
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<OrderByOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), vec(output_channels, output_channel_count),
+                                                        vec(sort_channels, sort_channel_count), vec(sort_orders, sort_channel_count));
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
 void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge)
 {
     if (!bridge) return;

@@ -614,4 +614,68 @@ std::unique_ptr<Operator> TopNOperatorFactory::create_operator()
     return std::make_unique<TopNOperator>(ctx_, operator_id_, types_, n_, sort_channels_, sort_orders_);
 }
 
+// =====================================================================================================================
+// OrderByOperator (M/operator/OrderByOperator.java:160-300): PagesIndex.addPage per input page, one sort at finish()
+// =====================================================================================================================
+class OrderByOperator : public Operator {
+public:
+    OrderByOperator(Context *ctx, int32_t id, const std::vector<int32_t> &types, const std::vector<int32_t> &output_channels,
+                    const std::vector<int32_t> &sort_channels, const std::vector<int32_t> &sort_orders)
+        : Operator(ctx, id), types_(types), output_channels_(output_channels), sort_channels_(sort_channels), sort_orders_(sort_orders), index_(ctx, types)
+    {
+    }
+
+    bool needs_input() override { return !finishing_; }
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        DevicePage in = ingest_page(ctx_, page);
+        TG_CHECK_ARG(in.cols.size() == types_.size(), "page channel count does not match the operator's types");
+        for (size_t i = 0; i < types_.size(); i++) TG_CHECK_ARG(in.cols[i].type == types_[i], "page channel type does not match the operator's types");
+        index_.add_page(in);
+    }
+
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (!finishing_ || finished_) return nullptr;
+        finished_ = true;
+        DevicePage all;
+        all.n = index_.position_count();
+        if (all.n == 0) return nullptr;
+        for (size_t i = 0; i < types_.size(); i++) all.cols.push_back(index_.column((int)i));
+        int64_t count = 0;
+        BufferPtr pos = TopNGpu::sorted_positions(ctx_, all, sort_channels_, sort_orders_, all.n, count);
+        DevicePage out;
+        out.n = count;
+        for (int32_t ch : output_channels_) out.cols.push_back(k::gather_column(ctx_, all.cols[(size_t)ch], pos->as<int32_t>(), count, false));
+        return wrap(std::move(out));
+    }
+
+    void finish() override { finishing_ = true; }
+    bool is_finished() override { return finished_ || (finishing_ && index_.position_count() == 0); }
+    int64_t memory_bytes() override { return index_.estimated_size(); }
+
+private:
+    std::vector<int32_t> types_, output_channels_, sort_channels_, sort_orders_;
+    PagesIndexGpu index_;
+    bool finishing_ = false, finished_ = false;
+};
+
+OrderByOperatorFactory::OrderByOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> output_channels,
+                                               std::vector<int32_t> sort_channels, std::vector<int32_t> sort_orders)
+    : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), output_channels_(std::move(output_channels)), sort_channels_(std::move(sort_channels)),
+      sort_orders_(std::move(sort_orders))
+{
+    TopNGpu check(ctx_, types_, 1, sort_channels_, sort_orders_);   // validates types / sort channels / sort orders
+    (void)check;
+    for (int32_t ch : output_channels_) TG_CHECK_ARG(ch >= 0 && ch < (int)types_.size(), "output channel out of range");
+}
+
+std::unique_ptr<Operator> OrderByOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<OrderByOperator>(ctx_, operator_id_, types_, output_channels_, sort_channels_, sort_orders_);
+}
+
 }  // namespace tgpu

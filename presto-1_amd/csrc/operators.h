@@ -184,6 +184,19 @@ private:
     int64_t n_;
 };
 
+// ---- OrderByOperator (M/operator/OrderByOperator.java:48-131,160-300) ----------------------------------------------------
+class OrderByOperatorFactory : public OperatorFactory {
+public:
+    OrderByOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> output_channels, std::vector<int32_t> sort_channels,
+                           std::vector<int32_t> sort_orders);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> types_, output_channels_, sort_channels_, sort_orders_;
+};
+
 }  // namespace tgpu
 
 struct tgpu_context {

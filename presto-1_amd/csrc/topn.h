@@ -18,9 +18,13 @@ public:
     DevicePage result();
     int64_t estimated_size() const { return kept_.estimated_size(); }
 
+    // row numbers of `page`'s first min(limit, rows) rows in the order of the sort channels (rows that compare equal keep their
+    // input order); limit >= rows sorts the whole page (OrderByOperator)
+    static BufferPtr sorted_positions(Context *ctx, const DevicePage &page, const std::vector<int32_t> &sort_channels, const std::vector<int32_t> &sort_orders,
+                                      int64_t limit, int64_t &count);
+
 private:
-    // row numbers of `page`'s first min(n, rows) rows in sort order
-    BufferPtr top_positions(const DevicePage &page, int64_t &count);
+    BufferPtr top_positions(const DevicePage &page, int64_t &count) { return sorted_positions(ctx_, page, sort_channels_, sort_orders_, n_, count); }
     Context *ctx_;
     std::vector<int32_t> types_, sort_channels_, sort_orders_;
     int64_t n_;

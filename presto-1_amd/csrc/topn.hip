@@ -186,10 +186,11 @@ TopNGpu::TopNGpu(Context *ctx, std::vector<int32_t> types, int64_t n, std::vecto
     for (int32_t t : types_) TG_CHECK_ARG(valid_type(t), "unknown type");
 }
 
-BufferPtr TopNGpu::top_positions(const DevicePage &page, int64_t &count)
+BufferPtr TopNGpu::sorted_positions(Context *ctx_, const DevicePage &page, const std::vector<int32_t> &sort_channels_, const std::vector<int32_t> &sort_orders_,
+                                    int64_t limit, int64_t &count)
 {
     const int64_t n = page.n;
-    const int64_t want = std::min<int64_t>(n_, n);
+    const int64_t want = std::min<int64_t>(limit, n);
     count = want;
     if (want == 0) return ctx_->alloc(4);
     TG_CHECK_ARG(n <= 0x7fffffffLL, "page too large");

@@ -270,6 +270,20 @@ class TopNOperatorFactory(OperatorFactory):
         super().__init__(h)
 
 
+class OrderByOperatorFactory(OperatorFactory):
+    """OrderByOperator.OrderByOperatorFactory (M/operator/OrderByOperator.java:48-131): all rows in the order of the sort channels."""
+
+    def __init__(self, ctx: Context, operator_id, types, output_channels, expected_positions, sort_channels, sort_orders):
+        t, nt = _i32(types)
+        oc, no = _i32(output_channels)
+        sc, ns = _i32(sort_channels)
+        so, nso = _i32(sort_orders)
+        assert ns == nso, "sort channels and sort orders differ in length"
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_order_by_factory_create(ctx.handle, operator_id, nt, t, no, oc, expected_positions, ns, sc, so, C.byref(h)))
+        super().__init__(h)
+
+
 class FilterProjectHashAggregationOperatorFactory(OperatorFactory):
     """FilterAndProjectOperator fused into HashAggregationOperator (HandTpchQuery1's pipeline shape): group_by_channels and the
     aggregates' channels index the page processor's projections; same results as the two reference operators back to back."""

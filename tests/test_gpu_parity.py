@@ -960,3 +960,36 @@ def test_top_n_matches_oracle(pkg, ctx, oracle, n_rows, n):
         got = np.concatenate([p.getBlock(4).values for p in out]) if out else np.zeros(0, dtype=np.int64)
         want = oracle.top_n(ocols, n, sort_channels, sort_orders)
         assert np.array_equal(got, want), (sort_channels, sort_orders)
+
+
+# ---- OrderBy (M/operator/OrderByOperator.java) ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["testSingleFieldKey", "testMultiFieldKey", "testReverseOrder"])
+def test_order_by_golden(pkg, ctx, name):
+    # T/operator/TestOrderByOperator.java:128-228
+    case = GOLD["order_by"][name]
+    types = [_TOPN_TYPES[t] for t in case["types"]]
+    pages = [pkg.Page(*[pkg.Block(t, [r[i] for r in pg]) for i, t in enumerate(types)]) for pg in case["pages"]]
+    fac = pkg.OrderByOperatorFactory(ctx, 0, types, case["output_channels"], 10, case["sort_channels"], [_SORT[o] for o in case["sort_orders"]])
+    out = pkg.to_pages(fac.createOperator(), pages)
+    assert [list(r) for p in out for r in p.rows()] == case["expect_rows"]
+
+
+def test_order_by_sequence_and_oracle(pkg, ctx, oracle):
+    # T/operator/TestOrderByOperator.java:90-126: 80 000-row sequence page sorted descending
+    n = 80_000
+    page = pkg.Page(pkg.Block(pkg.BIGINT, np.arange(n, dtype=np.int64)), pkg.Block(pkg.DOUBLE, np.arange(n, dtype=np.float64)))
+    fac = pkg.OrderByOperatorFactory(ctx, 0, [pkg.BIGINT, pkg.DOUBLE], [1], 10, [0], [pkg.DESC_NULLS_LAST])
+    out = pkg.to_pages(fac.createOperator(), [page])
+    got = np.concatenate([p.getBlock(0).values for p in out])
+    assert np.array_equal(got, np.arange(n, dtype=np.float64)[::-1])
+    # random multi-channel sort with nulls and ties over several pages == the oracle's order (equal rows in input order)
+    rng = np.random.default_rng(61)
+    m = 120_000
+    blocks = [rand_block(pkg, rng, pkg.BIGINT, m, 0.1, (-20, 20)), rand_block(pkg, rng, pkg.DOUBLE, m, 0.1), pkg.Block(pkg.BIGINT, np.arange(m, dtype=np.int64))]
+    types = [pkg.BIGINT, pkg.DOUBLE, pkg.BIGINT]
+    pages = [pkg.Page(*[pkg.Block(t, b.values[a:z], None if b.nulls is None else b.nulls[a:z]) for t, b in zip(types, blocks)]) for a, z in ((0, 50_000), (50_000, m))]
+    fac = pkg.OrderByOperatorFactory(ctx, 0, types, [2], 10, [0, 1], [pkg.ASC_NULLS_FIRST, pkg.DESC_NULLS_LAST])
+    out = pkg.to_pages(fac.createOperator(), pages)
+    got = np.concatenate([p.getBlock(0).values for p in out])
+    want = oracle.top_n([ocol(oracle, b) for b in blocks], m, [0, 1], [0, 3])
+    assert np.array_equal(got, want)

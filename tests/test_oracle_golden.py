@@ -250,3 +250,14 @@ def test_top_n_null_placement_and_double_order(oracle):
     assert order(1) == [6, 3, 4, 0, 5, 2, 1, 7]      # ASC_NULLS_LAST
     assert order(2) == [1, 7, 2, 5, 0, 4, 3, 6]      # DESC_NULLS_FIRST
     assert order(3) == [2, 5, 0, 4, 3, 6, 1, 7]      # DESC_NULLS_LAST
+
+
+@pytest.mark.parametrize("name", ["testSingleFieldKey", "testMultiFieldKey", "testReverseOrder"])
+def test_order_by_golden(oracle, name):
+    # T/operator/TestOrderByOperator.java:128-228: OrderBy = every row in the order TopN uses (n = all rows)
+    case = GOLD["order_by"][name]
+    rows = [r for page in case["pages"] for r in page]
+    types = [TYPE_ID[t] for t in case["types"]]
+    cols = [oracle.Col(t, [r[i] for r in rows]) for i, t in enumerate(types)]
+    pos = oracle.top_n(cols, len(rows), case["sort_channels"], [SORT_ORDER[o] for o in case["sort_orders"]])
+    assert [[rows[i][ch] for ch in case["output_channels"]] for i in pos] == case["expect_rows"]
