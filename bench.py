@@ -695,6 +695,9 @@ def main():
                      "workload": "tpch_q1_filter_project_hash_aggregation (BASELINE configs[2])",
                      "algorithmic_bytes_per_row": 46.0, "achieved_gbps_whole_step": 46.0 * n / s1 / 1e9, "frac_of_8TBps": 46.0 * n / s1 / 8e12,
                      "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])}}
+        # roofline of Q1's dominant kernel: the fused project+accumulate pass reads the 4-byte group id + four 8-byte inputs per row
+        out["q1"]["roofline"] = dominant(p1, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
+                                         {"fused_project_accumulate_lowcard": 36.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1()
         del b.q1, b.q1_page
         b.q1_result = None
@@ -708,6 +711,8 @@ def main():
                        "workload": "bigint_filter_project_sel10 (BASELINE configs[1])", "algorithmic_bytes_per_row": 10.4,
                        "achieved_gbps_whole_step": 10.4 * n2 / s2 / 1e9, "frac_of_8TBps": 10.4 * n2 / s2 / 8e12,
                        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p2.items(), key=lambda kv: -kv[1]["total_ms"])}}
+        # pass 1 streams the 8-byte filter column of every row
+        out["cfg2"]["roofline"] = dominant(p2, {"filter_count": n2}, {"filter_count": 8.0})
         out["checks"]["cfg2"] = b.check_cfg2()
         del b.c2, b.c2_page
         b.c2_out = None

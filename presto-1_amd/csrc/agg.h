@@ -39,8 +39,13 @@ public:
         long long *limbs;
         unsigned int *special;
         unsigned long long *i128;
+        double *dsum;   // ORDERED mode (limbs / special are null then)
     };
     void reserve(int64_t groups) { ensure(groups > 0 ? groups : 1); }
+    // For callers that run their own accumulate kernels (the JIT-fused operator): fixes the mode with the caller's own
+    // low-cardinality capacity; when the accumulators are (now) ORDERED, reserves the states and returns the page's
+    // (group id + 1, row) pairs in (group, row) order -- the caller then adds the rows of every group in that order.
+    bool begin_ordered(const int32_t *gids, int64_t n, int64_t groups, int64_t lowcard_max_groups, BufferPtr &keys, BufferPtr &rows);
     // the JIT-fused accumulate kernels address the exact (limb) state directly: they keep the accumulators out of ORDERED mode
     void set_allow_ordered(bool on) { allow_ordered_ = on; }
     bool ordered() const { return mode_ == Mode::ORDERED; }
@@ -62,7 +67,7 @@ private:
     };
     enum class Mode { UNDECIDED, EXACT, ORDERED };
     void ensure(int64_t groups);
-    void decide_mode(int64_t groups, int64_t n);
+    void decide_mode(int64_t groups, int64_t lowcard_max_groups);
     void sort_rows_by_group(const int32_t *gids, int64_t n, int64_t groups, BufferPtr &keys, BufferPtr &rows);
     Mode mode_ = Mode::UNDECIDED;
     bool allow_ordered_ = false;

@@ -375,6 +375,7 @@ GroupedAccumulators::DeviceState GroupedAccumulators::device_state(int k) const
     d.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
     d.special = st.special ? st.special->as<unsigned int>() : nullptr;
     d.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+    d.dsum = st.dsum ? st.dsum->as<double>() : nullptr;
     return d;
 }
 
@@ -451,12 +452,21 @@ static int64_t lowcard_bytes_per_group(const std::vector<tgpu_agg_spec> &specs)
 
 // The mode is fixed by the first page: ORDERED when it is allowed, the page has group ids and its groups do not fit the
 // low-cardinality LDS path; else EXACT.
-void GroupedAccumulators::decide_mode(int64_t groups, int64_t n)
+void GroupedAccumulators::decide_mode(int64_t groups, int64_t lowcard_max_groups)
 {
     if (mode_ != Mode::UNDECIDED) return;
-    (void)n;
-    const bool many = groups * lowcard_bytes_per_group(specs()) > 160 * 1024;
+    const bool many = groups > lowcard_max_groups;
     mode_ = (allow_ordered_ && many && getenv("TGPU_DISABLE_ORDERED") == nullptr) ? Mode::ORDERED : Mode::EXACT;
+}
+
+bool GroupedAccumulators::begin_ordered(const int32_t *gids, int64_t n, int64_t groups, int64_t lowcard_max_groups, BufferPtr &keys, BufferPtr &rows)
+{
+    if (!gids || n <= 0) return false;
+    decide_mode(groups > 0 ? groups : 1, lowcard_max_groups);
+    if (mode_ != Mode::ORDERED) return false;
+    ensure(groups > 0 ? groups : 1);
+    sort_rows_by_group(gids, n, groups, keys, rows);
+    return true;
 }
 
 // (group id + 1, row) pairs of the page in (group, row) order: stable LSD radix sort on the bits the group ids use
@@ -480,7 +490,7 @@ void GroupedAccumulators::sort_rows_by_group(const int32_t *gids, int64_t n, int
 void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
 {
     if (states_.empty() || n <= 0) return;
-    if (gids) decide_mode(group_count > 0 ? group_count : 1, n);
+    if (gids) decide_mode(group_count > 0 ? group_count : 1, (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1));
     else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
     ensure(group_count > 0 ? group_count : 1);
     AggArgs args{};
@@ -548,6 +558,7 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
             states.st[k].limbs = args.a[k].limbs;
             states.st[k].special = args.a[k].special;
             states.st[k].i128 = args.a[k].i128;
+            states.st[k].dsum = nullptr;
         }
         agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, states, plan, gids, n);
         check_launch("agg_accumulate_lowcard");
@@ -561,7 +572,7 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
 void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
 {
     if (states_.empty() || n <= 0) return;
-    if (gids) decide_mode(group_count > 0 ? group_count : 1, n);
+    if (gids) decide_mode(group_count > 0 ? group_count : 1, (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1));
     else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
     ensure(group_count > 0 ? group_count : 1);
     AggArgs args{};

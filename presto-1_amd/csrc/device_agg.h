@@ -22,6 +22,7 @@ struct TgAggState {
     long long *limbs;             // int64[g][TG_LIMBS]   exact accumulator of double sums
     unsigned int *special;        // uint32[g]            NaN / +inf / -inf seen
     unsigned long long *i128;     // uint64[g][2]         bigint sums
+    double *dsum;                 // double[g]            ORDERED mode: plain running sum (limbs / special are null then)
 };
 
 // exact, order-independent accumulation of one double into the limb array of its group

@@ -1463,6 +1463,8 @@ struct FaArgs {
   long long tiles;
   int lowcard;
   int pad;
+  const unsigned int* ord_keys;   // ORDERED mode: (group id + 1) of the page's rows in (group, row) order, 0 = filtered row
+  const int* ord_rows;            //               and their row numbers
 };
 #define FA_STRIPES @FA_STRIPES@
 #define FA_TILE (FA_STRIPES * 256)
@@ -1525,6 +1527,15 @@ extern "C" __global__ void __launch_bounds__(256) fa_accumulate_lowcard(FaArgs F
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F) {
   fa_accumulate_body<false>(F, (unsigned char*)0);
 }
+
+extern "C" __global__ void __launch_bounds__(256) fa_accumulate_ordered(FaArgs F) {
+  const FpArgs& A = F.fp;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (long long)gridDim.x * 256) {
+    const unsigned int key = F.ord_keys[i];
+    if (key == 0 || (i > 0 && F.ord_keys[i - 1] == key)) continue;
+    tg_accumulate_group_ordered(F, A, i, A.n);
+  }
+}
 )SRC";
 
 // host mirror of the generated FaArgs
@@ -1539,6 +1550,7 @@ struct FaArgsHost {
         long long *limbs;
         unsigned int *special;
         unsigned long long *i128;
+        double *dsum;
     } st[16];
     struct Plan {
         int32_t n_aggs, n_wide;
@@ -1552,6 +1564,8 @@ struct FaArgsHost {
     long long tiles;
     int32_t lowcard;
     int32_t pad;
+    const unsigned int *ord_keys;
+    const int *ord_rows;
 };
 
 }  // namespace
@@ -1713,7 +1727,7 @@ void FusedAggGpu::generate()
     Gen gr(nodes_, pool_, input_types_);
     gr.reg_mode = true;
     gr.tmp = gm.tmp;
-    std::ostringstream eval, lc_read, lc_upd, lc_write, gl, nf_any, nf_slow, nf_clear;
+    std::ostringstream eval, lc_read, lc_upd, lc_write, gl, nf_any, nf_slow, nf_clear, ord_decl, ord_upd, ord_write;
     for (size_t k = 0; k < aggs_.size(); k++) {
         const tgpu_agg_spec &a = aggs_[k];
         const int w = wide_slot_[k];
@@ -1771,6 +1785,20 @@ void FusedAggGpu::generate()
                    << " += (v_ < 0 ? -1 : 0) + (n_ < bl" << w << " ? 1 : 0); bl" << w << " = n_; }\n";
             lc_write << "  ((unsigned long long*)hi_base)[" << w << " * 256 + threadIdx.x] = bl" << w << "; ((long long*)lo_base)[" << w << " * 256 + threadIdx.x] = bh" << w << ";\n";
         }
+        // ORDERED mode: the rows of one group are added by one lane, in row order, into plain locals
+        ord_decl << "    long long oc" << k << " = 0;";
+        if (is_dbl) ord_decl << " double os" << k << " = F.st[" << k << "].dsum[g];";
+        if (is_big) ord_decl << " __int128 ob" << k << " = 0;";
+        ord_decl << "\n";
+        ord_upd << "      if (t" << k << ") { oc" << k << "++;";
+        if (is_dbl) ord_upd << " os" << k << " += x" << k << ";";
+        if (is_big) ord_upd << " ob" << k << " += y" << k << ";";
+        ord_upd << " }\n";
+        ord_write << "    if (oc" << k << ") F.st[" << k << "].counts[g] += oc" << k << ";\n";
+        if (is_dbl) ord_write << "    F.st[" << k << "].dsum[g] = os" << k << ";\n";
+        if (is_big)
+            ord_write << "    if (ob" << k << " != 0) { unsigned long long* p_ = &F.st[" << k << "].i128[(size_t)g * 2]; const unsigned __int128 n_ = (((unsigned __int128)p_[1] << 64) | p_[0]) + (unsigned __int128)ob"
+                      << k << "; p_[0] = (unsigned long long)n_; p_[1] = (unsigned long long)(n_ >> 64); }\n";
         // global: exact atomics per row
         gl << "  if (t" << k << ") {\n    atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], 1ULL);\n";
         if (is_dbl) gl << "    tg_kulisch_add(&F.st[" << k << "].limbs[(size_t)g * TG_LIMBS], &F.st[" << k << "].special[g], x" << k << ");\n";
@@ -2166,6 +2194,13 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
         << "  cnt_base[" << rows_slot_ << " * 256 + threadIdx.x] = rows_;\n}\n";
     src << "__device__ inline void tg_accumulate_row_gl(const FaArgs& F, const FpArgs& A, long long row, const TgRow& R, int g) {\n" << cols_decl(gr) << "  (void)row;\n"
         << eval_all << gl.str() << "}\n";
+    // many groups, ORDERED mode (agg.h): the lane that owns a group's first row in (group, row) order walks the group's rows and
+    // adds them in row order -- the order of the reference's per-position loop -- into plain doubles (NaN / inf flow through
+    // the additions as in Java: no special flags here)
+    src << "__device__ inline void tg_accumulate_group_ordered(const FaArgs& F, const FpArgs& A, long long i, long long n) {\n" << cols_decl(gr)
+        << "  const unsigned int key = F.ord_keys[i];\n  const long long g = (long long)key - 1;\n" << ord_decl.str()
+        << "  for (long long j = i; j < n && F.ord_keys[j] == key; j++) {\n    const long long row = F.ord_rows[j];\n    TgRow R;\n    tg_load_row(A, row, R);\n"
+        << eval.str() << ord_upd.str() << "  }\n" << ord_write.str() << "}\n";
     std::string tail = kernels.substr(split);
     const std::string tag = "@FA_STRIPES@";
     tail.replace(tail.find(tag), tag.size(), std::to_string(fa_stripes()));
@@ -2288,7 +2323,9 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
     JitModule *module = module_for(in);
     if (in.n == 0) return;
-    accs.reserve(groups);
+    BufferPtr ord_keys, ord_rows;
+    const bool ordered = gids != nullptr && accs.begin_ordered(gids, in.n, groups, max_groups_, ord_keys, ord_rows);
+    if (!ordered) accs.reserve(groups);
     FaArgsHost F{};
     fill_fp_cols(F.fp, in);
     BufferPtr err = ctx->alloc(8);
@@ -2302,6 +2339,16 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
         F.st[k].limbs = d.limbs;
         F.st[k].special = d.special;
         F.st[k].i128 = d.i128;
+        F.st[k].dsum = d.dsum;
+    }
+    if (ordered) {
+        F.ord_keys = ord_keys->as<unsigned int>();
+        F.ord_rows = ord_rows->as<int>();
+        ProfileScope ps(ctx, "fused_project_accumulate_ordered");
+        const int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8);
+        launch_args(module->fn("fa_accumulate_ordered"), (int)blocks, F, ctx->stream());
+        raise_if_error(ctx, err);
+        return;
     }
     F.plan.n_aggs = (int32_t)aggs_.size();
     F.plan.n_wide = n_wide_;

@@ -153,8 +153,7 @@ protected:
         accs_->set_allow_ordered(allow_ordered_accumulation());
         builder_ = true;
     }
-    // many groups: rows sorted by group id, one lane per group adds them in row order (agg.h); the JIT-fused accumulate kernels
-    // work on the exact state only
+    // many groups: rows sorted by group id, one lane per group adds them in row order (agg.h)
     virtual bool allow_ordered_accumulation() const { return true; }
     void reset_builder()
     {
@@ -507,8 +506,6 @@ public:
         : HashAggregationOperator(ctx, id, cfg), processor_(std::move(processor)), fused_(std::move(fused))
     {
     }
-
-    bool allow_ordered_accumulation() const override { return false; }
 
     void add_input(const tgpu_page *page) override
     {

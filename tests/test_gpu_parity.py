@@ -814,9 +814,11 @@ def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle
         out = pkg.to_pages(fac.createOperator(), [page, pkg.Page(*[pkg.Block(t, []) for t in T]), page])
         results[mode] = [r for p in out for r in p.rows()]
         prof = ctx.profile()
-        assert ("fused_project_accumulate_lowcard" in prof or "fused_project_accumulate" in prof) == (mode == "fused")
+        assert ("fused_project_accumulate_lowcard" in prof or "fused_project_accumulate_ordered" in prof) == (mode == "fused")
         if mode == "fused":
             assert ("fused_project_accumulate_lowcard" in prof) == (ngroups == 4)
+        else:
+            assert ("agg_accumulate_ordered" in prof) == (ngroups != 4)
         ctx.close()
     a, b = results["fused"], results["unfused"]
     assert len(a) == len(b) and [r[:2] for r in a] == [r[:2] for r in b]        # same groups in the same (first-seen) order
@@ -824,14 +826,8 @@ def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle
         assert ra[5] == rb[5] and ra[7] == rb[7] and ra[9] == rb[9] and ra[10] == rb[10]
         fa_ = [np.nan if x is None else x for x in (ra[2], ra[3], ra[4], ra[6], ra[8])]
         fb_ = [np.nan if x is None else x for x in (rb[2], rb[3], rb[4], rb[6], rb[8])]
-        if ngroups == 4:
-            assert ulp_diff(fa_, fb_).max() == 0
-        else:
-            # many groups: the unfused operator sums in row order (ORDERED mode, == the Java loop), the fused kernels keep the exact
-            # accumulators; the two differ by the row order's own rounding only (<= rows-per-group * eps, relative: no cancellation
-            # to speak of in these inputs)
-            for x, y in zip(fa_, fb_):
-                assert (np.isnan(x) and np.isnan(y)) or abs(x - y) <= 1e-12 * max(abs(x), abs(y), 1.0)
+        # few groups: both feed the exact accumulators; many groups: both sum in row order (ORDERED mode) -- identical bits either way
+        assert ulp_diff(fa_, fb_).max() == 0
     # oracle composition: filter -> projections -> MultiChannelGroupByHash -> exact sums
     prog = pkg.expressions.FlatProgram(filt, projs)
     cols = [ocol(oracle, blk) for blk in page.blocks]
@@ -842,9 +838,14 @@ def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle
     ng = og.group_count
     assert ng == len(a)
     v3, n3 = oracle.project(prog.nodes, prog.projection_roots[3], b"", cols, pos)
-    cnt3, sum3 = oracle.agg_double_sum_exact(gids, v3, ng, nulls=n3)
     got3 = np.array([np.nan if r[3] is None else r[3] for r in a])
-    want3 = np.where(cnt3 > 0, 2 * sum3, np.nan)   # the page was fed twice: exact doubling
+    if ngroups == 4:
+        cnt3, sum3 = oracle.agg_double_sum_exact(gids, v3, ng, nulls=n3)
+        want3 = np.where(cnt3 > 0, 2 * sum3, np.nan)   # the page was fed twice: exact doubling
+    else:
+        # many groups: row-order sums, the page's rows twice in a row (Java-order oracle, bit-identical)
+        cnt3, sum3 = oracle.agg_double_sum(np.concatenate([gids, gids]), np.concatenate([v3, v3]), ng, nulls=np.concatenate([n3, n3]))
+        want3 = np.where(cnt3 > 0, sum3, np.nan)
     assert ulp_diff(got3, want3).max() == 0
     assert [r[5] for r in a] == list(2 * oracle.agg_count(gids, len(pos), ng))
 
