@@ -461,9 +461,10 @@ void GroupedAccumulators::decide_mode(int64_t groups, int64_t lowcard_max_groups
 
 bool GroupedAccumulators::begin_ordered(const int32_t *gids, int64_t n, int64_t groups, int64_t lowcard_max_groups, BufferPtr &keys, BufferPtr &rows)
 {
-    if (!gids || n <= 0) return false;
-    decide_mode(groups > 0 ? groups : 1, lowcard_max_groups);
+    if (n <= 0) return false;
+    decide_mode(groups > 0 ? groups : 1, lowcard_max_groups);   // the first page fixes the mode, whatever path it takes
     if (mode_ != Mode::ORDERED) return false;
+    TG_CHECK_STATE(gids != nullptr, "ordered accumulation needs int32 group ids");
     ensure(groups > 0 ? groups : 1);
     sort_rows_by_group(gids, n, groups, keys, rows);
     return true;

@@ -18,6 +18,9 @@ struct GbhProbeLaunch {
     int32_t store_groups;
     int32_t *out;
     unsigned long long *counters;   // [0] pending rows, [2] table-full error
+    // compact mode (out == nullptr): one byte per row = group id + 1, 0 = row rejected by the fused filter, 255 = the row joined /
+    // created a group that is new in this sub-batch (counted in counters[0]; the sub-batch is then re-run in int32 mode)
+    uint8_t *out8 = nullptr;
 };
 using GbhProbeFn = std::function<void(const GbhProbeLaunch &)>;
 
@@ -30,8 +33,11 @@ public:
     // row_mask (optional, one byte per row): rows with 0 take no part and get id -1 (a filter fused in front of the table).
     // inline_hash: with hashes == nullptr, compute the raw hash inside the probe kernel instead of materialising it.
     // probe: optional external probe/insert kernel (replaces the generic one; it applies its own row filter)
-    void get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
-                       const uint8_t *row_mask = nullptr, bool inline_hash = false, const GbhProbeFn *probe = nullptr);
+    // out_gids8 (optional, with an external probe kernel): while the table holds fewer than 250 groups the ids are delivered as one
+    // byte per row (group id + 1, 0 = excluded row) instead of four -- on TPCH Q1's shape that is a tenth of the whole
+    // pipeline's HBM traffic.  Returns true when out_gids8 holds the page's ids (out_gids untouched), false when out_gids does.
+    bool get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
+                       const uint8_t *row_mask = nullptr, bool inline_hash = false, const GbhProbeFn *probe = nullptr, uint8_t *out_gids8 = nullptr);
     // lookup only (GroupByHash.contains): out[i] = group id or -1
     void lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids);
 
@@ -76,6 +82,7 @@ private:
     int64_t raw_hash_cap_ = 0;
     int32_t java_capacity_, java_max_fill_, java_rehashes_ = 0;
     int64_t sub_batch_;
+    int64_t last_new_groups_ = 0;   // new groups of the previous sub-batch (decides whether the next one ranks eagerly)
     int64_t next_sub_ = 0;   // size of the next sub-batch (ramps up, see get_group_ids)
     BufferPtr counters_;  // [0] pending rows, [1] new groups (scan total), [2] error flag, [3] scratch total
 };

@@ -98,6 +98,12 @@ __global__ void __launch_bounds__(kBlock) gbh_probe_kernel(const KeyCols *batch_
     }
 }
 
+// compact ids of a sub-batch that went through the full protocol: byte = final group id + 1 (0 = excluded row)
+__global__ void __launch_bounds__(kBlock) gbh_narrow_kernel(const int32_t *__restrict__ gids, int64_t n, uint8_t *__restrict__ out8)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) out8[r] = (uint8_t)(gids[r] + 1);
+}
+
 __global__ void __launch_bounds__(kBlock) gbh_mark_kernel(const int32_t *__restrict__ out, int64_t n, const uint64_t *__restrict__ words, int32_t *__restrict__ flags)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
@@ -366,12 +372,15 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
         gbh_mark_kernel<<<g, kBlock, 0, ctx_->stream()>>>(out, n, words_->as<uint64_t>(), flags->as<int32_t>());
         k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), rank->as<int32_t>(), n, (int64_t *)&ctr[1]);
     };
-    const bool eager = n <= (1ll << 22);
+    const bool eager = n <= (1ll << 22) && (groups_ == 0 || last_new_groups_ > 0);   // new groups are likely: worth the two passes up front
     if (eager) mark_and_rank();
     unsigned long long host_ctr[3];
     ctx_->download(host_ctr, ctr, sizeof(host_ctr));
     if (host_ctr[2] != 0) return false;  // table overflow
-    if (host_ctr[0] == 0) return true;   // every row hit an existing group
+    if (host_ctr[0] == 0) {              // every row hit an existing group
+        last_new_groups_ = 0;
+        return true;
+    }
     int64_t new_groups = (int64_t)host_ctr[1];
     if (!eager) {
         mark_and_rank();
@@ -410,6 +419,7 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
         check_launch("gbh_resolve");
     }
     groups_ += new_groups;
+    last_new_groups_ = new_groups;
     *new_groups_out = new_groups;
     advance_java_capacity();
     return true;
@@ -431,12 +441,18 @@ void GroupByHashGpu::rebuild_table(int64_t min_capacity)
     capacity_ = want;
 }
 
-void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
-                                   const uint8_t *row_mask, bool inline_hash, const GbhProbeFn *probe)
+bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
+                                   const uint8_t *row_mask, bool inline_hash, const GbhProbeFn *probe, uint8_t *out_gids8)
 {
     TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
     for (size_t i = 0; i < keys.size(); i++) TG_CHECK_ARG(keys[i]->type == types_[i], "group-by key channel type mismatch");
-    if (n <= 0) return;
+    if (n <= 0) return false;
+    constexpr int64_t kCompactGroups = 250;   // ids + 1 must stay below the 255 marker
+    bool compact = out_gids8 != nullptr && probe != nullptr && groups_ < kCompactGroups;
+    if (out_gids8 != nullptr && !compact) {   // no external probe kernel, or already too many groups for a byte
+        (void)get_group_ids(keys, hashes, n, out_gids, row_mask, inline_hash, probe, nullptr);
+        return false;
+    }
     BufferPtr own_hashes;
     if (!hashes && !inline_hash) {
         own_hashes = ctx_->alloc((size_t)n * 8);
@@ -460,8 +476,38 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
         std::vector<const DeviceColumn *> vp;
         for (auto &v : views) vp.push_back(&v);
         int64_t new_groups = 0;
-        const bool ok = process_sub_batch(key_cols_of(vp), hashes ? hashes + start : nullptr, row_mask ? row_mask + start : nullptr, start, len,
-                                          out_gids + start, probe, &new_groups);
+        bool ok = true;
+        if (compact) {
+            // compact attempt: the probe kernel answers with one byte per row; rows that meet a group that is new in this
+            // sub-batch are only counted
+            ensure_table(groups_ + std::min<int64_t>(len, sub_batch_));
+            ensure_store(groups_ > 0 ? groups_ : 1);
+            unsigned long long *ctr = counters_->as<unsigned long long>();
+            HIP_CHECK(hipMemsetAsync(ctr, 0, 8 * 8, ctx_->stream()));
+            GbhProbeLaunch l{start, len, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), nullptr, ctr,
+                             out_gids8 + start};
+            (*probe)(l);
+            unsigned long long host_ctr[3];
+            ctx_->download(host_ctr, ctr, sizeof(host_ctr));
+            ok = host_ctr[2] == 0;
+            if (ok && host_ctr[0] != 0) {
+                // new groups: the full protocol on a temporary int32 buffer (the re-run finds the slots it has just claimed), then
+                // the final ids are narrowed
+                BufferPtr tmp = ctx_->alloc((size_t)len * 4);
+                ok = process_sub_batch(key_cols_of(vp), nullptr, nullptr, start, len, tmp->as<int32_t>(), probe, &new_groups);
+                if (ok) {
+                    if (groups_ < kCompactGroups) {
+                        gbh_narrow_kernel<<<grid_for(ctx_, len), kBlock, 0, ctx_->stream()>>>(tmp->as<int32_t>(), len, out_gids8 + start);
+                        check_launch("gbh_narrow");
+                    }
+                    else compact = false;   // too many groups for a byte: the page is redone in int32 below
+                }
+            }
+            else if (ok) last_new_groups_ = 0;
+        }
+        else
+            ok = process_sub_batch(key_cols_of(vp), hashes ? hashes + start : nullptr, row_mask ? row_mask + start : nullptr, start, len, out_gids + start, probe,
+                                   &new_groups);
         if (!ok) {
             rebuild_table(capacity_ * 2);
             sub = std::max<int64_t>(std::min(sub_batch_, len / 4), 1);
@@ -471,7 +517,14 @@ void GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
         if (new_groups == 0) sub = std::min<int64_t>(sub * 64, 1ll << 30);
         else sub = sub < sub_batch_ ? std::min<int64_t>(sub * 8, sub_batch_) : sub_batch_;
         next_sub_ = sub;
+        if (out_gids8 != nullptr && !compact) break;   // compact mode was abandoned: see below
     }
+    if (out_gids8 != nullptr && !compact) {
+        // int32 ids for the whole page: every group met so far exists, so the rows before `start` are plain lookups
+        (void)get_group_ids(keys, hashes, n, out_gids, row_mask, inline_hash, probe, nullptr);
+        return false;
+    }
+    return out_gids8 != nullptr;
 }
 
 void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids)

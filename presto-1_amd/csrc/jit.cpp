@@ -1465,7 +1465,26 @@ struct FaArgs {
   int pad;
   const unsigned int* ord_keys;   // ORDERED mode: (group id + 1) of the page's rows in (group, row) order, 0 = filtered row
   const int* ord_rows;            //               and their row numbers
+  const unsigned char* gids8;     // compact group ids (id + 1, 0 = filtered row) instead of gids
 };
+// group id of a row: compact byte ids when the group-by table delivered them, else int32 ids, else the single global group
+// (FA_GID8 is a compile-time variant: a run-time choice would put branches around the pipelined loads)
+#ifndef FA_GID8
+#define FA_GID8 0
+#endif
+// FA_GID_RAW is what the pipelined load keeps in a register (no arithmetic on it before the tile is processed: that would
+// make the prefetch wait for its own load); FA_GID_ID / FA_GID_LIVE decode it at accumulation time
+#if FA_GID8
+#define FA_GID_RAW(F, row) ((int)(F).gids8[row])
+#define FA_GID_NONE 0
+#define FA_GID_LIVE(g) ((g) > 0)
+#define FA_GID_ID(g) ((g) - 1)
+#else
+#define FA_GID_RAW(F, row) ((F).gids ? (F).gids[row] : 0)
+#define FA_GID_NONE (-1)
+#define FA_GID_LIVE(g) ((g) >= 0)
+#define FA_GID_ID(g) (g)
+#endif
 #define FA_STRIPES @FA_STRIPES@
 #define FA_TILE (FA_STRIPES * 256)
 
@@ -1486,8 +1505,8 @@ template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, un
   for (int s = 0; s < FA_STRIPES; s++) {
     const long long row = (long long)blockIdx.x * FA_TILE + threadIdx.x + s * 256;
     tg_zero_row(cur[s]);
-    gcur[s] = -1;
-    if (blockIdx.x < F.tiles && row < A.n) { gcur[s] = F.gids ? F.gids[row] : 0; tg_load_row(A, row, cur[s]); }
+    gcur[s] = FA_GID_NONE;
+    if (blockIdx.x < F.tiles && row < A.n) { gcur[s] = FA_GID_RAW(F, row); tg_load_row(A, row, cur[s]); }
   }
   // drain the prologue loads here: otherwise their pending state flows into the loop header and the compiler's waitcnt
   // insertion (vmcnt is in-order) puts vmcnt(<=4) waits inside the tile processing, which also wait for the prefetch
@@ -1499,17 +1518,17 @@ template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, un
     for (int s = 0; s < FA_STRIPES; s++) {
       const long long row = ntile * FA_TILE + threadIdx.x + s * 256;
       tg_zero_row(nxt[s]);
-      gnxt[s] = -1;
-      if (ntile < F.tiles && row < A.n) { gnxt[s] = F.gids ? F.gids[row] : 0; tg_load_row(A, row, nxt[s]); }
+      gnxt[s] = FA_GID_NONE;
+      if (ntile < F.tiles && row < A.n) { gnxt[s] = FA_GID_RAW(F, row); tg_load_row(A, row, nxt[s]); }
     }
     // keep the prefetch loads up here (issued before the LDS phase, landing while it runs): without the fence the scheduler
     // sinks them next to their first use to save registers, which serialises HBM latency with the accumulation
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < FA_STRIPES; s++) {
-      if (gcur[s] >= 0) {
-        if (LC) tg_accumulate_row_lc(F, A, row0 + s * 256, cur[s], gcur[s], lds);
-        else tg_accumulate_row_gl(F, A, row0 + s * 256, cur[s], gcur[s]);
+      if (FA_GID_LIVE(gcur[s])) {
+        if (LC) tg_accumulate_row_lc(F, A, row0 + s * 256, cur[s], FA_GID_ID(gcur[s]), lds);
+        else tg_accumulate_row_gl(F, A, row0 + s * 256, cur[s], FA_GID_ID(gcur[s]));
       }
     }
 #pragma unroll
@@ -1566,6 +1585,7 @@ struct FaArgsHost {
     int32_t pad;
     const unsigned int *ord_keys;
     const int *ord_rows;
+    const unsigned char *gids8;
 };
 
 }  // namespace
@@ -1837,7 +1857,7 @@ void FusedAggGpu::generate()
         // key accessor generated for this key schema (the GPU counterpart of JoinCompiler's hashRow / positionNotDistinctFromRow)
         src << device_header("device_cols.h") << device_header("device_groupby.h");
         src << "struct FgArgs {\n  FpArgs fp;\n  TgKeyCols store;\n  unsigned long long* words;\n  unsigned long long mask;\n  int* out;\n  unsigned long long* counters;\n"
-               "  long long row0;\n  long long n;\n  int store_groups;\n  int pad;\n  const FgArgs* self;\n};\n";
+               "  long long row0;\n  long long n;\n  int store_groups;\n  int pad;\n  const FgArgs* self;\n  unsigned char* out8;\n};\n";
         auto cell = [&](int i, const std::string &row, const std::string &pfx) {
             // declares <pfx>n (null flag) and the cell's value variables for key column i of the raw input at `row`
             const int ch = key_inputs_[(size_t)i];
@@ -2173,7 +2193,10 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
           npending += (unsigned long long)(tp >> 32);
         }
       }
-      G.out[r] = result;
+      // compact mode: group id + 1 in one byte (0 = filtered row); 255 = a group that is new in this sub-batch (the host re-runs
+      // the sub-batch in int32 mode then)
+      if (G.out8) G.out8[r] = result < -1 ? (unsigned char)255 : (unsigned char)(result + 1);
+      else G.out[r] = result;
     }
   }
 #pragma unroll
@@ -2210,12 +2233,15 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
 
 // the specialisation for pages without null vectors: same source, FA_NO_NULLS 1
 static std::string no_nulls_source(const std::string &src) { return "#define FA_NO_NULLS 1\n" + src; }
+// the specialisation for compact (one byte per row) group ids
+static std::string gid8_source(const std::string &src) { return "#define FA_GID8 1\n" + src; }
 
 void FusedAggGpu::precompile()
 {
     if (!supported_) return;
     (void)code_object_for(source_);
     (void)code_object_for(no_nulls_source(source_));
+    (void)code_object_for(gid8_source(no_nulls_source(source_)));
 }
 
 void FusedAggGpu::ensure_loaded()
@@ -2223,11 +2249,16 @@ void FusedAggGpu::ensure_loaded()
     if (!module_) module_ = load_module(source_);
 }
 
-JitModule *FusedAggGpu::module_for(const DevicePage &in)
+JitModule *FusedAggGpu::module_for(const DevicePage &in, bool gid8)
 {
     std::lock_guard<std::mutex> lk(mu_);
     bool nulls = false;
     for (const DeviceColumn &c : in.cols) nulls = nulls || c.nulls != nullptr;
+    if (gid8) {
+        std::shared_ptr<JitModule> &m = nulls ? module_g8_ : module_nn_g8_;
+        if (!m) m = load_module(gid8_source(nulls ? source_ : no_nulls_source(source_)));
+        return m.get();
+    }
     if (nulls) {
         ensure_loaded();
         return module_.get();
@@ -2287,6 +2318,7 @@ struct FgArgsHost {
     int32_t store_groups;
     int32_t pad;
     const void *self;   // device copy of this block (read by the out-of-line table path)
+    unsigned char *out8;   // compact mode: one byte per row instead of `out` (GbhProbeLaunch)
 };
 }  // namespace
 
@@ -2303,6 +2335,7 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     G.words = (unsigned long long *)l.words;
     G.mask = l.mask;
     G.out = l.out;
+    G.out8 = l.out8;
     G.counters = l.counters;
     G.row0 = l.row0;
     G.n = l.n;
@@ -2318,13 +2351,27 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     raise_if_error(ctx, err);
 }
 
-void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, int64_t groups, GroupedAccumulators &accs)
+// gids8 -> gids, for the (rare) page whose ids arrived compact but whose groups do not fit the lane-private LDS path
+static __global__ void __launch_bounds__(256) widen_gids_kernel(const unsigned char *gids8, long long n, int *gids)
+{
+    for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long long)gridDim.x * 256) gids[r] = (int)gids8[r] - 1;
+}
+
+void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs)
 {
     TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
-    JitModule *module = module_for(in);
     if (in.n == 0) return;
+    BufferPtr widened;
+    if (gids8 && groups > max_groups_) {   // the ORDERED / exact-global paths take int32 ids
+        widened = ctx->alloc((size_t)in.n * 4);
+        widen_gids_kernel<<<(int)std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8), 256, 0, ctx->stream()>>>(gids8, in.n, widened->as<int>());
+        check_launch("widen_gids");
+        gids = widened->as<int32_t>();
+        gids8 = nullptr;
+    }
+    JitModule *module = module_for(in, gids8 != nullptr);
     BufferPtr ord_keys, ord_rows;
-    const bool ordered = gids != nullptr && accs.begin_ordered(gids, in.n, groups, max_groups_, ord_keys, ord_rows);
+    const bool ordered = accs.begin_ordered(gids, in.n, groups, max_groups_, ord_keys, ord_rows);
     if (!ordered) accs.reserve(groups);
     FaArgsHost F{};
     fill_fp_cols(F.fp, in);
@@ -2332,6 +2379,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
     F.fp.error = err->as<unsigned long long>();
     F.gids = gids;
+    F.gids8 = gids8;
     for (size_t k = 0; k < aggs_.size(); k++) {
         GroupedAccumulators::DeviceState d = accs.device_state((int)k);
         F.st[k].function = d.function;

@@ -153,12 +153,13 @@ public:
     // mask[row] = 1 iff the filter selects the row (PageFilter semantics); raises the filter's arithmetic errors
     void filter_mask(Context *ctx, const DevicePage &in, uint8_t *mask_out);
     // state[gid[row]] (+)= aggregate inputs of every row with gid >= 0
-    void accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, int64_t groups, GroupedAccumulators &accs);
+    // gids8 (optional, instead of gids): compact ids, one byte per row = group id + 1 (GroupByHashGpu::get_group_ids)
+    void accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs);
 
 private:
     void generate();
     void ensure_loaded();
-    struct JitModule *module_for(const DevicePage &in);   // the no-nulls specialisation when no column of the page has a null vector
+    struct JitModule *module_for(const DevicePage &in, bool gid8 = false);   // the no-nulls specialisation when no column of the page has a null vector
     std::mutex mu_;
     void raise_if_error(Context *ctx, BufferPtr &err);
     std::vector<int32_t> input_types_;
@@ -174,7 +175,7 @@ private:
     std::vector<std::vector<int>> cnt_inputs_;   // per count slot: the raw input channels its (mask, input) expressions read
     std::vector<bool> cnt_masked_;
     std::string source_;
-    std::shared_ptr<JitModule> module_, module_nn_;
+    std::shared_ptr<JitModule> module_, module_nn_, module_g8_, module_nn_g8_;
 };
 
 std::string resource_dir();

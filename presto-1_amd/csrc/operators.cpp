@@ -523,10 +523,11 @@ public:
         // for the key schema, and the raw hash is computed in the kernel (a $hashvalue channel equals it by construction)
         std::vector<const DeviceColumn *> keys;
         for (int raw : fused_->key_inputs()) keys.push_back(&in.cols[(size_t)raw]);
-        BufferPtr gids = ctx_->alloc((size_t)in.n * 4);
+        // few groups: the ids travel as one byte per row between the two fused kernels (int32 only if the table outgrows a byte)
+        BufferPtr gids = ctx_->alloc((size_t)in.n * 4), gids8 = ctx_->alloc((size_t)in.n);
         GbhProbeFn probe = [&](const GbhProbeLaunch &l) { fused_->probe_groups(ctx_, in, l); };
-        gbh_->get_group_ids(keys, nullptr, in.n, gids->as<int32_t>(), nullptr, /*inline_hash=*/true, &probe);
-        fused_->accumulate(ctx_, in, gids->as<int32_t>(), gbh_->group_count(), *accs_);
+        const bool compact = gbh_->get_group_ids(keys, nullptr, in.n, gids->as<int32_t>(), nullptr, /*inline_hash=*/true, &probe, gids8->as<uint8_t>());
+        fused_->accumulate(ctx_, in, compact ? nullptr : gids->as<int32_t>(), compact ? gids8->as<uint8_t>() : nullptr, gbh_->group_count(), *accs_);
     }
 
 private:

@@ -784,16 +784,17 @@ def test_hash_aggregation_many_groups_sums_in_java_row_order(pkg, oracle, step):
     assert [r[7] for r in rows] == list(cnt)
 
 
-@pytest.mark.parametrize("ngroups", [4, 3000])
+@pytest.mark.parametrize("ngroups", [4, 30, 3000])
 def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle, monkeypatch, ngroups):
     """FilterAndProject fused into HashAggregation (row mask + in-register projections) == the unfused composition == the
-    oracle composition; few groups exercise the lane-private LDS accumulators, many groups the exact global atomics"""
+    oracle composition; 4 groups exercise the lane-private LDS accumulators fed by one-byte group ids, 30 groups the one-byte ids
+    widened for the row-order (ORDERED) accumulation, 3000 groups int32 ids + ORDERED"""
     rng = np.random.default_rng(29)
     n = 120_000
     T = [pkg.VARCHAR, pkg.BIGINT, pkg.DOUBLE, pkg.DOUBLE, pkg.DOUBLE, pkg.DATE, pkg.BOOLEAN, pkg.BIGINT]
     nf = 0.0 if ngroups == 4 else 0.02
-    keys1 = rand_block(pkg, rng, pkg.VARCHAR, n, nf, (0, 2 if ngroups == 4 else 60))
-    keys2 = rand_block(pkg, rng, pkg.BIGINT, n, nf, (0, 2 if ngroups == 4 else 50))
+    keys1 = rand_block(pkg, rng, pkg.VARCHAR, n, nf, (0, {4: 2, 30: 6}.get(ngroups, 60)))
+    keys2 = rand_block(pkg, rng, pkg.BIGINT, n, nf, (0, {4: 2, 30: 4}.get(ngroups, 50)))
     page = pkg.Page(keys1, keys2, rand_block(pkg, rng, pkg.DOUBLE, n, 0.05), rand_block(pkg, rng, pkg.DOUBLE, n, 0.0, (0, 11)),
                     rand_block(pkg, rng, pkg.DOUBLE, n, 0.03, (0, 9)), rand_block(pkg, rng, pkg.DATE, n, 0.01, (9000, 9400)),
                     rand_block(pkg, rng, pkg.BOOLEAN, n, 0.1), rand_block(pkg, rng, pkg.BIGINT, n, 0.05, (-10**9, 10**9)))
