@@ -231,7 +231,8 @@ GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool ha
     sub_batch_ = env ? atoll(env) : (1ll << 24);
     if (sub_batch_ < 1) sub_batch_ = 1;
     // first sub-batch: small when few groups are expected (see get_group_ids), a full one when the planner expects many
-    next_sub_ = std::min<int64_t>(sub_batch_, std::max<int64_t>(1ll << 18, (int64_t)expected_size * 16));
+    const char *first = getenv("TGPU_GBH_FIRST_SUB");
+    next_sub_ = std::min<int64_t>(sub_batch_, std::max<int64_t>(first ? atoll(first) : (1ll << 14), (int64_t)expected_size * 16));
     counters_ = ctx_->alloc_zero(8 * 8);
 }
 
@@ -463,7 +464,7 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
     // of low-cardinality inputs: TPCH Q1 has 4 groups in 600 M rows) the next one is 64x larger: fewer, longer launches.  Such an
     // optimistic launch can overflow the table only if it meets tens of millions of new keys; the probe kernel then flags it,
     // the table is rebuilt twice as large and the rows are re-run in smaller pieces.
-    // With few expected groups the very first launches ramp up from a small piece (2^18 rows): while the table is empty every
+    // With few expected groups the very first launches ramp up from a small piece (2^14 rows): while the table is empty every
     // row takes the insert path and, with few distinct keys, they all contend for the same slots; once the first groups exist
     // the probe kernels answer from their cached copies.  next_sub_ persists across pages.
     int64_t sub = next_sub_;
@@ -477,7 +478,19 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
         for (auto &v : views) vp.push_back(&v);
         int64_t new_groups = 0;
         bool ok = true;
-        if (compact) {
+        if (compact && groups_ == 0) {
+            // nothing to look up yet: every group of this sub-batch is new, so the compact attempt would only be repeated
+            BufferPtr tmp = ctx_->alloc((size_t)len * 4);
+            ok = process_sub_batch(key_cols_of(vp), nullptr, nullptr, start, len, tmp->as<int32_t>(), probe, &new_groups);
+            if (ok) {
+                if (groups_ < kCompactGroups) {
+                    gbh_narrow_kernel<<<grid_for(ctx_, len), kBlock, 0, ctx_->stream()>>>(tmp->as<int32_t>(), len, out_gids8 + start);
+                    check_launch("gbh_narrow");
+                }
+                else compact = false;
+            }
+        }
+        else if (compact) {
             // compact attempt: the probe kernel answers with one byte per row; rows that meet a group that is new in this
             // sub-batch are only counted
             ensure_table(groups_ + std::min<int64_t>(len, sub_batch_));
@@ -514,7 +527,7 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             continue;
         }
         start += len;
-        if (new_groups == 0) sub = std::min<int64_t>(sub * 64, 1ll << 30);
+        if (new_groups == 0) sub = sub >= (1ll << 17) ? (1ll << 30) : sub * 64;   // a sizeable piece without a new group: take the rest in one launch
         else sub = sub < sub_batch_ ? std::min<int64_t>(sub * 8, sub_batch_) : sub_batch_;
         next_sub_ = sub;
         if (out_gids8 != nullptr && !compact) break;   // compact mode was abandoned: see below

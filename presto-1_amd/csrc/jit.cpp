@@ -737,7 +737,7 @@ std::string spec_key(const char *what, const std::vector<int32_t> &input_types, 
     for (int32_t i = 0; i < spec->projection_count; i++) put_i32(k, spec->projection_roots[i]);
     put_i32(k, (int32_t)extra.size());
     for (int32_t v : extra) put_i32(k, v);
-    for (const char *env : {"TGPU_FG_EXP", "TGPU_FJ_EXP", "TGPU_FA_STRIPES", "TGPU_FJ_STRIPES"}) {
+    for (const char *env : {"TGPU_FG_EXP", "TGPU_FJ_EXP", "TGPU_FA_STRIPES", "TGPU_FJ_STRIPES", "TGPU_FG_STRIPES"}) {
         const char *v = getenv(env);
         k += '|';
         if (v) k += v;
@@ -1833,6 +1833,7 @@ void FusedAggGpu::generate()
     std::ostringstream src;
     src << kPrelude;
     if (const char *exp = getenv("TGPU_FG_EXP")) src << "#define FG_EXP_" << exp << " 1\n";  // kernel-study switch, never set in production
+    if (const char *st = getenv("TGPU_FG_STRIPES")) src << "#define FG_STRIPES " << std::max(1, std::min(16, atoi(st))) << "\n";  // rows per lane per tile of fg_probe
     src << device_header("device_hash.h") << device_header("device_agg.h") << gm.consts.str() << gr.consts.str();
     src << "#define FA_LDS_BYTES " << std::max(64, max_groups_ * per_group_bytes_) << "\n";
     // FA_NO_NULLS 1: the specialisation for pages without null vectors (null loads and per-aggregate count slots fold away)
@@ -1943,16 +1944,17 @@ void FusedAggGpu::generate()
             else src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t))) << " v" << i << "; unsigned char n" << i << ";\n";
         }
         // phase A is loads only (no arithmetic on the loaded values): the loads of all stripes stay in flight together
-        src << "};\n__device__ inline void fg_load_key_a(const FpArgs& A, long long row, TgKeyRow& K) {\n";
+        // (addresses = uniform tile base + 32-bit lane offset: scalar base + 32-bit VGPR offset addressing, no 64-bit lane math)
+        src << "};\n__device__ inline void fg_load_key_a(const FpArgs& A, long long tb, unsigned int o, TgKeyRow& K) {\n";
         for (size_t i = 0; i < key_inputs_.size(); i++) {
             const int ch = key_inputs_[i];
             const int32_t t = input_types_[(size_t)ch];
-            src << "  K.n" << i << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? A.col_nulls[" << ch << "][row] : 0;\n";
+            src << "  K.n" << i << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? (A.col_nulls[" << ch << "] + tb)[o] : 0;\n";
             if (t == TGPU_VARCHAR)
-                src << "  K.a" << i << " = A.col_offsets[" << ch << "][row]; K.e" << i << " = A.col_offsets[" << ch << "][row + 1];\n";
+                src << "  K.a" << i << " = (A.col_offsets[" << ch << "] + tb)[o]; K.e" << i << " = (A.col_offsets[" << ch << "] + tb)[o + 1u];\n";
             else {
                 const char *T = t == TGPU_BOOLEAN ? "unsigned char" : (t == TGPU_DOUBLE ? "unsigned long long" : ctype(t));
-                src << "  K.v" << i << " = ((const " << T << "*)A.col_values[" << ch << "])[row];\n";
+                src << "  K.v" << i << " = ((const " << T << "*)A.col_values[" << ch << "] + tb)[o];\n";
             }
         }
         src << "}\n__device__ inline void fg_key_lengths(TgKeyRow& K) {\n";
@@ -1964,12 +1966,15 @@ void FusedAggGpu::generate()
             if (t == TGPU_VARCHAR) src << "  K.a" << i << " = 0; K.e" << i << " = 0; K.l" << i << " = 0; K.n" << i << " = 1; K.b" << i << " = 0;\n";
             else src << "  K.v" << i << " = 0; K.n" << i << " = 1;\n";
         }
-        src << "}\n__device__ inline void fg_load_key_b(const FpArgs& A, TgKeyRow& K) {\n";
+        // phase B is unconditional too (a branch around a load makes the compiler wait for every load in flight): a row that
+        // has no first byte to fetch reads byte 0 of the column (the host guarantees one readable byte) and ignores it
+        src << "}\n__device__ inline void fg_load_key_b(const FpArgs& A, TgKeyRow& K, bool live) {\n";
         for (size_t i = 0; i < key_inputs_.size(); i++) {
             const int ch = key_inputs_[i];
             if (input_types_[(size_t)ch] == TGPU_VARCHAR)
-                src << "  if (!K.n" << i << " && K.l" << i << " > 0) K.b" << i << " = ((const unsigned char*)A.col_values[" << ch << "])[K.a" << i << "];\n";
+                src << "  K.b" << i << " = ((const unsigned char*)A.col_values[" << ch << "])[(live && !K.n" << i << " && K.l" << i << " > 0) ? (unsigned int)K.a" << i << " : 0u];\n";
         }
+        src << "  (void)live;\n";
         src << "  (void)A; (void)K;\n}\n";
         // row vs LDS record: 1 equal, 0 different, -1 cannot decide here (long varchar: the table path decides)
         src << "__device__ inline int fg_eq_record(const FpArgs& A, const TgKeyRow& K, const unsigned char* rec, int g) {\n";
@@ -1989,86 +1994,81 @@ void FusedAggGpu::generate()
             src << "    }\n  }\n";
         }
         src << "  (void)A;\n  return 1;\n}\n";
-        // The first FG_REG_GROUPS records additionally live in registers as SIGNATURES: 32-bit words [null mask | one word per
-        // INTEGER / DATE / BOOLEAN key | two per BIGINT / DOUBLE key (DOUBLE canonicalised: one NaN, -0 -> +0) | one per VARCHAR
-        // key = min(length, 2^24-1) << 8 | first byte], compared two words at a time.  Equal signatures decide the row unless it
-        // has a varchar key longer than one byte ("open": the byte-wise LDS comparison decides).  A record that cannot be
-        // summarised (varchar longer than 16 bytes) gets a signature no row can produce for it... its first byte is 0 in the
-        // record, so at worst the row comes out "open" and the byte-wise path sends it to the table.
+        // The first FG_REG_GROUPS records additionally live in registers as SIGNATURES: bit fields [null mask | 32 bits per
+        // INTEGER / DATE key | 1 per BOOLEAN | 64 per BIGINT / DOUBLE key (DOUBLE canonicalised: one NaN, -0 -> +0) | 10 per VARCHAR
+        // key = min(length, 2) << 8 | first byte] packed into as few words as they need (one 32-bit word for two varchar keys).
+        // Equal signatures decide the row unless it has a varchar key longer than one byte ("open": the byte-wise LDS comparison
+        // decides -- which is also why lengths above one need not be told apart here).  A record that cannot be summarised
+        // (varchar longer than 16 bytes) has first byte 0 in the record: at worst the row comes out "open" and the byte-wise path
+        // sends it to the table.
         {
-            int nw = 1;
-            for (size_t i = 0; i < key_inputs_.size(); i++) {
-                const int32_t t = input_types_[(size_t)key_inputs_[i]];
-                nw += (t == TGPU_BIGINT || t == TGPU_DOUBLE) ? 2 : 1;
-            }
-            const int nw64 = (nw + 1) / 2;
-            src << "#define FG_REG_GROUPS 4\n#define FG_SIG_WORDS " << nw64 << "\nstruct TgRecReg { unsigned long long s[FG_SIG_WORDS]; };\n";
-            src << "__device__ inline unsigned long long fg_canon_double(unsigned long long bits) {\n  const double u = __longlong_as_double((long long)bits);\n"
-                   "  return u != u ? 0x7ff8000000000000ULL : (u == 0.0 ? 0ULL : bits);\n}\n";
-            auto pack = [&](const std::vector<std::string> &w, const std::string &dst) {
-                std::ostringstream o;
-                for (int j = 0; j < nw64; j++) {
-                    o << "  " << dst << "[" << j << "] = (unsigned long long)(" << w[(size_t)(2 * j)] << ")";
-                    if (2 * j + 1 < (int)w.size()) o << " | ((unsigned long long)(" << w[(size_t)(2 * j + 1)] << ") << 32)";
-                    o << ";\n";
+            struct Field { std::string expr; int bits; };
+            // greedy packing, a field never straddles a 64-bit word
+            auto pack = [&](const std::vector<Field> &f, const std::string &dst, int &words, bool &narrow) {
+                std::vector<std::string> w;
+                int used = 64, total = 0;
+                for (const Field &x : f) {
+                    total += x.bits;
+                    if (used + x.bits > 64) { w.push_back(""); used = 0; }
+                    std::string &cur = w.back();
+                    if (!cur.empty()) cur += " | ";
+                    cur += "((unsigned long long)(" + x.expr + ") << " + std::to_string(used) + ")";
+                    used += x.bits;
                 }
+                words = (int)w.size();
+                narrow = words == 1 && total <= 32;
+                std::ostringstream o;
+                for (size_t j = 0; j < w.size(); j++) o << "  " << dst << "[" << j << "] = (FG_SIG_T)(" << w[j] << ");\n";
                 return o.str();
             };
-            // signature of a row
-            src << "__device__ inline void fg_row_sig(const TgKeyRow& K, unsigned long long* sig, bool& open) {\n  open = false;\n  unsigned int nm = 0;\n";
-            std::vector<std::string> w{"nm"};
+            std::ostringstream row_sig, rec_sig;
+            std::vector<Field> fr{{"nm", (int)key_inputs_.size()}}, fg{{"nm", (int)key_inputs_.size()}};
+            row_sig << "  open = false;\n  unsigned int nm = 0;\n";
+            rec_sig << "  unsigned int nm = 0;\n";
             for (size_t i = 0; i < key_inputs_.size(); i++) {
                 const int32_t t = input_types_[(size_t)key_inputs_[i]];
                 const std::string I = std::to_string(i);
-                src << "  const bool n" << I << " = K.n" << I << " != 0; nm |= n" << I << " ? " << (1u << i) << "u : 0u;\n";
+                row_sig << "  const bool n" << I << " = K.n" << I << " != 0; nm |= n" << I << " ? " << (1u << i) << "u : 0u;\n";
+                rec_sig << "  const unsigned char* r" << I << " = rec + ((size_t)g * FG_NKEYS + " << I << ") * 32;\n  const bool n" << I << " = r" << I << "[20] != 0; nm |= n" << I
+                        << " ? " << (1u << i) << "u : 0u;\n";
                 if (t == TGPU_VARCHAR) {
-                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (((unsigned int)(K.l" << I << " < 0xffffff ? K.l" << I << " : 0xffffff) << 8) | (unsigned int)K.b" << I << ");\n"
-                        << "  open = open || (!n" << I << " && K.l" << I << " > 1);\n";
-                    w.push_back("w" + I);
+                    row_sig << "  const unsigned int w" << I << " = n" << I << " ? 0u : (((unsigned int)(K.l" << I << " < 2 ? K.l" << I << " : 2) << 8) | (K.l" << I << " > 0 ? (unsigned int)K.b" << I
+                            << " : 0u));\n  open = open || (!n" << I << " && K.l" << I << " > 1);\n";
+                    rec_sig << "  const int l" << I << " = *(const int*)(r" << I << " + 16);\n  const unsigned int w" << I << " = n" << I << " ? 0u : (((unsigned int)(l" << I << " < 2 ? l" << I
+                            << " : 2) << 8) | (l" << I << " > 0 ? (unsigned int)r" << I << "[0] : 0u));\n";
+                    fr.push_back({"w" + I, 10});
+                    fg.push_back({"w" + I, 10});
                 }
                 else if (t == TGPU_BIGINT || t == TGPU_DOUBLE) {
-                    src << "  const unsigned long long q" << I << " = n" << I << " ? 0ULL : " << (t == TGPU_DOUBLE ? "fg_canon_double((unsigned long long)K.v" + I + ")" : "(unsigned long long)K.v" + I) << ";\n";
-                    w.push_back("(unsigned int)q" + I);
-                    w.push_back("(unsigned int)(q" + I + " >> 32)");
+                    row_sig << "  const unsigned long long q" << I << " = n" << I << " ? 0ULL : "
+                            << (t == TGPU_DOUBLE ? "fg_canon_double((unsigned long long)K.v" + I + ")" : "(unsigned long long)K.v" + I) << ";\n";
+                    rec_sig << "  const unsigned long long q" << I << " = n" << I << " ? 0ULL : "
+                            << (t == TGPU_DOUBLE ? "fg_canon_double(*(const unsigned long long*)r" + I + ")" : "*(const unsigned long long*)r" + I) << ";\n";
+                    fr.push_back({"q" + I, 64});
+                    fg.push_back({"q" + I, 64});
                 }
                 else if (t == TGPU_BOOLEAN) {
-                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (K.v" << I << " != 0 ? 1u : 0u);\n";
-                    w.push_back("w" + I);
+                    row_sig << "  const unsigned int w" << I << " = n" << I << " ? 0u : (K.v" << I << " != 0 ? 1u : 0u);\n";
+                    rec_sig << "  const unsigned int w" << I << " = n" << I << " ? 0u : (*(const unsigned long long*)r" << I << " != 0 ? 1u : 0u);\n";
+                    fr.push_back({"w" + I, 1});
+                    fg.push_back({"w" + I, 1});
                 }
                 else {
-                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (unsigned int)K.v" << I << ";\n";
-                    w.push_back("w" + I);
+                    row_sig << "  const unsigned int w" << I << " = n" << I << " ? 0u : (unsigned int)K.v" << I << ";\n";
+                    rec_sig << "  const unsigned int w" << I << " = n" << I << " ? 0u : (unsigned int)*(const unsigned long long*)r" << I << ";\n";
+                    fr.push_back({"w" + I, 32});
+                    fg.push_back({"w" + I, 32});
                 }
             }
-            src << pack(w, "sig") << "}\n";
-            // signature of a cached group (from its LDS record)
-            src << "__device__ inline void fg_load_recreg(const unsigned char* rec, int g, TgRecReg& R) {\n  unsigned int nm = 0;\n";
-            w.assign(1, "nm");
-            for (size_t i = 0; i < key_inputs_.size(); i++) {
-                const int32_t t = input_types_[(size_t)key_inputs_[i]];
-                const std::string I = std::to_string(i);
-                src << "  const unsigned char* r" << I << " = rec + ((size_t)g * FG_NKEYS + " << I << ") * 32;\n  const bool n" << I << " = r" << I << "[20] != 0; nm |= n" << I << " ? "
-                    << (1u << i) << "u : 0u;\n";
-                if (t == TGPU_VARCHAR) {
-                    src << "  const int l" << I << " = *(const int*)(r" << I << " + 16);\n  const unsigned int w" << I << " = n" << I << " ? 0u : (((unsigned int)(l" << I << " < 0xffffff ? l" << I
-                        << " : 0xffffff) << 8) | (l" << I << " > 0 ? (unsigned int)r" << I << "[0] : 0u));\n";
-                    w.push_back("w" + I);
-                }
-                else if (t == TGPU_BIGINT || t == TGPU_DOUBLE) {
-                    src << "  const unsigned long long q" << I << " = n" << I << " ? 0ULL : " << (t == TGPU_DOUBLE ? "fg_canon_double(*(const unsigned long long*)r" + I + ")" : "*(const unsigned long long*)r" + I) << ";\n";
-                    w.push_back("(unsigned int)q" + I);
-                    w.push_back("(unsigned int)(q" + I + " >> 32)");
-                }
-                else if (t == TGPU_BOOLEAN) {
-                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (*(const unsigned long long*)r" << I << " != 0 ? 1u : 0u);\n";
-                    w.push_back("w" + I);
-                }
-                else {
-                    src << "  const unsigned int w" << I << " = n" << I << " ? 0u : (unsigned int)*(const unsigned long long*)r" << I << ";\n";
-                    w.push_back("w" + I);
-                }
-            }
-            src << pack(w, "R.s") << "}\n";
+            int words = 1;
+            bool narrow = false;
+            const std::string row_pack = pack(fr, "sig", words, narrow), rec_pack = pack(fg, "R.s", words, narrow);
+            src << "#define FG_REG_GROUPS 4\n#define FG_SIG_WORDS " << words << "\ntypedef " << (narrow ? "unsigned int" : "unsigned long long")
+                << " FG_SIG_T;\nstruct TgRecReg { FG_SIG_T s[FG_SIG_WORDS]; };\n";
+            src << "__device__ inline unsigned long long fg_canon_double(unsigned long long bits) {\n  const double u = __longlong_as_double((long long)bits);\n"
+                   "  return u != u ? 0x7ff8000000000000ULL : (u == 0.0 ? 0ULL : bits);\n}\n";
+            src << "__device__ inline void fg_row_sig(const TgKeyRow& K, FG_SIG_T* sig, bool& open) {\n" << row_sig.str() << row_pack << "}\n";
+            src << "__device__ inline void fg_load_recreg(const unsigned char* rec, int g, TgRecReg& R) {\n" << rec_sig.str() << rec_pack << "}\n";
         }
         // (c) the filter in register-row mode for the group probe: its fixed-width input columns are loaded in phase A
         {
@@ -2087,18 +2087,21 @@ void FusedAggGpu::generate()
                 src << "  " << (t == TGPU_BOOLEAN ? "unsigned char" : ctype(t)) << " c" << ch << "; unsigned char n" << ch << ";\n";
             }
             if (gf.reg_cols.empty()) src << "  int unused;\n";
-            src << "};\n__device__ inline void tg_load_frow(const FpArgs& A, long long row, TgFRow& R) {\n";
+            src << "};\n__device__ inline void tg_load_frow(const FpArgs& A, long long tb, unsigned int o, TgFRow& R) {\n";
             for (int ch : gf.reg_cols) {
                 const int32_t t = input_types_[(size_t)ch];
                 const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
-                src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "])[row]; R.n" << ch << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? A.col_nulls[" << ch << "][row] : 0;\n";
+                src << "  R.c" << ch << " = ((const " << T << "*)A.col_values[" << ch << "] + tb)[o]; R.n" << ch << " = (!FA_NO_NULLS && A.col_nulls[" << ch << "]) ? (A.col_nulls[" << ch
+                    << "] + tb)[o] : 0;\n";
             }
-            src << "  (void)A; (void)row; (void)R;\n}\n__device__ inline void tg_zero_frow(TgFRow& R) {\n";
+            src << "  (void)A; (void)tb; (void)o; (void)R;\n}\n__device__ inline void tg_zero_frow(TgFRow& R) {\n";
             for (int ch : gf.reg_cols) src << "  R.c" << ch << " = 0; R.n" << ch << " = 0;\n";
             src << "  (void)R;\n}\n__device__ inline bool tg_filter_f(const FpArgs& A, long long row, const TgFRow& R) {\n" << body.str() << "}\n";
         }
         src << R"SRC(
+#ifndef FG_STRIPES
 #define FG_STRIPES 8
+#endif
 #define FG_TILE (FG_STRIPES * 256)
 // the table path (hashing + probe / insert protocol) is rare once the first groups are cached in LDS: it is kept out of line
 // so that the hot loop stays small enough for the instruction cache
@@ -2112,6 +2115,19 @@ __device__ __attribute__((noinline)) long long fg_table_path(const FgArgs* Gm, l
   const int result = tg_gbh_probe<true>(K, r, G.words, G.mask, store_groups, G.counters, pending);
   return (long long)(unsigned int)result | (pending ? (1LL << 32) : 0LL);
 }
+// a row the register signatures did not decide: the byte-wise comparison against the LDS records of groups [from, lg), then
+// the table (store_groups 0 skips its own key-store scan unless a long varchar key left a cached group undecided).  Out of
+// line for the same reason; the key cells travel by value.
+__device__ __attribute__((noinline)) long long fg_slow_path(const FgArgs* Gm, const unsigned char* rec, TgKeyRow K, long long r, int from, int lg, bool redo) {
+  const FgArgs& G = *Gm;
+  bool undecided = redo;
+  for (int g = from; g < lg; g++) {
+    const int e = fg_eq_record(G.fp, K, rec, g);
+    if (e > 0) return (long long)(unsigned int)g;
+    undecided = undecided || e < 0;
+  }
+  return fg_table_path(Gm, r, undecided ? G.store_groups : 0);
+}
 // pass B: filter + group lookup / insert (protocol: device_groupby.h).  Eight rows per lane per tile, processed in phases so
 // that the loads of all eight rows are in flight together: (A) filter column + key cells, (B) first varchar bytes,
 // (C) compare against the LDS copies of the first groups' keys; only a row that matches none of them touches the table.
@@ -2122,81 +2138,69 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
   fg_build_records(G.store, lg, rec);
   TgRecReg rr[FG_REG_GROUPS];
 #pragma unroll
-  for (int g = 0; g < FG_REG_GROUPS; g++) fg_load_recreg(rec, g < lg ? g : 0, rr[g]);
+  for (int g = 0; g < FG_REG_GROUPS; g++) {
+    fg_load_recreg(rec, g < lg ? g : 0, rr[g]);
+    // an unused register slot gets a signature no row has (every key null AND value bits set): no "g < rg" test per row
+    if (g >= lg) rr[g].s[0] = ~(FG_SIG_T)0;
+  }
   const int rg = lg < FG_REG_GROUPS ? lg : FG_REG_GROUPS;
   const long long tiles = (G.n + FG_TILE - 1) / FG_TILE;
   unsigned long long npending = 0;
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const long long r0 = tile * FG_TILE + threadIdx.x;
+    // rows of the tile = uniform base + 32-bit lane offset (scalar-base addressing: no 64-bit lane arithmetic in the hot loop)
+    const long long t0 = tile * FG_TILE;
+    const long long tb = G.row0 + t0;
+    const long long left = G.n - t0;
+    const unsigned int lim = (unsigned int)(left < FG_TILE ? left : FG_TILE) - 1u;   // the tile's last row
     bool sel[FG_STRIPES];
     TgKeyRow kr[FG_STRIPES];
     {
       TgFRow fr[FG_STRIPES];
 #pragma unroll
       for (int s = 0; s < FG_STRIPES; s++) {   // phase A: loads only, unconditional (rows past the end re-read the last row)
-        const long long r = r0 + s * 256;
-        const long long rc = G.row0 + (r < G.n ? r : G.n - 1);
+        const unsigned int o = threadIdx.x + s * 256;
+        const unsigned int oc = o < lim ? o : lim;
         fg_zero_key(kr[s]);
-        tg_load_frow(A, rc, fr[s]);
-#ifndef FG_EXP_NOKEYS
-        fg_load_key_a(A, rc, kr[s]);
-#endif
+        tg_load_frow(A, tb, oc, fr[s]);
+        fg_load_key_a(A, tb, oc, kr[s]);
       }
 #pragma unroll
       for (int s = 0; s < FG_STRIPES; s++) {
-        const long long r = r0 + s * 256;
-        sel[s] = r < G.n && tg_filter_f(A, G.row0 + r, fr[s]);
+        const unsigned int o = threadIdx.x + s * 256;
+        sel[s] = o <= lim && tg_filter_f(A, tb + o, fr[s]);
         fg_key_lengths(kr[s]);
       }
     }
-#ifndef FG_EXP_NOKEYS
 #pragma unroll
-    for (int s = 0; s < FG_STRIPES; s++) if (sel[s]) fg_load_key_b(A, kr[s]);
-#endif
+    for (int s = 0; s < FG_STRIPES; s++) fg_load_key_b(A, kr[s], sel[s]);   // phase B
 #pragma unroll
     for (int s = 0; s < FG_STRIPES; s++) {
-      const long long r = r0 + s * 256;
-      if (r >= G.n) continue;
+      const unsigned int o = threadIdx.x + s * 256;
+      // phase C, branch-free for the common case: the row's signature against the register copies of the first groups
+      FG_SIG_T sig[FG_SIG_WORDS];
+      bool open;
+      fg_row_sig(kr[s], sig, open);
       int result = -1;
-      if (sel[s]) {
-        bool undecided = false;
-#ifdef FG_EXP_NOKEYS
-        result = 0;
-#else
-        unsigned long long sig[FG_SIG_WORDS];
-        bool open;
-        fg_row_sig(kr[s], sig, open);
 #pragma unroll
-        for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {   // distinct groups have distinct keys: at most one signature matches
-          bool same = g < rg;
+      for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {   // distinct groups have distinct keys: at most one signature matches
+        bool same = true;
 #pragma unroll
-          for (int j = 0; j < FG_SIG_WORDS; j++) same = same && sig[j] == rr[g].s[j];
-          result = same ? g : result;
-        }
-        undecided = open && result >= 0;
-        if (undecided) result = -1;   // a longer varchar key must be compared byte-wise: redo from group 0 below
-        for (int g = (undecided ? 0 : rg); g < lg && result < 0; g++) {
-          const int e = fg_eq_record(A, kr[s], rec, g);
-          if (e > 0) result = g;
-          undecided = undecided || e < 0;
-        }
-#endif
-#ifdef FG_EXP_NOTABLE
-        if (false) {
-#else
-        if (result < 0) {
-#endif
-          // not among the cached groups: the table decides (store_groups 0 skips its own key-store scan unless a long
-          // varchar key left a cached group undecided)
-          const long long tp = fg_table_path(G.self, r, undecided ? G.store_groups : 0);
-          result = (int)(unsigned int)(tp & 0xffffffffLL);
-          npending += (unsigned long long)(tp >> 32);
-        }
+        for (int j = 0; j < FG_SIG_WORDS; j++) same = same && sig[j] == rr[g].s[j];
+        result = same ? g : result;
       }
-      // compact mode: group id + 1 in one byte (0 = filtered row); 255 = a group that is new in this sub-batch (the host re-runs
-      // the sub-batch in int32 mode then)
-      if (G.out8) G.out8[r] = result < -1 ? (unsigned char)255 : (unsigned char)(result + 1);
-      else G.out[r] = result;
+      const bool redo = open && result >= 0;   // a longer varchar key must be compared byte-wise: from group 0 below
+      result = (redo || !sel[s]) ? -1 : result;
+      if (sel[s] && result < 0) {
+        const long long tp = fg_slow_path(G.self, rec, kr[s], t0 + o, redo ? 0 : rg, lg, redo);
+        result = (int)(unsigned int)(tp & 0xffffffffLL);
+        npending += (unsigned long long)(tp >> 32);
+      }
+      if (o <= lim) {
+        // compact mode: group id + 1 in one byte (0 = filtered row); 255 = a group that is new in this sub-batch (the host
+        // re-runs the sub-batch in int32 mode then)
+        if (G.out8) (G.out8 + t0)[o] = result < -1 ? (unsigned char)255 : (unsigned char)(result + 1);
+        else (G.out + t0)[o] = result;
+      }
     }
   }
 #pragma unroll
@@ -2331,6 +2335,16 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     BufferPtr err = ctx->alloc(8);
     HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
     G.fp.error = err->as<unsigned long long>();
+    // the kernel reads byte 0 of a varchar key column for rows without a first byte: give an all-empty column one to read
+    BufferPtr dummy;
+    for (int ch : key_inputs_)
+        if (input_types_[(size_t)ch] == TGPU_VARCHAR && G.fp.col_values[ch] == nullptr) {
+            if (!dummy) {
+                dummy = ctx->alloc(16);
+                HIP_CHECK(hipMemsetAsync(dummy->ptr(), 0, 16, ctx->stream()));
+            }
+            G.fp.col_values[ch] = dummy->ptr();
+        }
     G.store = l.store;
     G.words = (unsigned long long *)l.words;
     G.mask = l.mask;
@@ -2345,7 +2359,8 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     ctx->upload(self->ptr(), &G, sizeof(FgArgsHost));
     {
         ProfileScope ps(ctx, "fused_filter_group_probe");
-        int64_t blocks = std::min<int64_t>(ceil_div(l.n, 256), (int64_t)ctx->cu_count() * 8);
+        // persistent grid: exactly the resident workgroups, each walking tiles with a grid stride (no second wave of blocks)
+        const int64_t blocks = std::min<int64_t>(ceil_div(l.n, 256), (int64_t)ctx->cu_count() * module->blocks_per_cu("fg_probe"));
         launch_args(module->fn("fg_probe"), (int)blocks, G, ctx->stream());
     }
     raise_if_error(ctx, err);
