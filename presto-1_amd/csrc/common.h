@@ -95,6 +95,7 @@ public:
     int device() const { return device_; }
     hipStream_t stream() const { return stream_; }
     void sync();
+    void wait_stream();   // waits for the stream by polling (low latency): the wait in front of small read-backs
 
     // stream-ordered caching allocator (all work of a context is on one stream, so reuse after free is ordered)
     BufferPtr alloc(size_t bytes);
@@ -152,6 +153,7 @@ private:
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending_;
     std::vector<hipEvent_t> event_pool_;
+    hipEvent_t wait_event_ = nullptr;
     std::map<std::string, KernelStat> stats_;
     const char *cur_name_ = nullptr;
     hipEvent_t cur_a_ = nullptr;

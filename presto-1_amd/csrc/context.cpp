@@ -48,9 +48,29 @@ Context::~Context()
     for (auto &p : pending_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto ev : event_pool_) hipEventDestroy(ev);
     if (pinned_) hipHostFree(pinned_);
+    if (wait_event_) hipEventDestroy(wait_event_);
 }
 
 void Context::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+// The wait in front of a small read-back: polls an event instead of blocking in hipStreamSynchronize (whose wake-up costs tens
+// of microseconds -- with a dozen read-backs per page that is a sizeable part of a 5 ms step).  TGPU_BLOCKING_WAIT=1 restores
+// the blocking wait (an embedding that must not spin a core).
+void Context::wait_stream()
+{
+    static const bool blocking = getenv("TGPU_BLOCKING_WAIT") != nullptr;
+    if (blocking) {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        return;
+    }
+    if (!wait_event_) HIP_CHECK(hipEventCreateWithFlags(&wait_event_, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(wait_event_, stream_));
+    for (;;) {
+        const hipError_t e = hipEventQuery(wait_event_);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) HIP_CHECK(e);
+    }
+}
 
 static size_t round_capacity(size_t bytes)
 {
@@ -147,6 +167,15 @@ void Context::upload(void *dst, const void *src, size_t bytes)
 void Context::download(void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
+    if (bytes <= (64u << 10)) {
+        // the small read-backs between kernels (counts, flags, key ranges) go through the pinned staging buffer: a copy into
+        // pageable memory (a stack variable) takes the runtime's slow staged path, several times the latency of this one
+        void *stage = pinned(bytes);
+        HIP_CHECK(hipMemcpyAsync(stage, src, bytes, hipMemcpyDeviceToHost, stream_));
+        wait_stream();
+        memcpy(dst, stage, bytes);
+        return;
+    }
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
 }

@@ -27,9 +27,18 @@ struct TgPrefilter {
     const unsigned long long *bloom;    // nullptr = not available
     unsigned long long bloom_word_mask;
     // DIRECT layout (dense key domain without duplicate build keys): no hash table at all -- the bitmap says whether a key is
-    // in the build side and direct[key - key_min] is its build position (only the entries of present keys are defined)
+    // in the build side, and the key's RANK among the present keys (rank_base[word] = set bits in front of the bitmap word,
+    // plus the set bits below the key's own bit) indexes direct[], the build positions in key order.  Both side arrays are
+    // dense: 4 bytes per 64 key values + 4 bytes per build row, whatever the spread of the keys.
     const int *direct;
+    const int *rank_base;
 };
+
+// DIRECT layout: build position of the present key at offset d = key - key_min, `word` = its bitmap word
+__device__ inline int tg_direct_position(const TgPrefilter &pf, unsigned long long d, unsigned long long word)
+{
+    return pf.direct[pf.rank_base[d >> 6] + __popcll(word & ((1ULL << (d & 63)) - 1ULL))];
+}
 
 // Slot of a key in the int-key table: Fibonacci hashing, the top log2(capacity) bits of key * 2^64 / phi (one 64-bit multiply
 // per probe instead of the four of the reference's hash + a finaliser; the table layout is not observable, only build
@@ -45,8 +54,9 @@ __device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long
     if (pf.bitmap) {
         if (key < pf.key_min || key > pf.key_max) return -1;
         const unsigned long long d = (unsigned long long)(key - pf.key_min);
-        if (!((pf.bitmap[d >> 6] >> (d & 63)) & 1ULL)) return -1;
-        if (pf.direct) return pf.direct[d];
+        const unsigned long long word = pf.bitmap[d >> 6];
+        if (!((word >> (d & 63)) & 1ULL)) return -1;
+        if (pf.direct) return tg_direct_position(pf, d, word);
     }
     else if (pf.bloom) {
         const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(key));

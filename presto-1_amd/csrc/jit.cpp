@@ -993,7 +993,10 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
 #if FJ_PF == 3
-        if (sfl[s] & 1) head[s] = ssl[s].head;   // the bitmap is exact: the key is in the build side, this is its position
+        // the bitmap is exact: the key is in the build side.  The pair carries the key's rank among the build keys (present keys
+        // in front of its bitmap word, loaded by the previous iteration, + set bits below its own); fj_emit reads the build
+        // position at that rank, for the matching rows only
+        if (sfl[s] & 1) head[s] = ssl[s].head + (int)ssidx[s];
 #else
         if ((sfl[s] & 1) && ssl[s].head >= 0) {
           if (ssl[s].key == skey[s]) head[s] = ssl[s].head;
@@ -1031,9 +1034,15 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #ifdef FJ_EXP_NOPROBE
         maybe = false;
 #endif
+#if FJ_PF == 3
+        skey[s] = pkey[s]; ssidx[s] = (unsigned int)__popcll(pbw[s] & ((1ULL << pbits[s]) - 1ULL));   // set bits below the key's own
+        sfl[s] = (unsigned char)((maybe ? 1 : 0) | (pfl[s] & 2));
+        cidx[s] = maybe ? (psidx[s] >> 6) : 0u;                                                         // its bitmap word
+#else
         skey[s] = pkey[s]; ssidx[s] = psidx[s];
         sfl[s] = (unsigned char)((maybe ? 1 : 0) | (pfl[s] & 2));
         cidx[s] = maybe ? psidx[s] : 0u;
+#endif
       }
     }
     // stage B: tile jB -- filter + key from the rows loaded by the previous iteration; the pre-filter word (exact key bitmap
@@ -1088,7 +1097,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) {
 #if FJ_PF == 3
-      ssl[s].head = J.pf.direct[cidx[s]];   // DIRECT layout: the build position itself (entry 0 for lanes without a survivor: unused)
+      ssl[s].head = J.pf.rank_base[cidx[s]];   // DIRECT layout: present keys in front of the survivor's bitmap word (entry 0 otherwise: unused)
 #else
       ssl[s] = J.slots[cidx[s]];
 #endif
@@ -1172,7 +1181,12 @@ extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
     const long long dst = J.tile_dst[chunk];
     for (int i = threadIdx.x; i < cnt; i += 256) {
       const long long row = J.pair_probe[src + i];
+#if FJ_PF == 3
+      const int rank = J.pair_build[src + i];   // rank of the key among the build keys (-1: unmatched row of an outer probe)
+      J.out_build[dst + i] = rank < 0 ? -1 : J.pf.direct[rank];
+#else
       J.out_build[dst + i] = J.pair_build[src + i];
+#endif
       tg_emit_outputs(A, row, dst + i);
     }
   }
@@ -1368,6 +1382,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.bloom = tv.bloom;
     J.bloom_word_mask = tv.bloom_word_mask;
     J.direct = tv.direct;
+    J.rank_base = tv.rank_base;
     J.outer = outer ? 1 : 0;
     const int64_t tile_rows = (int64_t)fj_stripes() * 256;
     J.tiles = ceil_div(n, tile_rows);

@@ -82,6 +82,7 @@ struct FjArgs {  // must match the generated struct
     const unsigned long long *bloom;
     unsigned long long bloom_word_mask;
     const int32_t *direct;
+    const int32_t *rank_base;
     int32_t *tile_cnt;
     int32_t *tile_src;
     const int32_t *tile_dst;

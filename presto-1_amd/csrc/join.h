@@ -38,7 +38,8 @@ struct IntTableView {
     unsigned long long bloom_word_mask = 0;
     const unsigned long long *bitmap = nullptr;   // dense key domain: one bit per key value in [key_min, key_max]
     long long key_min = 0, key_max = -1;
-    const int32_t *direct = nullptr;        // DIRECT layout: build position by key - key_min (slots is then nullptr)
+    const int32_t *direct = nullptr;        // DIRECT layout: build positions in key order (slots is then nullptr)
+    const int32_t *rank_base = nullptr;     //   and the number of present keys in front of every bitmap word
     const int32_t *links = nullptr;         // nullptr = no duplicate build keys
     int32_t key_type = 0;
 };
@@ -78,7 +79,8 @@ private:
     BufferPtr bloom_;            // fast path: blocked Bloom filter over the build keys (sparse key domains)
     int64_t bloom_words_ = 0;
     BufferPtr bitmap_;           // fast path: exact bitmap over [key_min_, key_max_] (dense key domains)
-    BufferPtr direct_;           // fast path, DIRECT layout: int32 build position by key - key_min_ (no hash table)
+    BufferPtr direct_;           // fast path, DIRECT layout: int32 build positions in key order (no hash table)
+    BufferPtr rank_base_;        //   present keys in front of every bitmap word (device_join.h tg_direct_position)
     long long key_min_ = 0, key_max_ = -1;
     BufferPtr tags_;             // uint8[n]                           (PagesHash.positionToHashes)
     BufferPtr links_;            // int32[n] or empty when no duplicates (ArrayPositionLinks)

@@ -244,10 +244,9 @@ __global__ void __launch_bounds__(kBlock) key_range_kernel(ColView key, int64_t 
     block_minmax(lo, hi, minmax);
 }
 
-// DIRECT layout, step 2: one pass sets the key's bit in the (zeroed) bitmap and stores the row as the key's build position.
-// A bit that was already set means a repeated build key: counted in counters[0]; the caller then drops this layout (position
-// links need the hash table), so the plain store never has to order two rows of one key.
-__global__ void __launch_bounds__(kBlock) build_direct_kernel(ColView key, int64_t n, long long key_min, unsigned long long *bitmap, int *direct,
+// DIRECT layout, step 2: one pass sets the key's bit in the (zeroed) bitmap.  A bit that was already set means a repeated build
+// key: counted in counters[0]; the caller then drops this layout (position links need the hash table).
+__global__ void __launch_bounds__(kBlock) build_direct_kernel(ColView key, int64_t n, long long key_min, unsigned long long *bitmap,
                                                                unsigned long long *counters)
 {
     // Neighbouring rows often fall into the same bitmap word (build sides clustered by key: consecutive customer keys share one
@@ -261,7 +260,6 @@ __global__ void __launch_bounds__(kBlock) build_direct_kernel(ColView key, int64
         unsigned long long d = 0;
         if (active) {
             d = (unsigned long long)int_key_at(key, r) - (unsigned long long)key_min;
-            direct[d] = (int)r;
         }
         const unsigned int word = active ? (unsigned int)(d >> 6) : 0xffffffffu;
         unsigned long long bits = active ? (1ULL << (d & 63)) : 0ULL;
@@ -308,6 +306,24 @@ __global__ void __launch_bounds__(kBlock) init_slots_kernel(Slot16 *__restrict__
         s.head = -1;
         s.pad = 0;
         slots[i] = s;
+    }
+}
+
+// DIRECT layout, step 3: present keys per bitmap word (its exclusive scan is rank_base)
+__global__ void __launch_bounds__(kBlock) bitmap_popcount_kernel(const unsigned long long *__restrict__ bitmap, int64_t words, int32_t *__restrict__ counts)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < words; i += (int64_t)gridDim.x * kBlock) counts[i] = (int32_t)__popcll(bitmap[i]);
+}
+
+// DIRECT layout, step 4: every build row stores its position at the rank of its key: positions in key order, written densely
+// (a build side that arrives clustered by key writes them front to back)
+__global__ void __launch_bounds__(kBlock) build_rank_kernel(ColView key, int64_t n, long long key_min, const unsigned long long *__restrict__ bitmap,
+                                                             const int32_t *__restrict__ rank_base, int32_t *__restrict__ direct)
+{
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+        if (key.nulls && key.nulls[r]) continue;
+        const unsigned long long d = (unsigned long long)int_key_at(key, r) - (unsigned long long)key_min;
+        direct[rank_base[d >> 6] + __popcll(bitmap[d >> 6] & ((1ULL << (d & 63)) - 1ULL))] = (int32_t)r;
     }
 }
 
@@ -529,7 +545,7 @@ std::vector<int32_t> LookupSourceGpu::key_types() const
 
 int64_t LookupSourceGpu::estimated_size() const
 {
-    return index_->estimated_size() + (direct_ ? (int64_t)direct_->bytes() : capacity_ * (int_key_fast_ ? 16 : 4)) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0) +
+    return index_->estimated_size() + (direct_ ? (int64_t)(direct_->bytes() + rank_base_->bytes()) : capacity_ * (int_key_fast_ ? 16 : 4)) + (tags_ ? n_ : 0) + (links_ ? n_ * 4 : 0) +
            (bitmap_ ? (int64_t)bitmap_->bytes() : 0) + (bloom_ ? bloom_words_ * 8 : 0);
 }
 
@@ -547,6 +563,7 @@ void LookupSourceGpu::build()
     if (capacity_ > (1ll << 31)) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "hash table size cannot exceed 2 billion slots");
     link_count_ = 0;
     direct_.reset();
+    rank_base_.reset();
     links_.reset();
     tags_.reset();
     bitmap_.reset();
@@ -661,10 +678,12 @@ void LookupSourceGpu::build()
 }
 
 // DIRECT layout of the int-key fast path: when the key domain is dense (at least one key value in 64 is present, at most 2^31
-// values) and no build key repeats, the "table" is an exact bitmap over [key_min, key_max] plus the build position of every
-// present key, addressed by key - key_min: the build is one pass of one atomicOr + one store per row (no probing, no key
-// comparison), a probe is a bit test + one 4-byte load, and inputs clustered by key walk both arrays front to back.  Returns
-// false (nothing kept) when the keys do not qualify; the hash table is built then.
+// values) and no build key repeats, the "table" is an exact bitmap over [key_min, key_max] plus the build positions in key
+// order, addressed by the key's rank among the present keys (rank_base[word] + popcount of the lower bits of the word): the
+// build is one atomicOr per row, a scan over the bitmap words and one dense store per row (no probing, no key comparison, no
+// write amplification from scattering 4-byte entries over the key range); a probe is a bit test, and only a MATCH pays the two
+// further loads; inputs clustered by key walk all three arrays front to back.  Returns false (nothing kept) when the keys do
+// not qualify; the hash table is built then.
 bool LookupSourceGpu::build_direct(const KeyCols &keys)
 {
     const int g = grid_for(ctx_, n_);
@@ -683,19 +702,30 @@ bool LookupSourceGpu::build_direct(const KeyCols &keys)
     if (range == 0 || range > (1ULL << 31) || range / 64ULL > (unsigned long long)n_) return false;
     const int64_t words = (int64_t)((range + 63) / 64);
     BufferPtr bitmap = ctx_->alloc_zero((size_t)words * 8);
-    BufferPtr direct = ctx_->alloc((size_t)range * 4);
-    BufferPtr counters = ctx_->alloc_zero(8);
+    BufferPtr direct = ctx_->alloc((size_t)n_ * 4);
+    BufferPtr rank_base = ctx_->alloc((size_t)words * 4);
+    BufferPtr counters = ctx_->alloc_zero(16);
     {
         ProfileScope ps(ctx_, "join_build_insert");
-        build_direct_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, host_mm[0], bitmap->as<unsigned long long>(), direct->as<int>(),
-                                                             counters->as<unsigned long long>());
+        build_direct_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, host_mm[0], bitmap->as<unsigned long long>(), counters->as<unsigned long long>());
         check_launch("build_direct");
     }
+    {
+        ProfileScope ps(ctx_, "join_build_rank");
+        BufferPtr counts = ctx_->alloc((size_t)words * 4);
+        bitmap_popcount_kernel<<<grid_for(ctx_, words), kBlock, 0, ctx_->stream()>>>(bitmap->as<unsigned long long>(), words, counts->as<int32_t>());
+        check_launch("bitmap_popcount");
+        k::exclusive_scan_i32(ctx_, counts->as<int32_t>(), rank_base->as<int32_t>(), words, (int64_t *)(counters->as<unsigned long long>() + 1));
+        build_rank_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, host_mm[0], bitmap->as<unsigned long long>(), rank_base->as<int32_t>(), direct->as<int32_t>());
+        check_launch("build_rank");
+    }
+    // (with repeated keys two rows share a rank: the stores above stayed inside direct[], the layout is dropped here)
     if (ctx_->read_scalar(counters->as<unsigned long long>()) != 0) return false;   // repeated build keys: position links needed
     key_min_ = host_mm[0];
     key_max_ = host_mm[1];
     bitmap_ = bitmap;
     direct_ = direct;
+    rank_base_ = rank_base;
     return true;
 }
 
@@ -704,6 +734,7 @@ bool LookupSourceGpu::int_table(IntTableView &v) const
     if (!int_key_fast_ || (!slots16_ && !direct_)) return false;
     v.slots = slots16_ ? slots16_->ptr() : nullptr;
     v.direct = direct_ ? direct_->as<int32_t>() : nullptr;
+    v.rank_base = rank_base_ ? rank_base_->as<int32_t>() : nullptr;
     v.mask = (uint64_t)capacity_ - 1;
     v.bloom = bloom_ ? bloom_->as<unsigned long long>() : nullptr;
     v.bloom_word_mask = bloom_ ? (unsigned long long)bloom_words_ - 1 : 0;
@@ -752,6 +783,7 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
     t.pf.bloom = bloom_ ? bloom_->as<unsigned long long>() : nullptr;
     t.pf.bloom_word_mask = bloom_ ? (unsigned long long)bloom_words_ - 1 : 0;
     t.pf.direct = direct_ ? direct_->as<int>() : nullptr;
+    t.pf.rank_base = rank_base_ ? rank_base_->as<int>() : nullptr;
     BufferPtr heads = ctx_->alloc((size_t)n * 4), counts = ctx_->alloc((size_t)n * 4), offsets = ctx_->alloc((size_t)n * 4), total = ctx_->alloc(8);
     const int g = grid_for(ctx_, n);
     {
