@@ -235,11 +235,25 @@ __global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long 
 __global__ void __launch_bounds__(kBlock) key_range_kernel(ColView key, int64_t n, long long *minmax)
 {
     long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        if (key.nulls && key.nulls[r]) continue;
-        const long long k = int_key_at(key, r);
-        lo = k < lo ? k : lo;
-        hi = k > hi ? k : hi;
+    // four independent loads per lane and iteration; few, long-running blocks: every block ends in two atomics on the same
+    // two words, which serialise in L2
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t r0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; r0 < n; r0 += 4 * stride) {
+        long long k[4];
+        bool live[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t r = r0 + u * stride;
+            live[u] = r < n;
+            const int64_t rc = live[u] ? r : r0;
+            live[u] = live[u] && !(key.nulls && key.nulls[rc]);
+            k[u] = int_key_at(key, rc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            lo = (live[u] && k[u] < lo) ? k[u] : lo;
+            hi = (live[u] && k[u] > hi) ? k[u] : hi;
+        }
     }
     block_minmax(lo, hi, minmax);
 }
@@ -693,7 +707,7 @@ bool LookupSourceGpu::build_direct(const KeyCols &keys)
     long long host_mm[2];
     {
         ProfileScope ps(ctx_, "join_build_range");
-        key_range_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, mm->as<long long>());
+        key_range_kernel<<<std::min(g, ctx_->cu_count() * 2), kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, mm->as<long long>());
         check_launch("key_range");
     }
     ctx_->download(host_mm, mm->ptr(), 16);
