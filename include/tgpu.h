@@ -296,6 +296,19 @@ int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel
 int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels,
                             int32_t hash_channel, int32_t partition_count, int64_t *counts, tgpu_output_page **out);
 
+/* ---- SerializedPage <-> HBM: the reference's exchange / spill page format as the ingest / egress format ---- */
+/* PagesSerde.serialize + PagesSerdeUtil.writeSerializedPage (M/execution/buffer/PagesSerde.java:64-115, PagesSerdeUtil.java:45-71;
+ * block bodies: S/block/LongArrayBlockEncoding.java:37-61, IntArrayBlockEncoding, ByteArrayBlockEncoding, VariableWidthBlockEncoding.java:37-61,
+ * null bits S/block/EncoderUtil.java:33-71) of `page` into `out` (host memory, `capacity` bytes): positionCount | markers (none) |
+ * uncompressedSize | sizeInBytes | payload, byte for byte what the Java serde writes for the same flat blocks.  *out_len = bytes
+ * written.  out == NULL: *out_len = an upper bound of the size (nothing is computed), for sizing the buffer. */
+int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out, int64_t capacity, int64_t *out_len);
+/* PagesSerde.deserialize (PagesSerde.java:117-160) of one uncompressed, unencrypted SerializedPage in host memory, straight into a
+ * device-resident page: LONG_ARRAY / INT_ARRAY / BYTE_ARRAY / VARIABLE_WIDTH blocks, RLE and DICTIONARY (RunLengthBlockEncoding.java:31-53,
+ * DictionaryBlockEncoding.java:33-80) flattened on the device.  `types` = the tgpu_type of every channel (the encodings do not tell
+ * BIGINT from DOUBLE, INTEGER from DATE).  COMPRESSED / ENCRYPTED markers: TGPU_ERR_NOT_SUPPORTED. */
+int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len, int32_t type_count, const int32_t *types, tgpu_output_page **out);
+
 #ifdef __cplusplus
 }
 #endif

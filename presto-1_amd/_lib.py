@@ -110,6 +110,8 @@ SYMBOLS = {
     "tgpu_group_by_hash_append_values": (i32, [vp, P(vp)]),
     "tgpu_hash_page": (i32, [vp, P(Page), i32, P(i32), vp]),
     "tgpu_partition_page": (i32, [vp, P(Page), i32, P(i32), i32, i32, vp, P(vp)]),
+    "tgpu_serialize_page": (i32, [vp, P(Page), vp, i64, P(i64)]),
+    "tgpu_deserialize_page": (i32, [vp, vp, i64, i32, P(i32), P(vp)]),
 }
 # helpers outside tgpu.h (build / diagnostics)
 EXTRA_SYMBOLS = {

@@ -5,6 +5,7 @@
 
 #include "kernels.h"
 #include "operators.h"
+#include "serde.h"
 
 namespace tgpu {
 const std::string &last_error();
@@ -736,6 +737,26 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
         o.n = n;
         for (auto &col : in.cols) o.cols.push_back(k::gather_column(c, col, pos->as<int32_t>(), n, false));
         *out = release_output(make_output(c, std::move(o)));
+    });
+}
+
+int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out, int64_t capacity, int64_t *out_len)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && page && out_len, "null argument");
+        Context *c = ctx->ctx.get();
+        DevicePage in = ingest_page(c, page);
+        *out_len = serde::serialize(c, in, (uint8_t *)out, capacity);
+    });
+}
+
+int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len, int32_t type_count, const int32_t *types, tgpu_output_page **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && bytes && out && (types || type_count == 0), "null argument");
+        Context *c = ctx->ctx.get();
+        *out = nullptr;
+        *out = release_output(make_output(c, serde::deserialize(c, (const uint8_t *)bytes, len, types, type_count)));
     });
 }
 

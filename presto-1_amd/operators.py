@@ -65,6 +65,27 @@ class Context:
         _lib.check(_lib.lib().tgpu_partition_page(self.handle, C.byref(cp), n, ch, hash_channel, partition_count, counts.ctypes.data, C.byref(out)))
         return counts, OutputPage(out)
 
+    def serialize_page(self, page: Page, into=None):
+        """PagesSerde.serialize + writeSerializedPage (M/execution/buffer/PagesSerde.java:64-115): the page as the reference's wire
+        bytes.  `into` (a uint8 numpy buffer, e.g. a reused exchange buffer): written in place, returns the byte count."""
+        cp, keep = page.to_c()
+        need = C.c_int64()
+        if into is not None:
+            _lib.check(_lib.lib().tgpu_serialize_page(self.handle, C.byref(cp), into.ctypes.data, into.size, C.byref(need)))
+            return int(need.value)
+        _lib.check(_lib.lib().tgpu_serialize_page(self.handle, C.byref(cp), None, 0, C.byref(need)))
+        buf = np.empty(max(int(need.value), 1), dtype=np.uint8)
+        _lib.check(_lib.lib().tgpu_serialize_page(self.handle, C.byref(cp), buf.ctypes.data, buf.size, C.byref(need)))
+        return buf[: need.value].tobytes()
+
+    def deserialize_page(self, data: bytes, types):
+        """PagesSerde.deserialize (PagesSerde.java:117-160) into a device-resident OutputPage; `types` = channel types"""
+        t, n = _i32(types)
+        raw = np.frombuffer(data, dtype=np.uint8)
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_deserialize_page(self.handle, raw.ctypes.data, raw.size, n, t, C.byref(out)))
+        return OutputPage(out)
+
     def close(self):
         if self.handle:
             _lib.lib().tgpu_context_destroy(self.handle)

@@ -995,3 +995,120 @@ def test_order_by_sequence_and_oracle(pkg, ctx, oracle):
     got = np.concatenate([p.getBlock(0).values for p in out])
     want = oracle.top_n([ocol(oracle, b) for b in blocks], m, [0, 1], [0, 3])
     assert np.array_equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SerializedPage <-> HBM: byte-exact against the numpy restatement of the reference's serde
+# ---------------------------------------------------------------------------------------------------------------------
+SERDE_TYPES = lambda pkg: [pkg.BIGINT, pkg.INTEGER, pkg.DATE, pkg.DOUBLE, pkg.BOOLEAN, pkg.VARCHAR]
+
+
+def _assert_same_page(pkg, got, blocks, n):
+    assert got.position_count == n and len(got.blocks) == len(blocks)
+    for g, b in zip(got.blocks, blocks):
+        b = b.flatten()
+        nl = np.zeros(n, dtype=np.uint8) if b.nulls is None else np.asarray(b.nulls[:n], dtype=np.uint8)
+        gn = np.zeros(n, dtype=np.uint8) if g.nulls is None else np.asarray(g.nulls[:n], dtype=np.uint8)
+        assert np.array_equal(gn, nl)
+        if b.type == pkg.VARCHAR:
+            assert g.to_list() == b.to_list()
+        else:
+            keep = nl == 0
+            assert np.array_equal(np.asarray(g.values[:n])[keep].view(np.uint8), np.asarray(b.values[:n])[keep].view(np.uint8))
+
+
+@pytest.mark.parametrize("n,null_frac", [(0, 0.0), (1, 0.0), (1, 1.0), (7, 0.4), (8, 0.4), (9, 0.4), (1000, 0.0), (1000, 0.3), (100003, 0.2), (100003, 1.0)])
+def test_serialize_page_matches_reference_bytes(pkg, ctx, oracle, n, null_frac):
+    rng = np.random.default_rng(n + int(null_frac * 10))
+    blocks = [rand_block(pkg, rng, t, n, null_frac=null_frac) for t in SERDE_TYPES(pkg)]
+    page = pkg.Page(*blocks, position_count=n)
+    want = oracle.serialize_page([ocol(oracle, b) for b in blocks])
+    got = ctx.serialize_page(page)
+    assert got == want
+    # and back: the reference's bytes decode into the same page on the GPU
+    back = ctx.deserialize_page(want, SERDE_TYPES(pkg))
+    _assert_same_page(pkg, back.to_host(), blocks, n)
+    back.release()
+
+
+def test_serde_known_answer_sizes_on_gpu(pkg, ctx, oracle):
+    # TestPagesSerde.java:64-110 (tests/golden): sizes the reference asserts for its own writer
+    g = GOLD["pages_serde"]
+    one = ctx.serialize_page(pkg.Page(pkg.Block(pkg.BIGINT, np.array([123], dtype=np.int64))))
+    two = ctx.serialize_page(pkg.Page(pkg.Block(pkg.BIGINT, np.array([123, 456], dtype=np.int64))))
+    assert len(one) - g["bigint_page_overhead"] == g["bigint_first_value"] and len(two) - len(one) == g["bigint_second_value"]
+    a = ctx.serialize_page(pkg.Page(pkg.Block(pkg.VARCHAR, ["alice"])))
+    b = ctx.serialize_page(pkg.Page(pkg.Block(pkg.VARCHAR, ["alice", "bob"])))
+    assert len(a) - g["varchar_empty_page_bytes"] == g["varchar_alice"] and len(b) - len(a) == g["varchar_bob"]
+    # testRoundTrip: three identical VARCHAR channels
+    blk = pkg.Block(pkg.VARCHAR, g["roundtrip_strings"])
+    data = ctx.serialize_page(pkg.Page(blk, blk, blk))
+    out = ctx.deserialize_page(data, [pkg.VARCHAR] * 3)
+    assert [b.to_list() for b in out.to_host().blocks] == [g["roundtrip_strings"]] * 3
+    out.release()
+
+
+def test_deserialize_rle_and_dictionary_blocks(pkg, ctx, oracle):
+    O = oracle
+    # the empty BIGINT page exactly as the Java writer emits it (52 bytes): RLE around a one-position null block
+    null_block = O.serialize_block(O.Col(O.BIGINT, [0], nulls=[1]))
+    data = O.serialized_page(0, [O.rle_block(null_block, 0)])
+    assert len(data) == GOLD["pages_serde"]["bigint_empty_page_bytes"]
+    out = ctx.deserialize_page(data, [pkg.BIGINT])
+    assert out.position_count == 0
+    out.release()
+    # RLE of a value and of a null; DICTIONARY over varchar and double dictionaries with nulls
+    rng = np.random.default_rng(5)
+    n = 777
+    ids = rng.integers(0, 5, n)
+    words = ["", "a", None, "dictionary", "zz"]
+    dvals = np.array([1.5, -0.0, np.nan, 0.0, 7e300])
+    dnull = np.array([0, 0, 0, 1, 0], dtype=np.uint8)
+    blocks = [O.rle_block(O.serialize_block(O.Col(O.BIGINT, [42])), n), O.rle_block(O.serialize_block(O.Col(O.VARCHAR, [None])), n),
+              O.dictionary_block(O.serialize_block(O.Col(O.VARCHAR, words)), ids), O.dictionary_block(O.serialize_block(O.Col(O.DOUBLE, dvals, dnull)), ids)]
+    data = O.serialized_page(n, blocks)
+    types = [pkg.BIGINT, pkg.VARCHAR, pkg.VARCHAR, pkg.DOUBLE]
+    out = ctx.deserialize_page(data, types)
+    host = out.to_host()
+    _, want = O.deserialize_page(data, types)
+    assert host.blocks[0].to_list() == [42] * n
+    assert host.blocks[1].to_list() == [None] * n
+    assert host.blocks[2].to_list() == [words[i] for i in ids]
+    keep = dnull[ids] == 0
+    assert np.array_equal(np.asarray(host.blocks[3].nulls[:n]) != 0, ~keep)
+    assert np.array_equal(np.asarray(host.blocks[3].values[:n])[keep].view(np.int64), dvals[ids][keep].view(np.int64))
+    assert np.array_equal(want[3].values[keep].view(np.int64), dvals[ids][keep].view(np.int64))
+    out.release()
+
+
+def test_deserialize_rejects_what_it_cannot_read(pkg, ctx, oracle):
+    data = bytearray(oracle.serialize_page([oracle.Col(oracle.BIGINT, [1, 2, 3])]))
+    for marker in (1, 2):   # PageCodecMarker.java:24-25 COMPRESSED, ENCRYPTED
+        bad = bytearray(data)
+        bad[4] = marker
+        with pytest.raises(pkg.TgpuError) as e:
+            ctx.deserialize_page(bytes(bad), [pkg.BIGINT])
+        assert e.value.code == -8
+    with pytest.raises(pkg.TgpuError) as e:
+        ctx.deserialize_page(bytes(data[:-5]), [pkg.BIGINT])
+    assert e.value.code == -1
+    with pytest.raises(pkg.TgpuError) as e:   # a LONG_ARRAY block where the consumer expects a 4-byte type
+        ctx.deserialize_page(bytes(data), [pkg.INTEGER])
+    assert e.value.code == -1
+    with pytest.raises(pkg.TgpuError):
+        ctx.deserialize_page(bytes(data), [pkg.BIGINT, pkg.BIGINT])
+
+
+def test_serde_round_trip_device_page_full_size(pkg, ctx):
+    # size-independent property at a full page: serialize(deserialize(bytes)) == bytes, through a device-resident page (the
+    # decoded OutputPage is fed back without leaving HBM)
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    blocks = [rand_block(pkg, rng, pkg.BIGINT, n, null_frac=0.1), rand_block(pkg, rng, pkg.DOUBLE, n), rand_block(pkg, rng, pkg.DATE, n, null_frac=0.5),
+              pkg.Block(pkg.VARCHAR, np.frombuffer(rng.integers(65, 91, n).astype(np.uint8).tobytes(), dtype=np.uint8), None, np.arange(n + 1, dtype=np.int32))]
+    types = [pkg.BIGINT, pkg.DOUBLE, pkg.DATE, pkg.VARCHAR]
+    data = ctx.serialize_page(pkg.Page(*blocks, position_count=n))
+    out = ctx.deserialize_page(data, types)
+    again = ctx.serialize_page(out.as_device_page())
+    assert again == data
+    out.release()
