@@ -296,6 +296,22 @@ int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel
 int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels,
                             int32_t hash_channel, int32_t partition_count, int64_t *counts, tgpu_output_page **out);
 
+/* ---- PartitionedOutputOperator: the shuffle producer behind the Operator API ---- */
+/* M/operator/PartitionedOutputOperator.java:46-300, PagePartitioner :308-486.  A sink operator (getOutput() returns nothing, :303-306):
+ * addInput groups the page's rows by partition = (rawHash & 0x7fff...) % partition_count (HashGenerator.java:24-35) of `hash_channel`
+ * (>= 0: the precomputed raw hash) or of the `partition_channels` (InterpretedHashGenerator), rows in input order inside each
+ * partition; a row goes to EVERY partition when `null_channel` >= 0 is null there, and so does the first row ever seen when
+ * `replicates_any_row` is set (:411-418).  Constant partitioning arguments (:433-448): TGPU_ERR_NOT_SUPPORTED. */
+int32_t tgpu_partitioned_output_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int32_t partition_channel_count,
+                                               const int32_t *partition_channels, int32_t hash_channel /* -1 = hash the channels */, int32_t partition_count,
+                                               int32_t replicates_any_row, int32_t null_channel /* -1 = none */, tgpu_operator_factory **out);
+/* what the reference enqueues into its OutputBuffer (PagePartitioner.flush :451-470: outputBuffer.enqueue(partition, pages)): the next
+ * pending (partition, page) pair in enqueue order, device resident (serialize it with tgpu_serialize_page or hand it to a GPU
+ * exchange); *out = NULL when nothing is pending */
+int32_t tgpu_partitioned_output_poll(tgpu_operator *op, int32_t *partition, tgpu_output_page **out);
+/* PartitionedOutputInfo (:396-399) */
+int32_t tgpu_partitioned_output_info(tgpu_operator *op, int64_t *rows_added, int64_t *pages_added);
+
 /* ---- SerializedPage <-> HBM: the reference's exchange / spill page format as the ingest / egress format ---- */
 /* PagesSerde.serialize + PagesSerdeUtil.writeSerializedPage (M/execution/buffer/PagesSerde.java:64-115, PagesSerdeUtil.java:45-71;
  * block bodies: S/block/LongArrayBlockEncoding.java:37-61, IntArrayBlockEncoding, ByteArrayBlockEncoding, VariableWidthBlockEncoding.java:37-61,

@@ -349,34 +349,5 @@ void partition_ids(Context *ctx, const int64_t *raw_hashes, int64_t n, int32_t p
     check_launch("partition_ids");
 }
 
-__global__ void __launch_bounds__(kBlock) flag_eq_kernel(const int32_t *__restrict__ ids, int64_t n, int32_t v, int32_t *__restrict__ flags)
-{
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) flags[i] = ids[i] == v;
-}
-
-__global__ void __launch_bounds__(kBlock) scatter_eq_kernel(const int32_t *__restrict__ ids, const int32_t *__restrict__ rank, int64_t n, int32_t v,
-                                                             const int64_t *__restrict__ counts, int32_t *__restrict__ out)
-{
-    int64_t base = 0;
-    for (int p = 0; p < v; p++) base += counts[p];
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        if (ids[i] == v) out[base + rank[i]] = (int32_t)i;
-}
-
-void partition_positions(Context *ctx, const int32_t *part_ids, int64_t n, int32_t partitions, int32_t *positions_out, int64_t *counts_dev)
-{
-    HIP_CHECK(hipMemsetAsync(counts_dev, 0, (size_t)partitions * 8, ctx->stream()));
-    if (n <= 0) return;
-    ProfileScope ps(ctx, "partition_positions");
-    BufferPtr flags = ctx->alloc((size_t)n * 4), rank = ctx->alloc((size_t)n * 4);
-    int g = grid_for(ctx, n);
-    for (int32_t p = 0; p < partitions; p++) {
-        flag_eq_kernel<<<g, kBlock, 0, ctx->stream()>>>(part_ids, n, p, flags->as<int32_t>());
-        exclusive_scan_i32(ctx, flags->as<int32_t>(), rank->as<int32_t>(), n, counts_dev + p);
-        scatter_eq_kernel<<<g, kBlock, 0, ctx->stream()>>>(part_ids, rank->as<int32_t>(), n, p, counts_dev, positions_out);
-    }
-    check_launch("partition_positions");
-}
-
 }  // namespace k
 }  // namespace tgpu

@@ -24,8 +24,13 @@ void widen_i32_to_i64(Context *ctx, const int32_t *in, int64_t *out, int64_t n);
 void any_null(Context *ctx, const KeyCols &keys, int64_t n, uint8_t *out);
 // K10: partition id per row = (raw & 0x7fff...) % partitions
 void partition_ids(Context *ctx, const int64_t *raw_hashes, int64_t n, int32_t partitions, int32_t *out);
-// stable counting sort of row indices by partition id: positions (n) grouped by partition, counts[partitions] (device int64)
+// ---- partition.hip --------------------------------------------------------------------------------------------------
+// stable grouping of row indices by partition id: positions (n) grouped by partition in input order, counts[partitions] (device int64)
 void partition_positions(Context *ctx, const int32_t *part_ids, int64_t n, int32_t partitions, int32_t *positions_out, int64_t *counts_dev);
+// the same with replicated rows (PagePartitioner.partitionPage: a row whose `replicate` byte is set goes to EVERY partition):
+// (partition, position) pairs grouped by partition, positions ascending inside each; pairs_out = n + replicated rows x (partitions - 1)
+void partition_pairs(Context *ctx, const int32_t *part_ids, const uint8_t *replicate, int64_t n, int32_t partitions, BufferPtr &positions_out, int64_t &pairs_out,
+                     int64_t *counts_dev);
 
 }  // namespace k
 }  // namespace tgpu

@@ -2,6 +2,8 @@
 // the reference's Java operators; the work inside addInput / getOutput runs in the gfx950 kernels).
 #include "operators.h"
 
+#include <deque>
+
 #include "kernels.h"
 
 #include <cstdlib>
@@ -674,6 +676,154 @@ std::unique_ptr<Operator> OrderByOperatorFactory::create_operator()
 {
     TG_CHECK_STATE(!closed_, "Factory is already closed");
     return std::make_unique<OrderByOperator>(ctx_, operator_id_, types_, output_channels_, sort_channels_, sort_orders_);
+}
+
+
+// =====================================================================================================================
+// PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java; PagePartitioner.partitionPage :406-426)
+//   position -> every partition when (replicatesAnyRow and no row has been replicated yet) or the null channel is null there,
+//   else -> partitionFunction.getPartition = (rawHash & 0x7fff...) % partitionCount (HashGenerator.java:24-35) of the
+//   precomputed hash channel or of the partition channels' InterpretedHashGenerator hash.
+// Rows reach each partition in input order.  The reference appends them to per-partition PageBuilders and flushes full ones;
+// here every input page is flushed as it is partitioned (page boundaries are not part of the exchange contract).
+// =====================================================================================================================
+namespace {
+__global__ void __launch_bounds__(256) replicate_flags_kernel(const uint8_t *null_channel_nulls, int64_t n, int replicate_first, uint8_t *out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = (uint8_t)(((null_channel_nulls && null_channel_nulls[i]) || (replicate_first && i == 0)) ? 1 : 0);
+}
+}  // namespace
+
+class PartitionedOutputOperator : public Operator {
+public:
+    PartitionedOutputOperator(Context *ctx, int32_t id, const std::vector<int32_t> &types, const std::vector<int32_t> &partition_channels, int32_t hash_channel,
+                              int32_t partition_count, bool replicates_any_row, int32_t null_channel)
+        : Operator(ctx, id), types_(types), partition_channels_(partition_channels), hash_channel_(hash_channel), partition_count_(partition_count),
+          null_channel_(null_channel), replicates_any_row_(replicates_any_row)
+    {
+    }
+
+    bool needs_input() override { return !finishing_; }   // :268-271 (the output buffer's back pressure is the shim's business)
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        DevicePage in = ingest_page(ctx_, page);
+        TG_CHECK_ARG(in.cols.size() == types_.size(), "page channel count does not match the operator's types");
+        for (size_t i = 0; i < types_.size(); i++) TG_CHECK_ARG(in.cols[i].type == types_[i], "page channel type does not match the operator's types");
+        const int64_t n = in.n;
+        if (n == 0) return;   // :274-277
+        BufferPtr own_hashes;
+        const int64_t *hashes = nullptr;
+        if (hash_channel_ >= 0) hashes = (const int64_t *)in.cols[(size_t)hash_channel_].values;
+        else {
+            std::vector<const DeviceColumn *> keys;
+            for (int32_t ch : partition_channels_) keys.push_back(&in.cols[(size_t)ch]);
+            own_hashes = ctx_->alloc((size_t)n * 8);
+            k::hash_rows(ctx_, key_cols_of(keys), n, own_hashes->as<int64_t>());
+            hashes = own_hashes->as<int64_t>();
+        }
+        BufferPtr ids = ctx_->alloc((size_t)n * 4), cnt = ctx_->alloc((size_t)partition_count_ * 8);
+        k::partition_ids(ctx_, hashes, n, partition_count_, ids->as<int32_t>());
+        // replicated rows of this page
+        const uint8_t *null_flags = null_channel_ >= 0 ? in.cols[(size_t)null_channel_].nulls : nullptr;
+        const bool replicate_first = replicates_any_row_ && !has_any_row_been_replicated_;
+        BufferPtr replicate;
+        if (null_flags || replicate_first) {
+            replicate = ctx_->alloc((size_t)n);
+            replicate_flags_kernel<<<(int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx_->cu_count() * 8), 256, 0, ctx_->stream()>>>(null_flags, n, replicate_first ? 1 : 0,
+                                                                                                                                    replicate->as<uint8_t>());
+            check_launch("replicate_flags");
+            has_any_row_been_replicated_ = true;   // :411-418 (row 0 if the flag was pending; null rows replicate regardless)
+        }
+        BufferPtr positions;
+        int64_t pairs = 0;
+        k::partition_pairs(ctx_, ids->as<int32_t>(), replicate ? replicate->as<uint8_t>() : nullptr, n, partition_count_, positions, pairs, cnt->as<int64_t>());
+        std::vector<int64_t> counts((size_t)partition_count_);
+        ctx_->download(counts.data(), cnt->ptr(), (size_t)partition_count_ * 8);
+        DevicePage grouped;
+        grouped.n = pairs;
+        for (auto &col : in.cols) grouped.cols.push_back(k::gather_column(ctx_, col, positions->as<int32_t>(), pairs, false));
+        int64_t at = 0;
+        for (int32_t p = 0; p < partition_count_; p++) {
+            const int64_t len = counts[(size_t)p];
+            if (len > 0) {
+                DevicePage part;
+                part.n = len;
+                for (auto &col : grouped.cols) part.cols.push_back(k::region_of(ctx_, col, at, len));   // views: the buffers are shared
+                pending_.push_back({p, std::move(part)});
+                pages_added_++;
+                rows_added_ += len;
+            }
+            at += len;
+        }
+    }
+
+    std::unique_ptr<OutputPage> get_output() override { return nullptr; }   // :303-306
+    void finish() override { finishing_ = true; }                              // :255-259 flush(true): nothing is held back here
+    bool is_finished() override { return finishing_; }
+
+    int64_t memory_bytes() override
+    {
+        int64_t s = 0;
+        for (auto &e : pending_) s += e.second.size_in_bytes();
+        return s;
+    }
+
+    bool poll(int32_t *partition, std::unique_ptr<OutputPage> *out)
+    {
+        if (pending_.empty()) return false;
+        *partition = pending_.front().first;
+        *out = wrap(std::move(pending_.front().second));
+        pending_.pop_front();
+        return true;
+    }
+    int64_t rows_added_ = 0, pages_added_ = 0;   // PartitionedOutputInfo (:396-399)
+
+private:
+    std::vector<int32_t> types_, partition_channels_;
+    int32_t hash_channel_, partition_count_, null_channel_;
+    bool replicates_any_row_, has_any_row_been_replicated_ = false, finishing_ = false;
+    std::deque<std::pair<int32_t, DevicePage>> pending_;
+};
+
+PartitionedOutputOperatorFactory::PartitionedOutputOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> partition_channels,
+                                                                   int32_t hash_channel, int32_t partition_count, bool replicates_any_row, int32_t null_channel)
+    : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), partition_channels_(std::move(partition_channels)), hash_channel_(hash_channel),
+      partition_count_(partition_count), null_channel_(null_channel), replicates_any_row_(replicates_any_row)
+{
+    TG_CHECK_ARG(partition_count_ > 0 && partition_count_ <= 1024, "partition count must be in 1..1024");
+    TG_CHECK_ARG(null_channel_ < (int)types_.size(), "null channel out of range");
+    if (hash_channel_ >= 0) TG_CHECK_ARG(hash_channel_ < (int)types_.size() && types_[(size_t)hash_channel_] == TGPU_BIGINT, "bad hash channel");
+    else TG_CHECK_ARG(!partition_channels_.empty(), "partitioning needs partition channels or a hash channel");
+    for (int32_t ch : partition_channels_) {
+        // (a negative channel = a constant partitioning argument in the reference, :433-448)
+        if (ch < 0) fail(TGPU_ERR_NOT_SUPPORTED, "constant partitioning arguments are not supported");
+        TG_CHECK_ARG(ch < (int)types_.size(), "partition channel out of range");
+    }
+    TG_CHECK_ARG((int)partition_channels_.size() <= kMaxKeyChannels, "at most 8 partition channels are supported");
+}
+
+std::unique_ptr<Operator> PartitionedOutputOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<PartitionedOutputOperator>(ctx_, operator_id_, types_, partition_channels_, hash_channel_, partition_count_, replicates_any_row_, null_channel_);
+}
+
+bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<OutputPage> *out)
+{
+    auto *p = dynamic_cast<PartitionedOutputOperator *>(op);
+    TG_CHECK_ARG(p != nullptr, "not a PartitionedOutputOperator");
+    return p->poll(partition, out);
+}
+
+void partitioned_output_info(Operator *op, int64_t *rows_added, int64_t *pages_added)
+{
+    auto *p = dynamic_cast<PartitionedOutputOperator *>(op);
+    TG_CHECK_ARG(p != nullptr, "not a PartitionedOutputOperator");
+    *rows_added = p->rows_added_;
+    *pages_added = p->pages_added_;
 }
 
 }  // namespace tgpu

@@ -197,6 +197,27 @@ private:
     std::vector<int32_t> types_, output_channels_, sort_channels_, sort_orders_;
 };
 
+// ---- PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java:46-300; PagePartitioner :308-486) ---------------------
+// A sink: input rows are grouped by destination partition and handed out as (partition, page) pairs -- what the reference
+// enqueues into its OutputBuffer -- through poll(); get_output() returns nothing, as in the reference (:303-306).
+class PartitionedOutputOperator;
+class PartitionedOutputOperatorFactory : public OperatorFactory {
+public:
+    PartitionedOutputOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> partition_channels, int32_t hash_channel,
+                                     int32_t partition_count, bool replicates_any_row, int32_t null_channel);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> types_, partition_channels_;
+    int32_t hash_channel_, partition_count_, null_channel_;
+    bool replicates_any_row_;
+};
+// next pending (partition, page) pair of a PartitionedOutputOperator; false = nothing pending
+bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<OutputPage> *out);
+void partitioned_output_info(Operator *op, int64_t *rows_added, int64_t *pages_added);
+
 }  // namespace tgpu
 
 struct tgpu_context {

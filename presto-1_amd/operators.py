@@ -126,7 +126,10 @@ class Operator:
             self.handle = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # a constructor that failed before `handle` existed, or interpreter shutdown
+            pass
 
 
 class OperatorFactory:
@@ -148,7 +151,10 @@ class OperatorFactory:
             self.handle = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # a constructor that failed before `handle` existed, or interpreter shutdown
+            pass
 
 
 class FilterAndProjectOperatorFactory(OperatorFactory):
@@ -217,7 +223,10 @@ class LookupSourceFactory:
             self.handle = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # a constructor that failed before `handle` existed, or interpreter shutdown
+            pass
 
 
 class HashBuilderOperatorFactory(OperatorFactory):
@@ -394,7 +403,10 @@ class GroupByHash:
             self.handle = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # a constructor that failed before `handle` existed, or interpreter shutdown
+            pass
 
 
 def to_pages(operator: Operator, input_pages, to_host=True):
@@ -427,3 +439,37 @@ def to_pages(operator: Operator, input_pages, to_host=True):
     for o in outputs:
         o.release()
     return host
+
+
+class PartitionedOutputOperator(Operator):
+    """the sink side of PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java:46-300): poll() hands out what the
+    reference enqueues into its OutputBuffer"""
+
+    def poll(self):
+        """next pending (partition, OutputPage) pair, or None"""
+        part, out = C.c_int32(-1), C.c_void_p()
+        _lib.check(_lib.lib().tgpu_partitioned_output_poll(self.handle, C.byref(part), C.byref(out)))
+        return (int(part.value), OutputPage(out)) if out.value else None
+
+    def info(self):
+        rows, pages = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().tgpu_partitioned_output_info(self.handle, C.byref(rows), C.byref(pages)))
+        return {"rowsAdded": int(rows.value), "pagesAdded": int(pages.value)}
+
+
+class PartitionedOutputOperatorFactory(OperatorFactory):
+    """PartitionedOutputOperator.PartitionedOutputFactory (M/operator/PartitionedOutputOperator.java:52-130): hash partitioning on
+    `partition_channels` (or the precomputed `hash_channel`), `null_channel` / `replicates_any_row` replication (:411-418)."""
+
+    def __init__(self, ctx: Context, operator_id, types, partition_channels, partition_count, hash_channel=-1, replicates_any_row=False, null_channel=-1):
+        t, nt = _i32(types)
+        pc, npc = _i32(partition_channels)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_partitioned_output_factory_create(ctx.handle, operator_id, nt, t, npc, pc, hash_channel, partition_count,
+                                                                     1 if replicates_any_row else 0, null_channel, C.byref(h)))
+        super().__init__(h)
+
+    def createOperator(self):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_operator_factory_create_operator(self.handle, C.byref(h)))
+        return PartitionedOutputOperator(h)

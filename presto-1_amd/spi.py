@@ -278,4 +278,7 @@ class OutputPage:
             self.handle = None
 
     def __del__(self):
-        self.release()
+        try:
+            self.release()
+        except Exception:   # interpreter shutdown: module globals may already be gone
+            pass

@@ -1112,3 +1112,84 @@ def test_serde_round_trip_device_page_full_size(pkg, ctx):
     again = ctx.serialize_page(out.as_device_page())
     assert again == data
     out.release()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# PartitionedOutputOperator against the row-at-a-time PagePartitioner restatement
+# ---------------------------------------------------------------------------------------------------------------------
+def _drain_partitions(op, parts):
+    got = [[] for _ in range(parts)]
+    order = []
+    while True:
+        e = op.poll()
+        if e is None:
+            break
+        p, out = e
+        order.append(p)
+        got[p] += out.to_host().rows()
+        out.release()
+    return got, order
+
+
+@pytest.mark.parametrize("parts,replicates_any_row,null_channel,hash_channel", [(1, False, -1, -1), (8, False, -1, -1), (7, False, 0, -1), (8, True, -1, -1),
+                                                                               (5, True, 1, -1), (300, False, 0, -1), (8, False, -1, 3), (1024, False, -1, -1)])
+def test_partitioned_output_operator_vs_page_partitioner(pkg, ctx, oracle, parts, replicates_any_row, null_channel, hash_channel):
+    rng = np.random.default_rng(parts + 17 * int(replicates_any_row) + null_channel)
+    types = [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE, pkg.BIGINT]
+    fac = pkg.PartitionedOutputOperatorFactory(ctx, 31, types, [0, 1], parts, hash_channel=hash_channel, replicates_any_row=replicates_any_row, null_channel=null_channel)
+    op = fac.createOperator()
+    ref = oracle.PagePartitioner(parts, replicates_any_row, null_channel)
+    assert op.needsInput() and op.getOutput() is None
+    total_rows = 0
+    for n in (0, 1, 5000, 33333):   # several pages: the "replicate any row" state carries over (:411-418)
+        blocks = [rand_block(pkg, rng, pkg.BIGINT, n, 0.03, (0, 10**6)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.03, (0, 50)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.1),
+                  pkg.Block(pkg.BIGINT, rng.integers(-2**63, 2**63 - 1, n))]
+        page = pkg.Page(*blocks, position_count=n)
+        raw = blocks[3].values if hash_channel >= 0 else oracle.hash_rows([ocol(oracle, blocks[0]), ocol(oracle, blocks[1])])
+        want = ref.partition_page([ocol(oracle, b) for b in blocks], raw) if n else [[] for _ in range(parts)]
+        op.addInput(page)
+        got, order = _drain_partitions(op, parts)
+        assert order == sorted(order) and len(set(order)) == len(order)   # flush order: ascending partition, one page each (:451-470)
+        rows = page.rows()
+        for p in range(parts):
+            assert got[p] == [rows[i] for i in want[p]], (n, p)
+        total_rows += sum(len(w) for w in want)
+    assert op.info()["rowsAdded"] == total_rows
+    op.finish()
+    assert op.isFinished() and op.poll() is None
+    op.close()
+    fac.close()
+
+
+def test_partitioned_output_feeds_the_serde(pkg, ctx, oracle):
+    # the reference's flush: partition page -> PagesSerde.serialize -> OutputBuffer (:451-486); bytes must decode to the same rows
+    rng = np.random.default_rng(8)
+    n, parts = 20000, 4
+    types = [pkg.BIGINT, pkg.VARCHAR]
+    blocks = [rand_block(pkg, rng, pkg.BIGINT, n, 0.05, (0, 1000)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.05, (0, 30))]
+    page = pkg.Page(*blocks)
+    fac = pkg.PartitionedOutputOperatorFactory(ctx, 32, types, [0], parts)
+    op = fac.createOperator()
+    op.addInput(page)
+    pid = oracle.partition_remote(oracle.hash_rows([ocol(oracle, blocks[0])]), parts)
+    rows = page.rows()
+    while True:
+        e = op.poll()
+        if e is None:
+            break
+        p, out = e
+        data = ctx.serialize_page(out.as_device_page())
+        _, cols = oracle.deserialize_page(data, types)
+        back = ctx.deserialize_page(data, types)
+        assert back.to_host().rows() == [rows[i] for i in np.nonzero(pid == p)[0]]
+        assert cols[0].n == int((pid == p).sum())
+        back.release()
+        out.release()
+    op.close()
+    fac.close()
+
+
+def test_partitioned_output_rejects_constant_arguments(pkg, ctx):
+    with pytest.raises(pkg.TgpuError) as e:
+        pkg.PartitionedOutputOperatorFactory(ctx, 33, [pkg.BIGINT], [-1], 4)
+    assert e.value.code == -8
