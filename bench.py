@@ -615,7 +615,7 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected and corrected as documented there)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")))["kernels"].get(best)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")))["kernels"].get(best)
         if pmc:
             traffic = pmc["traffic_bytes_per_launch_avg"]
     except (OSError, ValueError, KeyError):
@@ -657,10 +657,12 @@ def main():
         b.dist.all_reduce(tt)
         total_probe = int(tt.item())
     # per-kernel algorithmic bytes per row (DESIGN.md "kernels and their rooflines")
-    # fused filter+probe kernel, launched twice per step (orders, lineitem).  Algorithmic bytes per launch:
-    # filter column 4 B x input rows + (key 8 B + one table slot 12 B) x rows passing the filter + 8 B x emitted pairs
+    # fused filter+probe kernel, launched twice per step (orders, lineitem).  Algorithmic bytes per launch, for the
+    # DIRECT table layout both TPCH build sides get: filter column 4 B x input rows + (key 8 B + one 8-byte bitmap word) x rows
+    # passing the filter + (rank word 4 B + pair 8 B) x emitted pairs.  (The hash-table layout reads a 12-byte slot instead of the
+    # bitmap word + rank word.)
     n_o, n_l = int(b.q3["o_orderkey"].numel()), int(b.q3["l_orderkey"].numel())
-    alg = ((4.0 * n_o + 20.0 * st["orders_probe_rows"] + 8.0 * st["orders_build_rows"]) + (4.0 * n_l + 20.0 * st["lineitem_probe_rows"] + 8.0 * st["lineitem_join_rows"])) / 2.0
+    alg = ((4.0 * n_o + 16.0 * st["orders_probe_rows"] + 12.0 * st["orders_build_rows"]) + (4.0 * n_l + 16.0 * st["lineitem_probe_rows"] + 12.0 * st["lineitem_join_rows"])) / 2.0
     rows_avg = (n_o + n_l) / 2.0
     if repartition:
         # behind the exchange the probe is the unfused kernel: key 8 B + one table slot 12 B + head/count out 8 B per probe row
