@@ -302,9 +302,15 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
  * (>= 0: the precomputed raw hash) or of the `partition_channels` (InterpretedHashGenerator), rows in input order inside each
  * partition; a row goes to EVERY partition when `null_channel` >= 0 is null there, and so does the first row ever seen when
  * `replicates_any_row` is set (:411-418).  Constant partitioning arguments (:433-448): TGPU_ERR_NOT_SUPPORTED. */
+typedef enum tgpu_partition_function {
+    TGPU_PARTITION_HASH_MODULO = 0, /* remote exchanges: (rawHash & 0x7fff...) % partition_count, M/operator/HashGenerator.java:24-35 */
+    TGPU_PARTITION_LOCAL = 1        /* LocalExchange (M/operator/exchange/PartitioningExchanger.java): (int) XxHash64.hash(Long.reverse(rawHash)) &
+                                     * (partition_count - 1), partition_count a power of two, M/operator/exchange/LocalPartitionGenerator.java:45-65 */
+} tgpu_partition_function;
 int32_t tgpu_partitioned_output_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int32_t partition_channel_count,
                                                const int32_t *partition_channels, int32_t hash_channel /* -1 = hash the channels */, int32_t partition_count,
-                                               int32_t replicates_any_row, int32_t null_channel /* -1 = none */, tgpu_operator_factory **out);
+                                               int32_t replicates_any_row, int32_t null_channel /* -1 = none */, int32_t partition_function,
+                                               tgpu_operator_factory **out);
 /* what the reference enqueues into its OutputBuffer (PagePartitioner.flush :451-470: outputBuffer.enqueue(partition, pages)): the next
  * pending (partition, page) pair in enqueue order, device resident (serialize it with tgpu_serialize_page or hand it to a GPU
  * exchange); *out = NULL when nothing is pending */

@@ -561,7 +561,8 @@ class PagePartitioner:
     """PagePartitioner.partitionPage (M/operator/PartitionedOutputOperator.java:406-426), row at a time: the positions every
     partition receives from each page, in append order.  partition = (rawHash & 0x7fff...) % count (HashGenerator.java:24-35)."""
 
-    def __init__(self, partition_count, replicates_any_row=False, null_channel=-1):
+    def __init__(self, partition_count, replicates_any_row=False, null_channel=-1, local=False):
+        self.local = local   # LocalPartitionGenerator.java:45-65 instead of HashGenerator.java:24-35
         self.count = partition_count
         self.replicates_any_row = replicates_any_row
         self.null_channel = null_channel
@@ -571,7 +572,7 @@ class PagePartitioner:
         n = cols[0].n if cols else 0
         out = [[] for _ in range(self.count)]
         nulls = cols[self.null_channel].nulls if self.null_channel >= 0 else None
-        parts = partition_remote(np.asarray(raw_hashes, dtype=np.int64), self.count) if n else []
+        parts = (partition_local if self.local else partition_remote)(np.asarray(raw_hashes, dtype=np.int64), self.count) if n else []
         for position in range(n):
             replicate = (self.replicates_any_row and not self.has_any_row_been_replicated) or (nulls is not None and nulls[position] != 0)
             if replicate:

@@ -336,16 +336,20 @@ DeviceColumn region_of(Context *ctx, const DeviceColumn &src, int64_t offset, in
 // K10 partition: partition id per row, then a stable grouping of row positions by partition
 // (M/operator/PartitionedOutputOperator.java:406-426 appends rows to per-partition builders in input order)
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool LOCAL>
 __global__ void __launch_bounds__(kBlock) partition_ids_kernel(const int64_t *__restrict__ raw, int64_t n, int32_t parts, int32_t *__restrict__ out)
 {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = tg_partition_remote(raw[i], parts);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = LOCAL ? tg_partition_local(raw[i], parts) : tg_partition_remote(raw[i], parts);
 }
 
-void partition_ids(Context *ctx, const int64_t *raw_hashes, int64_t n, int32_t partitions, int32_t *out)
+void partition_ids(Context *ctx, const int64_t *raw_hashes, int64_t n, int32_t partitions, int32_t *out, bool local)
 {
+    if (local) TG_CHECK_ARG((partitions & (partitions - 1)) == 0, "the local partition function needs a power-of-two partition count");
     if (n <= 0) return;
     ProfileScope ps(ctx, "partition_ids");
-    partition_ids_kernel<<<grid_for(ctx, n), kBlock, 0, ctx->stream()>>>(raw_hashes, n, partitions, out);
+    if (local) partition_ids_kernel<true><<<grid_for(ctx, n), kBlock, 0, ctx->stream()>>>(raw_hashes, n, partitions, out);
+    else partition_ids_kernel<false><<<grid_for(ctx, n), kBlock, 0, ctx->stream()>>>(raw_hashes, n, partitions, out);
     check_launch("partition_ids");
 }
 

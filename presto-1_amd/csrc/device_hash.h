@@ -101,3 +101,15 @@ TGPU_HD tg_u64 tg_fmix64(tg_u64 x)
 
 // H8 remote: M/operator/HashGenerator.java:24-35
 TGPU_HD int tg_partition_remote(tg_i64 raw, int n) { return (int)((raw & 0x7fffffffffffffffLL) % n); }
+// M/operator/exchange/LocalPartitionGenerator.java:45-65: (int) XxHash64.hash(Long.reverse(rawHash)) & (n - 1), n a power of two
+TGPU_HD int tg_partition_local(tg_i64 raw, int n)
+{
+    tg_u64 x = (tg_u64)raw;
+    x = ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = ((x >> 8) & 0x00FF00FF00FF00FFULL) | ((x & 0x00FF00FF00FF00FFULL) << 8);
+    x = ((x >> 16) & 0x0000FFFF0000FFFFULL) | ((x & 0x0000FFFF0000FFFFULL) << 16);
+    x = (x >> 32) | (x << 32);
+    return (int)tg_xxh64_long((tg_i64)x) & (n - 1);
+}

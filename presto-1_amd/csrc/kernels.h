@@ -22,8 +22,9 @@ void iota_i32(Context *ctx, int32_t *p, int64_t n);
 void widen_i32_to_i64(Context *ctx, const int32_t *in, int64_t *out, int64_t n);
 // any-null over the key columns: out[i] = 1 if any key cell of row i is null
 void any_null(Context *ctx, const KeyCols &keys, int64_t n, uint8_t *out);
-// K10: partition id per row = (raw & 0x7fff...) % partitions
-void partition_ids(Context *ctx, const int64_t *raw_hashes, int64_t n, int32_t partitions, int32_t *out);
+// K10: partition id per row = (raw & 0x7fff...) % partitions (HashGenerator, remote exchanges), or with `local` the
+// LocalPartitionGenerator function (int) xxh64(reverse(raw)) & (partitions - 1) of local exchanges
+void partition_ids(Context *ctx, const int64_t *raw_hashes, int64_t n, int32_t partitions, int32_t *out, bool local = false);
 // ---- partition.hip --------------------------------------------------------------------------------------------------
 // stable grouping of row indices by partition id: positions (n) grouped by partition in input order, counts[partitions] (device int64)
 void partition_positions(Context *ctx, const int32_t *part_ids, int64_t n, int32_t partitions, int32_t *positions_out, int64_t *counts_dev);

@@ -698,9 +698,9 @@ __global__ void __launch_bounds__(256) replicate_flags_kernel(const uint8_t *nul
 class PartitionedOutputOperator : public Operator {
 public:
     PartitionedOutputOperator(Context *ctx, int32_t id, const std::vector<int32_t> &types, const std::vector<int32_t> &partition_channels, int32_t hash_channel,
-                              int32_t partition_count, bool replicates_any_row, int32_t null_channel)
+                              int32_t partition_count, bool replicates_any_row, int32_t null_channel, bool local_function)
         : Operator(ctx, id), types_(types), partition_channels_(partition_channels), hash_channel_(hash_channel), partition_count_(partition_count),
-          null_channel_(null_channel), replicates_any_row_(replicates_any_row)
+          null_channel_(null_channel), replicates_any_row_(replicates_any_row), local_function_(local_function)
     {
     }
 
@@ -725,7 +725,7 @@ public:
             hashes = own_hashes->as<int64_t>();
         }
         BufferPtr ids = ctx_->alloc((size_t)n * 4), cnt = ctx_->alloc((size_t)partition_count_ * 8);
-        k::partition_ids(ctx_, hashes, n, partition_count_, ids->as<int32_t>());
+        k::partition_ids(ctx_, hashes, n, partition_count_, ids->as<int32_t>(), local_function_);
         // replicated rows of this page
         const uint8_t *null_flags = null_channel_ >= 0 ? in.cols[(size_t)null_channel_].nulls : nullptr;
         const bool replicate_first = replicates_any_row_ && !has_any_row_been_replicated_;
@@ -784,16 +784,19 @@ public:
 private:
     std::vector<int32_t> types_, partition_channels_;
     int32_t hash_channel_, partition_count_, null_channel_;
-    bool replicates_any_row_, has_any_row_been_replicated_ = false, finishing_ = false;
+    bool replicates_any_row_, local_function_, has_any_row_been_replicated_ = false, finishing_ = false;
     std::deque<std::pair<int32_t, DevicePage>> pending_;
 };
 
 PartitionedOutputOperatorFactory::PartitionedOutputOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> partition_channels,
-                                                                   int32_t hash_channel, int32_t partition_count, bool replicates_any_row, int32_t null_channel)
+                                                                   int32_t hash_channel, int32_t partition_count, bool replicates_any_row, int32_t null_channel,
+                                                                   int32_t partition_function)
     : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), partition_channels_(std::move(partition_channels)), hash_channel_(hash_channel),
-      partition_count_(partition_count), null_channel_(null_channel), replicates_any_row_(replicates_any_row)
+      partition_count_(partition_count), null_channel_(null_channel), replicates_any_row_(replicates_any_row), local_function_(partition_function == TGPU_PARTITION_LOCAL)
 {
     TG_CHECK_ARG(partition_count_ > 0 && partition_count_ <= 1024, "partition count must be in 1..1024");
+    TG_CHECK_ARG(partition_function == TGPU_PARTITION_HASH_MODULO || partition_function == TGPU_PARTITION_LOCAL, "unknown partition function");
+    if (local_function_) TG_CHECK_ARG((partition_count_ & (partition_count_ - 1)) == 0, "the local partition function needs a power-of-two partition count");
     TG_CHECK_ARG(null_channel_ < (int)types_.size(), "null channel out of range");
     if (hash_channel_ >= 0) TG_CHECK_ARG(hash_channel_ < (int)types_.size() && types_[(size_t)hash_channel_] == TGPU_BIGINT, "bad hash channel");
     else TG_CHECK_ARG(!partition_channels_.empty(), "partitioning needs partition channels or a hash channel");
@@ -808,7 +811,8 @@ PartitionedOutputOperatorFactory::PartitionedOutputOperatorFactory(Context *ctx,
 std::unique_ptr<Operator> PartitionedOutputOperatorFactory::create_operator()
 {
     TG_CHECK_STATE(!closed_, "Factory is already closed");
-    return std::make_unique<PartitionedOutputOperator>(ctx_, operator_id_, types_, partition_channels_, hash_channel_, partition_count_, replicates_any_row_, null_channel_);
+    return std::make_unique<PartitionedOutputOperator>(ctx_, operator_id_, types_, partition_channels_, hash_channel_, partition_count_, replicates_any_row_, null_channel_,
+                                                       local_function_);
 }
 
 bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<OutputPage> *out)

@@ -204,7 +204,7 @@ class PartitionedOutputOperator;
 class PartitionedOutputOperatorFactory : public OperatorFactory {
 public:
     PartitionedOutputOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> partition_channels, int32_t hash_channel,
-                                     int32_t partition_count, bool replicates_any_row, int32_t null_channel);
+                                     int32_t partition_count, bool replicates_any_row, int32_t null_channel, int32_t partition_function);
     std::unique_ptr<Operator> create_operator() override;
 
 private:
@@ -212,7 +212,7 @@ private:
     int32_t operator_id_;
     std::vector<int32_t> types_, partition_channels_;
     int32_t hash_channel_, partition_count_, null_channel_;
-    bool replicates_any_row_;
+    bool replicates_any_row_, local_function_;
 };
 // next pending (partition, page) pair of a PartitionedOutputOperator; false = nothing pending
 bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<OutputPage> *out);

@@ -461,12 +461,13 @@ class PartitionedOutputOperatorFactory(OperatorFactory):
     """PartitionedOutputOperator.PartitionedOutputFactory (M/operator/PartitionedOutputOperator.java:52-130): hash partitioning on
     `partition_channels` (or the precomputed `hash_channel`), `null_channel` / `replicates_any_row` replication (:411-418)."""
 
-    def __init__(self, ctx: Context, operator_id, types, partition_channels, partition_count, hash_channel=-1, replicates_any_row=False, null_channel=-1):
+    def __init__(self, ctx: Context, operator_id, types, partition_channels, partition_count, hash_channel=-1, replicates_any_row=False, null_channel=-1, local=False):
+        """local=True: the LocalExchange partition function (LocalPartitionGenerator.java:45-65; power-of-two partition count)"""
         t, nt = _i32(types)
         pc, npc = _i32(partition_channels)
         h = C.c_void_p()
         _lib.check(_lib.lib().tgpu_partitioned_output_factory_create(ctx.handle, operator_id, nt, t, npc, pc, hash_channel, partition_count,
-                                                                     1 if replicates_any_row else 0, null_channel, C.byref(h)))
+                                                                     1 if replicates_any_row else 0, null_channel, 1 if local else 0, C.byref(h)))
         super().__init__(h)
 
     def createOperator(self):

@@ -1131,14 +1131,16 @@ def _drain_partitions(op, parts):
     return got, order
 
 
-@pytest.mark.parametrize("parts,replicates_any_row,null_channel,hash_channel", [(1, False, -1, -1), (8, False, -1, -1), (7, False, 0, -1), (8, True, -1, -1),
-                                                                               (5, True, 1, -1), (300, False, 0, -1), (8, False, -1, 3), (1024, False, -1, -1)])
-def test_partitioned_output_operator_vs_page_partitioner(pkg, ctx, oracle, parts, replicates_any_row, null_channel, hash_channel):
+@pytest.mark.parametrize("parts,replicates_any_row,null_channel,hash_channel,local",
+                         [(1, False, -1, -1, False), (8, False, -1, -1, False), (7, False, 0, -1, False), (8, True, -1, -1, False), (5, True, 1, -1, False),
+                          (300, False, 0, -1, False), (8, False, -1, 3, False), (1024, False, -1, -1, False), (16, False, 1, -1, True), (64, True, -1, 3, True)])
+def test_partitioned_output_operator_vs_page_partitioner(pkg, ctx, oracle, parts, replicates_any_row, null_channel, hash_channel, local):
     rng = np.random.default_rng(parts + 17 * int(replicates_any_row) + null_channel)
     types = [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE, pkg.BIGINT]
-    fac = pkg.PartitionedOutputOperatorFactory(ctx, 31, types, [0, 1], parts, hash_channel=hash_channel, replicates_any_row=replicates_any_row, null_channel=null_channel)
+    fac = pkg.PartitionedOutputOperatorFactory(ctx, 31, types, [0, 1], parts, hash_channel=hash_channel, replicates_any_row=replicates_any_row, null_channel=null_channel,
+                                               local=local)
     op = fac.createOperator()
-    ref = oracle.PagePartitioner(parts, replicates_any_row, null_channel)
+    ref = oracle.PagePartitioner(parts, replicates_any_row, null_channel, local)
     assert op.needsInput() and op.getOutput() is None
     total_rows = 0
     for n in (0, 1, 5000, 33333):   # several pages: the "replicate any row" state carries over (:411-418)
@@ -1193,3 +1195,6 @@ def test_partitioned_output_rejects_constant_arguments(pkg, ctx):
     with pytest.raises(pkg.TgpuError) as e:
         pkg.PartitionedOutputOperatorFactory(ctx, 33, [pkg.BIGINT], [-1], 4)
     assert e.value.code == -8
+    with pytest.raises(pkg.TgpuError) as e:   # LocalPartitionGenerator masks with count - 1
+        pkg.PartitionedOutputOperatorFactory(ctx, 33, [pkg.BIGINT], [0], 6, local=True)
+    assert e.value.code == -1
