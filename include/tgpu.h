@@ -296,6 +296,15 @@ int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel
 int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels,
                             int32_t hash_channel, int32_t partition_count, int64_t *counts, tgpu_output_page **out);
 
+/* ---- MergePages as an operator: page coalescing in HBM ---- */
+/* M/operator/project/MergePages.java:64-190 (MergePagesTransformation.process): a page with >= min_row_count rows or >= min_page_size_in_bytes
+ * bytes passes through as it is, after the buffered rows; smaller pages are appended to a device buffer that is flushed when it reaches
+ * max_page_size_in_bytes (PageBuilder.isFull) or at finish().  Sizes follow the reference's accounting ((width + 1) bytes per fixed-width
+ * cell, length + 5 per VARCHAR cell).  The GPU operators want pages of tens of MB and more (DESIGN.md "Page granularity"): put this
+ * operator in front of them with large thresholds; the reference's 1 MB cap on min_page_size_in_bytes (MergePages.java:58) is not enforced. */
+int32_t tgpu_merge_pages_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int64_t min_page_size_in_bytes,
+                                        int32_t min_row_count, int64_t max_page_size_in_bytes, tgpu_operator_factory **out);
+
 /* ---- PartitionedOutputOperator: the shuffle producer behind the Operator API ---- */
 /* M/operator/PartitionedOutputOperator.java:46-300, PagePartitioner :308-486.  A sink operator (getOutput() returns nothing, :303-306):
  * addInput groups the page's rows by partition = (rawHash & 0x7fff...) % partition_count (HashGenerator.java:24-35) of `hash_channel`

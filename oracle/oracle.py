@@ -582,3 +582,48 @@ class PagePartitioner:
             else:
                 out[int(parts[position])].append(position)
         return out
+
+
+# ---- MergePages -------------------------------------------------------------------------------------------------------------
+def page_size_in_bytes(cols):
+    """Page.getSizeInBytes of flat blocks: (width + 1) per fixed-width cell (S/block/LongArrayBlock.java:69 and siblings),
+    length + 5 per VARCHAR cell (VariableWidthBlock.java:121-124)"""
+    s = 0
+    for c in cols:
+        if c.type == VARCHAR:
+            s += int(c.offsets[c.n]) - int(c.offsets[0]) + 5 * c.n
+        else:
+            s += (np.dtype(_NP[c.type]).itemsize + 1) * c.n
+    return s
+
+
+class MergePages:
+    """MergePagesTransformation.process (M/operator/project/MergePages.java:122-190), page at a time: returns, for the pages fed so
+    far, the list of output pages as lists of (input page index, row) pairs"""
+
+    def __init__(self, min_page_size_in_bytes, min_row_count, max_page_size_in_bytes):
+        self.min_size, self.min_rows, self.max_size = min_page_size_in_bytes, min_row_count, max_page_size_in_bytes
+        self.buffer, self.buffered_size, self.index = [], 0, 0
+
+    def add(self, cols):
+        n = cols[0].n
+        rows = [(self.index, r) for r in range(n)]
+        self.index += 1
+        out = []
+        if n >= self.min_rows or page_size_in_bytes(cols) >= self.min_size:   # :145-157 (an unloaded LazyBlock cannot occur here)
+            if self.buffer:
+                out.append(self.flush())
+            out.append(rows)
+            return out
+        self.buffer += rows   # :159
+        self.buffered_size += page_size_in_bytes(cols)
+        if self.buffered_size >= self.max_size:   # PageBuilder.isFull, S/PageBuilder.java:126-129
+            out.append(self.flush())
+        return out
+
+    def flush(self):
+        rows, self.buffer, self.buffered_size = self.buffer, [], 0
+        return rows
+
+    def finish(self):
+        return [self.flush()] if self.buffer else []   # :134-142

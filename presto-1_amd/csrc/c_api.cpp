@@ -740,6 +740,19 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
     });
 }
 
+int32_t tgpu_merge_pages_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int64_t min_page_size_in_bytes,
+                                        int32_t min_row_count, int64_t max_page_size_in_bytes, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out, "null argument");
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<MergePagesOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), min_page_size_in_bytes, min_row_count, max_page_size_in_bytes);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
 int32_t tgpu_partitioned_output_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int32_t partition_channel_count,
                                                const int32_t *partition_channels, int32_t hash_channel, int32_t partition_count, int32_t replicates_any_row,
                                                int32_t null_channel, int32_t partition_function, tgpu_operator_factory **out)

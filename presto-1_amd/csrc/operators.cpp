@@ -2,6 +2,7 @@
 // the reference's Java operators; the work inside addInput / getOutput runs in the gfx950 kernels).
 #include "operators.h"
 
+#include <array>
 #include <deque>
 
 #include "kernels.h"
@@ -678,6 +679,138 @@ std::unique_ptr<Operator> OrderByOperatorFactory::create_operator()
     return std::make_unique<OrderByOperator>(ctx_, operator_id_, types_, output_channels_, sort_channels_, sort_orders_);
 }
 
+
+// =====================================================================================================================
+// MergePages (M/operator/project/MergePages.java:86-190, MergePagesTransformation.process): the transformation the reference
+// puts behind every PageProcessor, as an operator.  A page with at least min_row_count rows or min_page_size_in_bytes bytes
+// passes through untouched (after whatever is buffered); smaller pages are appended to a buffer in HBM that is flushed when it
+// reaches max_page_size_in_bytes (PageBuilder.isFull, S/PageBuilder.java:126-129) or at finish.  Sizes are the reference's
+// accounting: (width + 1) bytes per fixed-width cell, length + 5 per VARCHAR cell (S/block/LongArrayBlock.java:69,
+// VariableWidthBlock.java:121-124 and the matching BlockBuilder.addBytes calls).  In front of the GPU operators the thresholds
+// are set to tens or hundreds of MB (DESIGN.md "Page granularity"); the reference's 1 MB cap on min_page_size_in_bytes
+// (MergePages.java:58,107) is therefore not enforced.
+// =====================================================================================================================
+class MergePagesOperator : public Operator {
+public:
+    MergePagesOperator(Context *ctx, int32_t id, const std::vector<int32_t> &types, int64_t min_page_size, int32_t min_row_count, int64_t max_page_size)
+        : Operator(ctx, id), types_(types), min_page_size_(min_page_size), max_page_size_(max_page_size), min_row_count_(min_row_count)
+    {
+    }
+
+    bool needs_input() override { return !finishing_ && output_.empty(); }
+
+    void add_input(const tgpu_page *page) override
+    {
+        TG_CHECK_STATE(needs_input(), "Operator does not need input");
+        DevicePage in = ingest_page(ctx_, page);
+        TG_CHECK_ARG(in.cols.size() == types_.size(), "page channel count does not match the operator's types");
+        for (size_t i = 0; i < types_.size(); i++) TG_CHECK_ARG(in.cols[i].type == types_[i], "page channel type does not match the operator's types");
+        const int64_t size = in.n >= min_row_count_ ? 0 : java_size_in_bytes(in);   // (only needed to classify a page with few rows)
+        if (in.n >= min_row_count_ || size >= min_page_size_) {   // :145-157
+            flush();
+            output_.push_back(owned(std::move(in)));
+            return;
+        }
+        if (in.n == 0) return;
+        if (!buffer_) buffer_ = std::make_unique<PagesIndexGpu>(ctx_, types_);
+        buffer_->add_page(in);   // :159 appendPage
+        buffered_size_ += size;
+        if (buffered_size_ >= max_page_size_ || buffer_->position_count() == 0x7fffffffLL) flush();   // :161-163
+    }
+
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (output_.empty()) return nullptr;
+        DevicePage p = std::move(output_.front());
+        output_.pop_front();
+        return wrap(std::move(p));
+    }
+
+    void finish() override
+    {
+        if (!finishing_) flush();   // :134-142
+        finishing_ = true;
+    }
+    bool is_finished() override { return finishing_ && output_.empty(); }
+    int64_t memory_bytes() override
+    {
+        int64_t s = buffer_ ? buffer_->estimated_size() : 0;
+        for (auto &p : output_) s += p.size_in_bytes();
+        return s;
+    }
+
+private:
+    // Page.getSizeInBytes of flat blocks; the byte counts of VARCHAR channels come back in one batched read
+    int64_t java_size_in_bytes(const DevicePage &p)
+    {
+        int64_t s = 0;
+        std::vector<std::array<int32_t, 2>> ends(p.cols.size(), {0, 0});
+        std::vector<Context::Transfer> reads;
+        for (size_t i = 0; i < p.cols.size(); i++) {
+            const DeviceColumn &c = p.cols[i];
+            if (c.type != TGPU_VARCHAR) s += (int64_t)(type_width(c.type) + 1) * p.n;
+            else if (p.n > 0) {
+                reads.push_back({&ends[i][0], c.offsets, 4});
+                reads.push_back({&ends[i][1], c.offsets + p.n, 4});
+            }
+        }
+        if (!reads.empty()) ctx_->download_batch(reads);
+        for (size_t i = 0; i < p.cols.size(); i++)
+            if (p.cols[i].type == TGPU_VARCHAR) s += ((int64_t)ends[i][1] - ends[i][0]) + 5 * p.n;
+        return s;
+    }
+
+    // a page that passes through must outlive the call: device-resident input is borrowed (common.h), so it is copied once
+    DevicePage owned(DevicePage &&p)
+    {
+        bool borrowed = false;
+        for (auto &c : p.cols) borrowed = borrowed || (c.n > 0 && !c.values_buf);
+        if (!borrowed) return std::move(p);
+        PagesIndexGpu copy(ctx_, types_);
+        copy.add_page(p);
+        DevicePage out;
+        out.n = p.n;
+        for (size_t i = 0; i < types_.size(); i++) out.cols.push_back(copy.column((int)i));
+        return out;
+    }
+
+    void flush()
+    {
+        if (!buffer_ || buffer_->position_count() == 0) return;
+        DevicePage out;
+        out.n = buffer_->position_count();
+        for (size_t i = 0; i < types_.size(); i++) out.cols.push_back(buffer_->column((int)i));
+        output_.push_back(std::move(out));
+        buffer_.reset();   // the flushed columns keep the buffers alive
+        buffered_size_ = 0;
+    }
+
+    std::vector<int32_t> types_;
+    int64_t min_page_size_, max_page_size_, buffered_size_ = 0;
+    int32_t min_row_count_;
+    bool finishing_ = false;
+    std::unique_ptr<PagesIndexGpu> buffer_;
+    std::deque<DevicePage> output_;
+};
+
+MergePagesOperatorFactory::MergePagesOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, int64_t min_page_size_in_bytes, int32_t min_row_count,
+                                                     int64_t max_page_size_in_bytes)
+    : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), min_page_size_(min_page_size_in_bytes), max_page_size_(max_page_size_in_bytes),
+      min_row_count_(min_row_count)
+{
+    // MergePages.java:102-106
+    TG_CHECK_ARG(min_page_size_ >= 0, "minPageSizeInBytes must be greater or equal than zero");
+    TG_CHECK_ARG(min_row_count_ >= 0, "minRowCount must be greater or equal than zero");
+    TG_CHECK_ARG(max_page_size_ > 0, "maxPageSizeInBytes must be greater than zero");
+    TG_CHECK_ARG(max_page_size_ >= min_page_size_, "maxPageSizeInBytes must be greater or equal than minPageSizeInBytes");
+    for (int32_t t : types_) TG_CHECK_ARG(valid_type(t), "unknown channel type");
+}
+
+std::unique_ptr<Operator> MergePagesOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<MergePagesOperator>(ctx_, operator_id_, types_, min_page_size_, min_row_count_, max_page_size_);
+}
 
 // =====================================================================================================================
 // PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java; PagePartitioner.partitionPage :406-426)

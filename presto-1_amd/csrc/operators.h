@@ -197,6 +197,21 @@ private:
     std::vector<int32_t> types_, output_channels_, sort_channels_, sort_orders_;
 };
 
+// ---- MergePages (M/operator/project/MergePages.java:40-190) as an operator: coalesces small pages in HBM -------------------------
+class MergePagesOperatorFactory : public OperatorFactory {
+public:
+    MergePagesOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, int64_t min_page_size_in_bytes, int32_t min_row_count,
+                              int64_t max_page_size_in_bytes);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> types_;
+    int64_t min_page_size_, max_page_size_;
+    int32_t min_row_count_;
+};
+
 // ---- PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java:46-300; PagePartitioner :308-486) ---------------------
 // A sink: input rows are grouped by destination partition and handed out as (partition, page) pairs -- what the reference
 // enqueues into its OutputBuffer -- through poll(); get_output() returns nothing, as in the reference (:303-306).

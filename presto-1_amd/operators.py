@@ -441,6 +441,17 @@ def to_pages(operator: Operator, input_pages, to_host=True):
     return host
 
 
+class MergePagesOperatorFactory(OperatorFactory):
+    """MergePages.mergePages (M/operator/project/MergePages.java:64-96) as an operator: small pages are coalesced in HBM, big ones pass through"""
+
+    def __init__(self, ctx: Context, operator_id, types, min_page_size_in_bytes, min_row_count, max_page_size_in_bytes=1024 * 1024):
+        t, nt = _i32(types)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_merge_pages_factory_create(ctx.handle, operator_id, nt, t, int(min_page_size_in_bytes), int(min_row_count), int(max_page_size_in_bytes),
+                                                              C.byref(h)))
+        super().__init__(h)
+
+
 class PartitionedOutputOperator(Operator):
     """the sink side of PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java:46-300): poll() hands out what the
     reference enqueues into its OutputBuffer"""

@@ -1198,3 +1198,95 @@ def test_partitioned_output_rejects_constant_arguments(pkg, ctx):
     with pytest.raises(pkg.TgpuError) as e:   # LocalPartitionGenerator masks with count - 1
         pkg.PartitionedOutputOperatorFactory(ctx, 33, [pkg.BIGINT], [0], 6, local=True)
     assert e.value.code == -1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# MergePages as an operator: the cases of T/operator/project/TestMergePages.java + random streams vs the
+# page-at-a-time restatement (same page boundaries, same rows)
+# ---------------------------------------------------------------------------------------------------------------------
+MERGE_TYPES = lambda pkg: [pkg.BIGINT, pkg.INTEGER, pkg.DOUBLE]   # TestMergePages.java:42 uses BIGINT, REAL, DOUBLE: REAL has INTEGER's 4-byte layout
+
+
+def _seq_page(pkg, types, n, start=0):
+    return pkg.Page(*[pkg.Block(t, v) for t, v in zip(types, sequence_page(types, n, *([start] * len(types))))], position_count=n)
+
+
+def _run_merge(pkg, ctx, oracle, types, pages, min_size, min_rows, max_size):
+    fac = pkg.MergePagesOperatorFactory(ctx, 41, types, min_size, min_rows, max_size)
+    op = fac.createOperator()
+    ref = oracle.MergePages(min_size, min_rows, max_size)
+    got, want = [], []
+    for page in pages:
+        assert op.needsInput()
+        op.addInput(page)
+        want += ref.add([ocol(oracle, b) for b in page.blocks])
+        while True:
+            o = op.getOutput()
+            if o is None:
+                break
+            got.append(o.to_host().rows())
+            o.release()
+    op.finish()
+    want += ref.finish()
+    while not op.isFinished():
+        o = op.getOutput()
+        assert o is not None
+        got.append(o.to_host().rows())
+        o.release()
+    op.close()
+    fac.close()
+    all_rows = [p.rows() for p in pages]
+    assert got == [[all_rows[i][r] for i, r in out] for out in want]
+    return got
+
+
+def test_merge_pages_reference_cases(pkg, ctx, oracle):
+    types = MERGE_TYPES(pkg)
+    size = lambda page: oracle.page_size_in_bytes([ocol(oracle, b) for b in page.blocks])
+    big = 2**31 - 1
+    page = _seq_page(pkg, types, 10)
+    assert size(page) == 10 * (9 + 5 + 9)
+    # testMinPageSizeThreshold (:45-59), testMinRowCountThreshold (:61-76): the page passes through as it is
+    assert _run_merge(pkg, ctx, oracle, types, [page], size(page), big, big) == [page.rows()]
+    assert _run_merge(pkg, ctx, oracle, types, [page], 1024 * 1024, 10, big) == [page.rows()]
+    # testBufferSmallPages (:107-124): two halves come out as one page
+    whole = _seq_page(pkg, types, 20)
+    halves = [_seq_page(pkg, types, 10, 0), _seq_page(pkg, types, 10, 10)]
+    assert _run_merge(pkg, ctx, oracle, types, halves, size(whole) + 1, 21, big) == [whole.rows()]
+    # testFlushOnBigPage (:126-143): the buffered small page first, then the big page
+    small, large = _seq_page(pkg, types, 10), _seq_page(pkg, types, 100)
+    assert _run_merge(pkg, ctx, oracle, types, [small, large], size(large), 100, big) == [small.rows(), large.rows()]
+    # testFlushOnFullPage (:145-164): BIGINT only, max page size = the whole page: two full pages out of four halves
+    t1 = [pkg.BIGINT]
+    whole = _seq_page(pkg, t1, 20)
+    halves = [_seq_page(pkg, t1, 10, 0), _seq_page(pkg, t1, 10, 10)]
+    assert _run_merge(pkg, ctx, oracle, t1, halves + halves, size(whole) // 2 + 1, 11, size(whole)) == [whole.rows(), whole.rows()]
+
+
+def test_merge_pages_random_stream_and_device_input(pkg, ctx, oracle):
+    rng = np.random.default_rng(12)
+    types = [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE, pkg.BOOLEAN]
+    pages = []
+    for n in rng.choice([0, 1, 3, 50, 700, 5000, 40000], 40):
+        pages.append(pkg.Page(*[rand_block(pkg, rng, t, int(n), null_frac=0.1 if i != 2 else 0.0) for i, t in enumerate(types)], position_count=int(n)))
+    _run_merge(pkg, ctx, oracle, types, pages, 64 * 1024, 4096, 256 * 1024)
+    # device-resident (borrowed) input pages: a passing-through page is copied once, results unchanged
+    fp = pkg.FilterAndProjectOperatorFactory(ctx, 42, [pkg.BIGINT], None, [pkg.field(0, pkg.BIGINT)])
+    op = fp.createOperator()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(100000, dtype=np.int64))))
+    dev = op.getOutput()
+    fac = pkg.MergePagesOperatorFactory(ctx, 43, [pkg.BIGINT], 1024, 10, 1 << 20)
+    m = fac.createOperator()
+    m.addInput(dev.as_device_page())
+    out = m.getOutput()
+    dev.release()   # the input may go away: the operator owns what it hands out
+    assert out.to_host().blocks[0].to_list() == list(range(100000))
+    out.release()
+    m.close(); fac.close(); op.close(); fp.close()
+
+
+def test_merge_pages_argument_checks(pkg, ctx):
+    for args in ((-1, 1, 10), (1, -1, 10), (1, 1, 0), (11, 1, 10)):   # MergePages.java:102-106
+        with pytest.raises(pkg.TgpuError) as e:
+            pkg.MergePagesOperatorFactory(ctx, 44, [pkg.BIGINT], *args)
+        assert e.value.code == -1
