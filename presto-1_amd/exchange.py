@@ -101,11 +101,13 @@ def all_gather_page(dist, device, page: Page) -> Page:
 
     cols = page_columns(page, device)
     blocks, keep = [], []
-    for c in cols:
-        any_nulls = torch.tensor([1 if c["nulls"] is not None else 0], device=coll)
-        dist.all_reduce(any_nulls, op=dist.ReduceOp.MAX)
+    # which channels carry a null vector on ANY rank: one collective for all channels (not one per channel)
+    any_nulls = torch.tensor([1 if c["nulls"] is not None else 0 for c in cols] or [0], device=coll)
+    dist.all_reduce(any_nulls, op=dist.ReduceOp.MAX)
+    any_nulls = any_nulls.tolist()
+    for i, c in enumerate(cols):
         nulls = None
-        if int(any_nulls.item()):
+        if any_nulls[i]:
             nulls = gather(c["nulls"] if c["nulls"] is not None else torch.zeros(n, dtype=torch.uint8, device=device), torch.uint8)
         values = gather(c["values"], TORCH_DTYPE[c["type"]])
         blocks.append(DeviceBlock(c["type"], total, values, nulls))
@@ -138,19 +140,24 @@ class HashExchange:
         """repartition `page` by the hash of `key_channels`; returns the rows this rank owns as a device (or host-tensor) Page"""
         w = self.world
         counts, cols = self.partitioner(page, key_channels, w)
-        send_counts = torch.as_tensor(np.asarray(counts, dtype=np.int64), device=self.coll_device)
-        recv_counts = torch.empty(w, dtype=torch.int64, device=self.coll_device)
-        self.dist.all_to_all_single(recv_counts, send_counts)
+        # one small all-to-all carries, per destination, the row count AND this rank's per-channel "has a null vector" flags (one
+        # collective + one read-back for the whole page header instead of one all-reduce per channel)
+        flags = [1 if c["nulls"] is not None else 0 for c in cols]
+        header = torch.as_tensor(np.asarray([[int(x)] + flags for x in counts], dtype=np.int64).reshape(-1), device=self.coll_device)
+        recv_header = torch.empty_like(header)
+        self.dist.all_to_all_single(recv_header, header)
+        recv_header = recv_header.reshape(w, 1 + len(cols)).tolist()
         sc = [int(x) for x in counts]
-        rc = [int(x) for x in recv_counts.tolist()]
+        rc = [int(r[0]) for r in recv_header]
+        # a channel travels with nulls when any SENDER has them; every rank must agree, so reduce over what all ranks told everyone:
+        # each rank told every destination its own flags, hence each rank now knows the flags of all ranks
+        any_nulls = [max(int(r[1 + i]) for r in recv_header) for i in range(len(cols))]
         n_out = sum(rc)
         blocks, keep = [], []
         row_starts = np.concatenate([[0], np.cumsum(sc)])
-        for c in cols:
-            any_nulls = torch.tensor([1 if c["nulls"] is not None else 0], device=self.coll_device)
-            self.dist.all_reduce(any_nulls, op=self.dist.ReduceOp.MAX)
+        for ci, c in enumerate(cols):
             nulls = None
-            if int(any_nulls.item()):
+            if any_nulls[ci]:
                 send_nulls = c["nulls"] if c["nulls"] is not None else torch.zeros(sum(sc), dtype=torch.uint8, device=self.device)
                 nulls = self._a2a(send_nulls, sc, rc)
             if c["type"] == VARCHAR:
