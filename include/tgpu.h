@@ -182,7 +182,9 @@ void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge);
 /* statistics of the built table (valid once the build operator finished): positions, table slots, position links */
 int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count);
 
-typedef enum tgpu_join_type { TGPU_JOIN_INNER = 0, TGPU_JOIN_PROBE_OUTER = 1 } tgpu_join_type;
+/* LookupJoinOperators.JoinType ordinals (M/operator/LookupJoinOperators.java:30-36).  LOOKUP_OUTER / FULL_OUTER probes also record the
+ * build positions they matched; the unmatched build rows come out of the LookupOuterOperator (tgpu_lookup_outer_factory_create) */
+typedef enum tgpu_join_type { TGPU_JOIN_INNER = 0, TGPU_JOIN_PROBE_OUTER = 1, TGPU_JOIN_LOOKUP_OUTER = 2, TGPU_JOIN_FULL_OUTER = 3 } tgpu_join_type;
 
 /* LookupJoinOperators.innerJoin / probeOuterJoin (M/operator/LookupJoinOperators.java:30-63).  Output page = probe output
  * channels then the build side's output channels (M/operator/LookupJoinPageBuilder.java:101-131). */
@@ -205,6 +207,13 @@ int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_
                                                        int32_t probe_hash_channel /* -1 = none */,
                                                        int32_t probe_output_channel_count, const int32_t *probe_output_channels,
                                                        int32_t join_type, tgpu_operator_factory **out);
+
+/* LookupOuterOperator.LookupOuterOperatorFactory (M/operator/LookupOuterOperator.java:35-110; created by LookupJoinOperatorFactory for
+ * LOOKUP_OUTER / FULL_OUTER joins, LookupJoinOperatorFactory.java:88-103): a source operator that, once every probe operator of the join
+ * has finished (is_blocked until then), emits the build rows no probe matched, in build-position order: `probe_output_types` channels of
+ * nulls followed by the build output channels. */
+int32_t tgpu_lookup_outer_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge, int32_t probe_output_type_count,
+                                         const int32_t *probe_output_types, tgpu_operator_factory **out);
 
 /* FilterAndProjectOperator feeding HashAggregationOperator as one fused pipeline (what LocalExecutionPlanner.visitAggregation,
  * M/sql/planner/LocalExecutionPlanner.java:1198,2965-3056, would construct over a filter/project source; the shape of

@@ -740,6 +740,19 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
     });
 }
 
+int32_t tgpu_lookup_outer_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge, int32_t probe_output_type_count,
+                                         const int32_t *probe_output_types, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && bridge && out, "null argument");
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<LookupOuterOperatorFactory>(ctx->ctx.get(), operator_id, vec(probe_output_types, probe_output_type_count), bridge->bridge);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
 int32_t tgpu_merge_pages_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int64_t min_page_size_in_bytes,
                                         int32_t min_row_count, int64_t max_page_size_in_bytes, tgpu_operator_factory **out)
 {

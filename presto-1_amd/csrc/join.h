@@ -65,6 +65,10 @@ public:
     void probe(const std::vector<const DeviceColumn *> &probe_keys, const int64_t *probe_hashes, int64_t n_probe, bool probe_outer,
                BufferPtr &out_probe_idx, BufferPtr &out_build_idx, int64_t &out_count);
     DeviceColumn gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const;
+    // OuterPositionTracker (M/operator/OuterLookupSource.java:146-190): LOOKUP_OUTER / FULL_OUTER probes record the build positions
+    // they emitted; unvisited_positions = OuterPositionIterator, every build position nobody matched, ascending
+    void mark_visited(const int32_t *build_positions, int64_t n);
+    void unvisited_positions(BufferPtr &positions, int64_t &count);
 
 private:
     bool build_direct(const KeyCols &keys);
@@ -74,6 +78,7 @@ private:
     int32_t hash_channel_;
     int64_t n_ = 0, capacity_ = 0, link_count_ = 0;
     bool int_key_fast_ = false;  // single BIGINT / INTEGER / DATE key: key stored inline in the slot
+    BufferPtr visited_;          // uint8[n]: build positions matched by an outer-tracking probe (allocated on first use)
     BufferPtr heads_;            // int32[capacity], -1 empty          (PagesHash.key)
     BufferPtr slots16_;          // fast path: {int64 key, int32 head, int32 pad}[capacity]
     BufferPtr bloom_;            // fast path: blocked Bloom filter over the build keys (sparse key domains)

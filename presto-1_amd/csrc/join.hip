@@ -842,4 +842,47 @@ DeviceColumn LookupSourceGpu::gather_build(int out_idx, const int32_t *build_pos
     return k::gather_column(ctx_, src, build_positions, n, negative_is_null);
 }
 
+
+// ---- outer position tracking ----------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(kBlock) mark_visited_kernel(const int32_t *__restrict__ positions, int64_t n, uint8_t *__restrict__ visited)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const int32_t p = positions[i];
+        if (p >= 0) visited[p] = 1;   // plain idempotent stores: several probes may mark the same position
+    }
+}
+__global__ void __launch_bounds__(kBlock) unvisited_flags_kernel(const uint8_t *__restrict__ visited, int64_t n, int32_t *__restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) flags[i] = (visited && visited[i]) ? 0 : 1;
+}
+__global__ void __launch_bounds__(kBlock) compact_positions_kernel(const int32_t *__restrict__ flags, const int32_t *__restrict__ rank, int64_t n, int32_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        if (flags[i]) out[rank[i]] = (int32_t)i;
+}
+}  // namespace
+
+void LookupSourceGpu::mark_visited(const int32_t *build_positions, int64_t n)
+{
+    if (n <= 0 || n_ <= 0) return;
+    if (!visited_) visited_ = ctx_->alloc_zero((size_t)n_);
+    mark_visited_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(build_positions, n, visited_->as<uint8_t>());
+    check_launch("mark_visited");
+}
+
+void LookupSourceGpu::unvisited_positions(BufferPtr &positions, int64_t &count)
+{
+    count = 0;
+    positions = ctx_->alloc((size_t)(n_ > 0 ? n_ : 1) * 4);
+    if (n_ <= 0) return;
+    BufferPtr flags = ctx_->alloc((size_t)n_ * 4), rank = ctx_->alloc((size_t)n_ * 4), total = ctx_->alloc(8);
+    unvisited_flags_kernel<<<grid_for(ctx_, n_), kBlock, 0, ctx_->stream()>>>(visited_ ? visited_->as<uint8_t>() : nullptr, n_, flags->as<int32_t>());
+    check_launch("unvisited_flags");
+    k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), rank->as<int32_t>(), n_, total->as<int64_t>());
+    compact_positions_kernel<<<grid_for(ctx_, n_), kBlock, 0, ctx_->stream()>>>(flags->as<int32_t>(), rank->as<int32_t>(), n_, positions->as<int32_t>());
+    check_launch("compact_positions");
+    count = ctx_->read_scalar(total->as<int64_t>());
+}
+
 }  // namespace tgpu

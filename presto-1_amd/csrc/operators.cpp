@@ -303,11 +303,12 @@ static bool probe_page(Context *ctx, LookupSourceGpu &source, const DevicePage &
         TG_CHECK_ARG(in.cols[(size_t)cfg.probe_hash_channel].type == TGPU_BIGINT, "probe hash channel must be BIGINT");
         hashes = (const int64_t *)in.cols[(size_t)cfg.probe_hash_channel].values;
     }
-    const bool outer = cfg.join_type == TGPU_JOIN_PROBE_OUTER;
+    const bool outer = cfg.join_type == TGPU_JOIN_PROBE_OUTER || cfg.join_type == TGPU_JOIN_FULL_OUTER;
     BufferPtr probe_idx, build_idx;
     int64_t count = 0;
     source.probe(keys, hashes, in.n, outer, probe_idx, build_idx, count);
     if (count == 0) return false;  // no output page for this probe page (:276-283 pageBuilder.isEmpty)
+    if (cfg.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg.join_type == TGPU_JOIN_FULL_OUTER) source.mark_visited(build_idx->as<int32_t>(), count);   // OuterLookupSource.appendTo
     out.n = count;
     ProfileScope ps(ctx, "join_gather");
     for (int32_t ch : cfg.probe_output_channels) out.cols.push_back(k::gather_column(ctx, in.cols[(size_t)ch], probe_idx->as<int32_t>(), count, false));
@@ -376,7 +377,8 @@ LookupJoinOperatorFactory::LookupJoinOperatorFactory(Context *ctx, int32_t opera
     for (int32_t ch : cfg_.probe_join_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe join channel out of range");
     for (int32_t ch : cfg_.probe_output_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe output channel out of range");
     TG_CHECK_ARG(cfg_.probe_hash_channel < nt, "probe hash channel out of range");
-    TG_CHECK_ARG(cfg_.join_type == TGPU_JOIN_INNER || cfg_.join_type == TGPU_JOIN_PROBE_OUTER, "only INNER and PROBE_OUTER joins are supported");
+    TG_CHECK_ARG(cfg_.join_type >= TGPU_JOIN_INNER && cfg_.join_type <= TGPU_JOIN_FULL_OUTER, "unknown join type");
+    if (cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER) bridge_->outer_expected();   // LookupJoinOperatorFactory.java:88-103
 }
 
 std::unique_ptr<Operator> LookupJoinOperatorFactory::create_operator()
@@ -389,6 +391,90 @@ void LookupJoinOperatorFactory::no_more_operators()
 {
     closed_ = true;
     bridge_->no_more_probes();
+}
+
+// =====================================================================================================================
+// LookupOuterOperator (M/operator/LookupOuterOperator.java:32-235): once every probe operator of a LOOKUP_OUTER / FULL_OUTER join
+// is done (the outer position iterator future, PartitionedLookupSourceFactory.java:259-297), the build rows nobody matched come
+// out in build-position order (OuterLookupSource.java:146-190 OuterPositionIterator -- rows with a null key included: they can never
+// match), probe-side output channels null (:188-197), build output channels behind them.  One page (the reference cuts it at
+// the page builder's size limit).
+// =====================================================================================================================
+class LookupOuterOperator : public Operator {
+public:
+    LookupOuterOperator(Context *ctx, int32_t id, const std::vector<int32_t> &probe_output_types, std::shared_ptr<LookupSourceFactory> bridge)
+        : Operator(ctx, id), probe_output_types_(probe_output_types), bridge_(std::move(bridge))
+    {
+    }
+    ~LookupOuterOperator() override { close(); }
+
+    bool is_blocked() override { return !closed_ && !(bridge_->probes_finished() && bridge_->lookup_source()); }
+    bool needs_input() override { return false; }                                                        // :163-167
+    void add_input(const tgpu_page *) override { fail(TGPU_ERR_NOT_SUPPORTED, "LookupOuterOperator takes no input"); }   // :169-173
+
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (closed_ || is_blocked()) return nullptr;
+        std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
+        BufferPtr positions;
+        int64_t count = 0;
+        source->unvisited_positions(positions, count);
+        std::unique_ptr<OutputPage> out;
+        if (count > 0) {
+            DevicePage page;
+            page.n = count;
+            // null probe channels: a one-position dummy column gathered at position -1 (= null) for every output row
+            BufferPtr minus_one = ctx_->alloc((size_t)count * 4);
+            k::fill_i32(ctx_, minus_one->as<int32_t>(), -1, count);
+            for (int32_t t : probe_output_types_) {
+                DeviceColumn dummy;
+                dummy.type = t;
+                dummy.n = 1;
+                dummy.values_buf = ctx_->alloc_zero(8);
+                dummy.values = dummy.values_buf->ptr();
+                if (t == TGPU_VARCHAR) {
+                    dummy.offsets_buf = ctx_->alloc_zero(8);
+                    dummy.offsets = dummy.offsets_buf->as<int32_t>();
+                }
+                page.cols.push_back(k::gather_column(ctx_, dummy, minus_one->as<int32_t>(), count, true));
+            }
+            const int nb = (int)source->output_channels().size();
+            for (int i = 0; i < nb; i++) page.cols.push_back(source->gather_build(i, positions->as<int32_t>(), count, false));
+            out = wrap(std::move(page));
+        }
+        close();   // :219-221
+        return out;
+    }
+
+    void finish() override { close(); }                    // :150-153
+    bool is_finished() override { return closed_; }
+    void close() override
+    {
+        if (!closed_) {
+            closed_ = true;
+            bridge_->outer_done();   // onClose: the build side may release the table now
+        }
+    }
+
+private:
+    std::vector<int32_t> probe_output_types_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    bool closed_ = false;
+};
+
+LookupOuterOperatorFactory::LookupOuterOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> probe_output_types, std::shared_ptr<LookupSourceFactory> bridge)
+    : ctx_(ctx), operator_id_(operator_id), probe_output_types_(std::move(probe_output_types)), bridge_(std::move(bridge))
+{
+    for (int32_t t : probe_output_types_) TG_CHECK_ARG(valid_type(t), "unknown type");
+    bridge_->outer_expected();
+}
+
+std::unique_ptr<Operator> LookupOuterOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    TG_CHECK_STATE(!created_, "Only one outer operator can be created");   // LookupOuterOperator.java:86-90 (one per lifespan)
+    created_ = true;
+    return std::make_unique<LookupOuterOperator>(ctx_, operator_id_, probe_output_types_, bridge_);
 }
 
 // =====================================================================================================================
@@ -415,7 +501,8 @@ public:
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
         DevicePage in = ingest_page(ctx_, page);
         if (in.n == 0) return;
-        const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER;
+        const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
+        const bool track = cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
         IntTableView tv;
         const bool fused_ok = fused_->supported() && cfg_.probe_join_channels.size() == 1 && source->int_table(tv) && tv.links == nullptr &&
                               tv.key_type == fused_->projection_types()[(size_t)cfg_.probe_join_channels[0]] && getenv("TGPU_DISABLE_FUSION") == nullptr;
@@ -426,6 +513,7 @@ public:
             fused_->process(ctx_, in, *source, outer, probe_out, build_idx, count, selected);
             probe_rows_ += selected;
             if (count == 0) return;
+            if (track) source->mark_visited(build_idx->as<int32_t>(), count);
             DevicePage out;
             out.n = count;
             out.cols = std::move(probe_out);
@@ -482,7 +570,8 @@ FusedFilterProjectJoinOperatorFactory::FusedFilterProjectJoinOperatorFactory(Con
     for (int32_t ch : cfg_.probe_join_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe join channel out of range");
     for (int32_t ch : cfg_.probe_output_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "probe output channel out of range");
     TG_CHECK_ARG(cfg_.probe_hash_channel < nt, "probe hash channel out of range");
-    TG_CHECK_ARG(cfg_.join_type == TGPU_JOIN_INNER || cfg_.join_type == TGPU_JOIN_PROBE_OUTER, "only INNER and PROBE_OUTER joins are supported");
+    TG_CHECK_ARG(cfg_.join_type >= TGPU_JOIN_INNER && cfg_.join_type <= TGPU_JOIN_FULL_OUTER, "unknown join type");
+    if (cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER) bridge_->outer_expected();
     fused_ = FusedProbeGpu::shared(input_types, spec, cfg_.probe_join_channels[0], cfg_.probe_output_channels);
 }
 

@@ -89,14 +89,19 @@ public:
     void probe_created() { live_probes_++; any_probe_ = true; }
     void probe_closed() { live_probes_--; }
     void no_more_probes() { no_more_probes_ = true; }
+    // every probe operator is done: the outer position iterator becomes available (PartitionedLookupSourceFactory.java:259-297)
+    bool probes_finished() const { return no_more_probes_ && live_probes_ == 0; }
+    // LOOKUP_OUTER / FULL_OUTER joins: the LookupOuterOperator keeps the table alive until it has emitted the unmatched rows
+    void outer_expected() { outer_expected_ = true; }
+    void outer_done() { outer_done_ = true; }
     // the build operator may release the table once every probe operator is done (HashBuilderOperator.java:429-470)
-    bool destroyed() const { return no_more_probes_ && live_probes_ == 0; }
+    bool destroyed() const { return probes_finished() && (!outer_expected_ || outer_done_); }
     std::vector<int32_t> build_output_types;
 
 private:
     std::shared_ptr<LookupSourceGpu> source_;
     int live_probes_ = 0;
-    bool any_probe_ = false, no_more_probes_ = false;
+    bool any_probe_ = false, no_more_probes_ = false, outer_expected_ = false, outer_done_ = false;
 };
 
 struct HashBuilderConfig {
@@ -135,6 +140,20 @@ private:
     int32_t operator_id_;
     LookupJoinConfig cfg_;
     std::shared_ptr<LookupSourceFactory> bridge_;
+};
+
+// ---- LookupOuterOperator (M/operator/LookupOuterOperator.java:32-235): the build rows no LOOKUP_OUTER / FULL_OUTER probe matched ----
+class LookupOuterOperatorFactory : public OperatorFactory {
+public:
+    LookupOuterOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> probe_output_types, std::shared_ptr<LookupSourceFactory> bridge);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> probe_output_types_;
+    std::shared_ptr<LookupSourceFactory> bridge_;
+    bool created_ = false;
 };
 
 // ---- FilterAndProject fused into the LookupJoin probe (operator fusion by codegen, jit.h FusedProbeGpu).  The pair behaves

@@ -18,7 +18,7 @@ COUNT_ALL, COUNT_COLUMN, SUM_BIGINT, SUM_DOUBLE, AVG_BIGINT, AVG_DOUBLE = 1, 2, 
 SINGLE, PARTIAL, FINAL = 0, 1, 2
 # S/connector/SortOrder.java:18-21
 ASC_NULLS_FIRST, ASC_NULLS_LAST, DESC_NULLS_FIRST, DESC_NULLS_LAST = 0, 1, 2, 3
-INNER, PROBE_OUTER = 0, 1
+INNER, PROBE_OUTER, LOOKUP_OUTER, FULL_OUTER = 0, 1, 2, 3   # LookupJoinOperators.JoinType ordinals
 
 
 def _i32(seq):
@@ -256,6 +256,18 @@ class LookupJoinOperatorFactory(OperatorFactory):
         h = C.c_void_p()
         _lib.check(_lib.lib().tgpu_lookup_join_factory_create(ctx.handle, operator_id, lookup_source_factory.handle, nt, t, nj, jc,
                                                               probe_hash_channel, no, oc, join_type, C.byref(h)))
+        super().__init__(h)
+        self._bridge = lookup_source_factory
+
+
+class LookupOuterOperatorFactory(OperatorFactory):
+    """LookupOuterOperator.LookupOuterOperatorFactory (M/operator/LookupOuterOperator.java:35-110): the unmatched build rows of a
+    LOOKUP_OUTER / FULL_OUTER join, after every probe operator has finished"""
+
+    def __init__(self, ctx: Context, operator_id, lookup_source_factory: LookupSourceFactory, probe_output_types):
+        t, nt = _i32(probe_output_types)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_lookup_outer_factory_create(ctx.handle, operator_id, lookup_source_factory.handle, nt, t, C.byref(h)))
         super().__init__(h)
         self._bridge = lookup_source_factory
 

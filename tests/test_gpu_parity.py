@@ -1290,3 +1290,93 @@ def test_merge_pages_argument_checks(pkg, ctx):
         with pytest.raises(pkg.TgpuError) as e:
             pkg.MergePagesOperatorFactory(ctx, 44, [pkg.BIGINT], *args)
         assert e.value.code == -1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LOOKUP_OUTER / FULL_OUTER joins + LookupOuterOperator against the oracle's pair list + visited set
+# ---------------------------------------------------------------------------------------------------------------------
+def _outer_join(pkg, ctx, build_pages, probe_page_lists, types_b, types_p, key_b, key_p, join_type, out_b, out_p, fused=None):
+    """several probe operators over one lookup source, then the outer operator; returns (probe rows per operator, outer rows)"""
+    bf = pkg.HashBuilderOperatorFactory(ctx, 1, types_b, out_b, key_b)
+    if fused is None:
+        jf = pkg.LookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, types_p, key_p, probe_output_channels=out_p, join_type=join_type)
+    else:
+        jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, types_p, fused[0], fused[1], key_p, probe_output_channels=out_p, join_type=join_type)
+    of = pkg.LookupOuterOperatorFactory(ctx, 3, bf.lookup_source_factory, [types_p[c] for c in out_p] if fused is None else fused[2])
+    build = bf.createOperator()
+    probes = [jf.createOperator() for _ in probe_page_lists]
+    outer = of.createOperator()
+    assert outer.isBlocked() and not outer.needsInput() and outer.getOutput() is None
+    for p in build_pages:
+        build.addInput(p)
+    build.finish()
+    assert outer.isBlocked()   # the probes are not done yet (PartitionedLookupSourceFactory.java:259-297)
+    probe_rows = []
+    for op, pages in zip(probes, probe_page_lists):
+        rows = []
+        for pg in pkg.to_pages(op, pages):
+            rows.extend(pg.rows())
+        probe_rows.append(rows)
+        op.close()
+        assert outer.isBlocked()   # ... and the factory may still create more probe operators
+    jf.noMoreOperators()
+    assert not outer.isBlocked() and not build.isFinished()   # the table stays alive for the outer operator
+    o = outer.getOutput()
+    outer_rows = o.to_host().rows() if o is not None else []
+    if o is not None:
+        o.release()
+    assert outer.isFinished() and outer.getOutput() is None
+    assert build.isFinished()
+    build.close(); outer.close(); jf.close(); of.close(); bf.close()
+    return probe_rows, outer_rows
+
+
+@pytest.mark.parametrize("join_type", ["LOOKUP_OUTER", "FULL_OUTER"])
+@pytest.mark.parametrize("key_type,domain", [("BIGINT", (0, 3000)), ("VARCHAR", (0, 400)), ("BIGINT", (10**12, 10**12 + 50))])
+def test_outer_joins_vs_oracle(pkg, ctx, oracle, join_type, key_type, domain):
+    rng = np.random.default_rng(len(join_type) + domain[1] % 97)
+    kt = getattr(pkg, key_type)
+    jt = getattr(pkg, join_type)
+    types = [kt, pkg.BIGINT]
+    build_pages = []
+    for n in (900, 1, 1400):
+        build_pages.append(pkg.Page(rand_block(pkg, rng, kt, n, 0.04, domain), pkg.Block(pkg.BIGINT, rng.integers(0, 10**9, n).astype(np.int64))))
+    probe_lists = [[pkg.Page(rand_block(pkg, rng, kt, n, 0.04, domain), pkg.Block(pkg.BIGINT, np.arange(n, dtype=np.int64)))] for n in (1200, 800)]
+    probe_rows, outer_rows = _outer_join(pkg, ctx, build_pages, probe_lists, types, types, [0], [0], jt, out_b=[0, 1], out_p=[0, 1])
+    cat = [pkg.Block(types[c], [v for pg in build_pages for v in pg.getBlock(c).to_list()]) for c in range(2)]
+    brows = list(zip(cat[0].to_list(), cat[1].to_list()))
+    ph = oracle.PagesHash([ocol(oracle, cat[0])])
+    visited = set()
+    for rows, pages in zip(probe_rows, probe_lists):
+        blk = pages[0].getBlock(0)
+        op, ob = ph.probe([ocol(oracle, blk)], probe_outer=(join_type == "FULL_OUTER"))
+        prow = pages[0].rows()
+        assert rows == [prow[i] + (brows[j] if j >= 0 else (None, None)) for i, j in zip(op, ob)]
+        visited |= {int(j) for j in ob if j >= 0}
+    # OuterPositionIterator: every build position nobody matched (null keys included), ascending; probe channels null
+    assert outer_rows == [(None, None) + brows[j] for j in range(len(brows)) if j not in visited]
+
+
+def test_outer_join_fused_probe_and_empty_sides(pkg, ctx, oracle):
+    # the JIT-fused filter + probe records its matches too (DIRECT table layout: dense unique keys)
+    B = pkg.BIGINT
+    n_b, n_p = 5000, 20000
+    build = pkg.Page(pkg.Block(B, np.arange(n_b, dtype=np.int64) * 2), pkg.Block(B, np.arange(n_b, dtype=np.int64) + 7))
+    rng = np.random.default_rng(3)
+    pk = rng.integers(0, 3 * n_b, n_p).astype(np.int64)
+    probe = pkg.Page(pkg.Block(B, pk), pkg.Block(B, np.arange(n_p, dtype=np.int64)))
+    f = pkg.field
+    fused = (f(1, B) < 15000, [f(0, B), f(1, B)], [B, B])
+    probe_rows, outer_rows = _outer_join(pkg, ctx, [build], [[probe]], [B, B], [B, B], [0], [0], pkg.FULL_OUTER, out_b=[1], out_p=[0, 1], fused=fused)
+    sel = np.arange(n_p) < 15000
+    hit = (pk % 2 == 0) & (pk < 2 * n_b)
+    assert probe_rows[0] == [(int(k), int(i), int(k // 2 + 7) if h else None) for k, i, h in zip(pk[sel], np.arange(n_p)[sel], hit[sel])]
+    matched = set((pk[sel & hit] // 2).tolist())
+    assert outer_rows == [(None, None, j + 7) for j in range(n_b) if j not in matched]
+    # T/operator/TestHashJoinOperator.java:1071-1108 testLookupOuterJoinWithEmptyLookupSource: no output at all
+    probe_rows, outer_rows = _outer_join(pkg, ctx, [], [[pkg.Page(pkg.Block(pkg.VARCHAR, ["test"]))]], [pkg.VARCHAR], [pkg.VARCHAR], [0], [0], pkg.LOOKUP_OUTER,
+                                         out_b=[0], out_p=[0])
+    assert probe_rows == [[]] and outer_rows == []
+    # no probe operator ever matched anything: the whole build side comes out
+    probe_rows, outer_rows = _outer_join(pkg, ctx, [build], [[]], [B, B], [B, B], [0], [0], pkg.LOOKUP_OUTER, out_b=[0, 1], out_p=[0])
+    assert outer_rows == [(None, 2 * j, j + 7) for j in range(n_b)]
