@@ -261,6 +261,9 @@ int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page);
 int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out);
 int32_t tgpu_operator_finish(tgpu_operator *op);
 int32_t tgpu_operator_is_finished(tgpu_operator *op);
+/* addInput with a page another operator of this library produced: the buffers are shared (reference counted), so an operator that keeps
+ * or forwards the page (MergePages passing a big page through) does not copy it; `page` may be released right after the call */
+int32_t tgpu_operator_add_input_output_page(tgpu_operator *op, const tgpu_output_page *page);
 int32_t tgpu_operator_is_blocked(tgpu_operator *op);    /* 1 = isBlocked() future not done (probe waiting for the build) */
 int64_t tgpu_operator_memory_bytes(tgpu_operator *op);  /* what the shim reports to LocalMemoryContext.setBytes */
 void tgpu_operator_close(tgpu_operator *op);            /* Operator.close(); also frees the handle */

@@ -110,6 +110,7 @@ SYMBOLS = {
     "tgpu_group_by_hash_append_values": (i32, [vp, P(vp)]),
     "tgpu_hash_page": (i32, [vp, P(Page), i32, P(i32), vp]),
     "tgpu_partition_page": (i32, [vp, P(Page), i32, P(i32), i32, i32, vp, P(vp)]),
+    "tgpu_operator_add_input_output_page": (i32, [vp, vp]),
     "tgpu_lookup_outer_factory_create": (i32, [vp, i32, vp, i32, P(i32), P(vp)]),
     "tgpu_merge_pages_factory_create": (i32, [vp, i32, i32, P(i32), i64, i32, i64, P(vp)]),
     "tgpu_partitioned_output_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, i32, i32, i32, i32, P(vp)]),

@@ -324,6 +324,7 @@ DeviceColumn region_of(Context *ctx, const DeviceColumn &src, int64_t offset, in
     if (src.type == TGPU_VARCHAR) {
         // offsets keep their absolute values into the shared pool (like VariableWidthBlock.getRegion)
         out.offsets = src.offsets + offset;
+        out.pool_exact = src.pool_exact && offset == 0 && len == src.n;
     }
     else {
         out.values = (const uint8_t *)src.values + offset * type_width(src.type);

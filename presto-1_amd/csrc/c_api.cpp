@@ -740,6 +740,14 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
     });
 }
 
+int32_t tgpu_operator_add_input_output_page(tgpu_operator *op, const tgpu_output_page *page)
+{
+    return guard([&] {
+        TG_CHECK_ARG(op && page, "null argument");
+        op->op->add_input_owned(page->page);
+    });
+}
+
 int32_t tgpu_lookup_outer_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge, int32_t probe_output_type_count,
                                          const int32_t *probe_output_types, tgpu_operator_factory **out)
 {

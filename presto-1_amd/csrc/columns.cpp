@@ -4,6 +4,8 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <array>
+
 namespace tgpu {
 
 namespace {
@@ -33,6 +35,7 @@ DeviceColumn upload_flat(Context *ctx, int32_t type, int64_t n, const void *valu
     ctx->upload(c.values_buf->ptr(), values, (size_t)value_bytes);
     if (type == TGPU_VARCHAR) {
         c.pool_bytes = value_bytes;
+        c.pool_exact = true;
         c.offsets_buf = ctx->alloc((size_t)(n + 1) * 4);
         c.offsets = c.offsets_buf->as<int32_t>();
         ctx->upload(c.offsets_buf->ptr(), offsets, (size_t)(n + 1) * 4);
@@ -47,7 +50,34 @@ DeviceColumn upload_flat(Context *ctx, int32_t type, int64_t n, const void *valu
 
 }  // namespace
 
+// reads offsets[0] / offsets[n] of the borrowed device-resident VARCHAR columns in one batched transfer
+static void resolve_varchar_ends(Context *ctx, std::vector<DeviceColumn *> cols)
+{
+    std::vector<std::array<int32_t, 2>> ends(cols.size(), {0, 0});
+    std::vector<Context::Transfer> reads;
+    for (size_t i = 0; i < cols.size(); i++) {
+        reads.push_back({&ends[i][0], cols[i]->offsets, 4});
+        reads.push_back({&ends[i][1], cols[i]->offsets + cols[i]->n, 4});
+    }
+    if (reads.empty()) return;
+    ctx->download_batch(reads);
+    for (size_t i = 0; i < cols.size(); i++) {
+        cols[i]->pool_first = ends[i][0];
+        cols[i]->pool_bytes = ends[i][1];
+        cols[i]->pool_exact = true;
+    }
+}
+
+static DeviceColumn ingest_block_raw(Context *ctx, const tgpu_block *b);
+
 DeviceColumn ingest_block(Context *ctx, const tgpu_block *b)
+{
+    DeviceColumn c = ingest_block_raw(ctx, b);
+    if (c.type == TGPU_VARCHAR && !c.pool_exact) resolve_varchar_ends(ctx, {&c});
+    return c;
+}
+
+static DeviceColumn ingest_block_raw(Context *ctx, const tgpu_block *b)
 {
     check_block(b);
     const int64_t n = b->position_count;
@@ -86,12 +116,9 @@ DeviceColumn ingest_block(Context *ctx, const tgpu_block *b)
         c.offsets = b->offsets;
         if (b->type == TGPU_VARCHAR) {
             TG_CHECK_ARG(b->offsets != nullptr, "varchar block without offsets");
-            int32_t ends[2] = {0, 0};
-            if (n > 0) {
-                ctx->download(&ends[0], b->offsets, 4);
-                ctx->download(&ends[1], b->offsets + n, 4);
-            }
-            c.pool_bytes = ends[1];  // offsets are absolute into the pool
+            // offsets are absolute into the pool: pool_first / pool_bytes = offsets[0] / offsets[n], read back by the caller
+            // (ingest_page batches the reads of all VARCHAR channels of a page into one round trip; see resolve_varchar_ends)
+            c.pool_exact = n == 0;
         }
         return c;
     }
@@ -125,11 +152,15 @@ DevicePage ingest_page(Context *ctx, const tgpu_page *page)
     for (int32_t c = 0; c < page->channel_count; c++) {
         TG_CHECK_ARG(page->blocks[c].position_count == page->position_count, "block position count differs from the page's");
         any_host |= page->blocks[c].memory == TGPU_HOST;
-        out.cols.push_back(ingest_block(ctx, &page->blocks[c]));
+        out.cols.push_back(ingest_block_raw(ctx, &page->blocks[c]));
     }
+    std::vector<DeviceColumn *> unresolved;
+    for (DeviceColumn &c : out.cols)
+        if (c.type == TGPU_VARCHAR && !c.pool_exact) unresolved.push_back(&c);
+    resolve_varchar_ends(ctx, unresolved);
     // ownership rule: the caller's (Java heap) arrays are only valid during the call, so the H2D copies must have
-    // consumed them before we return
-    if (any_host) ctx->sync();
+    // consumed them before we return (the batched read above has already waited for the stream)
+    if (any_host && unresolved.empty()) ctx->sync();
     return out;
 }
 

@@ -191,6 +191,8 @@ struct DeviceColumn {
     const uint8_t *nulls = nullptr;     // nullptr = no nulls
     const int32_t *offsets = nullptr;   // VARCHAR
     int64_t pool_bytes = 0;             // VARCHAR byte pool size
+    bool pool_exact = false;            // VARCHAR: offsets[0] == pool_first and offsets[n] == pool_bytes are known on the host (no read-back needed)
+    int32_t pool_first = 0;             //          offsets[0] (0 for columns the library built; a borrowed block may be a region of a larger one)
     BufferPtr values_buf, nulls_buf, offsets_buf;  // owners (may be empty for borrowed device input)
 
     int64_t value_bytes() const { return type == TGPU_VARCHAR ? pool_bytes : n * type_width(type); }

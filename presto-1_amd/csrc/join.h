@@ -1,6 +1,8 @@
 // join.h -- hash join on the GPU: PagesIndex (J2), PagesHash build (J5/J6, K7) and probe (J8/J9, K8) + gather (K9).
 #pragma once
 
+#include <array>
+
 #include "common.h"
 
 namespace tgpu {
@@ -10,7 +12,9 @@ namespace tgpu {
 class PagesIndexGpu {
 public:
     PagesIndexGpu(Context *ctx, std::vector<int32_t> types);
-    void add_page(const DevicePage &page);
+    // `varchar_ends` (optional): {offsets[0], offsets[n]} of every channel (only read for VARCHAR channels), when the caller already
+    // knows them -- otherwise they are read back (one stream synchronisation per VARCHAR channel whose pool is not known exactly)
+    void add_page(const DevicePage &page, const std::vector<std::array<int32_t, 2>> *varchar_ends = nullptr);
     int64_t position_count() const { return n_; }
     int64_t estimated_size() const;
     DeviceColumn column(int ch) const;

@@ -472,7 +472,7 @@ void PagesIndexGpu::reserve(int64_t rows)
     }
 }
 
-void PagesIndexGpu::add_page(const DevicePage &page)
+void PagesIndexGpu::add_page(const DevicePage &page, const std::vector<std::array<int32_t, 2>> *varchar_ends)
 {
     TG_CHECK_ARG(page.cols.size() == types_.size(), "page channel count does not match the index");
     if (page.n == 0) return;
@@ -489,8 +489,18 @@ void PagesIndexGpu::add_page(const DevicePage &page)
         }
         if (c.type == TGPU_VARCHAR) {
             int32_t a = 0, b = 0;
-            ctx_->download(&a, src.offsets, 4);
-            ctx_->download(&b, src.offsets + page.n, 4);
+            if (varchar_ends) {
+                a = (*varchar_ends)[i][0];
+                b = (*varchar_ends)[i][1];
+            }
+            else if (src.pool_exact) {
+                a = src.pool_first;
+                b = (int32_t)src.pool_bytes;
+            }
+            else {
+                ctx_->download(&a, src.offsets, 4);
+                ctx_->download(&b, src.offsets + page.n, 4);
+            }
             const int64_t bytes = (int64_t)b - a;
             if (c.pool_used + bytes > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "variable width channel of the pages index cannot exceed 2GB");
             if (c.pool_used + bytes > c.pool_cap) {
@@ -531,6 +541,7 @@ DeviceColumn PagesIndexGpu::column(int ch) const
         c.offsets_buf = s.offsets;
         c.offsets = s.offsets ? s.offsets->as<int32_t>() : nullptr;
         c.pool_bytes = s.pool_used;
+        c.pool_exact = true;
     }
     return c;
 }

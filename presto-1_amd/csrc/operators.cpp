@@ -769,6 +769,17 @@ std::unique_ptr<Operator> OrderByOperatorFactory::create_operator()
 }
 
 
+void Operator::add_input_owned(const DevicePage &page)
+{
+    std::vector<tgpu_block> blocks(page.cols.size());
+    for (size_t i = 0; i < page.cols.size(); i++) {
+        const DeviceColumn &c = page.cols[i];
+        blocks[i] = tgpu_block{c.type, TGPU_FLAT, TGPU_DEVICE, (int32_t)c.n, c.values, c.nulls, c.offsets, nullptr, nullptr};
+    }
+    tgpu_page p{(int32_t)page.n, (int32_t)blocks.size(), blocks.data()};
+    add_input(&p);
+}
+
 // =====================================================================================================================
 // MergePages (M/operator/project/MergePages.java:86-190, MergePagesTransformation.process): the transformation the reference
 // puts behind every PageProcessor, as an operator.  A page with at least min_row_count rows or min_page_size_in_bytes bytes
@@ -788,13 +799,16 @@ public:
 
     bool needs_input() override { return !finishing_ && output_.empty(); }
 
-    void add_input(const tgpu_page *page) override
+    void add_input(const tgpu_page *page) override { merge(ingest_page(ctx_, page)); }
+    void add_input_owned(const DevicePage &page) override { merge(DevicePage(page)); }   // shares the page's buffers
+
+    void merge(DevicePage in)
     {
         TG_CHECK_STATE(needs_input(), "Operator does not need input");
-        DevicePage in = ingest_page(ctx_, page);
         TG_CHECK_ARG(in.cols.size() == types_.size(), "page channel count does not match the operator's types");
         for (size_t i = 0; i < types_.size(); i++) TG_CHECK_ARG(in.cols[i].type == types_[i], "page channel type does not match the operator's types");
-        const int64_t size = in.n >= min_row_count_ ? 0 : java_size_in_bytes(in);   // (only needed to classify a page with few rows)
+        std::vector<std::array<int32_t, 2>> ends;
+        const int64_t size = in.n >= min_row_count_ ? 0 : java_size_in_bytes(in, ends);   // (only needed to classify a page with few rows)
         if (in.n >= min_row_count_ || size >= min_page_size_) {   // :145-157
             flush();
             output_.push_back(owned(std::move(in)));
@@ -802,7 +816,7 @@ public:
         }
         if (in.n == 0) return;
         if (!buffer_) buffer_ = std::make_unique<PagesIndexGpu>(ctx_, types_);
-        buffer_->add_page(in);   // :159 appendPage
+        buffer_->add_page(in, &ends);   // :159 appendPage
         buffered_size_ += size;
         if (buffered_size_ >= max_page_size_ || buffer_->position_count() == 0x7fffffffLL) flush();   // :161-163
     }
@@ -829,15 +843,17 @@ public:
     }
 
 private:
-    // Page.getSizeInBytes of flat blocks; the byte counts of VARCHAR channels come back in one batched read
-    int64_t java_size_in_bytes(const DevicePage &p)
+    // Page.getSizeInBytes of flat blocks.  The byte range of a VARCHAR channel is known on the host for pages that came through the
+    // host ingest; for device-resident input it comes back in one batched read (the only synchronisation of the per-page path)
+    int64_t java_size_in_bytes(const DevicePage &p, std::vector<std::array<int32_t, 2>> &ends)
     {
         int64_t s = 0;
-        std::vector<std::array<int32_t, 2>> ends(p.cols.size(), {0, 0});
+        ends.assign(p.cols.size(), {0, 0});
         std::vector<Context::Transfer> reads;
         for (size_t i = 0; i < p.cols.size(); i++) {
             const DeviceColumn &c = p.cols[i];
             if (c.type != TGPU_VARCHAR) s += (int64_t)(type_width(c.type) + 1) * p.n;
+            else if (c.pool_exact) ends[i] = {c.pool_first, (int32_t)c.pool_bytes};
             else if (p.n > 0) {
                 reads.push_back({&ends[i][0], c.offsets, 4});
                 reads.push_back({&ends[i][1], c.offsets + p.n, 4});

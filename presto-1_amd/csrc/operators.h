@@ -17,6 +17,9 @@ public:
     virtual ~Operator() {}
     virtual bool needs_input() = 0;
     virtual void add_input(const tgpu_page *page) = 0;
+    // the same with a page this library produced (an OutputPage): its buffers are shared, so an operator that keeps or forwards the
+    // page does so without copying it.  Default: the borrowed-page path.
+    virtual void add_input_owned(const DevicePage &page);
     virtual std::unique_ptr<OutputPage> get_output() = 0;  // nullptr = no page available
     virtual void finish() = 0;
     virtual bool is_finished() = 0;

@@ -216,6 +216,7 @@ DeviceColumn read_variable_width(Context *ctx, Reader &r, int32_t type)
     c.values_buf = upload_section(ctx, r.take(total), total);
     c.values = c.values_buf->ptr();
     c.pool_bytes = total;
+    c.pool_exact = true;
     return c;
 }
 

@@ -99,7 +99,10 @@ class Operator:
     def needsInput(self):
         return bool(_lib.check(_lib.lib().tgpu_operator_needs_input(self.handle)))
 
-    def addInput(self, page: Page):
+    def addInput(self, page):
+        if isinstance(page, OutputPage):   # a page of this library: buffers shared, nothing copied (tgpu_operator_add_input_output_page)
+            _lib.check(_lib.lib().tgpu_operator_add_input_output_page(self.handle, page.handle))
+            return
         cp, keep = page.to_c()
         _lib.check(_lib.lib().tgpu_operator_add_input(self.handle, C.byref(cp)))
 

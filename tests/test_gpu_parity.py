@@ -1282,7 +1282,35 @@ def test_merge_pages_random_stream_and_device_input(pkg, ctx, oracle):
     dev.release()   # the input may go away: the operator owns what it hands out
     assert out.to_host().blocks[0].to_list() == list(range(100000))
     out.release()
-    m.close(); fac.close(); op.close(); fp.close()
+    # the same page handed over as an output-page handle (tgpu_operator_add_input_output_page): buffers shared, no copy; small pages
+    # given that way are appended like any other, and every operator accepts the handle form
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(5, dtype=np.int64))))   # below both thresholds of `fac`: buffered
+    small = op.getOutput()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(100000, 200000, dtype=np.int64))))
+    big = op.getOutput()
+    m.addInput(small)
+    assert m.getOutput() is None
+    m.addInput(big)
+    small.release(); big.release()
+    outs = []
+    while True:
+        o = m.getOutput()
+        if o is None:
+            break
+        outs.append(o.to_host().blocks[0].to_list())
+        o.release()
+    assert outs == [list(range(5)), list(range(100000, 200000))]
+    agg = pkg.HashAggregationOperatorFactory(ctx, 45, [pkg.BIGINT], [0], [(pkg.COUNT_ALL, -1)], expected_groups=16)
+    a = agg.createOperator()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(1000, dtype=np.int64) % 7)))
+    pg = op.getOutput()
+    a.addInput(pg)
+    pg.release()
+    a.finish()
+    res = a.getOutput()
+    assert sorted(res.to_host().rows()) == [(k, len(range(k, 1000, 7))) for k in range(7)]
+    res.release()
+    a.close(); agg.close(); m.close(); fac.close(); op.close(); fp.close()
 
 
 def test_merge_pages_argument_checks(pkg, ctx):

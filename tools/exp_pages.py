@@ -23,6 +23,9 @@ def page(a, z):
     return pkg.Page(vb("returnflag"), vb("linestatus"), db(D, "quantity"), db(D, "extendedprice"), db(D, "discount"), db(D, "tax"), db(DT, "shipdate"), position_count=m)
 
 
+types = [V, V, D, D, D, D, DT]
+merge = os.environ.get("EXP_MERGE_MB")   # put a MergePagesOperator with this many MB of min/max page size in front
+mfac = pkg.MergePagesOperatorFactory(ctx, 20, types, int(merge) << 20, 1 << 27, (int(merge) << 20) * 2) if merge else None
 for rows in (n, 1 << 26, 1 << 24, 1 << 22, 1 << 20):
     pages = [page(a, min(a + rows, n)) for a in range(0, n, rows)]
     best = None
@@ -30,8 +33,25 @@ for rows in (n, 1 << 26, 1 << 24, 1 << 22, 1 << 20):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         op = fac.createOperator()
-        for pg in pages:
-            op.addInput(pg)
+        if mfac is None:
+            for pg in pages:
+                op.addInput(pg)
+        else:
+            m = mfac.createOperator()
+
+            def drain():
+                while True:
+                    o = m.getOutput()
+                    if o is None:
+                        break
+                    op.addInput(o.as_device_page())
+                    o.release()
+            for pg in pages:
+                m.addInput(pg)
+                drain()
+            m.finish()
+            drain()
+            m.close()
         op.finish()
         o = op.getOutput()
         res = o.to_host().rows()
@@ -39,5 +59,5 @@ for rows in (n, 1 << 26, 1 << 24, 1 << 22, 1 << 20):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    print(f"page rows {rows:>10} pages {len(pages):>5} best {best * 1e3:8.2f} ms  {n / best / 1e9:7.2f} G rows/s  groups {len(res)}", flush=True)
+    print(("merged " + merge + " MB  " if merge else "") + f"page rows {rows:>10} pages {len(pages):>5} best {best * 1e3:8.2f} ms  {n / best / 1e9:7.2f} G rows/s  groups {len(res)}", flush=True)
 ctx.close()
