@@ -670,6 +670,16 @@ def main():
         roof = dominant(prof, {"join_probe_count": rows_avg}, {"join_probe_count": 28.0})
     else:
         roof = dominant(prof, {"fused_filter_probe": rows_avg}, {"fused_filter_probe": alg / rows_avg})
+        if roof and roof["kernel"] == "fused_filter_probe" and "fused_filter_probe" in prof:
+            # the two launches of a step are different animals: the orders launch probes random keys (bound by
+            # divergent L2 lookups), the lineitem launch streams.  Their own figures, from the shortest (orders) and the longest
+            # (lineitem) launch of the timed region -- conservative for the lineitem launch:
+            fp = prof["fused_filter_probe"]
+            alg_o = 4.0 * n_o + 16.0 * st["orders_probe_rows"] + 12.0 * st["orders_build_rows"]
+            alg_l = 4.0 * n_l + 16.0 * st["lineitem_probe_rows"] + 12.0 * st["lineitem_join_rows"]
+            roof["per_launch"] = {
+                "orders": {"algorithmic_bytes": alg_o, "launch_ms": fp["min_ms"], "achieved": alg_o / (fp["min_ms"] * 1e-3) / 1e9, "frac": alg_o / (fp["min_ms"] * 1e-3) / 8e12},
+                "lineitem": {"algorithmic_bytes": alg_l, "launch_ms": fp["max_ms"], "achieved": alg_l / (fp["max_ms"] * 1e-3) / 1e9, "frac": alg_l / (fp["max_ms"] * 1e-3) / 8e12}}
     out.update({
         "metric": "probe_rows_per_sec", "value": total_probe / step_s, "unit": "rows/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64+f64", "data": "synthetic",
