@@ -83,12 +83,20 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
 // ORDERED mode (many groups): keys[i] = group id + 1 of the i-th row in (group, row) order (0 = row excluded by a filter),
 // rows[i] = its row number.  The lane that owns the first row of a group walks the group's rows in order.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) ordered_keys_kernel(const int32_t *__restrict__ gids, int64_t n, unsigned int *__restrict__ keys, int *__restrict__ rows)
+// *unsorted is set when some key is smaller than its predecessor: otherwise the pairs are already in (group, row) order -- the
+// usual case behind a join whose probe side is clustered by the group key (first-seen ids then ascend with the rows) -- and the
+// sort is skipped
+__global__ void __launch_bounds__(kBlock) ordered_keys_kernel(const int32_t *__restrict__ gids, int64_t n, unsigned int *__restrict__ keys, int *__restrict__ rows,
+                                                               unsigned int *__restrict__ unsorted)
 {
+    bool bad = false;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        keys[r] = (unsigned int)(gids[r] + 1);
+        const int32_t g = gids[r];
+        keys[r] = (unsigned int)(g + 1);
         rows[r] = (int)r;
+        bad = bad || (r > 0 && gids[r - 1] > g);
     }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *unsorted = 1u;   // idempotent plain store
 }
 
 template <bool INTERMEDIATE>
@@ -473,11 +481,17 @@ bool GroupedAccumulators::begin_ordered(const int32_t *gids, int64_t n, int64_t 
 // (group id + 1, row) pairs of the page in (group, row) order: stable LSD radix sort on the bits the group ids use
 void GroupedAccumulators::sort_rows_by_group(const int32_t *gids, int64_t n, int64_t groups, BufferPtr &keys, BufferPtr &rows)
 {
-    BufferPtr keys_in = ctx_->alloc((size_t)n * 4), rows_in = ctx_->alloc((size_t)n * 4);
+    BufferPtr keys_in = ctx_->alloc((size_t)n * 4), rows_in = ctx_->alloc((size_t)n * 4), unsorted = ctx_->alloc_zero(4);
+    ordered_keys_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(gids, n, keys_in->as<unsigned int>(), rows_in->as<int>(), unsorted->as<unsigned int>());
+    check_launch("ordered_keys");
+    // one small read-back (~25 us) against three or four radix sort passes over the page
+    if (getenv("TGPU_ALWAYS_SORT") == nullptr && ctx_->read_scalar(unsorted->as<unsigned int>()) == 0) {
+        keys = keys_in;
+        rows = rows_in;
+        return;
+    }
     keys = ctx_->alloc((size_t)n * 4);
     rows = ctx_->alloc((size_t)n * 4);
-    ordered_keys_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(gids, n, keys_in->as<unsigned int>(), rows_in->as<int>());
-    check_launch("ordered_keys");
     unsigned int end_bit = 1;
     while (end_bit < 32 && (1ull << end_bit) <= (unsigned long long)groups) end_bit++;   // keys are in [0, groups]
     size_t temp_bytes = 0;
