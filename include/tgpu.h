@@ -343,7 +343,9 @@ int32_t tgpu_partitioned_output_info(tgpu_operator *op, int64_t *rows_added, int
 /* PagesSerde.serialize + PagesSerdeUtil.writeSerializedPage (M/execution/buffer/PagesSerde.java:64-115, PagesSerdeUtil.java:45-71;
  * block bodies: S/block/LongArrayBlockEncoding.java:37-61, IntArrayBlockEncoding, ByteArrayBlockEncoding, VariableWidthBlockEncoding.java:37-61,
  * null bits S/block/EncoderUtil.java:33-71) of `page` into `out` (host memory, `capacity` bytes): positionCount | markers (none) |
- * uncompressedSize | sizeInBytes | payload, byte for byte what the Java serde writes for the same flat blocks.  *out_len = bytes
+ * uncompressedSize | sizeInBytes | payload, byte for byte what the Java serde writes for the same flat blocks (one representation
+ * detail aside: a null vector that holds no null is dropped at ingest, so such a block is written with mayHaveNull = 0 where Java
+ * keeps the flag of an all-false valueIsNull array -- both decode to equal blocks).  *out_len = bytes
  * written.  out == NULL: *out_len = an upper bound of the size (nothing is computed), for sizing the buffer. */
 int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out, int64_t capacity, int64_t *out_len);
 /* PagesSerde.deserialize (PagesSerde.java:117-160) of one uncompressed, unencrypted SerializedPage in host memory, straight into a
