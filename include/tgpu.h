@@ -20,7 +20,9 @@
  *   - tgpu_partition_page        <-> M/operator/PartitionedOutputOperator.java:406-426 + HashGenerator.java:24-35
  *
  * Threading rule = the reference's (M/operator/Driver.java:55-62): one caller at a time per handle; distinct
- * handles are independent; a built lookup source is immutable and shared read-only by probe operators.
+ * handles are independent, also when they belong to one context (their kernels then share its stream and execute in issue
+ * order; the context serialises its staging buffers; the per-kernel profile assumes a single driver thread); a built lookup
+ * source is immutable and shared read-only by probe operators (outer joins mark visited build positions with idempotent stores).
  * Ownership rule: input buffers are only read during the call (the library copies/uploads what it keeps);
  * output pages are owned by the library until tgpu_output_page_release.
  */

@@ -158,6 +158,7 @@ private:
     const char *cur_name_ = nullptr;
     hipEvent_t cur_a_ = nullptr;
     std::mutex mu_;
+    std::recursive_mutex io_mu_;   // the pinned staging buffer, the polling event and the profile lists: shared by every handle of the context
 };
 
 // RAII: times everything launched on the stream between construction and destruction under one name

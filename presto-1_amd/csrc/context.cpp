@@ -58,6 +58,7 @@ void Context::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
 // the blocking wait (an embedding that must not spin a core).
 void Context::wait_stream()
 {
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     static const bool blocking = getenv("TGPU_BLOCKING_WAIT") != nullptr;
     if (blocking) {
         HIP_CHECK(hipStreamSynchronize(stream_));
@@ -143,6 +144,7 @@ void Context::release(void *ptr, size_t capacity)
 
 void *Context::pinned(size_t bytes)
 {
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     if (bytes > pinned_bytes_) {
         if (pinned_) {
             HIP_CHECK(hipStreamSynchronize(stream_));
@@ -167,6 +169,8 @@ void Context::upload(void *dst, const void *src, size_t bytes)
 void Context::download(void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
+    // handles of one context may be driven by different threads (tgpu.h threading rule): they share the staging buffer
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     if (bytes <= (64u << 10)) {
         // the small read-backs between kernels (counts, flags, key ranges) go through the pinned staging buffer: a copy into
         // pageable memory (a stack variable) takes the runtime's slow staged path, several times the latency of this one
@@ -185,6 +189,7 @@ void Context::download_batch(const std::vector<Transfer> &transfers)
     size_t total = 0;
     for (auto &t : transfers) total += (t.bytes + 63) / 64 * 64;
     if (!total) return;
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     uint8_t *stage = static_cast<uint8_t *>(pinned(total));
     size_t off = 0;
     for (auto &t : transfers) {
@@ -203,12 +208,14 @@ void Context::set_profiling(bool on) { profiling_ = on; }
 
 void Context::profile_reset()
 {
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     profile_collect();
     stats_.clear();
 }
 
 void Context::profile_begin(const char *name)
 {
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     if (cur_name_) return;  // nested scopes: the outermost wins
     hipEvent_t a;
     if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); }
@@ -220,6 +227,7 @@ void Context::profile_begin(const char *name)
 
 void Context::profile_end()
 {
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     if (!cur_name_) return;
     hipEvent_t b;
     if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); }
@@ -233,6 +241,7 @@ void Context::profile_end()
 
 void Context::profile_collect()
 {
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
     if (pending_.empty()) return;
     HIP_CHECK(hipStreamSynchronize(stream_));
     for (auto &p : pending_) {

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <array>
+#include <mutex>
 
 #include "common.h"
 
@@ -83,6 +84,7 @@ private:
     int64_t n_ = 0, capacity_ = 0, link_count_ = 0;
     bool int_key_fast_ = false;  // single BIGINT / INTEGER / DATE key: key stored inline in the slot
     BufferPtr visited_;          // uint8[n]: build positions matched by an outer-tracking probe (allocated on first use)
+    std::mutex visited_mu_;      //   (several probe operators, possibly on different driver threads, share the table)
     BufferPtr heads_;            // int32[capacity], -1 empty          (PagesHash.key)
     BufferPtr slots16_;          // fast path: {int64 key, int32 head, int32 pad}[capacity]
     BufferPtr bloom_;            // fast path: blocked Bloom filter over the build keys (sparse key domains)

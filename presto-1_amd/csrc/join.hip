@@ -877,7 +877,10 @@ __global__ void __launch_bounds__(kBlock) compact_positions_kernel(const int32_t
 void LookupSourceGpu::mark_visited(const int32_t *build_positions, int64_t n)
 {
     if (n <= 0 || n_ <= 0) return;
-    if (!visited_) visited_ = ctx_->alloc_zero((size_t)n_);
+    {
+        std::lock_guard<std::mutex> lk(visited_mu_);
+        if (!visited_) visited_ = ctx_->alloc_zero((size_t)n_);
+    }
     mark_visited_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(build_positions, n, visited_->as<uint8_t>());
     check_launch("mark_visited");
 }

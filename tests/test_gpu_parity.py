@@ -1438,3 +1438,49 @@ def test_serde_many_small_random_pages(pkg, ctx, oracle):
         back = ctx.deserialize_page(want, types)
         _assert_same_page(pkg, back.to_host(), blocks, n)
         back.release()
+
+
+def test_two_threads_share_a_context(pkg, ctx, oracle):
+    """tgpu.h threading rule: distinct handles of one context may be driven from different threads (ctypes drops the GIL during
+    the calls, so the two drivers really overlap): results stay those of the single-threaded run"""
+    import threading
+
+    rng = np.random.default_rng(77)
+    n = 200_000
+    f = pkg.field
+    errors, results = [], {}
+
+    def drive(tag, seed):
+        try:
+            r = np.random.default_rng(seed)
+            keys = r.integers(0, 50, n).astype(np.int64)
+            vals = r.integers(-1000, 1000, n).astype(np.int64)
+            page = pkg.Page(pkg.Block(pkg.BIGINT, keys), pkg.Block(pkg.BIGINT, vals))
+            out = []
+            for it in range(15):
+                fp = pkg.FilterAndProjectOperatorFactory(ctx, 50, [pkg.BIGINT, pkg.BIGINT], f(1, pkg.BIGINT) < 500, [f(0, pkg.BIGINT), f(1, pkg.BIGINT)])
+                ag = pkg.HashAggregationOperatorFactory(ctx, 51, [pkg.BIGINT], [0], [(pkg.SUM_BIGINT, 1), (pkg.COUNT_ALL, -1)], expected_groups=64)
+                a, b = fp.createOperator(), ag.createOperator()
+                a.addInput(page)
+                mid = a.getOutput()
+                b.addInput(mid)
+                mid.release()
+                b.finish()
+                res = b.getOutput()
+                out.append(sorted(res.to_host().rows()))
+                res.release()
+                a.close(); b.close(); fp.close(); ag.close()
+            sel = vals < 500
+            want = sorted((int(k), int(vals[sel & (keys == k)].sum()), int((sel & (keys == k)).sum())) for k in np.unique(keys[sel]))
+            assert all(o == want for o in out)
+            results[tag] = True
+        except Exception as e:   # surfaced in the main thread below
+            errors.append((tag, repr(e)))
+
+    threads = [threading.Thread(target=drive, args=(i, 1000 + i)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 3
