@@ -30,7 +30,7 @@ def _make_rows(rank, n):
     pay = (np.arange(n, dtype=np.int64) + rank * 1_000_000)
     strs = [None if k % 11 == 0 else "s%d" % (k % 37) for k in keys]
     dbl = rng.standard_normal(n)
-    dnull = (rng.random(n) < 0.1).astype(np.uint8)
+    dnull = (rng.random(n) < 0.1).astype(np.uint8) if rank == 0 else np.zeros(n, dtype=np.uint8)   # rank 1 sends this channel WITHOUT a null vector
     return keys, pay, strs, dbl, dnull
 
 
@@ -54,7 +54,8 @@ def _worker(rank, world, port, n, out_q):
             {"type": pkg.BIGINT, "values": torch.from_numpy(pay[order]), "nulls": None, "offsets": None},
             {"type": pkg.VARCHAR, "values": torch.from_numpy(sb.values.copy()), "nulls": torch.from_numpy(sb.nulls.copy()) if sb.nulls is not None else None,
              "offsets": torch.from_numpy(sb.offsets.copy())},
-            {"type": pkg.DOUBLE, "values": torch.from_numpy(dbl[order]), "nulls": torch.from_numpy(dnull[order]), "offsets": None},
+            # (a channel travels with nulls when ANY rank has a null vector for it: the page header all-to-all carries the flags)
+            {"type": pkg.DOUBLE, "values": torch.from_numpy(dbl[order]), "nulls": torch.from_numpy(dnull[order]) if rank == 0 else None, "offsets": None},
         ]
         return counts, cols
 
