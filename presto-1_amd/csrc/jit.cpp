@@ -914,7 +914,8 @@ struct FjArgs {
   unsigned long long* counters;
   long long tiles;
   long long grid1;          // grid size of pass 1 (defines the region layout)
-  int outer;
+  int outer;                // bit 0: PROBE_OUTER / FULL_OUTER rows; bit 1: nobody reads the build positions (no build output channels,
+                            // no outer tracking): the DIRECT layout then skips the rank and position lookups
   int chunk_shift;          // a workgroup takes 2^chunk_shift consecutive tiles at a time
 };
 #define FJ_STRIPES @FJ_STRIPES@
@@ -1011,7 +1012,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
           }
         }
 #endif
-        emit[s] = head[s] >= 0 || (J.outer && (sfl[s] & 2));   // PROBE_OUTER: every row that passed the filter (LookupJoinOperator.java:354-361)
+        emit[s] = head[s] >= 0 || ((J.outer & 1) && (sfl[s] & 2));   // PROBE_OUTER: every row that passed the filter (LookupJoinOperator.java:354-361)
       }
     }
     // stage C: tile jC -- pre-filter verdicts; the survivors' first table slot is loaded below (lanes without a survivor read
@@ -1037,7 +1038,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #if FJ_PF == 3
         skey[s] = pkey[s]; ssidx[s] = (unsigned int)__popcll(pbw[s] & ((1ULL << pbits[s]) - 1ULL));   // set bits below the key's own
         sfl[s] = (unsigned char)((maybe ? 1 : 0) | (pfl[s] & 2));
-        cidx[s] = maybe ? (psidx[s] >> 6) : 0u;                                                         // its bitmap word
+        cidx[s] = (maybe && !(J.outer & 2)) ? (psidx[s] >> 6) : 0u;                                     // its bitmap word (entry 0 when the rank is not needed)
 #else
         skey[s] = pkey[s]; ssidx[s] = psidx[s];
         sfl[s] = (unsigned char)((maybe ? 1 : 0) | (pfl[s] & 2));
@@ -1182,10 +1183,12 @@ extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
     for (int i = threadIdx.x; i < cnt; i += 256) {
       const long long row = J.pair_probe[src + i];
 #if FJ_PF == 3
-      const int rank = J.pair_build[src + i];   // rank of the key among the build keys (-1: unmatched row of an outer probe)
-      J.out_build[dst + i] = rank < 0 ? -1 : J.pf.direct[rank];
+      if (!(J.outer & 2)) {
+        const int rank = J.pair_build[src + i];   // rank of the key among the build keys (-1: unmatched row of an outer probe)
+        J.out_build[dst + i] = rank < 0 ? -1 : J.pf.direct[rank];
+      }
 #else
-      J.out_build[dst + i] = J.pair_build[src + i];
+      if (!(J.outer & 2)) J.out_build[dst + i] = J.pair_build[src + i];
 #endif
       tg_emit_outputs(A, row, dst + i);
     }
@@ -1352,8 +1355,8 @@ JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls)
     return modules_[variant].get();
 }
 
-void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, std::vector<DeviceColumn> &probe_out,
-                            BufferPtr &build_idx, int64_t &count, int64_t &selected_rows)
+void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions,
+                            std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count, int64_t &selected_rows)
 {
     TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
@@ -1383,7 +1386,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.bloom_word_mask = tv.bloom_word_mask;
     J.direct = tv.direct;
     J.rank_base = tv.rank_base;
-    J.outer = outer ? 1 : 0;
+    J.outer = (outer ? 1 : 0) | (need_build_positions ? 0 : 2);
     const int64_t tile_rows = (int64_t)fj_stripes() * 256;
     J.tiles = ceil_div(n, tile_rows);
     TG_CHECK_ARG(n <= 0x7fffffffLL && J.tiles <= 0x7fffffffLL, "page too large");

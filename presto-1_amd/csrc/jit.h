@@ -109,7 +109,9 @@ public:
     bool supported() const { return supported_; }   // false -> the operator runs the unfused composition
     const std::vector<int32_t> &projection_types() const { return proj_types_; }
     // probes `in` against the lookup source's int-key table; returns the probe-side output columns + build positions
-    void process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, std::vector<DeviceColumn> &probe_out,
+    // need_build_positions = false (no build output channels, no outer tracking): build_idx is left undefined and the DIRECT
+    // layout skips its rank / position lookups
+    void process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, std::vector<DeviceColumn> &probe_out,
                  BufferPtr &build_idx, int64_t &count, int64_t &selected_rows);
     const std::string &source() const { return source_; }
 

@@ -510,7 +510,8 @@ public:
             std::vector<DeviceColumn> probe_out;
             BufferPtr build_idx;
             int64_t count = 0, selected = 0;
-            fused_->process(ctx_, in, *source, outer, probe_out, build_idx, count, selected);
+            const bool need_positions = track || !source->output_channels().empty();
+            fused_->process(ctx_, in, *source, outer, need_positions, probe_out, build_idx, count, selected);
             probe_rows_ += selected;
             if (count == 0) return;
             if (track) source->mark_visited(build_idx->as<int32_t>(), count);
