@@ -1360,6 +1360,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
 {
     TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
+    if (need_build_positions) source.ensure_rank();
     IntTableView tv;
     TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
     bool any_nulls = false;

@@ -73,6 +73,9 @@ public:
     // OuterPositionTracker (M/operator/OuterLookupSource.java:146-190): LOOKUP_OUTER / FULL_OUTER probes record the build positions
     // they emitted; unvisited_positions = OuterPositionIterator, every build position nobody matched, ascending
     void mark_visited(const int32_t *build_positions, int64_t n);
+    // DIRECT layout: the rank structure (rank_base + positions in key order) is built on first demand when the table has no output
+    // channels; everything that reads build positions calls this first
+    void ensure_rank() const;
     void unvisited_positions(BufferPtr &positions, int64_t &count);
 
 private:
@@ -84,7 +87,9 @@ private:
     int64_t n_ = 0, capacity_ = 0, link_count_ = 0;
     bool int_key_fast_ = false;  // single BIGINT / INTEGER / DATE key: key stored inline in the slot
     BufferPtr visited_;          // uint8[n]: build positions matched by an outer-tracking probe (allocated on first use)
-    std::mutex visited_mu_;      //   (several probe operators, possibly on different driver threads, share the table)
+    mutable std::mutex visited_mu_;   //   (several probe operators, possibly on different driver threads, share the table)
+    mutable bool rank_pending_ = false;   // DIRECT layout: rank_base_ / direct_ are allocated but not filled yet (ensure_rank)
+    ColView direct_key_{};
     BufferPtr heads_;            // int32[capacity], -1 empty          (PagesHash.key)
     BufferPtr slots16_;          // fast path: {int64 key, int32 head, int32 pad}[capacity]
     BufferPtr bloom_;            // fast path: blocked Bloom filter over the build keys (sparse key domains)

@@ -735,23 +735,37 @@ bool LookupSourceGpu::build_direct(const KeyCols &keys)
         build_direct_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, host_mm[0], bitmap->as<unsigned long long>(), counters->as<unsigned long long>());
         check_launch("build_direct");
     }
-    {
-        ProfileScope ps(ctx_, "join_build_rank");
-        BufferPtr counts = ctx_->alloc((size_t)words * 4);
-        bitmap_popcount_kernel<<<grid_for(ctx_, words), kBlock, 0, ctx_->stream()>>>(bitmap->as<unsigned long long>(), words, counts->as<int32_t>());
-        check_launch("bitmap_popcount");
-        k::exclusive_scan_i32(ctx_, counts->as<int32_t>(), rank_base->as<int32_t>(), words, (int64_t *)(counters->as<unsigned long long>() + 1));
-        build_rank_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys.c[0], n_, host_mm[0], bitmap->as<unsigned long long>(), rank_base->as<int32_t>(), direct->as<int32_t>());
-        check_launch("build_rank");
-    }
-    // (with repeated keys two rows share a rank: the stores above stayed inside direct[], the layout is dropped here)
     if (ctx_->read_scalar(counters->as<unsigned long long>()) != 0) return false;   // repeated build keys: position links needed
     key_min_ = host_mm[0];
     key_max_ = host_mm[1];
     bitmap_ = bitmap;
     direct_ = direct;
     rank_base_ = rank_base;
+    direct_key_ = keys.c[0];
+    rank_pending_ = true;
+    // a table without output channels is usually probed for membership only (the build side of a semi-join-like filter, Q3's
+    // customer table): the rank structure is then built on first demand (ensure_rank), i.e. normally never
+    if (!output_channels_.empty()) ensure_rank();
     return true;
+}
+
+// DIRECT layout: steps 3 and 4 (rank_base, positions in key order); idempotent, callable from any probe operator's thread
+void LookupSourceGpu::ensure_rank() const
+{
+    if (!direct_) return;
+    std::lock_guard<std::mutex> lk(visited_mu_);
+    if (!rank_pending_) return;
+    const int64_t range = (int64_t)((unsigned long long)key_max_ - (unsigned long long)key_min_ + 1ULL);
+    const int64_t words = (range + 63) / 64;
+    ProfileScope ps(ctx_, "join_build_rank");
+    BufferPtr counts = ctx_->alloc((size_t)words * 4), total = ctx_->alloc(8);
+    bitmap_popcount_kernel<<<grid_for(ctx_, words), kBlock, 0, ctx_->stream()>>>(bitmap_->as<unsigned long long>(), words, counts->as<int32_t>());
+    check_launch("bitmap_popcount");
+    k::exclusive_scan_i32(ctx_, counts->as<int32_t>(), rank_base_->as<int32_t>(), words, total->as<int64_t>());
+    build_rank_kernel<<<grid_for(ctx_, n_), kBlock, 0, ctx_->stream()>>>(direct_key_, n_, key_min_, bitmap_->as<unsigned long long>(), rank_base_->as<int32_t>(),
+                                                                        direct_->as<int32_t>());
+    check_launch("build_rank");
+    rank_pending_ = false;
 }
 
 bool LookupSourceGpu::int_table(IntTableView &v) const
@@ -786,6 +800,7 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
         out_build_idx = ctx_->alloc(4);
         return;
     }
+    ensure_rank();   // this path always produces build positions
     const KeyCols probe = key_cols_of(probe_keys);
     std::vector<const DeviceColumn *> kp;
     for (auto &c : key_cols_) kp.push_back(&c);
