@@ -1319,7 +1319,7 @@ void FusedProbeGpu::generate()
         const int32_t t = proj_types_[(size_t)ch];
         const char *T = t == TGPU_BOOLEAN ? "unsigned char" : ctype(t);
         src << "  { " << ctype(t) << " v = 0; const bool n = tg_p" << ch << "(A, row, v); ((" << T << "*)A.out_values[" << i << "])[o] = n ? (" << T << ")0 : (" << T
-            << ")v; A.out_nulls[" << i << "][o] = n ? 1 : 0; }\n";
+            << ")v; if (A.out_nulls[" << i << "]) A.out_nulls[" << i << "][o] = n ? 1 : 0; }\n";   // (no null vector: the host proved the channel null-free)
     }
     src << "}\n";
     // experiment switches for kernel studies (tools/exp_fused.py); never set in production
@@ -1443,10 +1443,17 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
         c.n = count;
         c.values_buf = ctx->alloc((size_t)count * type_width(c.type));
         c.values = c.values_buf->ptr();
-        c.nulls_buf = ctx->alloc((size_t)count);
-        c.nulls = c.nulls_buf->as<uint8_t>();
+        // an output that is a plain reference to an input column without a null vector cannot hold a null: no null vector is
+        // produced for it (what Block.mayHaveNull() == false gives the reference's downstream operators), so the build / group-by
+        // kernels behind the join skip their null checks for the channel
+        const tgpu_expr_node &root = nodes_[(size_t)proj_roots_[(size_t)output_channels_[i]]];
+        const bool null_free = root.kind == TGPU_EX_INPUT && root.op >= 0 && root.op < (int)in.cols.size() && in.cols[(size_t)root.op].nulls == nullptr;
+        if (!null_free) {
+            c.nulls_buf = ctx->alloc((size_t)count);
+            c.nulls = c.nulls_buf->as<uint8_t>();
+        }
         J.fp.out_values[i] = c.values_buf->ptr();
-        J.fp.out_nulls[i] = c.nulls_buf->as<uint8_t>();
+        J.fp.out_nulls[i] = null_free ? nullptr : c.nulls_buf->as<uint8_t>();
         probe_out.push_back(c);
     }
     {
