@@ -30,14 +30,15 @@ struct TgPrefilter {
     // in the build side, and the key's RANK among the present keys (rank_base[word] = set bits in front of the bitmap word,
     // plus the set bits below the key's own bit) indexes direct[], the build positions in key order.  Both side arrays are
     // dense: 4 bytes per 64 key values + 4 bytes per build row, whatever the spread of the keys.
-    const int *direct;
-    const int *rank_base;
+    const int *direct;      // nullptr with rank_base set: build positions ARE the ranks (build side in strictly ascending key order)
+    const int *rank_base;   // non-null = DIRECT layout
 };
 
 // DIRECT layout: build position of the present key at offset d = key - key_min, `word` = its bitmap word
 __device__ inline int tg_direct_position(const TgPrefilter &pf, unsigned long long d, unsigned long long word)
 {
-    return pf.direct[pf.rank_base[d >> 6] + __popcll(word & ((1ULL << (d & 63)) - 1ULL))];
+    const int rank = pf.rank_base[d >> 6] + __popcll(word & ((1ULL << (d & 63)) - 1ULL));
+    return pf.direct ? pf.direct[rank] : rank;   // no direct[]: the build side arrived in strictly ascending key order, position = rank
 }
 
 // Slot of a key in the int-key table: Fibonacci hashing, the top log2(capacity) bits of key * 2^64 / phi (one 64-bit multiply
@@ -56,7 +57,7 @@ __device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long
         const unsigned long long d = (unsigned long long)(key - pf.key_min);
         const unsigned long long word = pf.bitmap[d >> 6];
         if (!((word >> (d & 63)) & 1ULL)) return -1;
-        if (pf.direct) return tg_direct_position(pf, d, word);
+        if (pf.rank_base) return tg_direct_position(pf, d, word);
     }
     else if (pf.bloom) {
         const unsigned long long m = tg_fmix64((unsigned long long)tg_hash_long(key));

@@ -1185,7 +1185,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
 #if FJ_PF == 3
       if (!(J.outer & 2)) {
         const int rank = J.pair_build[src + i];   // rank of the key among the build keys (-1: unmatched row of an outer probe)
-        J.out_build[dst + i] = rank < 0 ? -1 : J.pf.direct[rank];
+        J.out_build[dst + i] = (rank < 0 || !J.pf.direct) ? rank : J.pf.direct[rank];
       }
 #else
       if (!(J.outer & 2)) J.out_build[dst + i] = J.pair_build[src + i];
@@ -1365,7 +1365,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
     bool any_nulls = false;
     for (const DeviceColumn &c : in.cols) any_nulls = any_nulls || c.nulls != nullptr;
-    JitModule *module = module_for(tv.direct ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls);
+    JitModule *module = module_for(tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls);
     const int64_t n = in.n;
     count = 0;
     selected_rows = 0;
