@@ -615,7 +615,7 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected and corrected as documented there)
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v4_pmc_traffic.json")))["kernels"].get(best)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))["kernels"].get(best)
         if pmc:
             traffic = pmc["traffic_bytes_per_launch_avg"]
     except (OSError, ValueError, KeyError):
