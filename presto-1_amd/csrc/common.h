@@ -174,6 +174,15 @@ struct ProfileScope {
     }
 };
 
+// an expression-error word written by a generated kernel: ~0 = none, else (row << 8) | code (7 = division by zero, else overflow)
+inline void raise_expression_error(unsigned long long e)
+{
+    if (e == ~0ull) return;
+    const long long row = (long long)(e >> 8);
+    if ((int)(e & 0xff) == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
+    fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
+}
+
 inline void check_launch(const char *what)
 {
     hipError_t e = hipGetLastError();

@@ -17,7 +17,8 @@ struct GbhProbeLaunch {
     KeyCols store;
     int32_t store_groups;
     int32_t *out;
-    unsigned long long *counters;   // [0] pending rows, [2] table-full error
+    unsigned long long *counters;   // [0] pending rows, [2] table-full error, [7] the probe kernel's expression-error word (~0 = none):
+                                    // it comes back with the other counters, one read-back for all of them
     // compact mode (out == nullptr): one byte per row = group id + 1, 0 = row rejected by the fused filter, 255 = the row joined /
     // created a group that is new in this sub-batch (counted in counters[0]; the sub-batch is then re-run in int32 mode)
     uint8_t *out8 = nullptr;

@@ -349,7 +349,8 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
     ensure_table(groups_ + std::min<int64_t>(n, sub_batch_));
     ensure_store(groups_ > 0 ? groups_ : 1);  // the store view must be addressable for OLD slots
     unsigned long long *ctr = counters_->as<unsigned long long>();
-    HIP_CHECK(hipMemsetAsync(ctr, 0, 8 * 8, ctx_->stream()));
+    HIP_CHECK(hipMemsetAsync(ctr, 0, 7 * 8, ctx_->stream()));
+    HIP_CHECK(hipMemsetAsync(ctr + 7, 0xff, 8, ctx_->stream()));   // [7]: expression-error word of a fused probe kernel
     const int g = grid_for(ctx_, n);
     if (probe) {
         GbhProbeLaunch l{row0, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr};
@@ -375,8 +376,9 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
     };
     const bool eager = n <= (1ll << 22) && (groups_ == 0 || last_new_groups_ > 0);   // new groups are likely: worth the two passes up front
     if (eager) mark_and_rank();
-    unsigned long long host_ctr[3];
+    unsigned long long host_ctr[8];
     ctx_->download(host_ctr, ctr, sizeof(host_ctr));
+    raise_expression_error(host_ctr[7]);
     if (host_ctr[2] != 0) return false;  // table overflow
     if (host_ctr[0] == 0) {              // every row hit an existing group
         last_new_groups_ = 0;
@@ -496,12 +498,14 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             ensure_table(groups_ + std::min<int64_t>(len, sub_batch_));
             ensure_store(groups_ > 0 ? groups_ : 1);
             unsigned long long *ctr = counters_->as<unsigned long long>();
-            HIP_CHECK(hipMemsetAsync(ctr, 0, 8 * 8, ctx_->stream()));
+            HIP_CHECK(hipMemsetAsync(ctr, 0, 7 * 8, ctx_->stream()));
+            HIP_CHECK(hipMemsetAsync(ctr + 7, 0xff, 8, ctx_->stream()));
             GbhProbeLaunch l{start, len, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), nullptr, ctr,
                              out_gids8 + start};
             (*probe)(l);
-            unsigned long long host_ctr[3];
+            unsigned long long host_ctr[8];
             ctx_->download(host_ctr, ctr, sizeof(host_ctr));
+            raise_expression_error(host_ctr[7]);
             ok = host_ctr[2] == 0;
             if (ok && host_ctr[0] != 0) {
                 // new groups: the full protocol on a temporary int32 buffer (the re-run finds the slots it has just claimed), then

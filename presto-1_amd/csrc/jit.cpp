@@ -826,14 +826,14 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
     HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
     args.error = err->as<unsigned long long>();
 
-    auto check_error = [&]() {
-        unsigned long long e = ctx->read_scalar(err->as<unsigned long long>());
+    auto raise_error = [&](unsigned long long e) {
         if (e == ~0ull) return;
         const long long row = (long long)(e >> 8);
         const int code = (int)(e & 0xff);
         if (code == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
         fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
     };
+    auto check_error = [&]() { raise_error(ctx->read_scalar(err->as<unsigned long long>())); };
 
     int64_t n_sel = n;
     BufferPtr positions, tile_counts, tile_offsets, sel_mask;
@@ -850,8 +850,10 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
             launch(fn_count_, (int)tiles, args, ctx->stream());
         }
         k::exclusive_scan_i32(ctx, tile_counts->as<int32_t>(), tile_offsets->as<int32_t>(), tiles, total->as<int64_t>());
-        n_sel = ctx->read_scalar(total->as<int64_t>());
-        check_error();  // filter errors surface before any projection runs
+        // the selected-row count and the filter's error word come back in one round trip
+        unsigned long long filter_error = ~0ull;
+        ctx->download_batch({{&n_sel, total->ptr(), 8}, {&filter_error, err->ptr(), 8}});
+        raise_error(filter_error);  // filter errors surface before any projection runs
         if (n_sel == 0) return false;  // PageProcessor.java:122-124
         positions = ctx->alloc((size_t)n_sel * 4);
         args.positions = positions->as<int32_t>();
@@ -2358,9 +2360,7 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     JitModule *module = module_for(in);
     FgArgsHost G{};
     fill_fp_cols(G.fp, in);
-    BufferPtr err = ctx->alloc(8);
-    HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
-    G.fp.error = err->as<unsigned long long>();
+    G.fp.error = l.counters + 7;   // the group-by table reads it back together with its own counters (GbhProbeLaunch)
     // the kernel reads byte 0 of a varchar key column for rows without a first byte: give an all-empty column one to read
     BufferPtr dummy;
     for (int ch : key_inputs_)
@@ -2389,7 +2389,6 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
         const int64_t blocks = std::min<int64_t>(ceil_div(l.n, 256), (int64_t)ctx->cu_count() * module->blocks_per_cu("fg_probe"));
         launch_args(module->fn("fg_probe"), (int)blocks, G, ctx->stream());
     }
-    raise_if_error(ctx, err);
 }
 
 // gids8 -> gids, for the (rare) page whose ids arrived compact but whose groups do not fit the lane-private LDS path
