@@ -1484,3 +1484,36 @@ def test_two_threads_share_a_context(pkg, ctx, oracle):
         t.join()
     assert not errors, errors
     assert len(results) == 3
+
+
+def test_fused_aggregation_filter_errors_surface(pkg, ctx):
+    """an arithmetic error inside the fused filter of FilterProject -> HashAggregation is raised by addInput, like the unfused
+    FilterAndProjectOperator would (the error word travels with the group-probe counters: one read-back)"""
+    n = 50_000
+    a = np.arange(n, dtype=np.int64) + 1
+    b = np.ones(n, dtype=np.int64)
+    f = pkg.field
+    T = [pkg.BIGINT, pkg.BIGINT, pkg.BIGINT]
+    keys = np.arange(n, dtype=np.int64) % 3
+
+    def run(divisors):
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 60, T, (f(0, pkg.BIGINT) / f(1, pkg.BIGINT)) > 0, [f(2, pkg.BIGINT), f(0, pkg.BIGINT)],
+                                                              [pkg.BIGINT], [0], [(pkg.COUNT_ALL, -1)])
+        op = fac.createOperator()
+        try:
+            op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, a), pkg.Block(pkg.BIGINT, divisors), pkg.Block(pkg.BIGINT, keys)))
+            op.finish()
+            out = op.getOutput()
+            rows = sorted(out.to_host().rows())
+            out.release()
+            return rows
+        finally:
+            op.close()
+            fac.close()
+
+    assert run(b) == [(k, len(range(k, n, 3))) for k in range(3)]
+    bad = b.copy()
+    bad[31_337] = 0
+    with pytest.raises(pkg.TgpuError) as e:
+        run(bad)
+    assert e.value.code == -7 and "31337" in e.value.message
