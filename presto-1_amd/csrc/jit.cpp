@@ -1666,6 +1666,10 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
         if (a.function != TGPU_AGG_COUNT_ALL) used.insert(a.input_channel);
         if (a.mask_channel >= 0) used.insert(a.mask_channel);
     }
+    // nothing the accumulate kernels evaluate can raise (TPCH Q1: double arithmetic only): their error word is never written and
+    // the per-page read-back of it is skipped
+    accumulate_can_raise_ = false;
+    for (int ch : used) accumulate_can_raise_ = accumulate_can_raise_ || can_raise(proj_roots_[(size_t)ch]);
     for (int ch = 0; ch < np; ch++)
         if (can_raise(proj_roots_[(size_t)ch])) {
             // a masked aggregate would skip evaluating its input on masked-out rows; an unused channel is never evaluated
@@ -2435,7 +2439,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
         ProfileScope ps(ctx, "fused_project_accumulate_ordered");
         const int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8);
         launch_args(module->fn("fa_accumulate_ordered"), (int)blocks, F, ctx->stream());
-        raise_if_error(ctx, err);
+        if (accumulate_can_raise_) raise_if_error(ctx, err);
         return;
     }
     F.plan.n_aggs = (int32_t)aggs_.size();
@@ -2464,7 +2468,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
         ProfileScope ps(ctx, F.lowcard ? "fused_project_accumulate_lowcard" : "fused_project_accumulate");
         launch_args(module->fn(F.lowcard ? "fa_accumulate_lowcard" : "fa_accumulate_global"), (int)blocks, F, ctx->stream());
     }
-    raise_if_error(ctx, err);
+    if (accumulate_can_raise_) raise_if_error(ctx, err);
 }
 
 }  // namespace tgpu

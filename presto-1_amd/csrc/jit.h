@@ -173,6 +173,7 @@ private:
     std::vector<tgpu_agg_spec> aggs_;
     std::vector<int> key_inputs_;
     bool supported_ = false;
+    bool accumulate_can_raise_ = true;   // false: no expression the accumulate kernels evaluate can raise (no error read-back)
     int n_wide_ = 0, n_cnt_ = 0, rows_slot_ = -1, per_group_bytes_ = 0, max_groups_ = 0;
     int wide_slot_[16], cnt_slot_[16];
     std::vector<std::vector<int>> cnt_inputs_;   // per count slot: the raw input channels its (mask, input) expressions read
