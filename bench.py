@@ -151,6 +151,8 @@ class Bench:
         torch.cuda.synchronize()
 
     def timed(self, fn, steps, warmup):
+        """(seconds per step, per-kernel profile); the profile's pseudo entry "__readbacks" (host <- device round trips of the timed
+        region) is moved to self.last_readbacks_per_step"""
         for _ in range(warmup):
             fn()
         self.ctx.profile_reset()
@@ -164,7 +166,9 @@ class Bench:
             tt = torch.tensor([dt], device=self.coll_dev, dtype=torch.float64)
             self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt / steps, self.ctx.profile()
+        prof = self.ctx.profile()
+        self.last_readbacks_per_step = prof.pop("__readbacks", {"count": 0})["count"] / steps
+        return dt / steps, prof
 
     def drive(self, op, page):
         """one page through one operator (Driver.processInternal for a single hop); returns device output pages"""
@@ -648,6 +652,7 @@ def main():
     repartition = distributed and os.environ.get("TGPU_BENCH_PLAN") == "repartition"
     step_fn = b.step_q3 if not distributed else (b.step_q3_dist_repartition if repartition else b.step_q3_dist)
     step_s, prof = b.timed(step_fn, args.steps, args.warmup)
+    q3_readbacks = b.last_readbacks_per_step
     q3_check = b.check_q3_dist() if distributed else b.check_q3()
     st = dict(b.q3_stats)
     probe_rows = st["lineitem_probe_rows"]
@@ -694,6 +699,7 @@ def main():
     })
     if not distributed and b.q3_result:
         extra["q3_top10"] = b.q3_top10(args.steps, args.warmup)
+    extra["q3_readbacks_per_step"] = q3_readbacks   # host <- device round trips (stream waits) of one Q3 step
     extra["q3_kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
     extra["q3_kernel_launch_min_max_ms"] = {k: [v["min_ms"], v["max_ms"], v["count"]] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
     b.q3_result = None

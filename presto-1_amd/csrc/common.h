@@ -154,6 +154,7 @@ private:
     std::vector<Pending> pending_;
     std::vector<hipEvent_t> event_pool_;
     hipEvent_t wait_event_ = nullptr;
+    int64_t readbacks_ = 0;   // host <- device round trips (each one waits for the stream) since the last profile_reset
     std::map<std::string, KernelStat> stats_;
     const char *cur_name_ = nullptr;
     hipEvent_t cur_a_ = nullptr;

@@ -171,6 +171,7 @@ void Context::download(void *dst, const void *src, size_t bytes)
     if (!bytes) return;
     // handles of one context may be driven by different threads (tgpu.h threading rule): they share the staging buffer
     std::lock_guard<std::recursive_mutex> io(io_mu_);
+    readbacks_++;
     if (bytes <= (64u << 10)) {
         // the small read-backs between kernels (counts, flags, key ranges) go through the pinned staging buffer: a copy into
         // pageable memory (a stack variable) takes the runtime's slow staged path, several times the latency of this one
@@ -190,6 +191,7 @@ void Context::download_batch(const std::vector<Transfer> &transfers)
     for (auto &t : transfers) total += (t.bytes + 63) / 64 * 64;
     if (!total) return;
     std::lock_guard<std::recursive_mutex> io(io_mu_);
+    readbacks_++;
     uint8_t *stage = static_cast<uint8_t *>(pinned(total));
     size_t off = 0;
     for (auto &t : transfers) {
@@ -211,6 +213,7 @@ void Context::profile_reset()
     std::lock_guard<std::recursive_mutex> io(io_mu_);
     profile_collect();
     stats_.clear();
+    readbacks_ = 0;
 }
 
 void Context::profile_begin(const char *name)
@@ -271,6 +274,9 @@ std::string Context::profile_json()
         os << "\"" << kv.first << "\": {\"count\": " << kv.second.count << ", \"total_ms\": " << kv.second.total_ms
            << ", \"min_ms\": " << kv.second.min_ms << ", \"max_ms\": " << kv.second.max_ms << "}";
     }
+    // pseudo entry: host <- device round trips since the last reset (every one of them waits for the stream)
+    if (!first) os << ", ";
+    os << "\"__readbacks\": {\"count\": " << readbacks_ << ", \"total_ms\": 0, \"min_ms\": 0, \"max_ms\": 0}";
     os << "}";
     return os.str();
 }

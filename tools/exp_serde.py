@@ -35,4 +35,4 @@ for null_frac in (0.0, 0.1):
     assert again == data
     print(f"null_frac {null_frac}: {len(data) / 1e6:.1f} MB, {n} rows; decode {(t1 - t0) * 1e3:.2f} ms = {len(data) / (t1 - t0) / 1e9:.2f} GB/s; "
           f"encode {(t3 - t2) * 1e3:.2f} ms = {len(data) / (t3 - t2) / 1e9:.2f} GB/s", flush=True)
-print({k: (round(v["total_ms"] / v["count"], 3), v["count"]) for k, v in ctx.profile().items()})
+print({k: (round(v["total_ms"] / v["count"], 3), v["count"]) for k, v in ctx.profile().items() if v["count"] and not k.startswith("__")})
