@@ -627,3 +627,82 @@ class MergePages:
 
     def finish(self):
         return [self.flush()] if self.buffer else []   # :134-142
+
+
+# ---- DynamicFilterSourceOperator --------------------------------------------------------------------------------------------
+class DynamicFilterSource:
+    """DynamicFilterSourceOperator.addInput / finish (M/operator/DynamicFilterSourceOperator.java:213-424) position at a time, with the
+    two documented deviations of the product (block-accounting size model instead of JVM retained sizes; min / max for BIGINT /
+    INTEGER / DATE only).  domain(k) -> ("all",) | ("values", [..first-seen order..]) | ("range", lo, hi) | ("none",)"""
+
+    def __init__(self, types, channels, max_distinct_values, max_filter_size_in_bytes, min_max_collection_limit):
+        self.types, self.channels = list(types), list(channels)
+        self.max_distinct, self.max_size, self.limit = max_distinct_values, max_filter_size_in_bytes, min_max_collection_limit
+        self.sets = [dict() for _ in channels]          # insertion-ordered: value (None = null, "nan" marker for NaN) -> True
+        self.min_max_channels = [k for k, ch in enumerate(channels) if min_max_collection_limit > 0 and self.types[ch] in (BIGINT, INTEGER, DATE)]
+        self.mins = {} if self.min_max_channels else None  # None = not collecting min / max
+        self.maxs = {}
+
+    @staticmethod
+    def _values(col):
+        out = []
+        for i in range(col.n):
+            if col.nulls is not None and col.nulls[i]:
+                out.append(None)
+            elif col.type == VARCHAR:
+                out.append(bytes(col.values[col.offsets[i]:col.offsets[i + 1]]).decode())
+            elif col.type == DOUBLE:
+                v = float(col.values[i])
+                out.append("nan" if v != v else (0.0 if v == 0.0 else v))   # one NaN group, -0.0 == +0.0 (the product's group-by equality)
+            elif col.type == BOOLEAN:
+                out.append(bool(col.values[i]))
+            else:
+                out.append(int(col.values[i]))
+        return out
+
+    def _size(self, k):
+        t = self.types[self.channels[k]]
+        d = len(self.sets[k])
+        if t == VARCHAR:
+            return sum(len(v.encode()) for v in self.sets[k] if v is not None) + 5 * d
+        return (np.dtype(_NP[t]).itemsize + 1) * d
+
+    def _update_min_max(self, k, values):
+        vals = [v for v in values if v is not None]
+        if not vals:
+            return
+        self.mins[k] = min(vals) if k not in self.mins else min(self.mins[k], min(vals))
+        self.maxs[k] = max(vals) if k not in self.maxs else max(self.maxs[k], max(vals))
+
+    def add(self, cols):
+        n = cols[0].n if cols else 0
+        if self.sets is None:
+            if self.mins is None:
+                return
+            self.limit -= n
+            if self.limit < 0:
+                self.mins = None                                    # handleMinMaxCollectionLimitExceeded
+                return
+            for k in self.min_max_channels:
+                self._update_min_max(k, self._values(cols[self.channels[k]]))
+            return
+        self.limit -= n
+        for k, ch in enumerate(self.channels):
+            for v in self._values(cols[ch]):
+                self.sets[k].setdefault(v, True)
+        if max(len(s) for s in self.sets) > self.max_distinct or sum(self._size(k) for k in range(len(self.channels))) > self.max_size:
+            if not self.min_max_channels or self.limit < 0:         # handleTooLargePredicate
+                self.mins = None
+            else:
+                for k in self.min_max_channels:
+                    self._update_min_max(k, list(self.sets[k]))
+            self.sets = None
+
+    def domain(self, k):
+        if self.sets is not None:
+            return ("values", [v for v in self.sets[k] if v is not None and v != "nan"])
+        if self.mins is None or k not in self.min_max_channels:
+            return ("all",)
+        if k not in self.mins:
+            return ("none",)
+        return ("range", self.mins[k], self.maxs[k])

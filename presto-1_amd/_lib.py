@@ -112,6 +112,8 @@ SYMBOLS = {
     "tgpu_partition_page": (i32, [vp, P(Page), i32, P(i32), i32, i32, vp, P(vp)]),
     "tgpu_operator_add_input_output_page": (i32, [vp, vp]),
     "tgpu_lookup_outer_factory_create": (i32, [vp, i32, vp, i32, P(i32), P(vp)]),
+    "tgpu_dynamic_filter_source_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, i64, i32, P(vp)]),
+    "tgpu_dynamic_filter_source_result": (i32, [vp, i32, P(i32), P(vp), P(i64), P(i64)]),
     "tgpu_merge_pages_factory_create": (i32, [vp, i32, i32, P(i32), i64, i32, i64, P(vp)]),
     "tgpu_partitioned_output_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, i32, i32, i32, i32, P(vp)]),
     "tgpu_partitioned_output_poll": (i32, [vp, P(i32), P(vp)]),

@@ -761,6 +761,32 @@ int32_t tgpu_lookup_outer_factory_create(tgpu_context *ctx, int32_t operator_id,
     });
 }
 
+int32_t tgpu_dynamic_filter_source_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int32_t channel_count,
+                                                  const int32_t *channels, int32_t max_distinct_values, int64_t max_filter_size_in_bytes,
+                                                  int32_t min_max_collection_limit, tgpu_operator_factory **out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(ctx && out, "null argument");
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<DynamicFilterSourceOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), vec(channels, channel_count), max_distinct_values,
+                                                                    max_filter_size_in_bytes, min_max_collection_limit);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
+int32_t tgpu_dynamic_filter_source_result(tgpu_operator *op, int32_t filter_channel, int32_t *kind, tgpu_output_page **values, int64_t *min, int64_t *max)
+{
+    return guard([&] {
+        TG_CHECK_ARG(op && kind && values && min && max, "null argument");
+        *values = nullptr;
+        std::unique_ptr<OutputPage> page;
+        dynamic_filter_result(op->op.get(), filter_channel, kind, &page, min, max);
+        if (page) *values = release_output(std::move(page));
+    });
+}
+
 int32_t tgpu_merge_pages_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int64_t min_page_size_in_bytes,
                                         int32_t min_row_count, int64_t max_page_size_in_bytes, tgpu_operator_factory **out)
 {

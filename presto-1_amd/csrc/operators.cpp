@@ -4,6 +4,7 @@
 
 #include <array>
 #include <deque>
+#include <set>
 
 #include "kernels.h"
 
@@ -769,6 +770,248 @@ std::unique_ptr<Operator> OrderByOperatorFactory::create_operator()
     return std::make_unique<OrderByOperator>(ctx_, operator_id_, types_, output_channels_, sort_channels_, sort_orders_);
 }
 
+
+// =====================================================================================================================
+// DynamicFilterSourceOperator (M/operator/DynamicFilterSourceOperator.java:145-425).  Pages pass through unchanged (:375-381);
+// per filter channel the operator keeps the set of distinct values (TypedSet -> a GroupByHash per channel here) while no
+// channel exceeds max_distinct_values and the collected blocks stay within max_filter_size_in_bytes (:238-262); beyond that it
+// falls back to min / max per orderable channel (:264-289, 291-338) as long as at most min_max_collection_limit rows were seen,
+// and to "all" after that (:283-289).  finish() publishes the domains (:383-424): distinct non-null non-NaN values, or a
+// [min, max] range, NONE for a channel that only saw nulls, ALL otherwise.
+// Deviations, both on the safe side of an advisory filter (any superset of the build values is a valid dynamic filter):
+// the size test uses the reference's BLOCK accounting of the collected values ((width + 1) or (length + 5) bytes per value)
+// instead of TypedSet's JVM retained size; min / max is kept for BIGINT / INTEGER / DATE channels only (the reference also
+// orders BOOLEAN and VARCHAR; DOUBLE is excluded there too, :194-196).
+// =====================================================================================================================
+namespace {
+__global__ void __launch_bounds__(256) df_minmax_kernel(ColView col, int64_t n, long long *minmax /* [min, max, any non-null] */)
+{
+    long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        if (col.nulls && col.nulls[r]) continue;
+        const long long v = col.type == TGPU_BIGINT ? ((const long long *)col.values)[r] : (long long)((const int *)col.values)[r];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const long long l2 = __shfl_down(lo, d, 64), h2 = __shfl_down(hi, d, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+        minmax[2] = 1;
+    }
+}
+// keep[i] = the distinct value i is neither null nor NaN (convertToDomain, :402-417)
+__global__ void __launch_bounds__(256) df_keep_kernel(ColView col, int64_t n, int32_t *keep)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        bool ok = !(col.nulls && col.nulls[r]);
+        if (ok && col.type == TGPU_DOUBLE) {
+            const double v = ((const double *)col.values)[r];
+            ok = v == v;
+        }
+        keep[r] = ok ? 1 : 0;
+    }
+}
+__global__ void __launch_bounds__(256) df_compact_kernel(const int32_t *keep, const int32_t *rank, int64_t n, int32_t *out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+        if (keep[r]) out[rank[r]] = (int32_t)r;
+}
+}  // namespace
+
+class DynamicFilterSourceOperator : public Operator {
+public:
+    DynamicFilterSourceOperator(Context *ctx, int32_t id, const std::vector<int32_t> &types, const std::vector<int32_t> &channels, int32_t max_distinct, int64_t max_size,
+                                int32_t min_max_limit)
+        : Operator(ctx, id), types_(types), channels_(channels), max_distinct_(max_distinct), max_size_(max_size), min_max_limit_(min_max_limit)
+    {
+        for (int32_t ch : channels_) {
+            const int32_t t = types_[(size_t)ch];
+            sets_.push_back(std::make_unique<GroupByHashGpu>(ctx, std::vector<int32_t>{t}, false, 1024));
+            const bool orderable = min_max_limit_ > 0 && (t == TGPU_BIGINT || t == TGPU_INTEGER || t == TGPU_DATE);   // :194-196
+            if (orderable) min_max_channels_.push_back((int)sets_.size() - 1);
+        }
+        collecting_sets_ = true;
+        collecting_min_max_ = !min_max_channels_.empty();
+        if (collecting_min_max_) {
+            minmax_ = ctx_->alloc(channels_.size() * 24);
+            std::vector<long long> init;
+            for (size_t k = 0; k < channels_.size(); k++) init.insert(init.end(), {0x7fffffffffffffffLL, -0x7fffffffffffffffLL - 1, 0});
+            ctx_->upload(minmax_->ptr(), init.data(), init.size() * 8);
+            ctx_->sync();
+        }
+    }
+
+    bool needs_input() override { return !current_ && !finished_; }   // :208-211
+
+    void add_input(const tgpu_page *page) override { collect(ingest_page(ctx_, page), true); }
+    void add_input_owned(const DevicePage &page) override { collect(DevicePage(page), false); }
+
+    std::unique_ptr<OutputPage> get_output() override { return std::move(current_); }   // :375-381
+
+    void finish() override { finished_ = true; }   // the domains are read through dynamic_filter_result (:383-400)
+    bool is_finished() override { return finished_ && !current_; }
+    int64_t memory_bytes() override
+    {
+        int64_t s = current_ ? current_->page.size_in_bytes() : 0;
+        for (auto &g : sets_) s += g ? g->estimated_size() : 0;
+        return s;
+    }
+
+    void result(int32_t k, int32_t *kind, std::unique_ptr<OutputPage> *values, int64_t *min, int64_t *max)
+    {
+        TG_CHECK_STATE(finished_, "the dynamic filter is available after finish()");
+        TG_CHECK_ARG(k >= 0 && k < (int)channels_.size(), "filter channel out of range");
+        *kind = 0;
+        *min = *max = 0;
+        if (collecting_sets_) {   // :393-399 convertToDomain
+            DevicePage keys = sets_[(size_t)k]->key_page(false);
+            const int64_t n = keys.n;
+            DevicePage out;
+            out.n = 0;
+            if (n > 0) {
+                BufferPtr keep = ctx_->alloc((size_t)n * 4), rank = ctx_->alloc((size_t)n * 4), pos = ctx_->alloc((size_t)n * 4), total = ctx_->alloc(8);
+                df_keep_kernel<<<(int)std::min<int64_t>(ceil_div(n, 256), 1024), 256, 0, ctx_->stream()>>>(view_of(keys.cols[0]), n, keep->as<int32_t>());
+                k::exclusive_scan_i32(ctx_, keep->as<int32_t>(), rank->as<int32_t>(), n, total->as<int64_t>());
+                df_compact_kernel<<<(int)std::min<int64_t>(ceil_div(n, 256), 1024), 256, 0, ctx_->stream()>>>(keep->as<int32_t>(), rank->as<int32_t>(), n, pos->as<int32_t>());
+                check_launch("df_compact");
+                out.n = ctx_->read_scalar(total->as<int64_t>());
+                out.cols.push_back(k::gather_column(ctx_, keys.cols[0], pos->as<int32_t>(), out.n, false));
+            }
+            else out.cols.push_back(keys.cols[0]);
+            *kind = 1;
+            *values = wrap(std::move(out));
+            return;
+        }
+        if (!collecting_min_max_) return;   // ALL (:386-390)
+        bool is_mm = false;
+        for (int c : min_max_channels_) is_mm = is_mm || c == k;
+        if (!is_mm) return;                 // a channel without min / max collection is left out of the tuple domain = ALL
+        long long mm[3];
+        ctx_->download(mm, minmax_->as<long long>() + 3 * k, 24);
+        if (!mm[2]) {
+            *kind = 3;   // all values were null: Domain.none (:366-369)
+            return;
+        }
+        *kind = 2;
+        *min = mm[0];
+        *max = mm[1];
+    }
+
+private:
+    void collect(DevicePage in, bool borrowed)
+    {
+        TG_CHECK_STATE(needs_input(), "DynamicFilterSourceOperator: addInput() may not be called after finish() or with a pending page");
+        TG_CHECK_ARG(in.cols.size() == types_.size(), "page channel count does not match the operator's types");
+        for (size_t i = 0; i < types_.size(); i++) TG_CHECK_ARG(in.cols[i].type == types_[i], "page channel type does not match the operator's types");
+        const int64_t n = in.n;
+        if (collecting_sets_) {   // :236-262
+            min_max_limit_left_sub(n);
+            int64_t size = 0, most = 0;
+            BufferPtr gids = ctx_->alloc((size_t)(n > 0 ? n : 1) * 4);
+            for (size_t k = 0; k < channels_.size(); k++) {
+                const DeviceColumn &c = in.cols[(size_t)channels_[k]];
+                if (n > 0) sets_[k]->get_group_ids({&c}, nullptr, n, gids->as<int32_t>());
+                const int64_t d = sets_[k]->group_count();
+                most = std::max(most, d);
+                DevicePage keys = sets_[k]->key_page(false);
+                size += keys.cols[0].type == TGPU_VARCHAR ? keys.cols[0].pool_bytes + 5 * d : (int64_t)(type_width(keys.cols[0].type) + 1) * d;
+            }
+            if (most > max_distinct_ || size > max_size_) too_large();
+        }
+        else if (collecting_min_max_) {   // :218-233
+            min_max_limit_left_sub(n);
+            if (min_max_limit_left_ < 0) collecting_min_max_ = false;   // handleMinMaxCollectionLimitExceeded: ALL
+            else
+                for (int k : min_max_channels_) update_min_max(k, in.cols[(size_t)channels_[(size_t)k]]);
+        }
+        // the page itself goes on unchanged; a borrowed (device-resident) input is copied once so that it outlives the call
+        if (borrowed) {
+            bool needs_copy = false;
+            for (auto &c : in.cols) needs_copy = needs_copy || (c.n > 0 && !c.values_buf);
+            if (needs_copy) {
+                PagesIndexGpu copy(ctx_, types_);
+                copy.add_page(in);
+                DevicePage owned;
+                owned.n = in.n;
+                for (size_t i = 0; i < types_.size(); i++) owned.cols.push_back(copy.column((int)i));
+                in = std::move(owned);
+            }
+        }
+        current_ = wrap(std::move(in));
+    }
+
+    void min_max_limit_left_sub(int64_t n)
+    {
+        if (!limit_started_) {
+            min_max_limit_left_ = min_max_limit_;
+            limit_started_ = true;
+        }
+        min_max_limit_left_ -= n;
+    }
+
+    void update_min_max(int k, const DeviceColumn &c)
+    {
+        if (c.n <= 0) return;
+        df_minmax_kernel<<<(int)std::min<int64_t>(ceil_div(c.n, 256), (int64_t)ctx_->cu_count() * 2), 256, 0, ctx_->stream()>>>(view_of(c), c.n, minmax_->as<long long>() + 3 * k);
+        check_launch("df_minmax");
+    }
+
+    void too_large()   // handleTooLargePredicate (:264-281)
+    {
+        if (min_max_channels_.empty() || min_max_limit_left_ < 0) collecting_min_max_ = false;   // ALL
+        else
+            for (int k : min_max_channels_) {   // min / max of what was collected so far = of every row seen so far
+                DevicePage keys = sets_[(size_t)k]->key_page(false);
+                update_min_max(k, keys.cols[0]);
+            }
+        collecting_sets_ = false;
+        for (auto &g : sets_) g.reset();
+    }
+
+    std::vector<int32_t> types_, channels_;
+    int32_t max_distinct_;
+    int64_t max_size_;
+    int32_t min_max_limit_;
+    int64_t min_max_limit_left_ = 0;
+    bool limit_started_ = false, collecting_sets_ = false, collecting_min_max_ = false, finished_ = false;
+    std::vector<std::unique_ptr<GroupByHashGpu>> sets_;
+    std::vector<int> min_max_channels_;
+    BufferPtr minmax_;
+    std::unique_ptr<OutputPage> current_;
+};
+
+DynamicFilterSourceOperatorFactory::DynamicFilterSourceOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> channels,
+                                                                       int32_t max_distinct_values, int64_t max_filter_size_in_bytes, int32_t min_max_collection_limit)
+    : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), channels_(std::move(channels)), max_distinct_(max_distinct_values),
+      min_max_limit_(min_max_collection_limit), max_size_(max_filter_size_in_bytes)
+{
+    for (int32_t t : types_) TG_CHECK_ARG(valid_type(t), "unknown type");
+    std::set<int32_t> seen;
+    for (int32_t ch : channels_) {
+        TG_CHECK_ARG(ch >= 0 && ch < (int)types_.size(), "filter channel out of range");
+        TG_CHECK_ARG(seen.insert(ch).second, "duplicate channel indices are not allowed");   // :105-106
+    }
+    TG_CHECK_ARG(max_distinct_ >= 0 && max_size_ >= 0, "limits must not be negative");
+}
+
+std::unique_ptr<Operator> DynamicFilterSourceOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<DynamicFilterSourceOperator>(ctx_, operator_id_, types_, channels_, max_distinct_, max_size_, min_max_limit_);
+}
+
+void dynamic_filter_result(Operator *op, int32_t k, int32_t *kind, std::unique_ptr<OutputPage> *values, int64_t *min, int64_t *max)
+{
+    auto *p = dynamic_cast<DynamicFilterSourceOperator *>(op);
+    TG_CHECK_ARG(p != nullptr, "not a DynamicFilterSourceOperator");
+    p->result(k, kind, values, min, max);
+}
 
 void Operator::add_input_owned(const DevicePage &page)
 {

@@ -219,6 +219,25 @@ private:
     std::vector<int32_t> types_, output_channels_, sort_channels_, sort_orders_;
 };
 
+// ---- DynamicFilterSourceOperator (M/operator/DynamicFilterSourceOperator.java:46-425) ---------------------------------------------
+// Passes the build side's pages through and collects, per join-key channel, what the probe side's scan may be narrowed to.
+class DynamicFilterSourceOperatorFactory : public OperatorFactory {
+public:
+    DynamicFilterSourceOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> channels, int32_t max_distinct_values,
+                                       int64_t max_filter_size_in_bytes, int32_t min_max_collection_limit);
+    std::unique_ptr<Operator> create_operator() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> types_, channels_;
+    int32_t max_distinct_, min_max_limit_;
+    int64_t max_size_;
+};
+// the collected domain of filter channel `k` after finish(): kind 0 = ALL, 1 = VALUES (*values: one channel holding the distinct
+// non-null, non-NaN values in first-seen order), 2 = RANGE [*min, *max] (BIGINT / INTEGER / DATE), 3 = NONE (only nulls were seen)
+void dynamic_filter_result(Operator *op, int32_t k, int32_t *kind, std::unique_ptr<OutputPage> *values, int64_t *min, int64_t *max);
+
 // ---- MergePages (M/operator/project/MergePages.java:40-190) as an operator: coalesces small pages in HBM -------------------------
 class MergePagesOperatorFactory : public OperatorFactory {
 public:

@@ -456,6 +456,39 @@ def to_pages(operator: Operator, input_pages, to_host=True):
     return host
 
 
+DF_ALL, DF_VALUES, DF_RANGE, DF_NONE = 0, 1, 2, 3
+
+
+class DynamicFilterSourceOperator(Operator):
+    def domain(self, filter_channel):
+        """after finish(): ("all",) | ("values", [..]) | ("range", lo, hi) | ("none",) -- DynamicFilterSourceOperator.finish() (:383-424)"""
+        kind, out, lo, hi = C.c_int32(), C.c_void_p(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().tgpu_dynamic_filter_source_result(self.handle, filter_channel, C.byref(kind), C.byref(out), C.byref(lo), C.byref(hi)))
+        if kind.value == DF_VALUES:
+            page = OutputPage(out)
+            vals = page.to_host().blocks[0].to_list() if page.position_count else []
+            page.release()
+            return ("values", vals)
+        return {DF_ALL: ("all",), DF_RANGE: ("range", int(lo.value), int(hi.value)), DF_NONE: ("none",)}[kind.value]
+
+
+class DynamicFilterSourceOperatorFactory(OperatorFactory):
+    """DynamicFilterSourceOperator.DynamicFilterSourceOperatorFactory (M/operator/DynamicFilterSourceOperator.java:74-143)"""
+
+    def __init__(self, ctx: Context, operator_id, types, channels, max_distinct_values, max_filter_size_in_bytes, min_max_collection_limit):
+        t, nt = _i32(types)
+        ch, nc = _i32(channels)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_dynamic_filter_source_factory_create(ctx.handle, operator_id, nt, t, nc, ch, int(max_distinct_values), int(max_filter_size_in_bytes),
+                                                                        int(min_max_collection_limit), C.byref(h)))
+        super().__init__(h)
+
+    def createOperator(self):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_operator_factory_create_operator(self.handle, C.byref(h)))
+        return DynamicFilterSourceOperator(h)
+
+
 class MergePagesOperatorFactory(OperatorFactory):
     """MergePages.mergePages (M/operator/project/MergePages.java:64-96) as an operator: small pages are coalesced in HBM, big ones pass through"""
 

@@ -1517,3 +1517,54 @@ def test_fused_aggregation_filter_errors_surface(pkg, ctx):
     with pytest.raises(pkg.TgpuError) as e:
         run(bad)
     assert e.value.code == -7 and "31337" in e.value.message
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DynamicFilterSourceOperator against the position-at-a-time restatement
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_distinct,max_size,limit", [(10_000, 1 << 30, 1 << 30), (50, 1 << 30, 1 << 30), (10_000, 2_000, 1 << 30), (50, 1 << 30, 3_000),
+                                                          (50, 1 << 30, 0), (10_000, 1 << 30, 100)])
+def test_dynamic_filter_source_vs_restatement(pkg, ctx, oracle, max_distinct, max_size, limit):
+    rng = np.random.default_rng(max_distinct + limit % 1000)
+    types = [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE, pkg.DATE, pkg.BIGINT]
+    channels = [0, 1, 2, 3]
+    fac = pkg.DynamicFilterSourceOperatorFactory(ctx, 70, types, channels, max_distinct, max_size, limit)
+    op = fac.createOperator()
+    ref = oracle.DynamicFilterSource(types, channels, max_distinct, max_size, limit)
+    for n in (300, 0, 1000, 2500):
+        blocks = [rand_block(pkg, rng, pkg.BIGINT, n, 0.05, (-500, 500)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.05, (0, 40)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.05, (0, 30)),
+                  rand_block(pkg, rng, pkg.DATE, n, 1.0 if n == 300 else 0.05, (9000, 9100)), pkg.Block(pkg.BIGINT, np.arange(n, dtype=np.int64))]
+        if n >= 1000:
+            blocks[2].values[:3] = [np.nan, -0.0, 0.0]
+        page = pkg.Page(*blocks, position_count=n)
+        assert op.needsInput()
+        op.addInput(page)
+        out = op.getOutput()   # the page passes through unchanged (:375-381)
+        norm = lambda rows: [tuple("nan" if isinstance(v, float) and v != v else v for v in r) for r in rows]
+        assert out is not None and norm(out.to_host().rows()) == norm(page.rows())
+        out.release()
+        ref.add([ocol(oracle, b) for b in blocks])
+    op.finish()
+    assert op.isFinished()
+    for k in range(len(channels)):
+        got, want = op.domain(k), ref.domain(k)
+        if want[0] == "values" and types[channels[k]] == pkg.DOUBLE:
+            assert got[0] == "values" and [float(v) for v in got[1]] == [float(v) for v in want[1]]
+        else:
+            assert got == want, (k, got[:1], want[:1])
+    op.close()
+    fac.close()
+
+
+def test_dynamic_filter_source_small_cases(pkg, ctx):
+    # only nulls in an orderable channel -> NONE once the sets were dropped (:366-369); duplicate channels rejected (:105-106)
+    fac = pkg.DynamicFilterSourceOperatorFactory(ctx, 71, [pkg.BIGINT, pkg.BIGINT], [0, 1], 2, 1 << 30, 1000)
+    op = fac.createOperator()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, [None, None, None, None]), pkg.Block(pkg.BIGINT, np.array([5, 7, 9, 11], dtype=np.int64))))
+    op.getOutput().release()
+    op.finish()
+    assert op.domain(0) == ("none",) and op.domain(1) == ("range", 5, 11)
+    op.close()
+    fac.close()
+    with pytest.raises(pkg.TgpuError):
+        pkg.DynamicFilterSourceOperatorFactory(ctx, 72, [pkg.BIGINT], [0, 0], 10, 10, 10)
