@@ -263,9 +263,10 @@ class Bench:
           * orders and lineitem are partitioned on orderkey by their connector (the tpch connector exposes that partitioning,
             P/trino-tpch TpchNodePartitioningProvider), so orders |x| customer and lineitem |x| orders are co-located: the same
             fused filter+probe operators as on one GPU, no exchange of the big probe sides;
-          * the aggregation is PARTIAL per rank, then a FIXED_HASH_DISTRIBUTION exchange on the group keys (K10 partition kernel
-            + RCCL all-to-all-v) feeds the FINAL HashAggregationOperator (HashAggregationOperator.java Step.PARTIAL / FINAL).
-        TGPU_BENCH_PLAN=repartition runs the plan with hash-repartitioned join inputs instead (step_q3_dist_repartition)."""
+          * the aggregation groups by (l_orderkey, ...), i.e. by a superset of the partitioning column: single-step per rank, no
+            exchange.  TGPU_BENCH_PLAN=partial_final runs it as PARTIAL -> FIXED_HASH_DISTRIBUTION exchange on the group keys (K10
+            partition kernels + RCCL all-to-all-v) -> FINAL instead (HashAggregationOperator.java Step.PARTIAL / FINAL).
+        TGPU_BENCH_PLAN=repartition runs the plan with hash-repartitioned join inputs (step_q3_dist_repartition)."""
         p, ctx, f, pages, ex = self.pkg, self.ctx, self.q3_fac, self.q3_pages, self.exchange
         B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
         st = self.q3_stats
@@ -296,8 +297,32 @@ class Bench:
             j.release()
         obuild.finish()
         ojoin.close()
-        # lineitem: filter/project fused into the probe of the local orders table -> PARTIAL aggregation
+        # lineitem: filter/project fused into the probe of the local orders table -> aggregation
         lj = p.FilterProjectLookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, *pp["q3_lineitem"], [0], probe_output_channels=[0, 1])
+        if os.environ.get("TGPU_BENCH_PLAN") != "partial_final":
+            # The join output is partitioned on l_orderkey (co-located join on the connector's orderkey partitioning) and the grouping
+            # keys contain it, so no group spans two ranks: AddExchanges keeps the aggregation SINGLE-step on each node, without an
+            # exchange (M/sql/planner/optimizations/AddExchanges.java visitAggregation: the child's partitioning satisfies the
+            # grouping keys).  check_q3_dist verifies exactly that (the per-rank group counts add up to the global count).
+            agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
+            ljoin = lj.createOperator()
+            aop = agg.createOperator()
+            st["lineitem_join_rows"] = 0
+            for j in self.drive(ljoin, pages["lineitem"]):
+                st["lineitem_join_rows"] = j.position_count
+                aop.addInput(j.as_device_page())
+                j.release()
+            outs = self.finish(aop)
+            st["groups"] = sum(o.position_count for o in outs)
+            st["partial_groups"] = st["groups"]
+            self.q3_result = outs
+            ljoin.close()
+            cbuild.close()
+            obuild.close()
+            aop.close()
+            return
+        # TGPU_BENCH_PLAN=partial_final: the aggregation as PARTIAL -> FIXED_HASH exchange on the group keys -> FINAL (what the plan
+        # would be if the join output were not known to be partitioned on the grouping keys); exercises the all-to-all-v path
         pagg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], step=p.PARTIAL, expected_groups=1 << 20)
         ljoin = lj.createOperator()
         paop = pagg.createOperator()
@@ -693,7 +718,9 @@ def main():
                    "lineitem_rows": int(b.q3["l_orderkey"].numel()), "orders_rows": int(b.q3["o_orderkey"].numel()), "customer_rows": int(b.q3["c_custkey"].numel()),
                    "lineitem_probe_rows": probe_rows, "orders_build_rows": st["orders_build_rows"], "join_output_rows": st["lineitem_join_rows"],
                    "groups": st["groups"], "parallelism": ("single GPU" if not distributed else f"hash-repartitioned joins x{b.world} (K10 partition + RCCL all-to-all-v)" if repartition else
-                                   f"x{b.world}: customer replicated (RCCL all-gather), orders/lineitem co-partitioned on orderkey, partial->final aggregation over a hash exchange (K10 partition + RCCL all-to-all-v)"),
+                                   f"x{b.world}: customer replicated (RCCL all-gather), orders/lineitem co-partitioned on orderkey, partial->final aggregation over a hash exchange (K10 partition + RCCL all-to-all-v)"
+                                   if os.environ.get("TGPU_BENCH_PLAN") == "partial_final" else
+                                   f"x{b.world}: customer replicated (RCCL all-gather), orders/lineitem and the aggregation co-partitioned on orderkey (no further exchange)"),
                    "exchange_bytes_sent_per_step": st.get("exchange_bytes_sent", 0)},
         "roofline": roof, "checks": {"q3": q3_check},
     })
