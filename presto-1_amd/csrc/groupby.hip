@@ -341,6 +341,12 @@ KeyCols GroupByHashGpu::store_view() const
     return k;
 }
 
+// one launch instead of two memsets: the eight counter words of a sub-batch, the last one being an error word whose "none" is ~0
+static __global__ void init_counters_kernel(unsigned long long *ctr)
+{
+    if (threadIdx.x < 8) ctr[threadIdx.x] = threadIdx.x == 7 ? ~0ull : 0ull;
+}
+
 bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hashes, const uint8_t *row_mask, int64_t row0, int64_t n, int32_t *out,
                                        const GbhProbeFn *probe, int64_t *new_groups_out)
 {
@@ -349,8 +355,7 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
     ensure_table(groups_ + std::min<int64_t>(n, sub_batch_));
     ensure_store(groups_ > 0 ? groups_ : 1);  // the store view must be addressable for OLD slots
     unsigned long long *ctr = counters_->as<unsigned long long>();
-    HIP_CHECK(hipMemsetAsync(ctr, 0, 7 * 8, ctx_->stream()));
-    HIP_CHECK(hipMemsetAsync(ctr + 7, 0xff, 8, ctx_->stream()));   // [7]: expression-error word of a fused probe kernel
+    init_counters_kernel<<<1, 64, 0, ctx_->stream()>>>(ctr);   // [0..6] = 0, [7] (expression-error word of a fused probe kernel) = ~0
     const int g = grid_for(ctx_, n);
     if (probe) {
         GbhProbeLaunch l{row0, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr};
@@ -498,8 +503,7 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             ensure_table(groups_ + std::min<int64_t>(len, sub_batch_));
             ensure_store(groups_ > 0 ? groups_ : 1);
             unsigned long long *ctr = counters_->as<unsigned long long>();
-            HIP_CHECK(hipMemsetAsync(ctr, 0, 7 * 8, ctx_->stream()));
-            HIP_CHECK(hipMemsetAsync(ctr + 7, 0xff, 8, ctx_->stream()));
+            init_counters_kernel<<<1, 64, 0, ctx_->stream()>>>(ctr);
             GbhProbeLaunch l{start, len, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), nullptr, ctr,
                              out_gids8 + start};
             (*probe)(l);

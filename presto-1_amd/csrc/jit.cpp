@@ -192,6 +192,12 @@ static std::string device_header(const char *name)
     return t;
 }
 
+// p[0 .. n_ones) = ~0 (error words: "none"), p[n_ones .. n_ones + n_zeros) = 0 (counters): one launch instead of two memsets
+static __global__ void init_words_kernel(unsigned long long *p, int n_ones, int n_zeros)
+{
+    if ((int)threadIdx.x < n_ones + n_zeros) p[threadIdx.x] = (int)threadIdx.x < n_ones ? ~0ull : 0ull;
+}
+
 template <typename Args> static void launch_args(hipFunction_t f, int grid, Args &args, hipStream_t stream)
 {
     size_t size = sizeof(Args);
@@ -1405,8 +1411,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.grid1 = grid1;
     BufferPtr tile_cnt = ctx->alloc((size_t)chunks * 4), tile_src = ctx->alloc((size_t)chunks * 4), tile_dst = ctx->alloc((size_t)chunks * 4);
     BufferPtr misc = ctx->alloc(32);  // [0] expression error word, [1] rows selected by the filter, [2] total pairs
-    HIP_CHECK(hipMemsetAsync(misc->ptr(), 0xff, 8, ctx->stream()));
-    HIP_CHECK(hipMemsetAsync(misc->as<uint8_t>() + 8, 0, 24, ctx->stream()));
+    init_words_kernel<<<1, 64, 0, ctx->stream()>>>(misc->as<unsigned long long>(), 1, 3);   // one launch: [0] = ~0 (no error), [1..3] = 0
     J.fp.error = misc->as<unsigned long long>();
     J.counters = misc->as<unsigned long long>() + 1;
     J.tile_cnt = tile_cnt->as<int32_t>();
@@ -2420,7 +2425,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     FaArgsHost F{};
     fill_fp_cols(F.fp, in);
     BufferPtr err = ctx->alloc(8);
-    HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
+    if (accumulate_can_raise_) HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));   // (never written, never read otherwise)
     F.fp.error = err->as<unsigned long long>();
     F.gids = gids;
     F.gids8 = gids8;
