@@ -16,6 +16,11 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _rng(seed):
+    """the same stream in the parent and in the spawned ranks (conftest's TGPU_TEST_SEED_OFFSET patch lives in the parent only)"""
+    return np.random.Generator(np.random.PCG64(seed))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -25,7 +30,7 @@ def _free_port():
 
 
 def _make_rows(rank, n):
-    rng = np.random.default_rng(100 + rank)
+    rng = _rng(100 + rank)
     keys = rng.integers(0, 5000, n).astype(np.int64)
     pay = (np.arange(n, dtype=np.int64) + rank * 1_000_000)
     strs = [None if k % 11 == 0 else "s%d" % (k % 37) for k in keys]
@@ -107,7 +112,7 @@ def test_hash_exchange_world2_gloo(oracle):
 
 def _gather_rows(rank):
     n = [0, 2500, 700][rank]          # ragged, and one rank contributes nothing
-    rng = np.random.default_rng(200 + rank)
+    rng = _rng(200 + rank)
     keys = rng.integers(0, 1 << 40, n).astype(np.int64)
     dates = rng.integers(8000, 10000, n).astype(np.int32)
     dnull = (rng.random(n) < 0.2).astype(np.uint8) if rank == 1 else None   # nulls on one rank only
