@@ -1003,6 +1003,16 @@ def test_order_by_sequence_and_oracle(pkg, ctx, oracle):
 SERDE_TYPES = lambda pkg: [pkg.BIGINT, pkg.INTEGER, pkg.DATE, pkg.DOUBLE, pkg.BOOLEAN, pkg.VARCHAR]
 
 
+def _serde_cols(oracle, blocks):
+    """oracle columns of the blocks as the product sees them: the ingest drops a null vector that holds no null, so such a block is
+    written with mayHaveNull = 0 where Java keeps the flag of an all-false valueIsNull array (tgpu.h; both decode to equal blocks)"""
+    cols = [ocol(oracle, b) for b in blocks]
+    for c in cols:
+        if c.nulls is not None and not c.nulls.any():
+            c.nulls = None
+    return cols
+
+
 def _assert_same_page(pkg, got, blocks, n):
     assert got.position_count == n and len(got.blocks) == len(blocks)
     for g, b in zip(got.blocks, blocks):
@@ -1022,7 +1032,7 @@ def test_serialize_page_matches_reference_bytes(pkg, ctx, oracle, n, null_frac):
     rng = np.random.default_rng(n + int(null_frac * 10))
     blocks = [rand_block(pkg, rng, t, n, null_frac=null_frac) for t in SERDE_TYPES(pkg)]
     page = pkg.Page(*blocks, position_count=n)
-    want = oracle.serialize_page([ocol(oracle, b) for b in blocks])
+    want = oracle.serialize_page(_serde_cols(oracle, blocks))
     got = ctx.serialize_page(page)
     assert got == want
     # and back: the reference's bytes decode into the same page on the GPU
@@ -1428,11 +1438,7 @@ def test_serde_many_small_random_pages(pkg, ctx, oracle):
                 blocks.append(rand_block(pkg, rng, t, n, null_frac=frac))
         # (the ingest drops a null vector that holds no null, so such a block is written with mayHaveNull = 0 where Java keeps the
         # flag of an all-false valueIsNull array; both decode to the same block -- the expectation is normalised the same way)
-        cols = [ocol(oracle, b) for b in blocks]
-        for c in cols:
-            if c.nulls is not None and not c.nulls.any():
-                c.nulls = None
-        want = oracle.serialize_page(cols)
+        want = oracle.serialize_page(_serde_cols(oracle, blocks))
         page = pkg.Page(*blocks, position_count=n)
         assert ctx.serialize_page(page) == want, (n, types)
         back = ctx.deserialize_page(want, types)
