@@ -1,4 +1,5 @@
-"""Ad-hoc large-size checks against numpy (needs a GPU): PartitionedOutputOperator with 1024 partitions and replicated null-key rows\n(5 M rows), byte-exact serde of a page with nulls, a FULL_OUTER join of 2 x 10 M probe rows against 5 M build rows + LookupOuterOperator."""
+"""Ad-hoc large-size checks against numpy (needs a GPU): PartitionedOutputOperator with 1024 partitions and replicated null-key rows
+(5 M rows), byte-exact serde of a page with nulls, a FULL_OUTER join of 2 x 10 M probe rows against 5 M build rows + LookupOuterOperator."""
 import importlib, sys, numpy as np
 sys.path.insert(0, '/root/repo')
 pkg = importlib.import_module("presto-1_amd")
