@@ -1056,7 +1056,11 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     }
     // stage B: tile jB -- filter + key from the rows loaded by the previous iteration; the pre-filter word (exact key bitmap
     // for dense key domains, else the blocked Bloom filter) is loaded below, again from an always-valid address
-    unsigned long long bidx[FJ_STRIPES];
+#if FJ_PF == 2
+    unsigned long long bidx[FJ_STRIPES];   // Bloom filter word
+#else
+    unsigned int bidx[FJ_STRIPES];         // bitmap word: the key range of the bitmap layouts is below 2^32 (32-bit offsets from a scalar base)
+#endif
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) bidx[s] = 0;
     if (doB) {
@@ -1079,7 +1083,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
           const unsigned long long d = (unsigned long long)key - (unsigned long long)J.pf.key_min;
           sel = sel && d <= key_range;
           pbits[s] = (unsigned int)d & 63u;
-          bidx[s] = sel ? (d >> 6) : 0ULL;
+          bidx[s] = sel ? (unsigned int)(d >> 6) : 0u;
         }
 #elif FJ_PF == 2
         {
