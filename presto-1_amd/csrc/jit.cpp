@@ -1044,7 +1044,8 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
         maybe = false;
 #endif
 #if FJ_PF == 3
-        skey[s] = pkey[s]; ssidx[s] = (unsigned int)__popcll(pbw[s] & ((1ULL << pbits[s]) - 1ULL));   // set bits below the key's own
+        skey[s] = pkey[s];
+        ssidx[s] = (J.outer & 2) ? 0u : (unsigned int)__popcll(pbw[s] & ((1ULL << pbits[s]) - 1ULL));   // set bits below the key's own (unless nobody reads positions)
         sfl[s] = (unsigned char)((maybe ? 1 : 0) | (pfl[s] & 2));
         cidx[s] = (maybe && !(J.outer & 2)) ? (psidx[s] >> 6) : 0u;                                     // its bitmap word (entry 0 when the rank is not needed)
 #else
