@@ -67,3 +67,41 @@ inv = np.empty(nb, dtype=np.int64); inv[(bkeys - 7) // 1000] = np.arange(nb)
 assert np.array_equal(hv, bkeys[np.sort(inv[~matched])])                 # unmatched build rows in build-position order
 o.release()
 print("full outer ok: unmatched", want_unmatched)
+
+# fused filter/project -> hash aggregation with many groups (ORDERED mode behind the JIT kernels), several pages, vs numpy
+n2, groups = 6_000_000, 500_000
+f = pkg.field
+fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 5, [pkg.BIGINT, pkg.DOUBLE, pkg.BIGINT], f(2, pkg.BIGINT) < 90, [f(0, pkg.BIGINT), f(1, pkg.DOUBLE) * pkg.constant(2.0, pkg.DOUBLE)],
+                                                      [pkg.BIGINT], [0], [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, -1)], expected_groups=1 << 19)
+op = fac.createOperator()
+want_sum, want_cnt, first_seen = np.zeros(groups), np.zeros(groups, dtype=np.int64), []
+seen = np.zeros(groups, dtype=bool)
+for part in range(3):
+    k = rng.integers(0, groups, n2).astype(np.int64)
+    v = rng.integers(-1000, 1000, n2).astype(np.float64)          # integer-valued: the sums are exact in any order
+    sel = rng.integers(0, 100, n2).astype(np.int64)
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, k), pkg.Block(pkg.DOUBLE, v), pkg.Block(pkg.BIGINT, sel)))
+    m = sel < 90
+    want_sum += np.bincount(k[m], weights=2.0 * v[m], minlength=groups)
+    want_cnt += np.bincount(k[m], minlength=groups)
+    ks = k[m]
+    u, idx = np.unique(ks, return_index=True)
+    new = u[~seen[u]]
+    first_seen.append(new[np.argsort(idx[~seen[u]], kind="stable")])
+    seen[u] = True
+op.finish()
+rows = []
+while True:
+    o = op.getOutput()
+    if o is None:
+        if op.isFinished():
+            break
+        continue
+    h = o.to_host()
+    rows.append((np.asarray(h.blocks[0].values[:h.position_count]), np.asarray(h.blocks[1].values[:h.position_count]), np.asarray(h.blocks[2].values[:h.position_count])))
+    o.release()
+gk = np.concatenate([r[0] for r in rows]); gs = np.concatenate([r[1] for r in rows]); gc = np.concatenate([r[2] for r in rows])
+order = np.concatenate(first_seen)
+assert np.array_equal(gk, order), "group output order is not first-seen order"
+assert np.array_equal(gs, want_sum[order]) and np.array_equal(gc, want_cnt[order])
+print("fused aggregation with", len(gk), "groups ok")
