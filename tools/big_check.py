@@ -105,3 +105,13 @@ order = np.concatenate(first_seen)
 assert np.array_equal(gk, order), "group output order is not first-seen order"
 assert np.array_equal(gs, want_sum[order]) and np.array_equal(gc, want_cnt[order])
 print("fused aggregation with", len(gk), "groups ok")
+
+# GroupByHash: 40 M distinct BIGINT keys in one page (several sub-batches, table growth), then the same page again (pure lookups)
+nk = 40_000_000
+keys40 = rng.permutation(nk).astype(np.int64) * 3 + 1
+gbh = pkg.GroupByHash(ctx, [pkg.BIGINT], [0], expected_size=1 << 20)
+ids = gbh.getGroupIds(pkg.Page(pkg.Block(pkg.BIGINT, keys40)))
+assert np.array_equal(ids, np.arange(nk)), "first-seen ids of distinct keys must be 0..n-1"
+ids2 = gbh.getGroupIds(pkg.Page(pkg.Block(pkg.BIGINT, keys40[::-1].copy())))
+assert np.array_equal(ids2, np.arange(nk)[::-1]) and gbh.getGroupCount() == nk
+print("group-by hash with", nk, "groups ok")
