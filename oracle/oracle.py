@@ -1,7 +1,11 @@
-"""ctypes wrapper over oracle/libtrino_oracle.so -- the CPU restatement of the reference algorithms.
+"""ctypes wrapper over oracle/libtrino_oracle.so -- the CPU restatement of the reference algorithms -- plus the restatements that
+are byte / index bookkeeping rather than arithmetic and therefore live here in numpy or small Python loops: the SerializedPage wire
+format (serialize_page / deserialize_page), PagePartitioner, MergePages and DynamicFilterSource (page- or position-at-a-time state
+machines, used on small test inputs only).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg,
-never by the product package.  See trino_oracle.h for the reference citations of every function.
+never by the product package.  See trino_oracle.h for the reference citations of the C functions; the Python restatements cite
+theirs next to each class.
 """
 import ctypes as C
 import os
