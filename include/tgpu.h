@@ -18,6 +18,15 @@
  *   - tgpu_group_by_hash_*       <-> M/operator/GroupByHash.java:45-99
  *   - tgpu_hash_page             <-> M/operator/InterpretedHashGenerator.java:56-70
  *   - tgpu_partition_page        <-> M/operator/PartitionedOutputOperator.java:406-426 + HashGenerator.java:24-35
+ *   - tgpu_partitioned_output_*  <-> M/operator/PartitionedOutputOperator.java:46-486 (operator + PagePartitioner)
+ *   - tgpu_top_n_* / tgpu_order_by_* <-> M/operator/TopNOperator.java:47-225, OrderByOperator.java:48-300
+ *   - tgpu_lookup_outer_*        <-> M/operator/LookupOuterOperator.java:32-235, OuterLookupSource.java:146-190
+ *   - tgpu_merge_pages_*         <-> M/operator/project/MergePages.java:64-190
+ *   - tgpu_dynamic_filter_source_* <-> M/operator/DynamicFilterSourceOperator.java:74-425
+ *   - tgpu_serialize_page / tgpu_deserialize_page <-> M/execution/buffer/PagesSerde.java:64-160, PagesSerdeUtil.java:45-71,
+ *                                    S/block/*BlockEncoding.java, EncoderUtil.java:33-118
+ *   - tgpu_operator_add_input_output_page: Operator.addInput with a page that never left the device (no reference counterpart:
+ *                                    on the JVM the Page object itself is what travels between operators)
  *
  * Threading rule = the reference's (M/operator/Driver.java:55-62): one caller at a time per handle; distinct
  * handles are independent, also when they belong to one context (their kernels then share its stream and execute in issue
