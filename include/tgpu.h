@@ -55,6 +55,7 @@ extern "C" {
 #define TGPU_ERR_DEVICE (-6)                        /* no HIP device / HIP runtime failure: the library never falls back to CPU */
 #define TGPU_ERR_DIVISION_BY_ZERO (-7)              /* DIVISION_BY_ZERO */
 #define TGPU_ERR_NOT_SUPPORTED (-8)                 /* NOT_SUPPORTED */
+#define TGPU_ERR_INVALID_CAST_ARGUMENT (-9)         /* INVALID_CAST_ARGUMENT: M/type/DoubleOperators.java:108-163 */
 
 /* ---- types (S/type): storage is what the reference's flat blocks hold ---- */
 typedef enum tgpu_type {

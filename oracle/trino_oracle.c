@@ -885,6 +885,23 @@ static int cmp_vals(int32_t type, const o_val *a, const o_val *b, int op)
     }
 }
 
+/* java.lang.Math.round(double) as a double: floor(x + 1/2) computed without the rounding error of the addition (values of
+ * magnitude >= 2^52 are integers already); the saturation of the long result is left to the caller's range check */
+static double java_math_round(double x)
+{
+    if (!(fabs(x) < 4503599627370496.0)) return x;
+    double f = floor(x);
+    return (x - f >= 0.5) ? f + 1.0 : f;
+}
+
+/* guava DoubleMath.roundToLong(x, HALF_UP) as a double: nearest integer, ties away from zero */
+static double java_half_up(double x)
+{
+    if (!(fabs(x) < 4503599627370496.0)) return x;
+    double t = trunc(x);
+    return (fabs(x - t) >= 0.5) ? t + (x < 0 ? -1.0 : 1.0) : t;
+}
+
 static o_val eval_call(o_eval_ctx *cx, const o_expr_node *nd, int32_t row)
 {
     o_val r; memset(&r, 0, sizeof(r));
@@ -971,6 +988,30 @@ static o_val eval_call(o_eval_ctx *cx, const o_expr_node *nd, int32_t row)
         if (nd->type == O_INTEGER && at == O_BIGINT) {
             if (a[0].i > INT32_MAX || a[0].i < INT32_MIN) { cx->err = O_ERR_NUMERIC_VALUE_OUT_OF_RANGE; return r; }
             r.i = a[0].i; return r;
+        }
+        /* castToBoolean: M/type/BigintOperators.java:115-120, IntegerOperators.java:146-151, DoubleOperators.java:101-106 (NaN != 0 is true) */
+        if (nd->type == O_BOOLEAN && (at == O_BIGINT || at == O_INTEGER)) { r.i = a[0].i != 0; return r; }
+        if (nd->type == O_BOOLEAN && at == O_DOUBLE) { r.i = a[0].d != 0; return r; }
+        /* M/type/BooleanOperators.java:37-63 */
+        if (at == O_BOOLEAN && (nd->type == O_BIGINT || nd->type == O_INTEGER)) { r.i = a[0].i ? 1 : 0; return r; }
+        if (at == O_BOOLEAN && nd->type == O_DOUBLE) { r.d = a[0].i ? 1.0 : 0.0; return r; }
+        if (nd->type == O_BIGINT && at == O_DOUBLE) {
+            /* DoubleOperators.castToLong :153-163 = guava DoubleMath.roundToLong(value, HALF_UP): nearest, ties away from zero;
+             * NaN, infinities and results outside [-2^63, 2^63) -> INVALID_CAST_ARGUMENT */
+            double x = a[0].d;
+            if (x != x || x - x != 0) { cx->err = O_ERR_INVALID_CAST_ARGUMENT; return r; }
+            double z = java_half_up(x);
+            if (!(z >= -9223372036854775808.0 && z < 9223372036854775808.0)) { cx->err = O_ERR_INVALID_CAST_ARGUMENT; return r; }
+            r.i = (int64_t)z; return r;
+        }
+        if (nd->type == O_INTEGER && at == O_DOUBLE) {
+            /* DoubleOperators.castToInteger :108-121: NaN -> INVALID_CAST_ARGUMENT; toIntExact((long) MathFunctions.round(value))
+             * (MathFunctions.java:821-833: -(Math.round(-x)) for x < 0, infinities pass through; the (long) conversion saturates) */
+            double x = a[0].d;
+            if (x != x) { cx->err = O_ERR_INVALID_CAST_ARGUMENT; return r; }
+            double z = (x - x != 0) ? x : (x < 0 ? -java_math_round(-x) : java_math_round(x));
+            if (!(z >= -2147483648.0 && z <= 2147483647.0)) { cx->err = O_ERR_NUMERIC_VALUE_OUT_OF_RANGE; return r; }
+            r.i = (int64_t)z; return r;
         }
         cx->err = O_ERR_INVALID;
         return r;

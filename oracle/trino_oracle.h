@@ -160,7 +160,8 @@ enum {
     O_ERR_INVALID = -1,
     O_ERR_NUMERIC_VALUE_OUT_OF_RANGE = -2,
     O_ERR_INSUFFICIENT_RESOURCES = -3,
-    O_ERR_DIVISION_BY_ZERO = -7
+    O_ERR_DIVISION_BY_ZERO = -7,
+    O_ERR_INVALID_CAST_ARGUMENT = -9
 };
 
 /* PageFilter.filter + positionsArrayToSelectedPositions (M/operator/project/PageFilter.java:27-50):

@@ -12,7 +12,7 @@ class TgpuError(RuntimeError):
     """Mirror of io.trino.spi.TrinoException: `code` is the tgpu.h status (StandardErrorCode mirror)."""
 
     NAMES = {-1: "INVALID_ARGUMENT", -2: "NUMERIC_VALUE_OUT_OF_RANGE", -3: "GENERIC_INSUFFICIENT_RESOURCES", -4: "COMPILER_ERROR",
-             -5: "GENERIC_INTERNAL_ERROR", -6: "DEVICE_ERROR", -7: "DIVISION_BY_ZERO", -8: "NOT_SUPPORTED"}
+             -5: "GENERIC_INTERNAL_ERROR", -6: "DEVICE_ERROR", -7: "DIVISION_BY_ZERO", -8: "NOT_SUPPORTED", -9: "INVALID_CAST_ARGUMENT"}
 
     def __init__(self, code, message):
         super().__init__(f"{self.NAMES.get(code, code)}: {message}")

@@ -175,12 +175,13 @@ struct ProfileScope {
     }
 };
 
-// an expression-error word written by a generated kernel: ~0 = none, else (row << 8) | code (7 = division by zero, else overflow)
+// an expression-error word written by a generated kernel: ~0 = none, else (row << 8) | code (7 = division by zero, 9 = invalid cast argument, else overflow)
 inline void raise_expression_error(unsigned long long e)
 {
     if (e == ~0ull) return;
     const long long row = (long long)(e >> 8);
     if ((int)(e & 0xff) == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
+    if ((int)(e & 0xff) == 9) fail(TGPU_ERR_INVALID_CAST_ARGUMENT, "Cannot cast double to an integer type: NaN or out of range (position " + std::to_string(row) + ")");
     fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
 }
 

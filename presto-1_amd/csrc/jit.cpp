@@ -421,6 +421,22 @@ struct Gen {
             else if (nd.type == TGPU_BIGINT && at == TGPU_INTEGER) os << ind(dd) << r.v << " = (long long)" << a.v << ";\n";
             else if (nd.type == TGPU_INTEGER && at == TGPU_BIGINT)
                 os << ind(dd) << "if (" << a.v << " > 2147483647LL || " << a.v << " < -2147483648LL) { tg_error(A.error, row, TG_E_RANGE); " << r.n << " = true; } else " << r.v << " = (int)" << a.v << ";\n";
+            // castToBoolean: M/type/BigintOperators.java:115-120, IntegerOperators.java:146-151, DoubleOperators.java:101-106 (NaN -> true)
+            else if (nd.type == TGPU_BOOLEAN && (at == TGPU_BIGINT || at == TGPU_INTEGER || at == TGPU_DOUBLE)) os << ind(dd) << r.v << " = " << a.v << " != 0;\n";
+            // M/type/BooleanOperators.java:37-63
+            else if (at == TGPU_BOOLEAN && (nd.type == TGPU_BIGINT || nd.type == TGPU_INTEGER)) os << ind(dd) << r.v << " = " << a.v << " ? 1 : 0;\n";
+            else if (at == TGPU_BOOLEAN && nd.type == TGPU_DOUBLE) os << ind(dd) << r.v << " = " << a.v << " ? 1.0 : 0.0;\n";
+            else if (nd.type == TGPU_BIGINT && at == TGPU_DOUBLE) {
+                // DoubleOperators.castToLong :153-163 (DoubleMath.roundToLong HALF_UP): ties away from zero; NaN / inf / out of long range -> INVALID_CAST_ARGUMENT
+                os << ind(dd) << "double z_ = tg_round_half_away(" << a.v << ");\n";
+                os << ind(dd) << "if (!(z_ >= -9223372036854775808.0 && z_ < 9223372036854775808.0)) { tg_error(A.error, row, TG_E_CAST); " << r.n << " = true; } else " << r.v << " = (long long)z_;\n";
+            }
+            else if (nd.type == TGPU_INTEGER && at == TGPU_DOUBLE) {
+                // DoubleOperators.castToInteger :108-121: NaN -> INVALID_CAST_ARGUMENT, else toIntExact((long) round(value))
+                os << ind(dd) << "double z_ = tg_round_half_away(" << a.v << ");\n";
+                os << ind(dd) << "if (" << a.v << " != " << a.v << ") { tg_error(A.error, row, TG_E_CAST); " << r.n << " = true; }\n";
+                os << ind(dd) << "else if (!(z_ >= -2147483648.0 && z_ <= 2147483647.0)) { tg_error(A.error, row, TG_E_RANGE); " << r.n << " = true; } else " << r.v << " = (int)z_;\n";
+            }
             else bad("unsupported cast");
             break;
         default:
@@ -537,6 +553,7 @@ const char *kPrelude = R"SRC(
 // generated by libtgpu (jit.cpp): fused filter + project kernels for gfx950
 #define TG_E_RANGE 2
 #define TG_E_DIV0 7
+#define TG_E_CAST 9
 #define TG_MAXC 24
 #define TG_MAXP 16
 struct FpArgs {
@@ -560,6 +577,12 @@ __device__ inline int tg_strcmp(const unsigned char* a, int la, const unsigned c
   int m = la < lb ? la : lb;
   for (int i = 0; i < m; i++) { int d = (int)a[i] - (int)b[i]; if (d) return d; }
   return la - lb;
+}
+// nearest integer, ties away from zero (java Math.round mirrored around zero = guava HALF_UP); NaN / inf pass through
+__device__ inline double tg_round_half_away(double x) {
+  if (!(fabs(x) < 4503599627370496.0)) return x;
+  const double t = trunc(x);
+  return (fabs(x - t) >= 0.5) ? t + (x < 0 ? -1.0 : 1.0) : t;
 }
 #define TG_TILE 1024
 #define TG_STRIPES 4
@@ -832,13 +855,7 @@ bool PageProcessorGpu::process(Context *ctx, const DevicePage &in, DevicePage &o
     HIP_CHECK(hipMemsetAsync(err->ptr(), 0xff, 8, ctx->stream()));
     args.error = err->as<unsigned long long>();
 
-    auto raise_error = [&](unsigned long long e) {
-        if (e == ~0ull) return;
-        const long long row = (long long)(e >> 8);
-        const int code = (int)(e & 0xff);
-        if (code == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
-        fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
-    };
+    auto raise_error = [&](unsigned long long e) { raise_expression_error(e); };
     auto check_error = [&]() { raise_error(ctx->read_scalar(err->as<unsigned long long>())); };
 
     int64_t n_sel = n;
@@ -1236,7 +1253,10 @@ FusedProbeGpu::FusedProbeGpu(std::vector<int32_t> input_types, const tgpu_page_p
         if (nd.kind == TGPU_EX_CALL) {
             const bool int_result = nd.type == TGPU_BIGINT || nd.type == TGPU_INTEGER;
             if (int_result && nd.op >= TGPU_OP_ADD && nd.op <= TGPU_OP_NEGATE) return true;
-            if (nd.op == TGPU_OP_CAST && nd.type == TGPU_INTEGER) return true;
+            if (nd.op == TGPU_OP_CAST && nd.n_args == 1 && int_result) {   // narrowing casts are checked (BIGINT -> INTEGER, DOUBLE -> BIGINT / INTEGER)
+                const int32_t from = nodes_[(size_t)nd.args[0]].type;
+                if (from == TGPU_DOUBLE || (from == TGPU_BIGINT && nd.type == TGPU_INTEGER)) return true;
+            }
         }
         if (nd.kind == TGPU_EX_CALL || nd.kind == TGPU_EX_SPECIAL)
             for (int k = 0; k < nd.n_args; k++)
@@ -1437,12 +1457,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     }
     struct { unsigned long long expr_err, selected, total; } h;
     ctx->download(&h, misc->ptr(), 24);
-    auto raise = [](unsigned long long e) {
-        const long long row = (long long)(e >> 8);
-        if ((int)(e & 0xff) == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
-        fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
-    };
-    if (h.expr_err != ~0ull) raise(h.expr_err);
+    raise_expression_error(h.expr_err);
     selected_rows = (int64_t)h.selected;
     count = (int64_t)h.total;
     if (count == 0) return;
@@ -1664,7 +1679,10 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
         if (nd.kind == TGPU_EX_CALL) {
             const bool int_result = nd.type == TGPU_BIGINT || nd.type == TGPU_INTEGER;
             if (int_result && nd.op >= TGPU_OP_ADD && nd.op <= TGPU_OP_NEGATE) return true;
-            if (nd.op == TGPU_OP_CAST && nd.type == TGPU_INTEGER) return true;
+            if (nd.op == TGPU_OP_CAST && nd.n_args == 1 && int_result) {   // narrowing casts are checked (BIGINT -> INTEGER, DOUBLE -> BIGINT / INTEGER)
+                const int32_t from = nodes_[(size_t)nd.args[0]].type;
+                if (from == TGPU_DOUBLE || (from == TGPU_BIGINT && nd.type == TGPU_INTEGER)) return true;
+            }
         }
         if (nd.kind == TGPU_EX_CALL || nd.kind == TGPU_EX_SPECIAL)
             for (int k = 0; k < nd.n_args; k++)
@@ -2315,11 +2333,7 @@ JitModule *FusedAggGpu::module_for(const DevicePage &in, bool gid8)
 
 void FusedAggGpu::raise_if_error(Context *ctx, BufferPtr &err)
 {
-    unsigned long long e = ctx->read_scalar(err->as<unsigned long long>());
-    if (e == ~0ull) return;
-    const long long row = (long long)(e >> 8);
-    if ((int)(e & 0xff) == 7) fail(TGPU_ERR_DIVISION_BY_ZERO, "Division by zero (position " + std::to_string(row) + ")");
-    fail(TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE, "numeric value out of range: arithmetic overflow (position " + std::to_string(row) + ")");
+    raise_expression_error(ctx->read_scalar(err->as<unsigned long long>()));
 }
 
 static void fill_fp_cols(FpArgs &fp, const DevicePage &in)
