@@ -139,6 +139,7 @@ class Bench:
         self.pkg = importlib.import_module("presto-1_amd")
         self.entry = importlib.import_module("__graft_entry__")
         self.ctx = self.pkg.Context(self.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        self.capture = None
 
     # -- helpers ------------------------------------------------------------------------------------------------------
     def dblock(self, type_id, values, offsets=None):
@@ -223,6 +224,7 @@ class Bench:
         op = f["cust_fp"].createOperator()
         for o in self.drive(op, pages["customer"]):
             st["customer_build_rows"] = o.position_count
+            self.captured("customer_filter", o)
             cbuild.addInput(o.as_device_page())
             o.release()
         cbuild.finish()
@@ -234,6 +236,7 @@ class Bench:
         ojoin = oj.createOperator()
         for j in self.drive(ojoin, pages["orders"]):
             st["orders_build_rows"] = j.position_count
+            self.captured("orders_join", j)
             obuild.addInput(j.as_device_page())
             j.release()
         obuild.finish()
@@ -245,6 +248,7 @@ class Bench:
         aop = agg.createOperator()
         for j in self.drive(ljoin, pages["lineitem"]):
             st["lineitem_join_rows"] = j.position_count
+            self.captured("lineitem_join", j)
             aop.addInput(j.as_device_page())
             j.release()
         outs = self.finish(aop)
@@ -254,6 +258,12 @@ class Bench:
         cbuild.close()
         obuild.close()
         aop.close()
+
+    def captured(self, name, out_page):
+        """tests/test_gpu_bench_programs.py sets self.capture = {}: host copies of the intermediate pages of one step, so that the very
+        pipeline this file times is compared with the oracle pair by pair (not part of a timed run: capture is None there)"""
+        if self.capture is not None:
+            self.capture.setdefault(name, []).append(out_page.to_host())
 
     def step_q3_dist(self):
         """Q3 as the distributed plan Trino's optimizer picks for these inputs (N ranks, one per GPU):

@@ -106,6 +106,15 @@ const char *tgpu_version(void);
 /* directory holding the JIT kernel sources/cache (defaults to the directory of libtgpu.so) */
 int32_t tgpu_set_resource_dir(const char *dir);
 
+/* Order in which sum(double) / avg(double) add their rows (DESIGN.md "DOUBLE aggregate policy"), for operators created afterwards:
+ *   EXACT (default): few groups -> the correctly rounded exact sum (order independent; equals the Java result whenever that is itself
+ *                    exact, else differs from it by the Java order's own rounding error); many groups -> rows added in row order;
+ *   JAVA:            always in row order, one group's rows after another -- the loop of DoubleSumAggregation.java:34-38 /
+ *                    AccumulatorCompiler.java:487-566, bit-identical to the Java operator for any input, at the price of a
+ *                    sequential chain per group (meant for page-sized inputs and strict-parity runs). */
+typedef enum tgpu_double_sum_order { TGPU_SUM_ORDER_EXACT = 0, TGPU_SUM_ORDER_JAVA = 1 } tgpu_double_sum_order;
+int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order);
+
 /* per-kernel HIP-event timing on the context's stream (bench.py's roofline leg) */
 int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled);
 int32_t tgpu_profile_reset(tgpu_context *ctx);

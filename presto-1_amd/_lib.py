@@ -68,6 +68,7 @@ SYMBOLS = {
     "tgpu_last_error": (cp, []),
     "tgpu_version": (cp, []),
     "tgpu_set_resource_dir": (i32, [cp]),
+    "tgpu_context_set_double_sum_order": (i32, [vp, i32]),
     "tgpu_profile_enable": (i32, [vp, i32]),
     "tgpu_profile_reset": (i32, [vp]),
     "tgpu_profile_dump": (i64, [vp, cp, i64]),
@@ -126,6 +127,7 @@ EXTRA_SYMBOLS = {
     "tgpu_precompile_page_processor": (i32, [i32, P(i32), P(PageProcessorSpec)]),
     "tgpu_page_processor_source": (i64, [i32, P(i32), P(PageProcessorSpec), cp, i64]),
     "tgpu_group_by_hash_rehash_count": (i32, [vp]),
+    "tgpu_debug_bind_count": (C.c_longlong, []),
     "tgpu_precompile_fused_probe": (i32, [i32, P(i32), P(PageProcessorSpec), i32, i32, P(i32)]),
     "tgpu_precompile_fused_aggregation": (i32, [i32, P(i32), P(PageProcessorSpec), i32, P(AggSpec), i32, P(i32)]),
 }

@@ -48,6 +48,9 @@ public:
     bool begin_ordered(const int32_t *gids, int64_t n, int64_t groups, int64_t lowcard_max_groups, BufferPtr &keys, BufferPtr &rows);
     // the JIT-fused accumulate kernels address the exact (limb) state directly: they keep the accumulators out of ORDERED mode
     void set_allow_ordered(bool on) { allow_ordered_ = on; }
+    // TGPU_SUM_ORDER_JAVA: ORDERED whatever the number of groups (every group's rows are added in row order)
+    void set_force_ordered(bool on) { force_ordered_ = on; }
+    bool force_ordered() const { return force_ordered_ && allow_ordered_; }
     bool ordered() const { return mode_ == Mode::ORDERED; }
     DeviceState device_state(int k) const;
     const std::vector<tgpu_agg_spec> specs() const;
@@ -70,7 +73,7 @@ private:
     void decide_mode(int64_t groups, int64_t lowcard_max_groups);
     void sort_rows_by_group(const int32_t *gids, int64_t n, int64_t groups, BufferPtr &keys, BufferPtr &rows);
     Mode mode_ = Mode::UNDECIDED;
-    bool allow_ordered_ = false;
+    bool allow_ordered_ = false, force_ordered_ = false;
     Context *ctx_;
     std::vector<State> states_;
     int32_t step_;

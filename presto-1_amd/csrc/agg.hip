@@ -463,7 +463,7 @@ static int64_t lowcard_bytes_per_group(const std::vector<tgpu_agg_spec> &specs)
 void GroupedAccumulators::decide_mode(int64_t groups, int64_t lowcard_max_groups)
 {
     if (mode_ != Mode::UNDECIDED) return;
-    const bool many = groups > lowcard_max_groups;
+    const bool many = groups > lowcard_max_groups || force_ordered_;
     mode_ = (allow_ordered_ && many && getenv("TGPU_DISABLE_ORDERED") == nullptr) ? Mode::ORDERED : Mode::EXACT;
 }
 
@@ -505,6 +505,11 @@ void GroupedAccumulators::sort_rows_by_group(const int32_t *gids, int64_t n, int
 void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
 {
     if (states_.empty() || n <= 0) return;
+    BufferPtr zero_gids;
+    if (!gids && force_ordered()) {   // a global aggregation in Java order: one group, id 0 for every row
+        zero_gids = ctx_->alloc_zero((size_t)n * 4);
+        gids = zero_gids->as<int32_t>();
+    }
     if (gids) decide_mode(group_count > 0 ? group_count : 1, (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1));
     else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
     ensure(group_count > 0 ? group_count : 1);
@@ -587,6 +592,11 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
 void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const DevicePage &page, int64_t group_count)
 {
     if (states_.empty() || n <= 0) return;
+    BufferPtr zero_gids;
+    if (!gids && force_ordered()) {
+        zero_gids = ctx_->alloc_zero((size_t)n * 4);
+        gids = zero_gids->as<int32_t>();
+    }
     if (gids) decide_mode(group_count > 0 ? group_count : 1, (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1));
     else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
     ensure(group_count > 0 ? group_count : 1);

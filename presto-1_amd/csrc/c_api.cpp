@@ -1,4 +1,5 @@
 // c_api.cpp -- the extern "C" boundary (include/tgpu.h): exceptions -> status codes, handles -> C++ objects.
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -34,6 +35,30 @@ template <typename F> int32_t guard(F &&f)
         return TGPU_ERR_INTERNAL;
     }
 }
+
+// Every entry point that works on a context's device binds the calling thread to that device first: HIP's current device is
+// per thread, and the handles of one context may be driven by any thread (tgpu.h threading rule; JVM driver-pool threads in the
+// JNI integration start on device 0 whatever device the context lives on).
+std::atomic<long long> g_bind_count{0};
+inline void bind_thread(Context *c)
+{
+    if (!c) return;
+    g_bind_count++;
+    HIP_CHECK(hipSetDevice(c->device()));
+}
+template <typename F> int32_t guard_on(Context *c, F &&f)
+{
+    return guard([&] {
+        bind_thread(c);
+        f();
+    });
+}
+inline Context *ctx_of(const tgpu_context *h) { return h ? h->ctx.get() : nullptr; }
+inline Context *ctx_of(const tgpu_operator *h) { return h ? h->ctx : nullptr; }
+inline Context *ctx_of(const tgpu_operator_factory *h) { return h ? h->ctx : nullptr; }
+inline Context *ctx_of(const tgpu_lookup_source_factory *h) { return h ? h->ctx : nullptr; }
+inline Context *ctx_of(const tgpu_group_by_hash *h) { return h ? h->ctx : nullptr; }
+inline Context *ctx_of(const tgpu_output_page *h) { return h ? h->ctx : nullptr; }
 
 std::vector<int32_t> vec(const int32_t *p, int32_t n)
 {
@@ -113,13 +138,15 @@ void tgpu_context_destroy(tgpu_context *ctx)
 
 int32_t tgpu_context_synchronize(tgpu_context *ctx)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx != nullptr, "context is null");
         ctx->ctx->sync();
     });
 }
 
 const char *tgpu_last_error(void) { return last_error().c_str(); }
+/* diagnostics: how many times entry points bound their thread to a context's device (tests) */
+long long tgpu_debug_bind_count(void) { return g_bind_count.load(); }
 const char *tgpu_version(void) { return "tgpu 0.1 (gfx950)"; }
 
 int32_t tgpu_set_resource_dir(const char *dir)
@@ -130,9 +157,18 @@ int32_t tgpu_set_resource_dir(const char *dir)
     });
 }
 
+int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        TG_CHECK_ARG(order == TGPU_SUM_ORDER_EXACT || order == TGPU_SUM_ORDER_JAVA, "unknown double sum order");
+        ctx->ctx->set_double_sum_order(order);
+    });
+}
+
 int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx != nullptr, "context is null");
         ctx->ctx->set_profiling(enabled != 0);
     });
@@ -140,7 +176,7 @@ int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled)
 
 int32_t tgpu_profile_reset(tgpu_context *ctx)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx != nullptr, "context is null");
         ctx->ctx->profile_reset();
     });
@@ -149,7 +185,7 @@ int32_t tgpu_profile_reset(tgpu_context *ctx)
 int64_t tgpu_profile_dump(tgpu_context *ctx, char *buf, int64_t buf_len)
 {
     int64_t need = 0;
-    int32_t rc = guard([&] {
+    int32_t rc = guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx != nullptr, "context is null");
         std::string s = ctx->ctx->profile_json();
         need = (int64_t)s.size() + 1;
@@ -162,7 +198,7 @@ int64_t tgpu_profile_dump(tgpu_context *ctx, char *buf, int64_t buf_len)
 int32_t tgpu_filter_project_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t input_type_count, const int32_t *input_types,
                                            const tgpu_page_processor_spec *spec, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<FilterAndProjectOperatorFactory>(ctx->ctx.get(), operator_id, vec(input_types, input_type_count), spec);
@@ -198,7 +234,7 @@ int32_t tgpu_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator
                                              const tgpu_agg_spec *aggs, int32_t expected_groups, int32_t produce_default_output,
                                              tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         TG_CHECK_ARG(agg_count >= 0 && (agg_count == 0 || aggs != nullptr), "null aggregate array");
         HashAggregationConfig cfg;
@@ -223,7 +259,7 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
                                          const int32_t *hash_channels, int32_t precomputed_hash_channel, int32_t expected_positions,
                                          tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out && bridge_out, "null argument");
         HashBuilderConfig cfg;
         cfg.types = vec(types, type_count);
@@ -248,7 +284,7 @@ int32_t tgpu_top_n_factory_create(tgpu_context *ctx, int32_t operator_id, int32_
                                   int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
                                   tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<TopNOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), n, vec(sort_channels, sort_channel_count),
@@ -264,7 +300,7 @@ int32_t tgpu_order_by_factory_create(tgpu_context *ctx, int32_t operator_id, int
                                      int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
                                      tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         (void)expected_positions;   // a sizing hint of the reference's PagesIndex; the device store grows by doubling
         auto f = std::make_unique<tgpu_operator_factory>();
@@ -286,7 +322,7 @@ void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge)
 
 int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count)
 {
-    return guard([&] {
+    return guard_on(ctx_of(bridge), [&] {
         TG_CHECK_ARG(bridge != nullptr, "bridge is null");
         auto s = bridge->bridge->lookup_source();
         TG_CHECK_STATE(s != nullptr, "Lookup source has not been built yet");
@@ -301,7 +337,7 @@ int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, 
                                         int32_t probe_hash_channel, int32_t probe_output_channel_count, const int32_t *probe_output_channels,
                                         int32_t join_type, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out && bridge, "null argument");
         LookupJoinConfig cfg;
         cfg.probe_types = vec(probe_types, probe_type_count);
@@ -322,7 +358,7 @@ int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_
                                                        const int32_t *probe_join_channels, int32_t probe_hash_channel, int32_t probe_output_channel_count,
                                                        const int32_t *probe_output_channels, int32_t join_type, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out && bridge && spec, "null argument");
         LookupJoinConfig cfg;
         cfg.probe_join_channels = vec(probe_join_channels, probe_join_channel_count);
@@ -342,7 +378,7 @@ int32_t tgpu_filter_project_hash_aggregation_factory_create(tgpu_context *ctx, i
                                                             const int32_t *group_by_channels, int32_t hash_channel, int32_t step, int32_t agg_count,
                                                             const tgpu_agg_spec *aggs, int32_t expected_groups, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out && spec, "null argument");
         TG_CHECK_ARG(agg_count >= 0 && (agg_count == 0 || aggs != nullptr), "null aggregate array");
         TG_CHECK_ARG(step == TGPU_STEP_SINGLE || step == TGPU_STEP_PARTIAL, "a fused filter/project feeds a SINGLE or PARTIAL aggregation");
@@ -383,7 +419,7 @@ int32_t tgpu_precompile_fused_probe(int32_t input_type_count, const int32_t *inp
 
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(factory), [&] {
         TG_CHECK_ARG(factory && out, "null argument");
         auto o = std::make_unique<tgpu_operator>();
         o->op = factory->f->create_operator();
@@ -395,7 +431,7 @@ int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tg
 
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory)
 {
-    return guard([&] {
+    return guard_on(ctx_of(factory), [&] {
         TG_CHECK_ARG(factory != nullptr, "factory is null");
         factory->f->no_more_operators();
     });
@@ -412,7 +448,7 @@ void tgpu_operator_factory_destroy(tgpu_operator_factory *factory)
 // ---- Operator -------------------------------------------------------------------------------------------------------
 #define OP_BOOL(expr)                                            \
     int32_t result = 0;                                          \
-    int32_t rc = guard([&] {                                     \
+    int32_t rc = guard_on(ctx_of(op), [&] {                      \
         TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed"); \
         result = (expr) ? 1 : 0;                                 \
     });                                                          \
@@ -424,7 +460,7 @@ int32_t tgpu_operator_is_blocked(tgpu_operator *op) { OP_BOOL(op->op->is_blocked
 
 int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
         TG_CHECK_ARG(page != nullptr, "page is null");
         TG_CHECK_STATE(op->op->needs_input(), "Operator does not need input");
@@ -434,7 +470,7 @@ int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page)
 
 int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op != nullptr && op->op && out, "null argument");
         *out = nullptr;
         std::unique_ptr<OutputPage> p = op->op->get_output();
@@ -444,7 +480,7 @@ int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
 
 int32_t tgpu_operator_finish(tgpu_operator *op)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
         op->op->finish();
     });
@@ -453,7 +489,7 @@ int32_t tgpu_operator_finish(tgpu_operator *op)
 int64_t tgpu_operator_memory_bytes(tgpu_operator *op)
 {
     int64_t v = 0;
-    int32_t rc = guard([&] {
+    int32_t rc = guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
         v = op->op->memory_bytes();
     });
@@ -463,7 +499,7 @@ int64_t tgpu_operator_memory_bytes(tgpu_operator *op)
 void tgpu_operator_close(tgpu_operator *op)
 {
     if (!op) return;
-    guard([&] {
+    guard_on(ctx_of(op), [&] {
         if (op->op) op->op->close();
     });
     Context *c = op->ctx;
@@ -477,7 +513,7 @@ int32_t tgpu_output_page_channel_count(const tgpu_output_page *page) { return pa
 
 int32_t tgpu_output_page_as_page(const tgpu_output_page *page, tgpu_page *out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(page), [&] {
         TG_CHECK_ARG(page && out, "null argument");
         auto *p = const_cast<tgpu_output_page *>(page);
         p->blocks.clear();
@@ -500,7 +536,7 @@ int32_t tgpu_output_page_as_page(const tgpu_output_page *page, tgpu_page *out)
 
 int32_t tgpu_output_page_block_info(const tgpu_output_page *page, int32_t ch, int32_t *type, int64_t *value_bytes, int32_t *may_have_nulls)
 {
-    return guard([&] {
+    return guard_on(ctx_of(page), [&] {
         TG_CHECK_ARG(page != nullptr && ch >= 0 && ch < (int)page->page.cols.size(), "bad page / channel");
         const DeviceColumn &c = page->page.cols[(size_t)ch];
         if (type) *type = c.type;
@@ -522,7 +558,7 @@ int32_t tgpu_output_page_block_info(const tgpu_output_page *page, int32_t ch, in
 
 int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, void *values, uint8_t *nulls, int32_t *offsets)
 {
-    return guard([&] {
+    return guard_on(ctx_of(page), [&] {
         TG_CHECK_ARG(page != nullptr && ch >= 0 && ch < (int)page->page.cols.size(), "bad page / channel");
         const DeviceColumn &c = page->page.cols[(size_t)ch];
         const int64_t n = page->page.n;
@@ -549,7 +585,7 @@ int32_t tgpu_output_page_copy_block(const tgpu_output_page *page, int32_t ch, vo
 int32_t tgpu_output_page_copy_blocks(const tgpu_output_page *page, int32_t channel_count, void *const *values, uint8_t *const *nulls,
                                      int32_t *const *offsets)
 {
-    return guard([&] {
+    return guard_on(ctx_of(page), [&] {
         TG_CHECK_ARG(page != nullptr && values != nullptr && nulls != nullptr && offsets != nullptr, "null argument");
         TG_CHECK_ARG(channel_count == (int)page->page.cols.size(), "channel count differs from the page's");
         const int64_t n = page->page.n;
@@ -594,7 +630,7 @@ void tgpu_output_page_release(tgpu_output_page *page)
 int32_t tgpu_group_by_hash_create(tgpu_context *ctx, int32_t type_count, const int32_t *types, const int32_t *hash_channels, int32_t input_hash_channel,
                                   int32_t expected_size, tgpu_group_by_hash **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         auto g = std::make_unique<tgpu_group_by_hash>();
         g->ctx = ctx->ctx.get();
@@ -629,7 +665,7 @@ static void gbh_inputs(tgpu_group_by_hash *g, const DevicePage &in, std::vector<
 
 int32_t tgpu_group_by_hash_get_group_ids(tgpu_group_by_hash *gbh, const tgpu_page *page, int64_t *group_ids, int64_t *group_count)
 {
-    return guard([&] {
+    return guard_on(ctx_of(gbh), [&] {
         TG_CHECK_ARG(gbh && page, "null argument");
         DevicePage in = ingest_page(gbh->ctx, page);
         std::vector<const DeviceColumn *> keys;
@@ -651,7 +687,7 @@ int32_t tgpu_group_by_hash_add_page(tgpu_group_by_hash *gbh, const tgpu_page *pa
 
 int32_t tgpu_group_by_hash_contains(tgpu_group_by_hash *gbh, int32_t position, const tgpu_page *page, int32_t *result)
 {
-    return guard([&] {
+    return guard_on(ctx_of(gbh), [&] {
         TG_CHECK_ARG(gbh && page && result, "null argument");
         DevicePage in = ingest_page(gbh->ctx, page);
         TG_CHECK_ARG(position >= 0 && position < in.n, "position out of range");
@@ -675,7 +711,7 @@ int32_t tgpu_group_by_hash_rehash_count(tgpu_group_by_hash *gbh) { return gbh ? 
 
 int32_t tgpu_group_by_hash_append_values(tgpu_group_by_hash *gbh, tgpu_output_page **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(gbh), [&] {
         TG_CHECK_ARG(gbh && out, "null argument");
         DevicePage p = gbh->gbh->key_page(gbh->input_hash_channel >= 0);
         *out = release_output(make_output(gbh->ctx, std::move(p)));
@@ -685,7 +721,7 @@ int32_t tgpu_group_by_hash_append_values(tgpu_group_by_hash *gbh, tgpu_output_pa
 // ---- hash / partition -----------------------------------------------------------------------------------------------
 int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel_count, const int32_t *channels, int64_t *hashes)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && page && hashes, "null argument");
         Context *c = ctx->ctx.get();
         DevicePage in = ingest_page(c, page);
@@ -704,7 +740,7 @@ int32_t tgpu_hash_page(tgpu_context *ctx, const tgpu_page *page, int32_t channel
 int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels, int32_t hash_channel,
                             int32_t partition_count, int64_t *counts, tgpu_output_page **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && page && counts && out, "null argument");
         TG_CHECK_ARG(partition_count > 0 && partition_count <= 1024, "partition count must be in 1..1024");
         Context *c = ctx->ctx.get();
@@ -742,7 +778,7 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
 
 int32_t tgpu_operator_add_input_output_page(tgpu_operator *op, const tgpu_output_page *page)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op && page, "null argument");
         op->op->add_input_owned(page->page);
     });
@@ -751,7 +787,7 @@ int32_t tgpu_operator_add_input_output_page(tgpu_operator *op, const tgpu_output
 int32_t tgpu_lookup_outer_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge, int32_t probe_output_type_count,
                                          const int32_t *probe_output_types, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && bridge && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<LookupOuterOperatorFactory>(ctx->ctx.get(), operator_id, vec(probe_output_types, probe_output_type_count), bridge->bridge);
@@ -765,7 +801,7 @@ int32_t tgpu_dynamic_filter_source_factory_create(tgpu_context *ctx, int32_t ope
                                                   const int32_t *channels, int32_t max_distinct_values, int64_t max_filter_size_in_bytes,
                                                   int32_t min_max_collection_limit, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<DynamicFilterSourceOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), vec(channels, channel_count), max_distinct_values,
@@ -778,7 +814,7 @@ int32_t tgpu_dynamic_filter_source_factory_create(tgpu_context *ctx, int32_t ope
 
 int32_t tgpu_dynamic_filter_source_result(tgpu_operator *op, int32_t filter_channel, int32_t *kind, tgpu_output_page **values, int64_t *min, int64_t *max)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op && kind && values && min && max, "null argument");
         *values = nullptr;
         std::unique_ptr<OutputPage> page;
@@ -790,7 +826,7 @@ int32_t tgpu_dynamic_filter_source_result(tgpu_operator *op, int32_t filter_chan
 int32_t tgpu_merge_pages_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int64_t min_page_size_in_bytes,
                                         int32_t min_row_count, int64_t max_page_size_in_bytes, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<MergePagesOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), min_page_size_in_bytes, min_row_count, max_page_size_in_bytes);
@@ -804,7 +840,7 @@ int32_t tgpu_partitioned_output_factory_create(tgpu_context *ctx, int32_t operat
                                                const int32_t *partition_channels, int32_t hash_channel, int32_t partition_count, int32_t replicates_any_row,
                                                int32_t null_channel, int32_t partition_function, tgpu_operator_factory **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out, "null argument");
         auto f = std::make_unique<tgpu_operator_factory>();
         f->f = std::make_unique<PartitionedOutputOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), vec(partition_channels, partition_channel_count),
@@ -817,7 +853,7 @@ int32_t tgpu_partitioned_output_factory_create(tgpu_context *ctx, int32_t operat
 
 int32_t tgpu_partitioned_output_poll(tgpu_operator *op, int32_t *partition, tgpu_output_page **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op && partition && out, "null argument");
         *out = nullptr;
         *partition = -1;
@@ -828,7 +864,7 @@ int32_t tgpu_partitioned_output_poll(tgpu_operator *op, int32_t *partition, tgpu
 
 int32_t tgpu_partitioned_output_info(tgpu_operator *op, int64_t *rows_added, int64_t *pages_added)
 {
-    return guard([&] {
+    return guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op && rows_added && pages_added, "null argument");
         partitioned_output_info(op->op.get(), rows_added, pages_added);
     });
@@ -836,7 +872,7 @@ int32_t tgpu_partitioned_output_info(tgpu_operator *op, int64_t *rows_added, int
 
 int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out, int64_t capacity, int64_t *out_len)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && page && out_len, "null argument");
         Context *c = ctx->ctx.get();
         DevicePage in = ingest_page(c, page);
@@ -846,7 +882,7 @@ int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out,
 
 int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len, int32_t type_count, const int32_t *types, tgpu_output_page **out)
 {
-    return guard([&] {
+    return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && bytes && out && (types || type_count == 0), "null argument");
         Context *c = ctx->ctx.get();
         *out = nullptr;

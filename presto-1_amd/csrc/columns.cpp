@@ -141,6 +141,29 @@ static DeviceColumn ingest_block_raw(Context *ctx, const tgpu_block *b)
     return c;
 }
 
+// A column that borrows caller memory (a device-resident input block: no owning buffers) is only valid during the call; an operator
+// that lets such a column out again (an identity projection, a page passing through) gives it buffers of its own first.
+void own_borrowed_columns(Context *ctx, DevicePage &page)
+{
+    for (DeviceColumn &c : page.cols) {
+        if (c.n <= 0 || c.values_buf) continue;
+        const size_t vbytes = (size_t)c.value_bytes();   // VARCHAR: the pool up to offsets[n] (offsets stay absolute)
+        c.values_buf = ctx->alloc(vbytes ? vbytes : 1);
+        if (vbytes) HIP_CHECK(hipMemcpyAsync(c.values_buf->ptr(), c.values, vbytes, hipMemcpyDeviceToDevice, ctx->stream()));
+        c.values = c.values_buf->ptr();
+        if (c.nulls) {
+            c.nulls_buf = ctx->alloc((size_t)c.n);
+            HIP_CHECK(hipMemcpyAsync(c.nulls_buf->ptr(), c.nulls, (size_t)c.n, hipMemcpyDeviceToDevice, ctx->stream()));
+            c.nulls = c.nulls_buf->as<uint8_t>();
+        }
+        if (c.offsets) {
+            c.offsets_buf = ctx->alloc((size_t)(c.n + 1) * 4);
+            HIP_CHECK(hipMemcpyAsync(c.offsets_buf->ptr(), c.offsets, (size_t)(c.n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream()));
+            c.offsets = c.offsets_buf->as<int32_t>();
+        }
+    }
+}
+
 DevicePage ingest_page(Context *ctx, const tgpu_page *page)
 {
     TG_CHECK_ARG(page != nullptr, "page is null");

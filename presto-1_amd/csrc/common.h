@@ -127,6 +127,9 @@ public:
     std::string profile_json();
 
     int cu_count() const { return cu_count_; }
+    // tgpu_context_set_double_sum_order: read by the aggregation operators when they create their accumulators
+    int double_sum_order() const { return double_sum_order_; }
+    void set_double_sum_order(int order) { double_sum_order_ = order; }
 
     // C-ABI handle accounting: the context outlives every factory / operator / output page created from it, whatever the
     // order in which the caller destroys its handles (tgpu_context_destroy defers until the last handle is gone)
@@ -145,6 +148,7 @@ private:
     hipStream_t stream_;
     bool own_stream_ = false;
     int cu_count_ = 256;
+    int double_sum_order_ = 0;
     std::multimap<size_t, void *> free_;
     size_t in_use_ = 0, cached_ = 0;
     void *pinned_ = nullptr;
@@ -244,6 +248,8 @@ inline KeyCols key_cols_of(const std::vector<const DeviceColumn *> &cols)
 // ingest: tgpu_page (host or device memory, any encoding) -> flat device columns.  columns.cpp
 DevicePage ingest_page(Context *ctx, const tgpu_page *page);
 DeviceColumn ingest_block(Context *ctx, const tgpu_block *block);
+// gives every column of `page` that still borrows caller memory (device-resident input) buffers of its own (a device copy)
+void own_borrowed_columns(Context *ctx, DevicePage &page);
 
 // output pages handed across the C ABI
 struct OutputPage {

@@ -117,7 +117,10 @@ BufferPtr Context::alloc(size_t bytes)
                 fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "out of device memory allocating " + std::to_string(cap) + " bytes");
         }
     }
-    in_use_ += cap;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        in_use_ += cap;
+    }
     return std::make_shared<DeviceBuffer>(this, p, bytes, cap);
 }
 

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <fstream>
 #include <functional>
+#include <list>
 #include <tuple>
 #include <set>
 #include <sstream>
@@ -63,13 +64,14 @@ static uint64_t fnv1a(const std::string &s)
     return h;
 }
 
+static const char *kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+
 static std::vector<char> compile_source(const std::string &source)
 {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, source.c_str(), "tgpu_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         fail(TGPU_ERR_COMPILER, "hiprtcCreateProgram failed");
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    hiprtcResult r = hiprtcCompileProgram(prog, 3, kCompileOptions);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -86,11 +88,46 @@ static std::vector<char> compile_source(const std::string &source)
     return code;
 }
 
+// What a cached code object depends on besides the source text: the compiler (hiprtc version), its options and the target.
+static const std::string &toolchain_tag()
+{
+    static const std::string tag = [] {
+        int major = 0, minor = 0;
+        hiprtcVersion(&major, &minor);
+        std::string t = "hiprtc " + std::to_string(major) + "." + std::to_string(minor);
+        for (const char *o : kCompileOptions) t += std::string(" ") + o;
+        return t;
+    }();
+    return tag;
+}
+
+static uint64_t fnv1a_seeded(const std::string &s, uint64_t h)
+{
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ULL; }
+    return h;
+}
+
 static std::string cache_path(const std::string &source)
 {
     char name[64];
-    snprintf(name, sizeof(name), "%016llx.hsaco", (unsigned long long)fnv1a(source));
+    snprintf(name, sizeof(name), "%016llx.hsaco", (unsigned long long)fnv1a(toolchain_tag() + "\n" + source));
     return resource_dir() + "/_kcache/" + name;
+}
+
+// A cache file = header {magic, a second independent hash of (toolchain, source), source length} + the code object: a file that was
+// written for another source with the same 64-bit name, by another toolchain, or cut short, is recompiled instead of loaded.
+struct CacheHeader {
+    char magic[8];
+    uint64_t check, source_len, code_len;
+};
+static CacheHeader header_for(const std::string &source, size_t code_len)
+{
+    CacheHeader h{};
+    memcpy(h.magic, "TGPUJIT2", 8);
+    h.check = fnv1a_seeded(source + "\n" + toolchain_tag(), 0x9E3779B97F4A7C15ULL);
+    h.source_len = source.size();
+    h.code_len = code_len;
+    return h;
 }
 
 // compile (or fetch from the disk cache) the code object of `source`
@@ -105,8 +142,12 @@ static std::vector<char> code_object_for(const std::string &source)
     {
         std::ifstream f(path, std::ios::binary);
         if (f) {
-            std::vector<char> code((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-            if (!code.empty()) return code;
+            std::vector<char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            if (file.size() > sizeof(CacheHeader)) {
+                CacheHeader got, want = header_for(source, file.size() - sizeof(CacheHeader));
+                memcpy(&got, file.data(), sizeof(got));
+                if (memcmp(&got, &want, sizeof(got)) == 0) return std::vector<char>(file.begin() + sizeof(CacheHeader), file.end());
+            }
         }
     }
     std::vector<char> code = compile_source(source);
@@ -115,12 +156,56 @@ static std::vector<char> code_object_for(const std::string &source)
     {
         std::ofstream f(tmp, std::ios::binary);
         if (f) {
+            const CacheHeader h = header_for(source, code.size());
+            f.write(reinterpret_cast<const char *>(&h), sizeof(h));
             f.write(code.data(), (std::streamsize)code.size());
             f.close();
             rename(tmp.c_str(), path.c_str());  // atomic publish; a read-only tree just skips the cache
         }
     }
     return code;
+}
+
+// A process-wide cache bounded like the reference's compiled-class caches (PageFunctionCompiler's expression caches hold a
+// configured maximum, M/sql/gen/PageFunctionCompiler.java:101-139): least recently used entries are dropped; whoever still
+// uses an evicted object keeps it alive through its shared_ptr.
+template <typename V> class LruCache {
+public:
+    explicit LruCache(size_t capacity) : capacity_(capacity) {}
+    template <typename Make> std::shared_ptr<V> get(const std::string &key, Make make)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = map_.find(key);
+        if (it != map_.end()) {
+            order_.splice(order_.begin(), order_, it->second.second);
+            return it->second.first;
+        }
+        std::shared_ptr<V> obj = make();
+        order_.push_front(key);
+        map_[key] = {obj, order_.begin()};
+        while (map_.size() > capacity_) {
+            map_.erase(order_.back());
+            order_.pop_back();
+        }
+        return obj;
+    }
+    size_t size()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return map_.size();
+    }
+
+private:
+    size_t capacity_;
+    std::mutex mu_;
+    std::list<std::string> order_;
+    std::map<std::string, std::pair<std::shared_ptr<V>, std::list<std::string>::iterator>> map_;
+};
+static size_t jit_cache_capacity()
+{
+    const char *v = getenv("TGPU_JIT_CACHE_ENTRIES");
+    const long n = v ? atol(v) : 0;
+    return n > 0 ? (size_t)n : 1000;   // the reference's expression-cache-size default is 1000 entries
 }
 
 struct JitModule {
@@ -162,20 +247,17 @@ struct JitModule {
 // :101-139 and JoinCompiler.java:89-107).
 static std::shared_ptr<JitModule> load_module(const std::string &source)
 {
-    static std::mutex mu;
-    static std::map<std::string, std::shared_ptr<JitModule>> loaded;
+    static LruCache<JitModule> loaded(jit_cache_capacity());
     int device = 0;
-    HIP_CHECK(hipGetDevice(&device));
+    HIP_CHECK(hipGetDevice(&device));   // the calling thread is bound to the context's device (c_api.cpp bind_thread)
     const std::string key = std::to_string(device) + ":" + std::to_string(source.size()) + ":" + cache_path(source);
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = loaded.find(key);
-    if (it != loaded.end()) return it->second;
-    std::vector<char> code = code_object_for(source);
-    auto m = std::make_shared<JitModule>();
-    hipError_t e = hipModuleLoadData(&m->mod, code.data());
-    if (e != hipSuccess) fail(TGPU_ERR_COMPILER, std::string("hipModuleLoadData failed: ") + hipGetErrorString(e));
-    loaded[key] = m;
-    return m;
+    return loaded.get(key, [&] {
+        std::vector<char> code = code_object_for(source);
+        auto m = std::make_shared<JitModule>();
+        hipError_t e = hipModuleLoadData(&m->mod, code.data());
+        if (e != hipSuccess) fail(TGPU_ERR_COMPILER, std::string("hipModuleLoadData failed: ") + hipGetErrorString(e));
+        return m;
+    });
 }
 
 // text of a device header shipped next to the library (csrc/), with its #pragma once removed, for embedding in JIT sources
@@ -776,14 +858,8 @@ std::string spec_key(const char *what, const std::vector<int32_t> &input_types, 
 
 template <typename T, typename Make> std::shared_ptr<T> cached_object(const std::string &key, Make make)
 {
-    static std::mutex mu;
-    static std::map<std::string, std::shared_ptr<T>> objects;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = objects.find(key);
-    if (it != objects.end()) return it->second;
-    std::shared_ptr<T> obj = make();
-    objects[key] = obj;
-    return obj;
+    static LruCache<T> objects(jit_cache_capacity());
+    return objects.get(key, make);
 }
 }  // namespace
 
@@ -2430,7 +2506,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
     if (in.n == 0) return;
     BufferPtr widened;
-    if (gids8 && groups > max_groups_) {   // the ORDERED / exact-global paths take int32 ids
+    if (gids8 && (groups > max_groups_ || accs.force_ordered())) {   // the ORDERED / exact-global paths take int32 ids
         widened = ctx->alloc((size_t)in.n * 4);
         widen_gids_kernel<<<(int)std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8), 256, 0, ctx->stream()>>>(gids8, in.n, widened->as<int>());
         check_launch("widen_gids");

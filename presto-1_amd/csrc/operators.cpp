@@ -28,12 +28,14 @@ public:
     {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
         TG_CHECK_STATE(!pending_, "Operator still has pending output");
-        DevicePage in = ingest_page(ctx_, page);
-        DevicePage out;
-        if (processor_->process(ctx_, in, out)) {
-            retained_ = std::move(in);  // identity projections may alias input blocks
-            pending_ = wrap(std::move(out));
-        }
+        run(ingest_page(ctx_, page));
+    }
+    // a page of this library: identity projections that pass a block through share its (reference counted) buffers
+    void add_input_owned(const DevicePage &page) override
+    {
+        TG_CHECK_STATE(!finishing_, "Operator is already finishing");
+        TG_CHECK_STATE(!pending_, "Operator still has pending output");
+        run(DevicePage(page));
     }
 
     std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
@@ -42,9 +44,19 @@ public:
     int64_t memory_bytes() override { return pending_ ? pending_->page.size_in_bytes() : 0; }
 
 private:
+    void run(DevicePage in)
+    {
+        DevicePage out;
+        if (!processor_->process(ctx_, in, out)) return;
+        // An identity projection (InputPageProjection) may pass an input block through unchanged.  The output page must outlive
+        // the call and the input page (tgpu.h ownership rule): a passed-through block that borrows the caller's device memory
+        // is copied; one that came with owners (host ingest, add_input_owned) keeps them alive through its BufferPtrs.
+        own_borrowed_columns(ctx_, out);
+        pending_ = wrap(std::move(out));
+    }
+
     std::shared_ptr<PageProcessorGpu> processor_;
     std::unique_ptr<OutputPage> pending_;
-    DevicePage retained_;
     bool finishing_ = false;
 };
 
@@ -155,6 +167,7 @@ protected:
             gbh_ = std::make_unique<GroupByHashGpu>(ctx_, cfg_.group_by_types, cfg_.hash_channel >= 0, cfg_.expected_groups);
         accs_ = std::make_unique<GroupedAccumulators>(ctx_, cfg_.aggs, cfg_.step);
         accs_->set_allow_ordered(allow_ordered_accumulation());
+        accs_->set_force_ordered(ctx_->double_sum_order() == TGPU_SUM_ORDER_JAVA);
         builder_ = true;
     }
     // many groups: rows sorted by group id, one lane per group adds them in row order (agg.h)

@@ -87,21 +87,61 @@ private:
 // ---- join bridge: PartitionedLookupSourceFactory with one partition (M/operator/PartitionedLookupSourceFactory.java:146-205)
 class LookupSourceFactory {
 public:
-    std::shared_ptr<LookupSourceGpu> lookup_source() const { return source_; }
-    void lend(std::shared_ptr<LookupSourceGpu> s) { source_ = std::move(s); }
-    void probe_created() { live_probes_++; any_probe_ = true; }
-    void probe_closed() { live_probes_--; }
-    void no_more_probes() { no_more_probes_ = true; }
+    // The bridge is shared by the build operator, every probe operator and the outer operator, which the reference runs in
+    // different drivers (threads): all of its state is guarded by one mutex.
+    std::shared_ptr<LookupSourceGpu> lookup_source() const
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return source_;
+    }
+    void lend(std::shared_ptr<LookupSourceGpu> s)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        source_ = std::move(s);
+    }
+    void probe_created()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        live_probes_++;
+        any_probe_ = true;
+    }
+    void probe_closed()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        live_probes_--;
+    }
+    void no_more_probes()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        no_more_probes_ = true;
+    }
     // every probe operator is done: the outer position iterator becomes available (PartitionedLookupSourceFactory.java:259-297)
-    bool probes_finished() const { return no_more_probes_ && live_probes_ == 0; }
+    bool probes_finished() const
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return no_more_probes_ && live_probes_ == 0;
+    }
     // LOOKUP_OUTER / FULL_OUTER joins: the LookupOuterOperator keeps the table alive until it has emitted the unmatched rows
-    void outer_expected() { outer_expected_ = true; }
-    void outer_done() { outer_done_ = true; }
+    void outer_expected()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        outer_expected_ = true;
+    }
+    void outer_done()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        outer_done_ = true;
+    }
     // the build operator may release the table once every probe operator is done (HashBuilderOperator.java:429-470)
-    bool destroyed() const { return probes_finished() && (!outer_expected_ || outer_done_); }
-    std::vector<int32_t> build_output_types;
+    bool destroyed() const
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return no_more_probes_ && live_probes_ == 0 && (!outer_expected_ || outer_done_);
+    }
+    std::vector<int32_t> build_output_types;   // written by the build factory's constructor, read-only afterwards
 
 private:
+    mutable std::mutex mu_;
     std::shared_ptr<LookupSourceGpu> source_;
     int live_probes_ = 0;
     bool any_probe_ = false, no_more_probes_ = false, outer_expected_ = false, outer_done_ = false;

@@ -140,12 +140,21 @@ BufferPtr upload_section(Context *ctx, const uint8_t *src, int64_t bytes)
 }
 
 // null bits of `n` positions: fills c.nulls (device) and returns the exclusive scan of the not-null flags (nullptr = no nulls)
-BufferPtr read_null_bits(Context *ctx, Reader &r, int64_t n, DeviceColumn &c)
+// *null_count (optional): the number of set null bits among the n positions, counted on the host from the wire bytes
+BufferPtr read_null_bits(Context *ctx, Reader &r, int64_t n, DeviceColumn &c, int64_t *null_count = nullptr)
 {
     const uint8_t may_have_null = r.u8();
+    if (null_count) *null_count = 0;
     if (!may_have_null) return nullptr;
     const int64_t bytes = (n + 7) / 8;
-    BufferPtr packed = upload_section(ctx, r.take(bytes), bytes);
+    const uint8_t *bits = r.take(bytes);
+    if (null_count) {   // EncoderUtil.java:33-71: 8 positions per byte, MSB first; the tail byte's unused low bits are ignored
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < n / 8; i++) cnt += __builtin_popcount(bits[i]);
+        if (n % 8) cnt += __builtin_popcount(bits[n / 8] >> (8 - n % 8));
+        *null_count = cnt;
+    }
+    BufferPtr packed = upload_section(ctx, bits, bytes);
     c.nulls_buf = ctx->alloc((size_t)(n > 0 ? n : 1));
     c.nulls = c.nulls_buf->as<uint8_t>();
     BufferPtr flags = ctx->alloc((size_t)(n > 0 ? n : 1) * 4), rank = ctx->alloc((size_t)(n > 0 ? n : 1) * 4), total = ctx->alloc(8);
@@ -173,14 +182,17 @@ DeviceColumn read_fixed(Context *ctx, Reader &r, int32_t type, int width)
     DeviceColumn c;
     c.type = type;
     c.n = n;
-    BufferPtr rank = read_null_bits(ctx, r, n, c);
+    int64_t null_count = 0;
+    BufferPtr rank = read_null_bits(ctx, r, n, c, &null_count);
     if (!rank) {
         c.values_buf = upload_section(ctx, r.take(n * width), n * width);
         c.values = c.values_buf->ptr();
         return c;
     }
     const int64_t non_null = r.i32();
-    TG_CHECK_ARG(non_null >= 0 && non_null <= n, "bad non-null position count");
+    // the expansion kernel indexes the compacted values by the rank among the clear null bits: the two must agree
+    // (the JVM would fail with an IndexOutOfBounds on such a page; here it would be an out-of-bounds device read)
+    TG_CHECK_ARG(non_null == n - null_count, "non-null position count does not match the null bits");
     BufferPtr compact = upload_section(ctx, r.take(non_null * width), non_null * width);
     c.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1) * (size_t)width);
     c.values = c.values_buf->ptr();
@@ -201,6 +213,15 @@ DeviceColumn read_variable_width(Context *ctx, Reader &r, int32_t type)
     c.type = type;
     c.n = n;
     const uint8_t *ends = r.take(n * 4);
+    {   // every kernel that touches a VARCHAR column trusts its offsets: validate them here, like the dictionary ids below
+        int32_t prev = 0;
+        for (int64_t i = 0; i < n; i++) {
+            int32_t e;
+            memcpy(&e, ends + i * 4, 4);
+            TG_CHECK_ARG(e >= prev, "variable width offsets are negative or not ascending");
+            prev = e;
+        }
+    }
     c.offsets_buf = ctx->alloc((size_t)(n + 1) * 4);
     c.offsets = c.offsets_buf->as<int32_t>();
     HIP_CHECK(hipMemsetAsync(c.offsets_buf->ptr(), 0, 4, ctx->stream()));

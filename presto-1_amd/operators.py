@@ -19,6 +19,7 @@ SINGLE, PARTIAL, FINAL = 0, 1, 2
 # S/connector/SortOrder.java:18-21
 ASC_NULLS_FIRST, ASC_NULLS_LAST, DESC_NULLS_FIRST, DESC_NULLS_LAST = 0, 1, 2, 3
 INNER, PROBE_OUTER, LOOKUP_OUTER, FULL_OUTER = 0, 1, 2, 3   # LookupJoinOperators.JoinType ordinals
+SUM_ORDER_EXACT, SUM_ORDER_JAVA = 0, 1                      # tgpu_double_sum_order
 
 
 def _i32(seq):
@@ -36,6 +37,10 @@ class Context:
 
     def synchronize(self):
         _lib.check(_lib.lib().tgpu_context_synchronize(self.handle))
+
+    def set_double_sum_order(self, order):
+        """SUM_ORDER_EXACT (default) or SUM_ORDER_JAVA for the aggregation operators created from now on (tgpu.h)"""
+        _lib.check(_lib.lib().tgpu_context_set_double_sum_order(self.handle, order))
 
     def profile_enable(self, on=True):
         _lib.check(_lib.lib().tgpu_profile_enable(self.handle, int(on)))

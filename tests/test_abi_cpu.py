@@ -76,3 +76,20 @@ def test_jit_compiles_without_gpu(pkg, tmp_path):
     with pytest.raises(pkg.TgpuError) as e:  # type errors surface as COMPILER_ERROR like PageFunctionCompiler.java:199-205
         pkg.precompile_page_processor([pkg.BIGINT], f(0, pkg.DOUBLE) < 7.0, [])
     assert e.value.code == -4
+
+
+def test_every_handle_entry_point_binds_the_device():
+    """source-level check (no GPU here): every extern "C" function of c_api.cpp that takes a handle and reaches device code goes
+    through guard_on(ctx_of(handle), ...), which binds the calling thread to the context's device (hipSetDevice is per thread)"""
+    text = open(os.path.join(ROOT, "presto-1_amd", "csrc", "c_api.cpp")).read()
+    body = text[text.index('extern "C" {'):]
+    fns = re.split(r"\n(?=(?:int32_t|int64_t|void|const char \*)\s*\*?tgpu_[a-z0-9_]+\()", body)
+    handle = re.compile(r"(?:const\s+)?tgpu_(?:context|operator_factory|operator|lookup_source_factory|group_by_hash|output_page)\s*\*\s*[a-z_]+")
+    checked = 0
+    for fn in fns:
+        sig = fn.split("{", 1)[0]
+        if not handle.search(sig) or not re.search(r"\bguard(_on)?\(", fn):
+            continue
+        checked += 1
+        assert "guard_on(ctx_of(" in fn, sig.strip()[:80]
+    assert checked >= 40

@@ -1109,6 +1109,34 @@ def test_deserialize_rejects_what_it_cannot_read(pkg, ctx, oracle):
         ctx.deserialize_page(bytes(data), [pkg.BIGINT, pkg.BIGINT])
 
 
+def test_deserialize_rejects_inconsistent_offsets_and_null_counts(pkg, ctx, oracle):
+    """corrupt exchange / spill pages must fail on the host (the JVM would throw IndexOutOfBounds), never reach a kernel:
+    VARIABLE_WIDTH end offsets that are negative, descending or beyond the block size; a nonNullCount that disagrees with the null bits"""
+    import struct
+    good = oracle.serialize_page([oracle.Col(oracle.VARCHAR, ["ab", "cde", "", "f"])])
+    ends = struct.pack("<4i", 2, 5, 5, 6)
+    at = good.index(ends)
+    assert ctx.deserialize_page(good, [pkg.VARCHAR]).to_host().getBlock(0).to_list() == ["ab", "cde", "", "f"]
+    for tampered in [(2, 1, 5, 6), (-1, 5, 5, 6), (2, 5, 7, 6), (2, 5, 5, 9)]:
+        bad = bytearray(good)
+        bad[at:at + 16] = struct.pack("<4i", *tampered)
+        with pytest.raises(pkg.TgpuError) as e:
+            ctx.deserialize_page(bytes(bad), [pkg.VARCHAR])
+        assert e.value.code == -1, tampered
+    col = oracle.Col(oracle.BIGINT, np.array([7, 0, 9, 0, 11], dtype=np.int64), np.array([0, 1, 0, 1, 0], dtype=np.uint8))
+    good = oracle.serialize_page([col])
+    assert ctx.deserialize_page(good, [pkg.BIGINT]).to_host().getBlock(0).to_list() == [7, None, 9, None, 11]
+    # LongArrayBlockEncoding with nulls: ... mayHaveNull(1) | null bits (1 byte for 5 positions) | nonNullCount(int32) | values
+    bits = bytes([0b01010000])
+    at = good.index(b"\x01" + bits + struct.pack("<i", 3)) + 2
+    for count in (2, 4, 5, 0):
+        bad = bytearray(good)
+        bad[at:at + 4] = struct.pack("<i", count)
+        with pytest.raises(pkg.TgpuError) as e:
+            ctx.deserialize_page(bytes(bad), [pkg.BIGINT])
+        assert e.value.code == -1, count
+
+
 def test_serde_round_trip_device_page_full_size(pkg, ctx):
     # size-independent property at a full page: serialize(deserialize(bytes)) == bytes, through a device-resident page (the
     # decoded OutputPage is fed back without leaving HBM)
@@ -1574,3 +1602,126 @@ def test_dynamic_filter_source_small_cases(pkg, ctx):
     fac.close()
     with pytest.raises(pkg.TgpuError):
         pkg.DynamicFilterSourceOperatorFactory(ctx, 72, [pkg.BIGINT], [0, 0], 10, 10, 10)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ownership / lifetime / threading regressions (round-1 review)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["borrowed", "owned"])
+def test_identity_projection_output_survives_release_of_its_input(pkg, ctx, mode):
+    """tgpu.h ownership rule: an output page is valid until ITS release, whatever happens to the page it was computed from.  A
+    FilterAndProject whose filter selects every row passes identity projections through: the passed-through blocks must keep
+    (owned input) or get (borrowed device input) buffers of their own -- the upstream page is released and its memory reused
+    before the output is read."""
+    n = 300_000
+    B, V = pkg.BIGINT, pkg.VARCHAR
+    f = pkg.field
+    vals = np.arange(n, dtype=np.int64)
+    strs = [f"s{i % 97}" for i in range(n)]
+    nulls = (vals % 11 == 0).astype(np.uint8)
+    up = pkg.FilterAndProjectOperatorFactory(ctx, 0, [B, V], None, [f(0, B) + 1, f(1, V)])
+    upstream = pkg.to_pages(up.createOperator(), [pkg.Page(pkg.Block(B, vals, nulls), pkg.Block(V, strs))], to_host=False)[0]
+    fp = pkg.FilterAndProjectOperatorFactory(ctx, 1, [B, V], pkg.or_(f(0, B) >= 0, pkg.is_null(f(0, B))), [f(0, B), f(1, V)])
+    op = fp.createOperator()
+    op.addInput(upstream if mode == "owned" else upstream.as_device_page())
+    out = op.getOutput()
+    upstream.release()
+    # the caching allocator hands the freed buffers to the next allocations of the same size: overwrite them
+    junk = pkg.to_pages(up.createOperator(), [pkg.Page(pkg.Block(B, vals * 0 - 7), pkg.Block(V, ["zzzzzz"] * n))], to_host=False)
+    ctx.synchronize()
+    host = out.to_host()
+    want = [None if nulls[i] else int(vals[i]) + 1 for i in range(n)]
+    assert host.getBlock(0).to_list() == want
+    assert host.getBlock(1).to_list() == strs
+    out.release()
+    for j in junk:
+        j.release()
+    op.close()
+
+
+def test_context_destroyed_before_its_handles(pkg):
+    """tgpu_context_destroy defers until the last factory / operator / output page created from the context is gone, whatever the
+    order in which the caller drops its handles (an operator finalised after its context used to crash the host)"""
+    c = pkg.Context(0)
+    f = pkg.field
+    fac = pkg.FilterAndProjectOperatorFactory(c, 0, [pkg.BIGINT], f(0, pkg.BIGINT) > 2, [f(0, pkg.BIGINT) * 2])
+    op = fac.createOperator()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(10, dtype=np.int64))))
+    out = op.getOutput()
+    g = pkg.GroupByHash(c, [pkg.BIGINT], [0])
+    c.close()                                            # requested; handles are still alive
+    assert out.to_host().getBlock(0).to_list() == [6, 8, 10, 12, 14, 16, 18]
+    assert list(g.getGroupIds(pkg.Page(pkg.Block(pkg.BIGINT, np.array([5, 5, 9], dtype=np.int64))))) == [0, 0, 1]
+    out.release()
+    op.close()
+    g.close()
+    fac.close()                                          # the last handle destroys the context
+    c2 = pkg.Context(0)                                  # and the device is still usable
+    assert c2.hash_page(pkg.Page(pkg.Block(pkg.BIGINT, np.array([1], dtype=np.int64))), [0]).shape == (1,)
+    c2.close()
+
+
+def test_entry_points_bind_the_calling_thread_to_the_context_device(pkg, ctx):
+    """HIP's current device is per thread; every entry point that takes a handle binds the caller to the context's device first
+    (c_api.cpp bind_thread) -- also on a thread that never touched HIP before"""
+    import threading
+    L = pkg._lib.lib()
+    before = L.tgpu_debug_bind_count()
+    got = {}
+
+    def run():
+        got["h"] = ctx.hash_page(pkg.Page(pkg.Block(pkg.BIGINT, np.array([1, 2, 3], dtype=np.int64))), [0])
+
+    t = threading.Thread(target=run)
+    t.start()
+    t.join()
+    assert len(got["h"]) == 3 and L.tgpu_debug_bind_count() > before
+
+
+def test_join_bridge_shared_by_driver_threads(pkg, ctx, oracle):
+    """the lookup-source bridge is shared by the build driver and several probe drivers on their own threads (the reference's
+    model: PartitionedLookupSourceFactory.java:146-205): probes are created / blocked / probing / closed while the build side lends
+    the table; every probe sees the oracle's pairs and the build operator unblocks once the last probe is gone"""
+    import threading
+    import time
+    rng = np.random.default_rng(5)
+    bk = rng.permutation(40_000)[:15_000].astype(np.int64)
+    bf = pkg.HashBuilderOperatorFactory(ctx, 2, [pkg.BIGINT], [0], [0])
+    jf = pkg.LookupJoinOperatorFactory(ctx, 3, bf.lookup_source_factory, [pkg.BIGINT], [0])
+    src = oracle.PagesHash([oracle.Col(oracle.BIGINT, bk)])
+    errors = []
+
+    def probe_driver(seed):
+        try:
+            r = np.random.default_rng(seed)
+            for _ in range(5):
+                pk = r.integers(0, 40_000, 30_000).astype(np.int64)
+                op = jf.createOperator()
+                while op.isBlocked():
+                    time.sleep(0.0005)
+                op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, pk)))
+                out = op.getOutput()
+                wp, wb = src.probe([oracle.Col(oracle.BIGINT, pk)])
+                host = out.to_host()
+                assert np.array_equal(host.getBlock(0).values, pk[wp]) and np.array_equal(host.getBlock(1).values, bk[wb])
+                out.release()
+                op.finish()
+                assert op.isFinished()
+                op.close()
+        except Exception as e:
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=probe_driver, args=(100 + i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    b = bf.createOperator()
+    time.sleep(0.01)
+    b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, bk)))
+    b.finish()
+    assert b.isBlocked()                   # probes may still be running
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    jf.noMoreOperators()
+    assert not b.isBlocked() and b.isFinished()
+    b.close()
