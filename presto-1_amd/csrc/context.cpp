@@ -121,6 +121,10 @@ BufferPtr Context::alloc(size_t bytes)
         std::lock_guard<std::mutex> lk(mu_);
         in_use_ += cap;
     }
+    // TGPU_POISON_ALLOC=<byte>: every buffer is filled with that byte when it is handed out, so that a kernel that reads memory it
+    // never wrote sees the same garbage on every run (test mode: recycled buffers otherwise hold whatever their last user left)
+    static const int poison = getenv("TGPU_POISON_ALLOC") ? atoi(getenv("TGPU_POISON_ALLOC")) & 0xff : -1;
+    if (poison >= 0) HIP_CHECK(hipMemsetAsync(p, poison, cap, stream_));
     return std::make_shared<DeviceBuffer>(this, p, bytes, cap);
 }
 

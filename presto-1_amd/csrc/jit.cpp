@@ -64,14 +64,17 @@ static uint64_t fnv1a(const std::string &s)
     return h;
 }
 
-static const char *kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+// -ffp-contract=off: the JVM never fuses a multiply into an add; a projection's product feeding an accumulator's `sum += v` must be
+// rounded first, like DoubleSumAggregation.java:34-38 sees it (hipcc's default, fp-contract=fast, would emit an FMA there)
+static const char *kCompileOptions[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+constexpr int kCompileOptionCount = (int)(sizeof(kCompileOptions) / sizeof(kCompileOptions[0]));
 
 static std::vector<char> compile_source(const std::string &source)
 {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, source.c_str(), "tgpu_jit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         fail(TGPU_ERR_COMPILER, "hiprtcCreateProgram failed");
-    hiprtcResult r = hiprtcCompileProgram(prog, 3, kCompileOptions);
+    hiprtcResult r = hiprtcCompileProgram(prog, kCompileOptionCount, kCompileOptions);
     if (r != HIPRTC_SUCCESS) {
         size_t ls = 0;
         hiprtcGetProgramLogSize(prog, &ls);
@@ -1098,7 +1101,8 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
         // the bitmap is exact: the key is in the build side.  The pair carries the key's rank among the build keys (present keys
         // in front of its bitmap word, loaded by the previous iteration, + set bits below its own); fj_emit reads the build
         // position at that rank, for the matching rows only
-        if (sfl[s] & 1) head[s] = ssl[s].head + (int)ssidx[s];
+        // (nobody reads the build positions: the rank structure may not even be built -- rank_base[0] is then whatever the buffer held)
+        if (sfl[s] & 1) head[s] = (J.outer & 2) ? 0 : ssl[s].head + (int)ssidx[s];
 #else
         if ((sfl[s] & 1) && ssl[s].head >= 0) {
           if (ssl[s].key == skey[s]) head[s] = ssl[s].head;
