@@ -557,7 +557,7 @@ class Bench:
         self.q1_result = [o.to_host().rows() for o in outs]
         aop.close()
 
-    def check_q1(self):
+    def check_q1(self, java_order_distance=False):
         t = self.q1
         sel = t["shipdate"] <= 10471
         rows = [r for pg in self.q1_result for r in pg]
@@ -585,7 +585,23 @@ class Bench:
             if len(first) == 4:
                 break
         order_ok = [(r[0], r[1]) for r in rows] == sorted(first, key=first.get) if len(first) == 4 else True
-        return {"groups": len(rows), "sum_rel_err_vs_torch": worst, "group_order_ok": bool(order_ok), "ok": bool(ok and order_ok and worst < 1e-9)}
+        out = {"groups": len(rows), "sum_rel_err_vs_torch": worst, "group_order_ok": bool(order_ok), "ok": bool(ok and order_ok and worst < 1e-9)}
+        if java_order_distance and rows:
+            # DoubleSumAggregation.java:34-38 adds the rows of a group left to right; numpy's cumsum is that very loop (a sequential ufunc
+            # accumulate).  Distance of the GPU's exactly rounded sum(extendedprice) to it, in ULP -- the Java order's own rounding error at
+            # this many rows per group (DESIGN.md "DOUBLE aggregate policy"); SUM_ORDER_JAVA gives 0 here at the price of a sequential chain
+            t0 = time.perf_counter()
+            price = t["extendedprice"].cpu().numpy()
+            rf, ls, sd = t["returnflag"].cpu().numpy(), t["linestatus"].cpu().numpy(), t["shipdate"].cpu().numpy()
+            dist = {}
+            for r in rows:
+                m = (sd <= 10471) & (rf == ord(r[0])) & (ls == ord(r[1]))
+                java = float(np.cumsum(price[m])[-1])
+                a, b = np.float64(r[3]).view(np.int64), np.float64(java).view(np.int64)
+                dist[r[0] + r[1]] = int(abs(int(a) - int(b)))
+            out["sum_extendedprice_ulp_distance_to_java_order"] = dist
+            out["java_order_check_seconds"] = time.perf_counter() - t0
+        return out
 
     # -- cfg2 ---------------------------------------------------------------------------------------------------------
     def setup_cfg2(self, n):
@@ -608,34 +624,240 @@ class Bench:
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# CPU baseline: the oracle (row-at-a-time C port of the Java operators) on a bounded sample of the Q3 workload, 1 core
+# Sub-benchmarks (N = 1 only; each with its own `roofline`): the table layouts and operator shapes the TPCH headline never reaches
+# -- both TPCH build sides get the DIRECT bitmap + rank layout --, so that the open-address tables north_star names are measured too:
+#   join_hash_layout : a Q3-lineitem-shaped fused filter + probe whose build keys are sparse random 64-bit values
+#                      (TgSlot16 open-address table + blocked Bloom pre-filter), one DOUBLE build output channel
+#   join_duplicate_keys : every build key twice (position links, PagesHash.java:102-117), unfused LookupJoinOperator
+#   group_by_hash    : T/operator/BenchmarkGroupByHash.java:65-74,119-137 bigintGroupByHash: addPage of BIGINT keys uniform in
+#                      [0, groups) + appendValuesTo of every group (10 M rows / 3 M groups as in the reference, and 100 M / 40 M)
 # ---------------------------------------------------------------------------------------------------------------------
+def sub_join_hash_layout(b, steps, warmup, sf):
+    p, ctx, dev = b.pkg, b.ctx, b.dev
+    B, D, I = p.BIGINT, p.DOUBLE, p.INTEGER
+    nb, n = int(146_000 * sf), int(6_000_000 * sf)
+    bi = torch.arange(nb, device=dev, dtype=torch.int64)
+    bkeys = splitmix64(bi + 7_777_777)                        # a bijection: distinct, spread over all 64 bits
+    payload = bi.to(torch.float64)
+    i = torch.arange(n, device=dev, dtype=torch.int64)
+    r = rnd(31, i, 8 * nb)                                    # 1 probe row in 8 hits the build side
+    pkeys = splitmix64(r + 7_777_777)
+    fcol = rnd(32, i, 100).to(torch.int32)
+    f = p.field
+    filt, projs = f(1, I) > 45, [f(0, B)]                    # 54 % pass, like Q3's shipdate filter
+    bpage = p.Page(b.dblock(B, bkeys), b.dblock(D, payload))
+    ppage = p.Page(b.dblock(B, pkeys), b.dblock(I, fcol))
+    res = {}
+
+    def step():
+        bf = p.HashBuilderOperatorFactory(ctx, 40, [B, D], [1], [0])
+        bop = bf.createOperator()
+        bop.addInput(bpage)
+        bop.finish()
+        jf = p.FilterProjectLookupJoinOperatorFactory(ctx, 41, bf.lookup_source_factory, [B, I], filt, projs, [0], probe_output_channels=[0])
+        jop = jf.createOperator()
+        for o in res.pop("outs", []):
+            o.release()
+        outs = b.drive(jop, ppage)
+        res["stats"] = bf.lookup_source_factory.stats()
+        res["pairs"] = sum(o.position_count for o in outs)
+        res["outs"] = outs            # checked after the timed region
+        jop.close()
+        bop.close()
+
+    step_s, prof = b.timed(step, steps, warmup)
+    passing = fcol > 45
+    hit = passing & (r < nb)
+    want_pairs, want_sum = int(hit.sum().item()), float(r[hit].to(torch.float64).sum().item())
+    n_pass = int(passing.sum().item())
+    got_sum = 0.0
+    for o in res.pop("outs", []):
+        got_sum += float(np.sum(o.to_host().getBlock(1).values))
+        o.release()
+    ok = res["pairs"] == want_pairs and abs(got_sum - want_sum) <= 1e-9 * max(abs(want_sum), 1.0) and res["stats"]["link_count"] == 0
+    # algorithmic bytes of the probe launch, hash layout: filter column 4 B x input rows + (key 8 B + one 16-byte TgSlot16) x rows
+    # passing the filter + 8 B per emitted pair (the Bloom word in front of the table is an optimisation, not priced)
+    alg = 4.0 * n + 24.0 * n_pass + 8.0 * want_pairs
+    roof = dominant(prof, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n})
+    return {"workload": "fused filter + probe, sparse random 64-bit build keys (open-address TgSlot16 table + Bloom pre-filter)", "build_rows": nb, "input_rows": n,
+            "probe_rows": n_pass, "pairs": want_pairs, "table_slots": res["stats"]["hash_size"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n_pass / step_s,
+            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
+
+
+def sub_join_duplicate_keys(b, steps, warmup, sf):
+    p, ctx, dev = b.pkg, b.ctx, b.dev
+    B = p.BIGINT
+    nb, n = int(146_000 * sf), int(1_000_000 * sf)
+    bi = torch.arange(nb, device=dev, dtype=torch.int64)
+    bkeys = splitmix64((bi // 2) + 99_999)                    # every key twice -> position links
+    i = torch.arange(n, device=dev, dtype=torch.int64)
+    r = rnd(33, i, 2 * nb)                                    # distinct keys: nb / 2 -> 1 probe row in 4 matches, two pairs each
+    pkeys = splitmix64(r + 99_999)
+    bpage, ppage = p.Page(b.dblock(B, bkeys)), p.Page(b.dblock(B, pkeys))
+    res = {}
+
+    def step():
+        bf = p.HashBuilderOperatorFactory(ctx, 42, [B], [0], [0])
+        bop = bf.createOperator()
+        bop.addInput(bpage)
+        bop.finish()
+        jf = p.LookupJoinOperatorFactory(ctx, 43, bf.lookup_source_factory, [B], [0])
+        jop = jf.createOperator()
+        outs = b.drive(jop, ppage)
+        res["stats"] = bf.lookup_source_factory.stats()
+        res["pairs"] = sum(o.position_count for o in outs)
+        for o in outs:
+            o.release()
+        jop.close()
+        bop.close()
+
+    step_s, prof = b.timed(step, steps, warmup)
+    want_pairs = 2 * int((r < (nb + 1) // 2).sum().item())
+    ok = res["pairs"] == want_pairs and res["stats"]["link_count"] > 0
+    # unfused probe: key 8 B + one table slot 16 B + head / count out 8 B per probe row
+    roof = dominant(prof, {"join_probe_count": n}, {"join_probe_count": 32.0})
+    return {"workload": "LookupJoinOperator over a table with every build key twice (position links, newest -> oldest chains)", "build_rows": nb, "probe_rows": n,
+            "pairs": want_pairs, "link_count": res["stats"]["link_count"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n / step_s,
+            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
+
+
+def sub_group_by_hash(b, steps, warmup, rows, groups):
+    p, ctx, dev = b.pkg, b.ctx, b.dev
+    B = p.BIGINT
+    i = torch.arange(rows, device=dev, dtype=torch.int64)
+    keys = rnd(34, i, groups)
+    page = p.Page(b.dblock(B, keys))
+    res = {}
+
+    def step():
+        g = p.GroupByHash(ctx, [B], [0], expected_size=10_000)   # EXPECTED_SIZE of the reference benchmark: the table grows by rehashing
+        g.addPage(page)
+        out = g.appendValuesDevice()
+        res["groups"] = out.position_count
+        out.release()
+        g.close()
+
+    step_s, prof = b.timed(step, steps, warmup)
+    want = int(torch.unique(keys).numel())
+    # gbh_insert per row: key 8 B + one 8-byte table word + the 4-byte group id it answers with
+    roof = dominant(prof, {"gbh_insert": rows}, {"gbh_insert": 20.0})
+    return {"workload": f"BenchmarkGroupByHash.bigintGroupByHash shape: addPage of {rows} BIGINT keys uniform in [0, {groups}) + appendValuesTo of every group",
+            "rows": rows, "groups": want, "ms_per_step": step_s * 1e3, "rows_per_sec": rows / step_s, "ns_per_row": step_s * 1e9 / rows,
+            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
+            "ok": bool(res["groups"] == want)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle = a row-at-a-time C port of the Java operators, timed on this box's host cores on a
+# bounded sample of the Q3 workload -- on 1 thread and on T = all cores of this process's CPU share, one independent operator
+# instance per thread over a row-range shard (Trino's task.concurrency drivers, M/execution/TaskManagerConfig.java:69).
+# Every step is the row-at-a-time port: filters (o_filter), projections (o_project), PagesHash build + JoinProbe, MultiChannelGroupByHash
+# over the three grouping keys, DoubleSum in row order; numpy only moves columns between the steps (what LookupJoinPageBuilder /
+# PageBuilder do in the reference).
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_q3_pipeline(oracle, pkg, entry, h, threads):
+    from concurrent.futures import ThreadPoolExecutor
+    E = pkg.expressions
+    pp = entry.bench_page_processors(pkg)
+
+    def program(name):
+        types, filt, projs = pp[name]
+        return E.FlatProgram(filt, projs)
+
+    def shards(n):
+        step = (n + threads - 1) // threads
+        return [(a, min(a + step, n)) for a in range(0, n, step)]
+
+    pool = ThreadPoolExecutor(max_workers=threads)
+    # customer: mktsegment = 'BUILDING' -> build on custkey
+    prog = program("q3_customer")
+    ccols = [oracle.Col(oracle.BIGINT, h["c_custkey"]), oracle.Col(oracle.VARCHAR, h["c_seg_bytes"], None, h["c_seg_off"])]
+    cpos = oracle.filter_positions(prog.nodes, prog.filter_root, bytes(prog.pool), ccols)
+    ck = h["c_custkey"][cpos]
+    cust = oracle.PagesHash([oracle.Col(oracle.BIGINT, ck)])
+
+    # orders: orderdate < 1995-03-15, probe customers on custkey -> (orderkey, orderdate, shippriority)
+    oprog = program("q3_orders")
+
+    def orders_shard(rng):
+        a, b = rng
+        cols = [oracle.Col(oracle.BIGINT, h["o_orderkey"][a:b]), oracle.Col(oracle.BIGINT, h["o_custkey"][a:b]), oracle.Col(oracle.DATE, h["o_orderdate"][a:b]),
+                oracle.Col(oracle.INTEGER, h["o_shippriority"][a:b])]
+        pos = oracle.filter_positions(oprog.nodes, oprog.filter_root, b"", cols)
+        op, _ = cust.probe([oracle.Col(oracle.BIGINT, h["o_custkey"][a:b][pos])])
+        rows = pos[op] + a
+        return h["o_orderkey"][rows], h["o_orderdate"][rows], h["o_shippriority"][rows]
+
+    parts = list(pool.map(orders_shard, shards(len(h["o_orderkey"]))))
+    okeys, odate, oprio = (np.concatenate([p[k] for p in parts]) for k in range(3))
+    orders = oracle.PagesHash([oracle.Col(oracle.BIGINT, okeys)])
+
+    # lineitem: shipdate > 1995-03-15, revenue = extendedprice * (1 - discount), probe orders, group by 3 keys, sum(revenue)
+    lprog = program("q3_lineitem")
+    probe_rows = [0]
+
+    def lineitem_shard(rng):
+        a, b = rng
+        cols = [oracle.Col(oracle.BIGINT, h["l_orderkey"][a:b]), oracle.Col(oracle.DOUBLE, h["l_extendedprice"][a:b]), oracle.Col(oracle.DOUBLE, h["l_discount"][a:b]),
+                oracle.Col(oracle.DATE, h["l_shipdate"][a:b])]
+        pos = oracle.filter_positions(lprog.nodes, lprog.filter_root, b"", cols)
+        rev, _ = oracle.project(lprog.nodes, lprog.projection_roots[1], b"", cols, pos)
+        lk = h["l_orderkey"][a:b][pos]
+        lp, lb = orders.probe([oracle.Col(oracle.BIGINT, lk)])
+        kcols = [oracle.Col(oracle.BIGINT, lk[lp]), oracle.Col(oracle.DATE, odate[lb]), oracle.Col(oracle.INTEGER, oprio[lb])]
+        g = oracle.MultiChannelGroupByHash([oracle.BIGINT, oracle.DATE, oracle.INTEGER], 1 << 16)
+        gids = g.get_group_ids(kcols, oracle.hash_rows(kcols))
+        cnt, sums = oracle.agg_double_sum(gids, rev[lp], g.group_count)
+        first, _ = g.group_rows()
+        return len(pos), lk[lp][first], odate[lb][first], oprio[lb][first], cnt, sums
+
+    parts = list(pool.map(lineitem_shard, shards(len(h["l_orderkey"]))))
+    probe_rows = sum(p[0] for p in parts)
+    if threads > 1:   # FINAL step over the per-thread partial aggregates (HashAggregationOperator Step.PARTIAL -> FINAL)
+        kcols = [oracle.Col(oracle.BIGINT, np.concatenate([p[1] for p in parts])), oracle.Col(oracle.DATE, np.concatenate([p[2] for p in parts])),
+                 oracle.Col(oracle.INTEGER, np.concatenate([p[3] for p in parts]))]
+        g = oracle.MultiChannelGroupByHash([oracle.BIGINT, oracle.DATE, oracle.INTEGER], 1 << 16)
+        gids = g.get_group_ids(kcols, oracle.hash_rows(kcols))
+        oracle.agg_double_sum(gids, np.concatenate([p[5] for p in parts]), g.group_count)
+        groups = g.group_count
+    else:
+        groups = len(parts[0][4])
+    pool.shutdown()
+    return probe_rows, len(okeys), groups
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(bench, sample_sf):
     from oracle import oracle
     t = gen_q3(bench.dev, sample_sf, 0)
     h = {k: v.cpu().numpy() for k, v in t.items()}
     del t
     torch.cuda.empty_cache()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.perf_counter()
-    seg_first = h["c_seg_bytes"][h["c_seg_off"][:-1]]
-    ck = h["c_custkey"][seg_first == ord("B")]
-    cust = oracle.PagesHash([oracle.Col(oracle.BIGINT, ck)])
-    om = h["o_orderdate"] < D_1995_03_15
-    o_key, o_cust = h["o_orderkey"][om], h["o_custkey"][om]
-    op, ob = cust.probe([oracle.Col(oracle.BIGINT, o_cust)])
-    okeys = o_key[op]
-    orders = oracle.PagesHash([oracle.Col(oracle.BIGINT, okeys)])
-    lm = h["l_shipdate"] > D_1995_03_15
-    lk = h["l_orderkey"][lm]
-    rev = (h["l_extendedprice"] * (1.0 - h["l_discount"]))[lm]
-    lp, lb = orders.probe([oracle.Col(oracle.BIGINT, lk)])
-    g = oracle.BigintGroupByHash(1 << 16)
-    gids = g.get_group_ids(oracle.Col(oracle.BIGINT, lk[lp]))
-    oracle.agg_double_sum(gids, rev[lp], g.group_count)
-    dt = time.perf_counter() - t0
-    return {"value": float(len(lk) / dt), "unit": "probe rows/s", "cores": 1, "kind": "port",
-            "sample": f"same Q3 pipeline at SF{sample_sf:g} ({len(lk)} lineitem probe rows, {len(okeys)} build rows): C oracle = row-at-a-time port of "
-                      f"PagesHash/JoinHash/BigintGroupByHash/DoubleSum, numpy filters, 1 thread, {dt:.1f} s; reference Java operators not runnable: no JVM"}
+    probe_rows, build_rows, groups = cpu_q3_pipeline(oracle, bench.pkg, bench.entry, h, 1)
+    dt1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    probe_rows_t, _, groups_t = cpu_q3_pipeline(oracle, bench.pkg, bench.entry, h, cores)
+    dtt = time.perf_counter() - t0
+    assert probe_rows_t == probe_rows and groups_t == groups
+    return {"value": float(probe_rows / dtt), "unit": "probe rows/s", "cores": cores, "kind": "port",
+            "value_1_thread": float(probe_rows / dt1), "seconds_1_thread": dt1, "seconds_all_threads": dtt, "cpu": cpu_model(),
+            "sample": f"same Q3 pipeline at SF{sample_sf:g} ({probe_rows} lineitem probe rows, {build_rows} build rows, {groups} groups): C oracle = row-at-a-time port of "
+                      f"the generated filter / projection loops, PagesHash / JoinHash, MultiChannelGroupByHash and DoubleSum; 1 thread {dt1:.1f} s, {cores} threads "
+                      f"(one operator instance per row-range shard, partial -> final aggregation) {dtt:.1f} s; reference Java operators not runnable: no JVM"}
+
+
+PMC_PROFILES = ["r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"]   # newest first
 
 
 def dominant(profile, rows_by_kernel, bytes_per_row):
@@ -651,15 +873,18 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
     avg_ms = st["total_ms"] / st["count"]
     alg_bytes = bytes_per_row[best] * rows_by_kernel[best]
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/, collected and corrected as documented there)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v5_pmc_traffic.json")))["kernels"].get(best)
+    # HBM bytes per launch: NOT measured by this process (PMC counters need their own rocprofv3 --pmc passes); the figure is read from
+    # the committed summary of those passes over this very command and labelled as such (`traffic_source`); null when absent
+    traffic, traffic_source = None, None
+    for name in PMC_PROFILES:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"].get(best)
+        except (OSError, ValueError, KeyError):
+            continue
         if pmc:
-            traffic = pmc["traffic_bytes_per_launch_avg"]
-    except (OSError, ValueError, KeyError):
-        traffic = None
-    return {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+            traffic, traffic_source = pmc["traffic_bytes_per_launch_avg"], f"profiles/{name} (committed rocprofv3 --pmc passes of `python bench.py`, not this run)"
+            break
+    return {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_ms": avg_ms, "launches": st["count"], "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_per_row": bytes_per_row[best], "rows_per_launch": rows_by_kernel[best]}
 
@@ -670,13 +895,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--sf", type=float, default=100.0, help="TPCH scale factor per GPU")
-    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2 (default: all at N=1, q3 only at N>1)")
+    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2,sub (default: all at N=1, q3 only at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-sf", type=float, default=60.0, help="scale factor of the bounded sample the CPU baseline runs (~15 s of CPU work)")
+    ap.add_argument("--cpu-sample-sf", type=float, default=20.0, help="scale factor of the bounded sample the CPU baseline runs (~10-25 s of CPU work)")
     args = ap.parse_args()
     b = Bench(args)
     assert b.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={b.world}"
-    only = set(args.only.split(",")) if args.only else ({"q3", "q1", "cfg2"} if b.world == 1 else {"q3"})
+    only = set(args.only.split(",")) if args.only else ({"q3", "q1", "cfg2", "sub"} if b.world == 1 else {"q3"})
     b.ctx.profile_enable(os.environ.get("TGPU_BENCH_NOPROFILE") is None)   # (kernel study: cost of the event timers)
     out = {}
     extra = {}
@@ -755,7 +980,7 @@ def main():
         # low-cardinality mode Q1 runs in, int32 otherwise) + four 8-byte inputs per row
         out["q1"]["roofline"] = dominant(p1, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
                                          {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
-        out["checks"]["q1"] = b.check_q1()
+        out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
         del b.q1, b.q1_page
         b.q1_result = None
         torch.cuda.empty_cache()
@@ -767,6 +992,9 @@ def main():
         out["cfg2"] = {"metric": "input_rows_per_sec", "value": n2 / s2, "unit": "rows/s", "ms_per_step": s2 * 1e3, "rows": n2,
                        "workload": "bigint_filter_project_sel10 (BASELINE configs[1])", "algorithmic_bytes_per_row": 10.4,
                        "achieved_gbps_whole_step": 10.4 * n2 / s2 / 1e9, "frac_of_8TBps": 10.4 * n2 / s2 / 8e12,
+                       # SURVEY.md 8d's second bound: at 10 % selectivity nearly every 128-byte line of col1 / col2 holds a selected row, so
+                       # the memory system moves the full columns (8 + 16 read + 0.8 written = 24.8 B/row)
+                       "full_column_bytes_per_row": 24.8, "achieved_gbps_full_column_bound": 24.8 * n2 / s2 / 1e9, "frac_of_8TBps_full_column_bound": 24.8 * n2 / s2 / 8e12,
                        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p2.items(), key=lambda kv: -kv[1]["total_ms"])}}
         # pass 1 streams the 8-byte filter column of every row
         out["cfg2"]["roofline"] = dominant(p2, {"filter_count": n2}, {"filter_count": 8.0})
@@ -775,6 +1003,18 @@ def main():
         b.c2_out = None
         torch.cuda.empty_cache()
 
+    if b.world == 1 and "sub" in only:
+        torch.cuda.empty_cache()
+        sub = {}
+        sub["join_hash_layout"] = sub_join_hash_layout(b, args.steps, args.warmup, args.sf)
+        torch.cuda.empty_cache()
+        sub["join_duplicate_keys"] = sub_join_duplicate_keys(b, args.steps, args.warmup, args.sf)
+        torch.cuda.empty_cache()
+        sub["group_by_hash_10M_3M"] = sub_group_by_hash(b, args.steps, args.warmup, int(100_000 * args.sf), int(30_000 * args.sf))
+        sub["group_by_hash_100M_40M"] = sub_group_by_hash(b, args.steps, args.warmup, int(1_000_000 * args.sf), int(400_000 * args.sf))
+        torch.cuda.empty_cache()
+        out["sub_benchmarks"] = sub
+        out["checks"]["sub_benchmarks"] = {k: v["ok"] for k, v in sub.items()}
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(b, args.cpu_sample_sf)
     out.update(extra)

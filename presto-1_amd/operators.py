@@ -417,6 +417,12 @@ class GroupByHash:
         op.release()
         return pg
 
+    def appendValuesDevice(self) -> OutputPage:
+        """appendValuesTo for every group, left on the device (the caller releases the page)"""
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_group_by_hash_append_values(self.handle, C.byref(out)))
+        return OutputPage(out)
+
     def close(self):
         if self.handle:
             _lib.lib().tgpu_group_by_hash_destroy(self.handle)
