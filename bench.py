@@ -140,6 +140,7 @@ class Bench:
         self.entry = importlib.import_module("__graft_entry__")
         self.ctx = self.pkg.Context(self.local_rank, stream=torch.cuda.current_stream().cuda_stream)
         self.capture = None
+        self.exchange = None
 
     # -- helpers ------------------------------------------------------------------------------------------------------
     def dblock(self, type_id, values, offsets=None):
@@ -196,9 +197,21 @@ class Bench:
     def setup_q3(self, sf):
         p = self.pkg
         self.q3 = gen_q3(self.dev, sf, self.rank, self.world)
-        if self.dist is not None:
+        if self.dist is not None and getattr(self, "exchange", None) is None:
+            # the exchange is the native library's (tgpu_exchange_*: RCCL send / recv groups over xGMI); torch.distributed only hands
+            # rank 0's RCCL unique id to the other ranks.  Rehearsals of several ranks on one GPU (TGPU_BENCH_BACKEND=gloo) run the same
+            # library code over its callback transport with host staging.
             ex_mod = importlib.import_module("presto-1_amd.exchange")
-            self.exchange = ex_mod.HashExchange(self.dist, self.dev, ex_mod.hip_partitioner(self.ctx, self.dev))
+            if self.backend == "nccl":
+                def broadcast(payload):
+                    t = torch.zeros(ex_mod.ID_BYTES, dtype=torch.uint8, device=self.dev)
+                    if payload is not None:
+                        t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+                    self.dist.broadcast(t, src=0)
+                    return bytes(t.cpu().numpy().tobytes())
+                self.exchange = ex_mod.Exchange.over_rccl(self.ctx, self.rank, self.world, broadcast)
+            else:
+                self.exchange = ex_mod.Exchange.over_transport(self.ctx, self.rank, self.world, ex_mod.GlooTransport(self.dist, ex_mod.TorchDeviceMemory(self.dev)))
         pp = self.entry.bench_page_processors(p)
         B, D, DT, V, I = p.BIGINT, p.DOUBLE, p.DATE, p.VARCHAR, p.INTEGER
         self.q3_fac = {
@@ -280,20 +293,21 @@ class Bench:
         p, ctx, f, pages, ex = self.pkg, self.ctx, self.q3_fac, self.q3_pages, self.exchange
         B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
         st = self.q3_stats
-        ex_mod = importlib.import_module("presto-1_amd.exchange")
+        sent0 = ex.bytes_sent
         # customer: filter -> broadcast -> build on every rank
         cb = p.HashBuilderOperatorFactory(ctx, 10, [B], [], [0])
         cbuild = cb.createOperator()
         outs = self.drive(f["cust_fp"].createOperator(), pages["customer"])
         local = outs[0].as_device_page() if outs else p.Page(self.dblock(B, torch.zeros(0, dtype=torch.int64, device=self.dev)), position_count=0)
-        allc = ex_mod.all_gather_page(self.dist, self.dev, local)
+        allc = ex.all_gather(local)
         st["customer_build_rows"] = allc.position_count
-        st["exchange_bytes_sent"] = local.position_count * 8 * (self.world - 1)
         if allc.position_count:
             cbuild.addInput(allc)
+        allc.release()
         cbuild.finish()
         for o in outs:
             o.release()
+        st["exchange_bytes_sent"] = ex.bytes_sent - sent0
         # orders: filter/project fused into the probe of the replicated customer table -> local build on orderkey
         pp = self.entry.bench_page_processors(p)
         oj = p.FilterProjectLookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, *pp["q3_orders"], [1], probe_output_channels=[0, 2, 3])
@@ -346,22 +360,24 @@ class Bench:
         fagg = p.HashAggregationOperatorFactory(ctx, 15, [B, DT, I], [0, 1, 2], [(p.SUM_DOUBLE, 3)], step=p.FINAL, expected_groups=1 << 20)
         faop = fagg.createOperator()
         st["partial_groups"] = 0
-        sent0 = ex.bytes_sent
+        sent1 = ex.bytes_sent
         empty = None
         for o in partial:
             st["partial_groups"] += o.position_count
-            pg = ex.exchange(o.as_device_page(), [0, 1, 2])
+            pg = ex.repartition(o.as_device_page(), [0, 1, 2])
             o.release()
             if pg.position_count:
                 faop.addInput(pg)
+            pg.release()
         if not partial:   # a rank without groups still takes part in the collectives
             empty = p.Page(self.dblock(B, torch.zeros(0, dtype=torch.int64, device=self.dev)), self.dblock(DT, torch.zeros(0, dtype=torch.int32, device=self.dev)),
                            self.dblock(I, torch.zeros(0, dtype=torch.int32, device=self.dev)), self.dblock(B, torch.zeros(0, dtype=torch.int64, device=self.dev)),
                            self.dblock(D, torch.zeros(0, dtype=torch.float64, device=self.dev)), position_count=0)
-            pg = ex.exchange(empty, [0, 1, 2])
+            pg = ex.repartition(empty, [0, 1, 2])
             if pg.position_count:
                 faop.addInput(pg)
-        st["exchange_bytes_sent"] += ex.bytes_sent - sent0
+            pg.release()
+        st["exchange_bytes_sent"] += ex.bytes_sent - sent1
         outs = self.finish(faop)
         st["groups"] = sum(o.position_count for o in outs)
         self.q3_result = outs
@@ -383,48 +399,58 @@ class Bench:
             outs = self.drive(fac.createOperator(), page)
             return outs[0] if outs else None
 
-        def repartition(out_page, keys):
-            pg = ex.exchange(out_page.as_device_page(), keys)
+        sent0 = ex.bytes_sent
+
+        def repartition(out_page, keys, empty_types=None):
+            """all ranks take part in every exchange, also a rank whose upstream produced no page"""
+            if out_page is None:
+                blocks = [self.dblock(t, torch.zeros(0, dtype={B: torch.int64, D: torch.float64}.get(t, torch.int32), device=self.dev)) for t in empty_types]
+                return ex.repartition(p.Page(*blocks, position_count=0), keys)
+            pg = ex.repartition(out_page.as_device_page(), keys)
             out_page.release()
             return pg
 
         # customer: filter -> exchange(custkey) -> build
         cb = p.HashBuilderOperatorFactory(ctx, 10, [B], [], [0])
         cbuild = cb.createOperator()
-        cpage = repartition(filtered(f["cust_fp"], pages["customer"]), [0])
+        cpage = repartition(filtered(f["cust_fp"], pages["customer"]), [0], [B])
         st["customer_build_rows"] = cpage.position_count
-        cbuild.addInput(cpage)
+        if cpage.position_count:
+            cbuild.addInput(cpage)
+        cpage.release()
         cbuild.finish()
         # orders: filter -> exchange(custkey) -> probe customers -> exchange(orderkey) -> build
-        opage = repartition(filtered(f["ord_fp"], pages["orders"]), [1])
+        opage = repartition(filtered(f["ord_fp"], pages["orders"]), [1], [B, B, DT, I])
         st["orders_probe_rows"] = opage.position_count
         oj = p.LookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, [B, B, DT, I], [1], probe_output_channels=[0, 2, 3])
         ojoin = oj.createOperator()
-        joined = self.drive(ojoin, opage)
+        joined = self.drive(ojoin, opage) if opage.position_count else []
+        opage.release()
         ob = p.HashBuilderOperatorFactory(ctx, 12, [B, DT, I], [1, 2], [0])
         obuild = ob.createOperator()
-        if joined:
-            bpage = repartition(joined[0], [0])
-            st["orders_build_rows"] = bpage.position_count
+        bpage = repartition(joined[0] if joined else None, [0], [B, DT, I])
+        st["orders_build_rows"] = bpage.position_count
+        if bpage.position_count:
             obuild.addInput(bpage)
+        bpage.release()
         obuild.finish()
         ojoin.close()
         # lineitem: filter/project -> exchange(orderkey) -> probe orders -> aggregate (groups are co-located: no second exchange)
-        lpage = repartition(filtered(f["li_fp"], pages["lineitem"]), [0])
+        lpage = repartition(filtered(f["li_fp"], pages["lineitem"]), [0], [B, D])
         st["lineitem_probe_rows"] = lpage.position_count
         lj = p.LookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, [B, D], [0], probe_output_channels=[0, 1])
         agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
         ljoin = lj.createOperator()
         aop = agg.createOperator()
         st["lineitem_join_rows"] = 0
-        for j in self.drive(ljoin, lpage):
+        for j in (self.drive(ljoin, lpage) if lpage.position_count else []):
             st["lineitem_join_rows"] = j.position_count
             aop.addInput(j.as_device_page())
             j.release()
+        lpage.release()
         outs = self.finish(aop)
         st["groups"] = sum(o.position_count for o in outs)
-        st["exchange_bytes_sent"] = ex.bytes_sent
-        ex.bytes_sent = 0
+        st["exchange_bytes_sent"] = ex.bytes_sent - sent0
         self.q3_result = outs
         ljoin.close()
         cbuild.close()
@@ -450,9 +476,8 @@ class Bench:
             op.close()
 
         step_s, prof = self.timed(step, steps, warmup)
-        ex_mod = importlib.import_module("presto-1_amd.exchange")
-        rev = torch.cat([ex_mod.page_columns(pg, self.dev)[3]["values"] for pg in pages])
-        want = torch.topk(rev, min(10, rev.numel())).values.tolist()
+        rev = np.concatenate([o.to_host().getBlock(3).values for o in self.q3_result])
+        want = np.sort(rev)[::-1][:10].tolist()
         got = [r[3] for r in result["rows"]]
         return {"workload": "TopN(10) ORDER BY revenue DESC, o_orderdate over the Q3 groups", "input_rows": rows, "ms_per_step": step_s * 1e3,
                 "rows_per_sec": rows / step_s, "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in prof.items()}, "ok": got == want}
@@ -460,8 +485,6 @@ class Bench:
     def check_q3_dist(self):
         """N > 1, replicated-customer plan: every count and the revenue total against a reference computed independently with torch
         (each rank evaluates its own split against the all-gathered customer segment flags; totals are all-reduced)."""
-        if os.environ.get("TGPU_BENCH_PLAN") == "repartition":
-            return self.check_q3_dist_repartition()
         st, t, dist = self.q3_stats, self.q3, self.dist
         n_c = t["c_custkey"].numel()
         seg_ok = (t["c_seg_bytes"][t["c_seg_off"][:-1].to(torch.int64)] == ord("B")).to(torch.uint8)
@@ -913,8 +936,31 @@ def main():
     step_fn = b.step_q3 if not distributed else (b.step_q3_dist_repartition if repartition else b.step_q3_dist)
     step_s, prof = b.timed(step_fn, args.steps, args.warmup)
     q3_readbacks = b.last_readbacks_per_step
-    q3_check = b.check_q3_dist() if distributed else b.check_q3()
+    q3_check = (b.check_q3_dist_repartition() if repartition else b.check_q3_dist()) if distributed else b.check_q3()
     st = dict(b.q3_stats)
+    if distributed and not repartition and os.environ.get("TGPU_BENCH_PLAN") is None:
+        # the alternative plan in the same line: every join input hash-repartitioned over xGMI (the all-to-all BASELINE.json's metric
+        # names); `value` stays the plan the optimizer picks (co-partitioned joins), this object says what the exchange-heavy plan costs
+        for o in (b.q3_result or []):
+            o.release()
+        b.q3_result = None
+        keep = dict(b.q3_stats)
+        s_rp, prof_rp = b.timed(b.step_q3_dist_repartition, args.steps, args.warmup)
+        chk_rp = b.check_q3_dist_repartition()
+        st_rp = dict(b.q3_stats)
+        tt = torch.tensor([st_rp["lineitem_probe_rows"], st_rp.get("exchange_bytes_sent", 0)], device=b.coll_dev, dtype=torch.int64)
+        b.dist.all_reduce(tt)
+        ex_ms = prof_rp.get("exchange_all_to_all_v", {"total_ms": 0.0})["total_ms"] / args.steps
+        extra["repartition_plan"] = {
+            "plan": f"hash-repartitioned joins x{b.world}: K10 partition kernels + grouped RCCL send/recv all-to-all-v of every join input (tgpu_exchange_repartition)",
+            "ms_per_step": s_rp * 1e3, "probe_rows_per_sec": int(tt[0].item()) / s_rp, "exchange_bytes_sent_per_step_all_ranks": int(tt[1].item()),
+            "exchange_bytes_sent_per_step_this_rank": st_rp.get("exchange_bytes_sent", 0), "exchange_ms_per_step_this_rank": ex_ms,
+            "achieved_xgmi_GBps_this_rank": (st_rp.get("exchange_bytes_sent", 0) / (ex_ms * 1e-3) / 1e9) if ex_ms > 0 else None,
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(prof_rp.items(), key=lambda kv: -kv[1]["total_ms"])[:10]}, "check": chk_rp}
+        for o in (b.q3_result or []):
+            o.release()
+        b.q3_result = None
+        b.q3_stats = keep
     probe_rows = st["lineitem_probe_rows"]
     total_probe = probe_rows
     if b.dist is not None:

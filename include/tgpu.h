@@ -25,6 +25,8 @@
  *   - tgpu_dynamic_filter_source_* <-> M/operator/DynamicFilterSourceOperator.java:74-425
  *   - tgpu_serialize_page / tgpu_deserialize_page <-> M/execution/buffer/PagesSerde.java:64-160, PagesSerdeUtil.java:45-71,
  *                                    S/block/*BlockEncoding.java, EncoderUtil.java:33-118
+ *   - tgpu_exchange_*            <-> M/operator/PartitionedOutputOperator.java:406-476 -> M/operator/ExchangeOperator.java (the hop between
+ *                                    the stages of a FIXED_HASH / FIXED_BROADCAST distribution), over RCCL / xGMI instead of HTTP
  *   - tgpu_operator_add_input_output_page: Operator.addInput with a page that never left the device (no reference counterpart:
  *                                    on the JVM the Page object itself is what travels between operators)
  *
@@ -389,6 +391,42 @@ int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out,
  * DictionaryBlockEncoding.java:33-80) flattened on the device.  `types` = the tgpu_type of every channel (the encodings do not tell
  * BIGINT from DOUBLE, INTEGER from DATE).  COMPRESSED / ENCRYPTED markers: TGPU_ERR_NOT_SUPPORTED. */
 int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len, int32_t type_count, const int32_t *types, tgpu_output_page **out);
+
+/* ---- exchange between the GPUs of one node ---- */
+/* What replaces PartitionedOutputOperator -> OutputBuffer -> HTTP -> ExchangeOperator (M/operator/PartitionedOutputOperator.java:406-476,
+ * M/operator/ExchangeOperator.java) when the consumers of a FIXED_HASH_DISTRIBUTION / FIXED_BROADCAST_DISTRIBUTION stage
+ * (M/sql/planner/SystemPartitioningHandle.java:59-60) are the GPUs of one node, one rank (process, context) per GPU: pages stay in HBM
+ * and travel over xGMI.  One header all-to-all per page (row counts, null-vector flags, VARCHAR byte counts), then ONE grouped RCCL
+ * ncclSend / ncclRecv exchange carrying every buffer of every channel to every peer.  Every call is collective: all ranks of the
+ * exchange make the same calls in the same order (as the stages of one query do). */
+typedef struct tgpu_exchange tgpu_exchange;
+#define TGPU_EXCHANGE_ID_BYTES 128
+/* rank 0 creates the id and hands it to the other ranks out of band (in the engine: with the task's exchange locations) */
+int32_t tgpu_exchange_unique_id(void *id_out /* TGPU_EXCHANGE_ID_BYTES */);
+int32_t tgpu_exchange_create(tgpu_context *ctx, const void *unique_id, int32_t rank, int32_t world, tgpu_exchange **out);
+/* The same exchange over a transport of the caller's (rehearsals of several ranks on one GPU -- RCCL refuses two ranks on one device --
+ * and tests).  all_to_all_meta: host int64 values, per_rank of them per destination / source.  all_to_all_v: device buffers; entry
+ * [t * world + r] of the four arrays describes what goes to / comes from rank r in transfer t; the library has synchronised its stream
+ * before the call and expects the bytes in place when it returns.  Entries for the caller's own rank are zero (handled inside). */
+typedef struct tgpu_exchange_transport {
+    void *user;
+    int32_t (*all_to_all_meta)(void *user, const int64_t *send, int64_t *recv, int32_t per_rank);
+    int32_t (*all_to_all_v)(void *user, int32_t transfers, const void *const *send_ptr, const int64_t *send_bytes, void *const *recv_ptr, const int64_t *recv_bytes);
+} tgpu_exchange_transport;
+int32_t tgpu_exchange_create_with_transport(tgpu_context *ctx, int32_t rank, int32_t world, const tgpu_exchange_transport *transport, tgpu_exchange **out);
+void tgpu_exchange_destroy(tgpu_exchange *ex);
+/* hash repartition of `page`: rows go to rank (rawHash & 0x7fff...) % world (M/operator/HashGenerator.java:24-35) of the key channels
+ * (hash_channel >= 0: of that precomputed raw hash); *out = the rows this rank owns, grouped by source rank, input order kept */
+int32_t tgpu_exchange_repartition(tgpu_exchange *ex, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels, int32_t hash_channel,
+                                  tgpu_output_page **out);
+/* the pages a PartitionedOutputOperator with partition_count == world has pending (tgpu_partitioned_output_poll) shuffled to their
+ * ranks: the shuffle producer and the exchange back to back without leaving the library */
+int32_t tgpu_exchange_partitioned_output(tgpu_exchange *ex, tgpu_operator *partitioned_output_operator, int32_t type_count, const int32_t *types,
+                                         tgpu_output_page **out);
+/* broadcast (replicated join build side): every rank receives the pages of all ranks, concatenated in rank order */
+int32_t tgpu_exchange_all_gather(tgpu_exchange *ex, const tgpu_page *page, tgpu_output_page **out);
+/* bytes this rank has sent to OTHER ranks so far (xGMI traffic; bench.py's exchange_bytes_sent_per_step) */
+int64_t tgpu_exchange_bytes_sent(tgpu_exchange *ex);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,14 @@ class PageProcessorSpec(C.Structure):
                 ("filter_root", C.c_int32), ("projection_count", C.c_int32), ("projection_roots", C.POINTER(C.c_int32))]
 
 
+TRANSPORT_META_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32)
+TRANSPORT_V_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+
+class ExchangeTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_to_all_meta", TRANSPORT_META_FN), ("all_to_all_v", TRANSPORT_V_FN)]
+
+
 class AggSpec(C.Structure):
     _fields_ = [("function", C.c_int32), ("input_channel", C.c_int32), ("mask_channel", C.c_int32)]
 
@@ -121,6 +129,14 @@ SYMBOLS = {
     "tgpu_partitioned_output_info": (i32, [vp, P(i64), P(i64)]),
     "tgpu_serialize_page": (i32, [vp, P(Page), vp, i64, P(i64)]),
     "tgpu_deserialize_page": (i32, [vp, vp, i64, i32, P(i32), P(vp)]),
+    "tgpu_exchange_unique_id": (i32, [vp]),
+    "tgpu_exchange_create": (i32, [vp, cp, i32, i32, P(vp)]),
+    "tgpu_exchange_create_with_transport": (i32, [vp, i32, i32, P(ExchangeTransport), P(vp)]),
+    "tgpu_exchange_destroy": (None, [vp]),
+    "tgpu_exchange_repartition": (i32, [vp, P(Page), i32, P(i32), i32, P(vp)]),
+    "tgpu_exchange_partitioned_output": (i32, [vp, vp, i32, P(i32), P(vp)]),
+    "tgpu_exchange_all_gather": (i32, [vp, P(Page), P(vp)]),
+    "tgpu_exchange_bytes_sent": (i64, [vp]),
 }
 # helpers outside tgpu.h (build / diagnostics)
 EXTRA_SYMBOLS = {

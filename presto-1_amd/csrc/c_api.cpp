@@ -4,6 +4,7 @@
 #include <map>
 #include <mutex>
 
+#include "exchange.h"
 #include "kernels.h"
 #include "operators.h"
 #include "serde.h"
@@ -59,6 +60,7 @@ inline Context *ctx_of(const tgpu_operator_factory *h) { return h ? h->ctx : nul
 inline Context *ctx_of(const tgpu_lookup_source_factory *h) { return h ? h->ctx : nullptr; }
 inline Context *ctx_of(const tgpu_group_by_hash *h) { return h ? h->ctx : nullptr; }
 inline Context *ctx_of(const tgpu_output_page *h) { return h ? h->ctx : nullptr; }
+inline Context *ctx_of(const tgpu_exchange *h) { return h ? h->ctx : nullptr; }
 
 std::vector<int32_t> vec(const int32_t *p, int32_t n)
 {
@@ -889,5 +891,95 @@ int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len,
         *out = release_output(make_output(c, serde::deserialize(c, (const uint8_t *)bytes, len, types, type_count)));
     });
 }
+
+// ---- exchange -------------------------------------------------------------------------------------------------------
+int32_t tgpu_exchange_unique_id(void *id_out)
+{
+    return guard([&] {
+        TG_CHECK_ARG(id_out != nullptr, "id_out is null");
+        rccl_unique_id(id_out);
+    });
+}
+
+static int32_t exchange_create(tgpu_context *ctx, int32_t rank, int32_t world, std::unique_ptr<ExchangeTransport> (*make)(Context *, const void *, int, int), const void *arg,
+                               tgpu_exchange **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && arg, "null argument");
+        TG_CHECK_ARG(world >= 1 && rank >= 0 && rank < world, "bad rank / world size");
+        auto e = std::make_unique<tgpu_exchange>();
+        e->ex = std::make_unique<Exchange>(ctx->ctx.get(), rank, world, make(ctx->ctx.get(), arg, rank, world));
+        e->ctx = ctx->ctx.get();
+        retain(e->ctx);
+        *out = e.release();
+    });
+}
+
+int32_t tgpu_exchange_create(tgpu_context *ctx, const void *unique_id, int32_t rank, int32_t world, tgpu_exchange **out)
+{
+    return exchange_create(ctx, rank, world, [](Context *c, const void *id, int r, int w) { return make_rccl_transport(c, id, r, w); }, unique_id, out);
+}
+
+int32_t tgpu_exchange_create_with_transport(tgpu_context *ctx, int32_t rank, int32_t world, const tgpu_exchange_transport *transport, tgpu_exchange **out)
+{
+    return exchange_create(ctx, rank, world, [](Context *c, const void *t, int, int w) { return make_callback_transport(c, (const tgpu_exchange_transport *)t, w); },
+                           transport, out);
+}
+
+void tgpu_exchange_destroy(tgpu_exchange *ex)
+{
+    if (!ex) return;
+    Context *c = ex->ctx;
+    guard_on(c, [&] { ex->ex.reset(); });
+    delete ex;
+    if (c) drop(c);
+}
+
+int32_t tgpu_exchange_repartition(tgpu_exchange *ex, const tgpu_page *page, int32_t key_channel_count, const int32_t *key_channels, int32_t hash_channel,
+                                  tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ex), [&] {
+        TG_CHECK_ARG(ex && page && out, "null argument");
+        DevicePage in = ingest_page(ex->ctx, page);
+        *out = release_output(make_output(ex->ctx, ex->ex->repartition(in, vec(key_channels, key_channel_count), hash_channel)));
+    });
+}
+
+int32_t tgpu_exchange_partitioned_output(tgpu_exchange *ex, tgpu_operator *op, int32_t type_count, const int32_t *types, tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ex), [&] {
+        TG_CHECK_ARG(ex && op && op->op && out, "null argument");
+        TG_CHECK_ARG(op->ctx == ex->ctx, "the operator and the exchange belong to different contexts");
+        const int W = ex->ex->world();
+        // pending (partition, page) pairs in enqueue order; several pages of one partition (several input pages) are shuffled round by round
+        std::vector<std::vector<std::unique_ptr<OutputPage>>> by_dest((size_t)W);
+        for (;;) {
+            int32_t part = -1;
+            std::unique_ptr<OutputPage> pg;
+            if (!partitioned_output_poll(op->op.get(), &part, &pg)) break;
+            TG_CHECK_ARG(part >= 0 && part < W, "the operator's partition count differs from the exchange's world size");
+            by_dest[(size_t)part].push_back(std::move(pg));
+        }
+        size_t rounds = 0;
+        for (auto &v : by_dest) rounds = std::max(rounds, v.size());
+        // every rank must run the same number of collective rounds: agree on the maximum through the transport's header exchange
+        TG_CHECK_ARG(rounds <= 1, "tgpu_exchange_partitioned_output moves the pages of ONE input page per call: call it after every add_input");
+        std::vector<const DevicePage *> per((size_t)W, nullptr);
+        for (int r = 0; r < W; r++)
+            if (!by_dest[(size_t)r].empty()) per[(size_t)r] = &by_dest[(size_t)r][0]->page;
+        *out = release_output(make_output(ex->ctx, ex->ex->shuffle(vec(types, type_count), per)));
+    });
+}
+
+int32_t tgpu_exchange_all_gather(tgpu_exchange *ex, const tgpu_page *page, tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ex), [&] {
+        TG_CHECK_ARG(ex && page && out, "null argument");
+        DevicePage in = ingest_page(ex->ctx, page);
+        *out = release_output(make_output(ex->ctx, ex->ex->all_gather(in)));
+    });
+}
+
+int64_t tgpu_exchange_bytes_sent(tgpu_exchange *ex) { return ex ? ex->ex->bytes_sent() : TGPU_ERR_INVALID_ARGUMENT; }
 
 }  // extern "C"

@@ -1,188 +1,161 @@
-"""Hash repartition exchange across GPUs: the reference's PartitionedOutputOperator -> HTTP page exchange ->
-ExchangeOperator hop (M/operator/PartitionedOutputOperator.java:406-476, HttpPageBufferClient.java, ExchangeOperator.java)
-collapsed into
+"""Exchange between the GPUs of one node: ctypes mirror of tgpu_exchange_* (include/tgpu.h).
 
-    1. K10 partition kernel (tgpu_partition_page): rows grouped by destination = (rawHash & 0x7fff...) % world
-       (M/operator/HashGenerator.java:24-35), input order kept inside each destination;
-    2. one all-to-all of the row counts, then one all-to-all-v per column buffer (RCCL over xGMI through torch.distributed's
-       `nccl` backend; every rank talks to its 7 peers at once, one xGMI link per pair).
+The exchange itself -- K10 partition kernels, page-header all-to-all, one grouped RCCL ncclSend / ncclRecv all-to-all-v per page over
+xGMI, VARCHAR offset rebasing -- lives in libtgpu.so (csrc/exchange.hip); nothing here touches the rows.  What this module adds is
+bootstrap plumbing for Python hosts:
 
-Rows never leave HBM.  One process per GPU; `torch.distributed` must be initialised by the caller.  The partitioner is
-injectable so that the CPU-only test-suite can drive the same exchange code over `gloo` (tests inject a reference
-partitioner); the default -- and the only one the product ever uses -- is the HIP kernel behind the C ABI.
+  * `Exchange.over_rccl(ctx, rank, world, broadcast)`: rank 0 makes the RCCL unique id, `broadcast(bytes) -> bytes` hands it to the
+    other ranks (bench.py uses torch.distributed for that; a JVM host would ship it with the task's exchange locations);
+  * `GlooTransport`: the library's transport callbacks (tgpu_exchange_transport) over torch.distributed's `gloo` backend with host
+    staging -- for rehearsing several ranks on ONE GPU (RCCL refuses two ranks on one device) and for CPU tests of the transport.
 """
+import ctypes as C
+
 import numpy as np
-import torch
 
-from .spi import BIGINT, BOOLEAN, DATE, DOUBLE, INTEGER, VARCHAR, DeviceBlock, Page
+from . import _lib
+from .spi import OutputPage, Page
 
-TORCH_DTYPE = {BIGINT: torch.int64, INTEGER: torch.int32, DATE: torch.int32, DOUBLE: torch.float64, BOOLEAN: torch.uint8}
-_TYPESTR = {torch.int64: "<i8", torch.int32: "<i4", torch.float64: "<f8", torch.uint8: "|u1"}
-
-
-class _DevArray:
-    """a raw device pointer exposed through __cuda_array_interface__ (zero-copy view for torch); keeps its owner alive"""
-
-    def __init__(self, ptr, n, dtype, owner):
-        self.owner = owner
-        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": _TYPESTR[dtype], "data": (int(ptr), False), "version": 3}
+ID_BYTES = 128
 
 
-def device_view(ptr, n, dtype, owner, device):
-    if n == 0 or not ptr:
-        return torch.empty(0, dtype=dtype, device=device)
-    return torch.as_tensor(_DevArray(ptr, n, dtype, owner), device=device)
+class Exchange:
+    def __init__(self, handle, keep=None):
+        self.handle = handle
+        self._keep = keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(ID_BYTES)
+        _lib.check(_lib.lib().tgpu_exchange_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def over_rccl(cls, ctx, rank, world, broadcast):
+        """collective: every rank calls it; `broadcast(payload_or_None) -> bytes` returns rank 0's payload on every rank"""
+        uid = broadcast(cls.unique_id() if rank == 0 else None)
+        assert len(uid) == ID_BYTES
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_exchange_create(ctx.handle, uid, rank, world, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def over_transport(cls, ctx, rank, world, transport):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_exchange_create_with_transport(ctx.handle, rank, world, C.byref(transport.struct), C.byref(h)))
+        return cls(h, keep=transport)
+
+    def repartition(self, page: Page, key_channels, hash_channel=-1) -> OutputPage:
+        """FIXED_HASH_DISTRIBUTION: the rows of `page` go to rank (rawHash & 0x7fff...) % world; returns this rank's rows"""
+        ch = (C.c_int32 * max(1, len(key_channels)))(*key_channels)
+        cp, keep = page.to_c()
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_exchange_repartition(self.handle, C.byref(cp), len(key_channels), ch, hash_channel, C.byref(out)))
+        return OutputPage(out)
+
+    def partitioned_output(self, operator, types) -> OutputPage:
+        """shuffles what a PartitionedOutputOperator (partition_count == world) has pending after one addInput"""
+        t = (C.c_int32 * max(1, len(types)))(*types)
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_exchange_partitioned_output(self.handle, operator.handle, len(types), t, C.byref(out)))
+        return OutputPage(out)
+
+    def all_gather(self, page: Page) -> OutputPage:
+        """FIXED_BROADCAST_DISTRIBUTION: every rank's rows on every rank, in rank order"""
+        cp, keep = page.to_c()
+        out = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_exchange_all_gather(self.handle, C.byref(cp), C.byref(out)))
+        return OutputPage(out)
+
+    @property
+    def bytes_sent(self):
+        return int(_lib.lib().tgpu_exchange_bytes_sent(self.handle))
+
+    def close(self):
+        if self.handle:
+            _lib.lib().tgpu_exchange_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown
+            pass
 
 
-def hip_partitioner(ctx, device):
-    """the product partitioner: K10 on the GPU.  Returns (counts[world] numpy, columns) where each column is a dict of torch
-    tensors {type, values, nulls|None, offsets|None} holding the rows grouped by destination."""
+class HostMemory:
+    """buffers addressed by the callbacks are host memory (CPU tests of the transport)"""
 
-    def run(page: Page, key_channels, world):
-        counts, out = ctx.partition_page(page, key_channels, world)
-        dp = out.as_device_page()
-        cols = []
-        n = dp.position_count
-        for b in dp.blocks:
-            if b.type == VARCHAR:
-                offsets = device_view(b.offsets, n + 1, torch.int32, out, device)
-                nbytes = int(offsets[-1].item()) if n else 0
-                values = device_view(b.values, nbytes, torch.uint8, out, device)
-            else:
-                offsets = None
-                values = device_view(b.values, n, TORCH_DTYPE[b.type], out, device)
-            nulls = device_view(b.nulls, n, torch.uint8, out, device) if b.nulls else None
-            cols.append({"type": b.type, "values": values, "nulls": nulls, "offsets": offsets})
-        return counts, cols
+    @staticmethod
+    def read(ptr, nbytes):
+        return np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(ptr)).copy()
 
-    return run
+    @staticmethod
+    def write(ptr, data):
+        C.memmove(ptr, data.ctypes.data, data.nbytes)
 
 
-def page_columns(page: Page, device):
-    """torch views of a device Page's fixed-width columns: [{type, values, nulls|None}] (VARCHAR is not handled here)"""
-    cols = []
-    n = page.position_count
-    for b in page.blocks:
-        if b.type == VARCHAR:
-            raise NotImplementedError("all_gather_page replicates fixed-width columns only")
-        values = b.values if hasattr(b.values, "data_ptr") else device_view(b.values, n, TORCH_DTYPE[b.type], page, device)
-        nulls = None
-        if hasattr(b.nulls, "data_ptr"):
-            nulls = b.nulls
-        elif b.nulls:   # a raw device address (None / 0 = no null vector)
-            nulls = device_view(b.nulls, n, torch.uint8, page, device)
-        cols.append({"type": b.type, "values": values, "nulls": nulls})
-    return cols
+class TorchDeviceMemory:
+    """buffers addressed by the callbacks are device memory: staged through the host with torch (rehearsal on one GPU)"""
+
+    def __init__(self, device):
+        import torch
+        self.torch, self.device = torch, device
+
+    def _view(self, ptr, nbytes):
+        class _Dev:
+            __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+        return self.torch.as_tensor(_Dev(), device=self.device)
+
+    def read(self, ptr, nbytes):
+        return self._view(ptr, nbytes).cpu().numpy()
+
+    def write(self, ptr, data):
+        self._view(ptr, data.nbytes).copy_(self.torch.from_numpy(data))
+        self.torch.cuda.synchronize(self.device)
 
 
-def all_gather_page(dist, device, page: Page) -> Page:
-    """REPLICATED distribution of a (small) build side: every rank receives the rows of all ranks, concatenated in rank order --
-    the broadcast exchange in front of a replicated join (M/sql/planner/SystemPartitioningHandle.java:59 FIXED_BROADCAST_DISTRIBUTION).
-    One all-gather of the row counts, then one all-gather per column buffer (RCCL over xGMI), padded to the largest rank."""
-    w = dist.get_world_size()
-    host_staging = dist.get_backend() == "gloo" and torch.device(device).type == "cuda"
-    coll = torch.device("cpu") if host_staging else torch.device(device)
-    n = int(page.position_count)
-    counts = [torch.zeros(1, dtype=torch.int64, device=coll) for _ in range(w)]
-    dist.all_gather(counts, torch.tensor([n], dtype=torch.int64, device=coll))
-    counts = [int(c.item()) for c in counts]
-    m = max(max(counts), 1)
-    total = sum(counts)
+class GlooTransport:
+    """tgpu_exchange_transport over torch.distributed (any backend that moves host tensors, i.e. gloo)"""
 
-    def gather(t, dtype):
-        pad = torch.zeros(m, dtype=dtype, device=coll)
-        if n:
-            pad[:n] = t.to(coll) if host_staging else t
-        outs = [torch.empty(m, dtype=dtype, device=coll) for _ in range(w)]
-        dist.all_gather(outs, pad)
-        parts = [outs[r][: counts[r]] for r in range(w)]
-        res = torch.cat(parts) if total else torch.zeros(1, dtype=dtype, device=coll)
-        return res.to(device) if host_staging else res
+    def __init__(self, dist, memory):
+        import torch
+        self.torch, self.dist, self.memory = torch, dist, memory
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.error = None
+        self._meta = _lib.TRANSPORT_META_FN(self._all_to_all_meta)
+        self._v = _lib.TRANSPORT_V_FN(self._all_to_all_v)
+        self.struct = _lib.ExchangeTransport(None, self._meta, self._v)
 
-    cols = page_columns(page, device)
-    blocks, keep = [], []
-    # which channels carry a null vector on ANY rank: one collective for all channels (not one per channel)
-    any_nulls = torch.tensor([1 if c["nulls"] is not None else 0 for c in cols] or [0], device=coll)
-    dist.all_reduce(any_nulls, op=dist.ReduceOp.MAX)
-    any_nulls = any_nulls.tolist()
-    for i, c in enumerate(cols):
-        nulls = None
-        if any_nulls[i]:
-            nulls = gather(c["nulls"] if c["nulls"] is not None else torch.zeros(n, dtype=torch.uint8, device=device), torch.uint8)
-        values = gather(c["values"], TORCH_DTYPE[c["type"]])
-        blocks.append(DeviceBlock(c["type"], total, values, nulls))
-        keep += [values, nulls]
-    out = Page(*blocks, position_count=total)
-    out._keep = keep
-    return out
+    def _all_to_all_meta(self, user, send, recv, per_rank):
+        try:
+            n = self.world * per_rank
+            s = self.torch.from_numpy(np.ctypeslib.as_array(send, shape=(n,)).copy())
+            r = self.torch.empty_like(s)
+            self.dist.all_to_all_single(r, s)
+            np.ctypeslib.as_array(recv, shape=(n,))[:] = r.numpy()
+            return 0
+        except Exception as e:   # an exception must not unwind through the C frames
+            self.error = e
+            return -1
 
-
-class HashExchange:
-    def __init__(self, dist, device, partitioner):
-        self.dist = dist
-        self.device = device
-        self.partitioner = partitioner
-        self.world = dist.get_world_size()
-        self.bytes_sent = 0
-        # rehearsal only (several ranks sharing one GPU over `gloo`): gloo moves host tensors, so stage through the host
-        self.host_staging = dist.get_backend() == "gloo" and torch.device(device).type == "cuda"
-        self.coll_device = torch.device("cpu") if self.host_staging else torch.device(device)
-
-    def _a2a(self, send, send_splits, recv_splits):
-        if self.host_staging:
-            send = send.cpu()
-        recv = torch.empty(int(sum(recv_splits)), dtype=send.dtype, device=send.device)
-        self.dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=[int(x) for x in recv_splits], input_split_sizes=[int(x) for x in send_splits])
-        self.bytes_sent += send.numel() * send.element_size()
-        return recv.to(self.device) if self.host_staging else recv
-
-    def exchange(self, page: Page, key_channels):
-        """repartition `page` by the hash of `key_channels`; returns the rows this rank owns as a device (or host-tensor) Page"""
-        w = self.world
-        counts, cols = self.partitioner(page, key_channels, w)
-        # one small all-to-all carries, per destination, the row count AND this rank's per-channel "has a null vector" flags (one
-        # collective + one read-back for the whole page header instead of one all-reduce per channel)
-        flags = [1 if c["nulls"] is not None else 0 for c in cols]
-        header = torch.as_tensor(np.asarray([[int(x)] + flags for x in counts], dtype=np.int64).reshape(-1), device=self.coll_device)
-        recv_header = torch.empty_like(header)
-        self.dist.all_to_all_single(recv_header, header)
-        recv_header = recv_header.reshape(w, 1 + len(cols)).tolist()
-        sc = [int(x) for x in counts]
-        rc = [int(r[0]) for r in recv_header]
-        # a channel travels with nulls when any SENDER has them; every rank must agree, so reduce over what all ranks told everyone:
-        # each rank told every destination its own flags, hence each rank now knows the flags of all ranks
-        any_nulls = [max(int(r[1 + i]) for r in recv_header) for i in range(len(cols))]
-        n_out = sum(rc)
-        blocks, keep = [], []
-        row_starts = np.concatenate([[0], np.cumsum(sc)])
-        for ci, c in enumerate(cols):
-            nulls = None
-            if any_nulls[ci]:
-                send_nulls = c["nulls"] if c["nulls"] is not None else torch.zeros(sum(sc), dtype=torch.uint8, device=self.device)
-                nulls = self._a2a(send_nulls, sc, rc)
-            if c["type"] == VARCHAR:
-                off = c["offsets"].to(torch.int64)
-                lens = (off[1:] - off[:-1]).to(torch.int32)
-                recv_lens = self._a2a(lens, sc, rc)
-                seg = off[torch.as_tensor(row_starts, device=off.device)]
-                send_bytes = [int(x) for x in (seg[1:] - seg[:-1]).tolist()]
-                sb = torch.as_tensor(np.asarray(send_bytes, dtype=np.int64), device=self.coll_device)
-                rb = torch.empty(w, dtype=torch.int64, device=self.coll_device)
-                self.dist.all_to_all_single(rb, sb)
-                values = self._a2a(c["values"][: sum(send_bytes)], send_bytes, [int(x) for x in rb.tolist()])
-                offsets = torch.zeros(n_out + 1, dtype=torch.int32, device=self.device)
-                if n_out:
-                    offsets[1:] = torch.cumsum(recv_lens.to(torch.int64), 0).to(torch.int32)
-                if values.numel() == 0:
-                    values = torch.zeros(1, dtype=torch.uint8, device=self.device)
-                blocks.append(DeviceBlock(VARCHAR, n_out, values, nulls, offsets))
-                keep += [values, offsets, nulls]
-            else:
-                values = self._a2a(c["values"], sc, rc)
-                if values.numel() == 0:
-                    values = torch.zeros(1, dtype=values.dtype, device=self.device)
-                blocks.append(DeviceBlock(c["type"], n_out, values, nulls))
-                keep += [values, nulls]
-        out = Page(*blocks, position_count=n_out)
-        out._keep = keep
-        return out
+    def _all_to_all_v(self, user, transfers, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        try:
+            w = self.world
+            for t in range(transfers):
+                sb = [int(send_bytes[t * w + r]) for r in range(w)]
+                rb = [int(recv_bytes[t * w + r]) for r in range(w)]
+                parts = [self.memory.read(send_ptr[t * w + r], sb[r]) if sb[r] else np.zeros(0, dtype=np.uint8) for r in range(w)]
+                send = self.torch.from_numpy(np.concatenate(parts)) if sum(sb) else self.torch.zeros(0, dtype=self.torch.uint8)
+                recv = self.torch.empty(sum(rb), dtype=self.torch.uint8)
+                self.dist.all_to_all_single(recv, send, output_split_sizes=rb, input_split_sizes=sb)
+                at = 0
+                got = recv.numpy()
+                for r in range(w):
+                    if rb[r]:
+                        self.memory.write(recv_ptr[t * w + r], np.ascontiguousarray(got[at:at + rb[r]]))
+                    at += rb[r]
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1

@@ -1,0 +1,151 @@
+"""The native exchange (csrc/exchange.hip behind tgpu_exchange_*) on the GPU:
+  * over RCCL at world size 1 (the single-GPU box): partition kernels -> page header -> grouped ncclSend / ncclRecv -> device page;
+  * a 2-rank rehearsal on ONE GPU (two processes, RCCL would refuse two ranks on one device): the same library code over the
+    callback transport (GlooTransport, host staging) -- rows land on the rank that owns their hash partition
+    ((rawHash & 0x7fff...) % world, M/operator/HashGenerator.java:24-35, checked with the oracle), nothing lost or duplicated, source
+    order kept, VARCHAR / null vectors (present on one rank only) / empty contributions survive."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from gpu_common import rand_block
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def test_exchange_world1_rccl(pkg, ctx, oracle):
+    ex_mod = importlib.import_module("presto-1_amd.exchange")
+    ex = ex_mod.Exchange.over_rccl(ctx, 0, 1, lambda payload: payload)
+    rng = np.random.default_rng(37)
+    n = 50_000
+    T = [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE]
+    page = pkg.Page(rand_block(pkg, rng, pkg.BIGINT, n, 0.02, (0, 10**6)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.05, (0, 40)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.1))
+    out = ex.repartition(page, [0])
+    assert out.to_host().rows() == page.rows()          # one partition: input order preserved
+    out.release()
+    # the PartitionedOutputOperator (shuffle producer) feeding the exchange inside the library
+    pf = pkg.PartitionedOutputOperatorFactory(ctx, 0, T, [0], 1)
+    pop = pf.createOperator()
+    pop.addInput(page)
+    out = ex.partitioned_output(pop, T)
+    assert out.to_host().rows() == page.rows()
+    out.release()
+    pop.finish()
+    pop.close()
+    # broadcast of an operator's device output page, then into a join build
+    keys = rng.permutation(200_000)[:60_000].astype(np.int64)
+    f = pkg.field
+    fp = pkg.FilterAndProjectOperatorFactory(ctx, 1, [pkg.BIGINT], None, [f(0, pkg.BIGINT)])
+    op = fp.createOperator()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, keys)))
+    o = op.getOutput()
+    rep = ex.all_gather(o.as_device_page())
+    o.release()
+    assert rep.position_count == len(keys)
+    bf = pkg.HashBuilderOperatorFactory(ctx, 2, [pkg.BIGINT], [0], [0])
+    b = bf.createOperator()
+    b.addInput(rep)
+    b.finish()
+    rep.release()
+    jf = pkg.LookupJoinOperatorFactory(ctx, 3, bf.lookup_source_factory, [pkg.BIGINT], [0], probe_output_channels=[0])
+    probe = rng.integers(0, 200_000, 100_000).astype(np.int64)
+    joined = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, probe))])
+    want_p, want_b = oracle.PagesHash([oracle.Col(pkg.BIGINT, keys)]).probe([oracle.Col(pkg.BIGINT, probe)])
+    assert [r for pg in joined for r in pg.rows()] == [(int(probe[i]), int(keys[j])) for i, j in zip(want_p, want_b)]
+    assert ex.bytes_sent == 0                           # nothing leaves a single rank
+    # an empty page takes part in the collectives like any other
+    empty = pkg.Page(pkg.Block(pkg.BIGINT, np.zeros(0, dtype=np.int64)), pkg.Block(pkg.VARCHAR, []), pkg.Block(pkg.DOUBLE, np.zeros(0)))
+    out = ex.repartition(empty, [0])
+    assert out.position_count == 0
+    out.release()
+    ex.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rows(rank, n):
+    rng = np.random.Generator(np.random.PCG64(100 + rank))
+    keys = rng.integers(0, 5000, n).astype(np.int64)
+    pay = np.arange(n, dtype=np.int64) + rank * 1_000_000
+    strs = [None if k % 11 == 0 else "s%d" % (k % 37) * (1 + k % 3) for k in keys]
+    dbl = rng.standard_normal(n)
+    dnull = (rng.random(n) < 0.1).astype(np.uint8) if rank == 0 else None     # a null vector on one rank only
+    return keys, pay, strs, dbl, dnull
+
+
+def _rehearsal_worker(rank, world, port, n, out_q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pkg = importlib.import_module("presto-1_amd")
+        ex_mod = importlib.import_module("presto-1_amd.exchange")
+        ctx = pkg.Context(0)
+        dev = torch.device("cuda", 0)
+        ex = ex_mod.Exchange.over_transport(ctx, rank, world, ex_mod.GlooTransport(dist, ex_mod.TorchDeviceMemory(dev)))
+        keys, pay, strs, dbl, dnull = _rows(rank, n if rank == 0 else n // 3)
+        page = pkg.Page(pkg.Block(pkg.BIGINT, keys), pkg.Block(pkg.BIGINT, pay), pkg.Block(pkg.VARCHAR, strs), pkg.Block(pkg.DOUBLE, dbl, dnull))
+        got = ex.repartition(page, [0]).to_host()
+        rep = ex.all_gather(pkg.Page(pkg.Block(pkg.BIGINT, pay[: 5 + 3 * rank]), pkg.Block(pkg.VARCHAR, strs[: 5 + 3 * rank]))).to_host()
+        empty = pkg.Page(pkg.Block(pkg.BIGINT, np.zeros(0, dtype=np.int64)), pkg.Block(pkg.BIGINT, np.zeros(0, dtype=np.int64)), pkg.Block(pkg.VARCHAR, []),
+                         pkg.Block(pkg.DOUBLE, np.zeros(0)))
+        lonely = ex.repartition(page if rank == 1 else empty, [0]).to_host()       # one rank contributes nothing
+        out_q.put((rank, got.rows(), rep.rows(), lonely.rows(), ex.bytes_sent, None))
+        ex.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:   # surfaced by the parent
+        import traceback
+        out_q.put((rank, None, None, None, 0, traceback.format_exc()))
+
+
+def test_exchange_two_ranks_on_one_gpu_over_the_callback_transport(pkg, oracle):
+    import torch.multiprocessing as mp
+    world, n = 2, 3000
+    port = _free_port()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_rehearsal_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in results:
+        assert r[5] is None, r[5]
+    sent = {}
+    for r in range(world):
+        keys, pay, strs, dbl, dnull = _rows(r, n if r == 0 else n // 3)
+        sent[r] = [(int(k), int(p), s, None if (dnull is not None and dnull[i]) else float(d)) for i, (k, p, s, d) in enumerate(zip(keys, pay, strs, dbl))]
+
+    def owner(key):
+        return int(oracle.partition_remote(oracle.hash_rows([oracle.Col(oracle.BIGINT, np.array([key], dtype=np.int64))]), world)[0])
+
+    for rank, got, rep, lonely, nbytes, _ in results:
+        want = [row for src in range(world) for row in sent[src] if owner(row[0]) == rank]     # grouped by source rank, source order kept
+        assert got == want
+        assert nbytes > 0
+        want_rep = [(row[1], row[2]) for src in range(world) for row in sent[src][: 5 + 3 * src]]
+        assert rep == want_rep
+        assert lonely == [row for row in sent[1] if owner(row[0]) == rank]

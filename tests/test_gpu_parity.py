@@ -867,50 +867,7 @@ def test_group_by_hash_optimistic_sub_batch_overflow_retry(pkg, oracle, monkeypa
     c.close()
 
 
-def test_hash_exchange_single_rank_nccl(pkg, ctx, oracle):
-    """the exchange code path on the GPU with RCCL (world size 1 on the single-GPU box): K10 partition kernel -> zero-copy torch
-    views of the library's device buffers -> all_to_all_single -> device page"""
-    import torch
-    import torch.distributed as dist
-    ex_mod = importlib.import_module("presto-1_amd.exchange")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dev = torch.device("cuda", 0)
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        rng = np.random.default_rng(37)
-        n = 50_000
-        blocks = [rand_block(pkg, rng, pkg.BIGINT, n, 0.02, (0, 10**6)), rand_block(pkg, rng, pkg.VARCHAR, n, 0.05, (0, 40)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.1)]
-        page = pkg.Page(*blocks)
-        ex = ex_mod.HashExchange(dist, dev, ex_mod.hip_partitioner(ctx, dev))
-        out = ex.exchange(page, [0])
-        assert out.position_count == n
-        # feed the exchanged device page to an operator: identity filter/project brings it back to the host
-        f = pkg.field
-        fac = pkg.FilterAndProjectOperatorFactory(ctx, 0, [pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE], None, [f(0, pkg.BIGINT), f(1, pkg.VARCHAR), f(2, pkg.DOUBLE)])
-        got = pkg.to_pages(fac.createOperator(), [out])
-        assert got[0].rows() == page.rows()   # world size 1: one partition, input order preserved
-        # the REPLICATED distribution (all-gather) of an operator's device output page over RCCL, then into a join build
-        keys = rng.permutation(200_000)[:60_000].astype(np.int64)
-        fp = pkg.FilterAndProjectOperatorFactory(ctx, 1, [pkg.BIGINT], None, [f(0, pkg.BIGINT)])
-        op = fp.createOperator()
-        op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, keys)))
-        o = op.getOutput()
-        rep = ex_mod.all_gather_page(dist, dev, o.as_device_page())
-        assert rep.position_count == len(keys)
-        bf = pkg.HashBuilderOperatorFactory(ctx, 2, [pkg.BIGINT], [0], [0])
-        b = bf.createOperator()
-        b.addInput(rep)
-        b.finish()
-        o.release()
-        jf = pkg.LookupJoinOperatorFactory(ctx, 3, bf.lookup_source_factory, [pkg.BIGINT], [0], probe_output_channels=[0])
-        probe = rng.integers(0, 200_000, 100_000).astype(np.int64)
-        joined = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, probe))])
-        want_p, want_b = oracle.PagesHash([oracle.Col(pkg.BIGINT, keys)]).probe([oracle.Col(pkg.BIGINT, probe)])
-        assert [r for pg in joined for r in pg.rows()] == [(int(probe[i]), int(keys[j])) for i, j in zip(want_p, want_b)]
-    finally:
-        dist.destroy_process_group()
+# (the exchange tests live in tests/test_gpu_exchange.py)
 
 
 # ---- TopN (M/operator/TopNOperator.java) ---------------------------------------------------------------------------------------
