@@ -29,10 +29,17 @@ struct Rccl {
 const Rccl &rccl()
 {
     static const Rccl api = [] {
+        // One RCCL per process: a host that already carries one (PyTorch ships its own librccl) must not get a second copy of the
+        // same soname mixed in -- reuse what is loaded (RTLD_NOLOAD), else load ROCm's, with local symbol scope either way.
         void *h = nullptr;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *name : names) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (h) break;
+        }
+        for (const char *name : names) {
+            if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!h) fail(TGPU_ERR_DEVICE, std::string("cannot load librccl: ") + dlerror());
         Rccl a;

@@ -15,6 +15,7 @@ import pytest
 from gpu_common import rand_block
 
 pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")   # first: the library then reuses the RCCL PyTorch has loaded instead of adding a second copy
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
