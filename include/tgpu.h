@@ -202,6 +202,14 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
                                          int32_t precomputed_hash_channel /* -1 = none */, int32_t expected_positions,
                                          tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out);
 void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge);
+/* JoinFilterFunction (M/operator/JoinHash.java:44-47,82-130; M/sql/gen/JoinFilterFunctionCompiler.java; handed to the build side like
+ * JoinHashSupplier.java:54-70): a predicate over (build row, probe row) that a join position must pass besides key equality.  `spec`'s
+ * filter expression is that predicate (its projections are ignored); its input channels [0, build type count) are the build side's
+ * channels (the hash builder's `types`), channel build-type-count + k is probe channel k.  A key's chain is walked newest -> oldest and
+ * rejected positions are skipped; a PROBE_OUTER / FULL_OUTER row all of whose candidates are rejected comes out with a null build side.
+ * Call before the probe operators are created. */
+int32_t tgpu_lookup_source_factory_set_join_filter(tgpu_lookup_source_factory *bridge, int32_t probe_type_count, const int32_t *probe_types,
+                                                   const tgpu_page_processor_spec *spec);
 /* statistics of the built table (valid once the build operator finished): positions, table slots, position links */
 int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count);
 

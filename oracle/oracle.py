@@ -710,3 +710,43 @@ class DynamicFilterSource:
         if k not in self.mins:
             return ("none",)
         return ("range", self.mins[k], self.maxs[k])
+
+
+# ---- join filter function -------------------------------------------------------------------------
+def probe_with_filter(pages_hash, probe_key_cols, build_cols, probe_cols, flat_nodes, root, pool, probe_outer=False):
+    """JoinHash.getJoinPosition / getNextJoinPosition with a JoinFilterFunction (M/operator/JoinHash.java:82-130): the positions of a
+    key's chain are visited newest -> oldest and a position is eligible only if filter(build position, probe position, probe page) holds;
+    a PROBE_OUTER row without an eligible position comes out once with build position -1 (LookupJoinOperator.java:354-361).
+    The expression's channels [0, len(build_cols)) are the build side's, the following ones the probe page's.  Returns (probe idx, build idx)."""
+    op, ob = pages_hash.probe(probe_key_cols)                    # key-equal candidates in chain order
+    keep = np.zeros(len(op), dtype=bool)
+    if len(op):
+        def take(c, idx):
+            if c.type == VARCHAR:
+                items = []
+                for i in idx:
+                    if c.nulls is not None and c.nulls[i]:
+                        items.append(None)
+                    else:
+                        items.append(bytes(c.values[c.offsets[i]:c.offsets[i + 1]]))
+                return Col(VARCHAR, items)
+            return Col(c.type, c.values[idx], None if c.nulls is None else c.nulls[idx])
+        pair_cols = [take(c, ob) for c in build_cols] + [take(c, op) for c in probe_cols]
+        pos = filter_positions(flat_nodes, root, pool, pair_cols)   # row-at-a-time: selected = !wasNull && value
+        keep[pos] = True
+    op, ob = op[keep], ob[keep]
+    if not probe_outer:
+        return op, ob
+    n = probe_key_cols[0].n
+    out_p, out_b, at = [], [], 0
+    for r in range(n):
+        any_match = False
+        while at < len(op) and op[at] == r:
+            out_p.append(r)
+            out_b.append(int(ob[at]))
+            at += 1
+            any_match = True
+        if not any_match:
+            out_p.append(r)
+            out_b.append(-1)
+    return np.array(out_p, dtype=np.int32), np.array(out_b, dtype=np.int32)

@@ -85,6 +85,7 @@ SYMBOLS = {
     "tgpu_hash_builder_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, P(i32), i32, i32, P(vp), P(vp)]),
     "tgpu_lookup_source_factory_destroy": (None, [vp]),
     "tgpu_lookup_source_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
+    "tgpu_lookup_source_factory_set_join_filter": (i32, [vp, i32, P(i32), P(PageProcessorSpec)]),
     "tgpu_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
     "tgpu_top_n_factory_create": (i32, [vp, i32, i32, P(i32), C.c_int64, i32, P(i32), P(i32), P(vp)]),
     "tgpu_order_by_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, i32, P(i32), P(i32), P(vp)]),

@@ -322,6 +322,30 @@ void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge)
     if (c) drop(c);
 }
 
+int32_t tgpu_lookup_source_factory_set_join_filter(tgpu_lookup_source_factory *bridge, int32_t probe_type_count, const int32_t *probe_types,
+                                                   const tgpu_page_processor_spec *spec)
+{
+    return guard_on(ctx_of(bridge), [&] {
+        TG_CHECK_ARG(bridge && spec, "null argument");
+        TG_CHECK_ARG(spec->filter_root >= 0 && spec->filter_root < spec->node_count, "the join filter is the spec's filter expression");
+        auto f = std::make_shared<JoinFilter>();
+        f->nodes.assign(spec->nodes, spec->nodes + spec->node_count);
+        if (spec->string_pool && spec->string_pool_len > 0) f->pool.assign(spec->string_pool, spec->string_pool + spec->string_pool_len);
+        f->root = spec->filter_root;
+        f->build_types = bridge->bridge->build_types;
+        f->probe_types = vec(probe_types, probe_type_count);
+        TG_CHECK_ARG(f->nodes[(size_t)f->root].type == TGPU_BOOLEAN, "the join filter must be a BOOLEAN expression");
+        const int limit = (int)f->build_types.size() + probe_type_count;
+        for (auto &nd : f->nodes) {
+            if (nd.kind != TGPU_EX_INPUT) continue;
+            TG_CHECK_ARG(nd.op >= 0 && nd.op < limit, "join filter: input channel out of range");
+            const int32_t t = nd.op < (int)f->build_types.size() ? f->build_types[(size_t)nd.op] : f->probe_types[(size_t)nd.op - f->build_types.size()];
+            TG_CHECK_ARG(t == nd.type, "join filter: input reference type does not match the channel type");
+        }
+        bridge->bridge->set_join_filter(f);
+    });
+}
+
 int32_t tgpu_lookup_source_stats(tgpu_lookup_source_factory *bridge, int64_t *positions, int64_t *hash_size, int64_t *link_count)
 {
     return guard_on(ctx_of(bridge), [&] {

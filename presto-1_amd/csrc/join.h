@@ -70,6 +70,8 @@ public:
     void probe(const std::vector<const DeviceColumn *> &probe_keys, const int64_t *probe_hashes, int64_t n_probe, bool probe_outer,
                BufferPtr &out_probe_idx, BufferPtr &out_build_idx, int64_t &out_count);
     DeviceColumn gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const;
+    // any channel of the build side (a join filter function may read channels that are not output channels)
+    DeviceColumn gather_index_channel(int channel, const int32_t *build_positions, int64_t n) const;
     // OuterPositionTracker (M/operator/OuterLookupSource.java:146-190): LOOKUP_OUTER / FULL_OUTER probes record the build positions
     // they emitted; unvisited_positions = OuterPositionIterator, every build position nobody matched, ascending
     void mark_visited(const int32_t *build_positions, int64_t n);

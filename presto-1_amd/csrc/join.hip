@@ -865,6 +865,12 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
     }
 }
 
+DeviceColumn LookupSourceGpu::gather_index_channel(int channel, const int32_t *build_positions, int64_t n) const
+{
+    TG_CHECK_ARG(channel >= 0 && channel < (int)index_->types().size(), "build channel out of range");
+    return k::gather_column(ctx_, index_->column(channel), build_positions, n, false);
+}
+
 DeviceColumn LookupSourceGpu::gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const
 {
     DeviceColumn src = index_->column(output_channels_[out_idx]);

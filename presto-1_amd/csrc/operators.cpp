@@ -293,6 +293,7 @@ HashBuilderOperatorFactory::HashBuilderOperatorFactory(Context *ctx, int32_t ope
     for (int32_t ch : cfg_.hash_channels) TG_CHECK_ARG(ch >= 0 && ch < nt, "join channel out of range");
     TG_CHECK_ARG(cfg_.precomputed_hash_channel < nt, "hash channel out of range");
     for (int32_t ch : cfg_.output_channels) bridge_->build_output_types.push_back(cfg_.types[(size_t)ch]);
+    bridge_->build_types = cfg_.types;
 }
 
 std::unique_ptr<Operator> HashBuilderOperatorFactory::create_operator()
@@ -303,10 +304,132 @@ std::unique_ptr<Operator> HashBuilderOperatorFactory::create_operator()
     return std::make_unique<HashBuilderOperator>(ctx_, operator_id_, cfg_, bridge_);
 }
 
+// ---- join filter function: the candidate pairs of a probe page, filtered --------------------------------------------------------
+namespace {
+// pairs are in (probe position, chain) order: count[row] = surviving pairs of the probe row
+__global__ void __launch_bounds__(256) jf_count_kernel(const int32_t *probe_idx, int64_t pairs, int32_t *count)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * 256) atomicAdd(&count[probe_idx[i]], 1);
+}
+__global__ void __launch_bounds__(256) jf_emit_count_kernel(const int32_t *count, int64_t n, int32_t *emit)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) emit[r] = count[r] > 0 ? count[r] : 1;
+}
+// PROBE_OUTER output: every probe row's surviving pairs, or (row, -1) when it has none (LookupJoinOperator.java:354-361)
+__global__ void __launch_bounds__(256) jf_outer_rows_kernel(const int32_t *count, const int32_t *offset, int64_t n, int32_t *out_probe, int32_t *out_build)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+        if (count[r] == 0) {
+            out_probe[offset[r]] = (int32_t)r;
+            out_build[offset[r]] = -1;
+        }
+}
+__global__ void __launch_bounds__(256) jf_outer_pairs_kernel(const int32_t *probe_idx, const int32_t *build_idx, int64_t pairs, const int32_t *start, const int32_t *offset,
+                                                             int32_t *out_probe, int32_t *out_build)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * 256) {
+        const int32_t r = probe_idx[i];
+        const int64_t at = (int64_t)offset[r] + (i - start[r]);   // the pair's rank among its row's survivors: pairs of a row are adjacent
+        out_probe[at] = r;
+        out_build[at] = build_idx[i];
+    }
+}
+}  // namespace
+
+// JoinHash.getJoinPosition / getNextJoinPosition with a filter function (M/operator/JoinHash.java:82-130): the positions of a key's
+// chain are visited newest -> oldest and those the filter rejects are skipped; a PROBE_OUTER row whose every candidate is rejected comes
+// out with a null build side.  Here: the key-equal candidate pairs (in that very order) are filtered by a generated kernel
+// evaluating the predicate over (build channels gathered at the build position, probe channels gathered at the probe position).
+static void apply_join_filter(Context *ctx, LookupSourceGpu &source, const JoinFilter &jf, const DevicePage &in, bool outer, BufferPtr &probe_idx, BufferPtr &build_idx,
+                              int64_t &count)
+{
+    const int nb = (int)jf.build_types.size();
+    TG_CHECK_ARG(jf.probe_types.size() == in.cols.size(), "the join filter's probe types differ from the probe page's channels");
+    // the channels the predicate reads, compacted: [referenced build channels..., referenced probe channels..., probe index, build index]
+    std::vector<tgpu_expr_node> nodes = jf.nodes;
+    std::vector<int> remap((size_t)nb + in.cols.size(), -1);
+    std::vector<int32_t> types;
+    std::vector<int> sources;
+    for (auto &nd : nodes)
+        if (nd.kind == TGPU_EX_INPUT) {
+            TG_CHECK_ARG(nd.op >= 0 && nd.op < (int)remap.size(), "join filter: input channel out of range");
+            if (remap[(size_t)nd.op] < 0) {
+                remap[(size_t)nd.op] = (int)types.size();
+                types.push_back(nd.op < nb ? jf.build_types[(size_t)nd.op] : jf.probe_types[(size_t)(nd.op - nb)]);
+                sources.push_back(nd.op);
+            }
+            nd.op = remap[(size_t)nd.op];
+        }
+    const int idx_ch = (int)types.size();
+    types.push_back(TGPU_INTEGER);
+    types.push_back(TGPU_INTEGER);
+    tgpu_expr_node pi{}, bi{};
+    pi.kind = bi.kind = TGPU_EX_INPUT;
+    pi.type = bi.type = TGPU_INTEGER;
+    pi.op = idx_ch;
+    bi.op = idx_ch + 1;
+    nodes.push_back(pi);
+    nodes.push_back(bi);
+    const int32_t roots[2] = {(int32_t)nodes.size() - 2, (int32_t)nodes.size() - 1};
+    tgpu_page_processor_spec spec{nodes.data(), (int32_t)nodes.size(), jf.pool.data(), (int32_t)jf.pool.size(), jf.root, 2, roots};
+    std::shared_ptr<PageProcessorGpu> pp = PageProcessorGpu::shared(types, &spec);
+
+    // candidate pairs (inner semantics: the outer rows are added after the filter)
+    DevicePage cand;
+    cand.n = count;
+    for (int src : sources) {
+        if (src < nb) cand.cols.push_back(source.gather_index_channel(src, build_idx->as<int32_t>(), count));
+        else cand.cols.push_back(k::gather_column(ctx, in.cols[(size_t)(src - nb)], probe_idx->as<int32_t>(), count, false));
+    }
+    auto idx_col = [&](const BufferPtr &b) {
+        DeviceColumn c;
+        c.type = TGPU_INTEGER;
+        c.n = count;
+        c.values_buf = b;
+        c.values = b->ptr();
+        return c;
+    };
+    cand.cols.push_back(idx_col(probe_idx));
+    cand.cols.push_back(idx_col(build_idx));
+    DevicePage kept;
+    int64_t survivors = 0;
+    if (count > 0 && pp->process(ctx, cand, kept)) {
+        survivors = kept.n;
+        probe_idx = kept.cols[0].values_buf;
+        build_idx = kept.cols[1].values_buf;
+    }
+    if (!outer) {
+        count = survivors;
+        return;
+    }
+    // PROBE_OUTER / FULL_OUTER: a probe row without a surviving candidate is emitted once, build side null, at its place in the order
+    const int64_t n = in.n;
+    ProfileScope ps(ctx, "join_filter_outer");
+    BufferPtr cnt = ctx->alloc_zero((size_t)n * 4), emit = ctx->alloc((size_t)n * 4), start = ctx->alloc((size_t)n * 4), offset = ctx->alloc((size_t)n * 4), total = ctx->alloc(16);
+    const int g = (int)std::min<int64_t>(ceil_div(std::max<int64_t>(n, 1), 256), (int64_t)ctx->cu_count() * 8);
+    if (survivors > 0) jf_count_kernel<<<g, 256, 0, ctx->stream()>>>(probe_idx->as<int32_t>(), survivors, cnt->as<int32_t>());
+    jf_emit_count_kernel<<<g, 256, 0, ctx->stream()>>>(cnt->as<int32_t>(), n, emit->as<int32_t>());
+    k::exclusive_scan_i32(ctx, cnt->as<int32_t>(), start->as<int32_t>(), n, total->as<int64_t>());
+    k::exclusive_scan_i32(ctx, emit->as<int32_t>(), offset->as<int32_t>(), n, total->as<int64_t>() + 1);
+    int64_t totals[2];
+    ctx->download(totals, total->ptr(), 16);
+    const int64_t out_count = totals[1];
+    if (out_count > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "join output of one probe page cannot exceed 2 billion rows");
+    BufferPtr op = ctx->alloc((size_t)out_count * 4), ob = ctx->alloc((size_t)out_count * 4);
+    jf_outer_rows_kernel<<<g, 256, 0, ctx->stream()>>>(cnt->as<int32_t>(), offset->as<int32_t>(), n, op->as<int32_t>(), ob->as<int32_t>());
+    if (survivors > 0)
+        jf_outer_pairs_kernel<<<g, 256, 0, ctx->stream()>>>(probe_idx->as<int32_t>(), build_idx->as<int32_t>(), survivors, start->as<int32_t>(), offset->as<int32_t>(),
+                                                           op->as<int32_t>(), ob->as<int32_t>());
+    check_launch("join_filter_outer");
+    probe_idx = op;
+    build_idx = ob;
+    count = out_count;
+}
+
 // PageJoiner.processProbe + LookupJoinPageBuilder.build for one probe page (M/operator/LookupJoinOperator.java:299-347,
 // LookupJoinPageBuilder.java:101-131): probe columns by probe index, then the build side's output columns.
 // Returns false when the page produces no output row.
-static bool probe_page(Context *ctx, LookupSourceGpu &source, const DevicePage &in, const LookupJoinConfig &cfg, DevicePage &out)
+static bool probe_page(Context *ctx, LookupSourceGpu &source, const DevicePage &in, const LookupJoinConfig &cfg, DevicePage &out, const JoinFilter *filter = nullptr)
 {
     TG_CHECK_ARG(in.cols.size() == cfg.probe_types.size(), "probe page channel count differs from the operator's types");
     if (in.n == 0) return false;
@@ -320,7 +443,8 @@ static bool probe_page(Context *ctx, LookupSourceGpu &source, const DevicePage &
     const bool outer = cfg.join_type == TGPU_JOIN_PROBE_OUTER || cfg.join_type == TGPU_JOIN_FULL_OUTER;
     BufferPtr probe_idx, build_idx;
     int64_t count = 0;
-    source.probe(keys, hashes, in.n, outer, probe_idx, build_idx, count);
+    source.probe(keys, hashes, in.n, outer && !filter, probe_idx, build_idx, count);
+    if (filter) apply_join_filter(ctx, source, *filter, in, outer, probe_idx, build_idx, count);
     if (count == 0) return false;  // no output page for this probe page (:276-283 pageBuilder.isEmpty)
     if (cfg.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg.join_type == TGPU_JOIN_FULL_OUTER) source.mark_visited(build_idx->as<int32_t>(), count);   // OuterLookupSource.appendTo
     out.n = count;
@@ -355,7 +479,8 @@ public:
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
         DevicePage in = ingest_page(ctx_, page);
         DevicePage out;
-        if (probe_page(ctx_, *source, in, cfg_, out)) pending_ = wrap(std::move(out));
+        std::shared_ptr<const JoinFilter> filter = bridge_->join_filter();
+        if (probe_page(ctx_, *source, in, cfg_, out, filter.get())) pending_ = wrap(std::move(out));
     }
 
     std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
@@ -518,7 +643,8 @@ public:
         const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
         const bool track = cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
         IntTableView tv;
-        const bool fused_ok = fused_->supported() && cfg_.probe_join_channels.size() == 1 && source->int_table(tv) && tv.links == nullptr &&
+        std::shared_ptr<const JoinFilter> filter = bridge_->join_filter();   // a join filter function runs on the unfused composition
+        const bool fused_ok = !filter && fused_->supported() && cfg_.probe_join_channels.size() == 1 && source->int_table(tv) && tv.links == nullptr &&
                               tv.key_type == fused_->projection_types()[(size_t)cfg_.probe_join_channels[0]] && getenv("TGPU_DISABLE_FUSION") == nullptr;
         if (fused_ok) {
             std::vector<DeviceColumn> probe_out;
@@ -542,7 +668,7 @@ public:
         DevicePage mid, out;
         if (!processor_->process(ctx_, in, mid)) return;
         probe_rows_ += mid.n;
-        if (probe_page(ctx_, *source, mid, cfg_, out)) pending_ = wrap(std::move(out));
+        if (probe_page(ctx_, *source, mid, cfg_, out, filter.get())) pending_ = wrap(std::move(out));
     }
 
     std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }

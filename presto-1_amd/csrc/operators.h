@@ -84,6 +84,16 @@ private:
     HashAggregationConfig cfg_;
 };
 
+// ---- JoinFilterFunction (M/operator/JoinHash.java:44-47,118-130; M/sql/gen/JoinFilterFunctionCompiler.java): a predicate over
+// (build row, probe row) that a join position must pass besides key equality.  Input channels [0, build types) of the expression
+// are the build side's channels, the following ones the probe page's.
+struct JoinFilter {
+    std::vector<tgpu_expr_node> nodes;
+    std::string pool;
+    int32_t root = -1;
+    std::vector<int32_t> build_types, probe_types;
+};
+
 // ---- join bridge: PartitionedLookupSourceFactory with one partition (M/operator/PartitionedLookupSourceFactory.java:146-205)
 class LookupSourceFactory {
 public:
@@ -138,10 +148,22 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         return no_more_probes_ && live_probes_ == 0 && (!outer_expected_ || outer_done_);
     }
-    std::vector<int32_t> build_output_types;   // written by the build factory's constructor, read-only afterwards
+    std::vector<int32_t> build_output_types, build_types;   // written by the build factory's constructor, read-only afterwards
+    // set before the probe operators are created (the reference passes it to the build side: JoinHashSupplier.java:54-70)
+    void set_join_filter(std::shared_ptr<const JoinFilter> f)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        filter_ = std::move(f);
+    }
+    std::shared_ptr<const JoinFilter> join_filter() const
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        return filter_;
+    }
 
 private:
     mutable std::mutex mu_;
+    std::shared_ptr<const JoinFilter> filter_;
     std::shared_ptr<LookupSourceGpu> source_;
     int live_probes_ = 0;
     bool any_probe_ = false, no_more_probes_ = false, outer_expected_ = false, outer_done_ = false;

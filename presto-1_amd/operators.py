@@ -220,6 +220,13 @@ class LookupSourceFactory:
     def __init__(self, handle):
         self.handle = handle
 
+    def setJoinFilter(self, probe_types, filter_expr):
+        """JoinFilterFunction (M/operator/JoinHash.java:44-47,118-130): `filter_expr` over (build channels..., probe channels...)"""
+        prog = FlatProgram(filter_expr, [])
+        spec, keep = prog.to_c()
+        t, nt = _i32(probe_types)
+        _lib.check(_lib.lib().tgpu_lookup_source_factory_set_join_filter(self.handle, nt, t, C.byref(spec)))
+
     def stats(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
         _lib.check(_lib.lib().tgpu_lookup_source_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))

@@ -1682,3 +1682,105 @@ def test_join_bridge_shared_by_driver_threads(pkg, ctx, oracle):
     jf.noMoreOperators()
     assert not b.isBlocked() and b.isFinished()
     b.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# J7: join filter functions (M/operator/JoinHash.java:44-47,82-130) + the outer-join fixtures of T/operator/TestHashJoinOperator.java:714-1200
+# ---------------------------------------------------------------------------------------------------------------------
+def _golden_filter(pkg, case, n_build_channels):
+    f = pkg.field
+    if case["source"].startswith("T/operator/TestHashJoinOperator.java:714"):
+        return f(n_build_channels + 1, pkg.BIGINT) >= 1025
+    vals = case["filter_probe_values"]
+    e = f(n_build_channels, pkg.VARCHAR).eq(vals[0])
+    for v in vals[1:]:
+        e = pkg.or_(e, f(n_build_channels, pkg.VARCHAR).eq(v))
+    return e
+
+
+@pytest.mark.parametrize("name", ["testProbeOuterJoinWithFilterFunction", "testOuterJoinWithNullProbe", "testOuterJoinWithNullProbeAndFilterFunction",
+                                  "testOuterJoinWithNullBuild", "testOuterJoinWithNullBuildAndFilterFunction", "testOuterJoinWithNullOnBothSides",
+                                  "testOuterJoinWithNullOnBothSidesAndFilterFunction"])
+def test_outer_joins_and_join_filter_function_golden(pkg, ctx, name):
+    case = GOLD["hash_join"][name]
+    if isinstance(case["build"], str):
+        T = [pkg.VARCHAR, pkg.BIGINT, pkg.BIGINT]
+        bpage, ppage = pkg.Page(*blocks_of(pkg, T, sequence_page(T, 10, 20, 30, 40))), pkg.Page(*blocks_of(pkg, T, sequence_page(T, 15, 20, 1020, 2020)))
+    else:
+        T = [pkg.VARCHAR]
+        bpage, ppage = pkg.Page(pkg.Block(pkg.VARCHAR, case["build"])), pkg.Page(pkg.Block(pkg.VARCHAR, case["probe"]))
+    bf = pkg.HashBuilderOperatorFactory(ctx, 0, T, list(range(len(T))), [0])
+    if case["filter"]:
+        bf.lookup_source_factory.setJoinFilter(T, _golden_filter(pkg, case, len(T)))
+    b = bf.createOperator()
+    b.addInput(bpage)
+    b.finish()
+    jf = pkg.LookupJoinOperatorFactory(ctx, 1, bf.lookup_source_factory, T, [0], join_type=pkg.PROBE_OUTER)
+    rows = [list(r) for pg in pkg.to_pages(jf.createOperator(), [ppage]) for r in pg.rows()]
+    assert rows == case["expect_rows"]
+
+
+@pytest.mark.parametrize("join_type", ["INNER", "PROBE_OUTER", "LOOKUP_OUTER", "FULL_OUTER"])
+def test_joins_with_empty_lookup_source_golden(pkg, ctx, join_type):
+    want = GOLD["hash_join"]["emptyLookupSource"]["expect_rows_by_join_type"][join_type]
+    T = [pkg.VARCHAR]
+    bf = pkg.HashBuilderOperatorFactory(ctx, 0, T, [0], [0])
+    b = bf.createOperator()
+    b.finish()
+    jf = pkg.LookupJoinOperatorFactory(ctx, 1, bf.lookup_source_factory, T, [0], join_type=getattr(pkg, join_type))
+    rows = [list(r) for pg in pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.VARCHAR, ["test"]))]) for r in pg.rows()]
+    assert rows == want
+
+
+def test_lookup_join_page_builder_scenarios(pkg, ctx):
+    """T/operator/TestLookupJoinPageBuilder.java:86-156: the (probe position, build position) pair patterns of testDifferentPositions as joins"""
+    G = GOLD["lookup_join_page_builder"]
+    vals = np.arange(100, dtype=np.int64)
+    bf = pkg.HashBuilderOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [0])
+    b = bf.createOperator()
+    b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, vals)))
+    b.finish()
+    jf = pkg.LookupJoinOperatorFactory(ctx, 1, bf.lookup_source_factory, [pkg.BIGINT], [0])
+    probes = {"non_sequential_positions": [int(v) if v % 2 == 0 else None for v in vals], "everything": [int(v) for v in vals],
+              "some_sequential_positions": [int(v) if 10 <= v < 50 else None for v in vals], "empty": [None] * 100}
+    for name, probe in probes.items():
+        rows = [list(r) for pg in pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(pkg.BIGINT, probe))]) for r in pg.rows()]
+        assert rows == G[name]["expect_rows"], name
+
+
+@pytest.mark.parametrize("join_type", ["INNER", "PROBE_OUTER", "LOOKUP_OUTER", "FULL_OUTER"])
+def test_join_filter_function_random_vs_oracle(pkg, ctx, oracle, join_type):
+    """duplicate build keys (chains), nulls on both sides, a predicate over build AND probe channels; LOOKUP_OUTER / FULL_OUTER: only
+    positions that passed the filter count as visited"""
+    rng = np.random.default_rng(91)
+    nb, npr = 4000, 9000
+    B, D = pkg.BIGINT, pkg.DOUBLE
+    bkey = rand_block(pkg, rng, B, nb, 0.05, (0, 600))
+    bval = rand_block(pkg, rng, B, nb, 0.1, (-50, 50))
+    pkey = rand_block(pkg, rng, B, npr, 0.05, (0, 700))
+    pval = rand_block(pkg, rng, B, npr, 0.1, (-50, 50))
+    f = pkg.field
+    # build channels 0, 1; probe channels 2, 3: build.val < probe.val AND probe.val <> 7
+    filt = pkg.and_(f(1, B) < f(3, B), f(3, B).ne(7))
+    bf = pkg.HashBuilderOperatorFactory(ctx, 0, [B, B], [0, 1], [0])
+    bf.lookup_source_factory.setJoinFilter([B, B], filt)
+    b = bf.createOperator()
+    b.addInput(pkg.Page(bkey, bval))
+    b.finish()
+    jt = getattr(pkg, join_type)
+    jf = pkg.LookupJoinOperatorFactory(ctx, 1, bf.lookup_source_factory, [B, B], [0], join_type=jt)
+    got = [r for pg in pkg.to_pages(jf.createOperator(), [pkg.Page(pkey, pval)]) for r in pg.rows()]
+    prog = pkg.expressions.FlatProgram(filt, [])
+    ph = oracle.PagesHash([ocol(oracle, bkey)])
+    outer = join_type in ("PROBE_OUTER", "FULL_OUTER")
+    op, ob = oracle.probe_with_filter(ph, [ocol(oracle, pkey)], [ocol(oracle, bkey), ocol(oracle, bval)], [ocol(oracle, pkey), ocol(oracle, pval)],
+                                      prog.nodes, prog.filter_root, b"", probe_outer=outer)
+    pk, pv, bk, bv = pkey.to_list(), pval.to_list(), bkey.to_list(), bval.to_list()
+    want = [(pk[p], pv[p]) + ((None, None) if q < 0 else (bk[q], bv[q])) for p, q in zip(op, ob)]
+    assert got == want
+    if join_type in ("LOOKUP_OUTER", "FULL_OUTER"):
+        jf.noMoreOperators()
+        of = pkg.LookupOuterOperatorFactory(ctx, 2, bf.lookup_source_factory, [B, B])
+        outer_rows = [r for pg in pkg.to_pages(of.createOperator(), []) for r in pg.rows()]
+        visited = set(int(q) for q in ob if q >= 0)
+        assert outer_rows == [(None, None, bk[q], bv[q]) for q in range(nb) if q not in visited]

@@ -261,3 +261,45 @@ def test_order_by_golden(oracle, name):
     cols = [oracle.Col(t, [r[i] for r in rows]) for i, t in enumerate(types)]
     pos = oracle.top_n(cols, len(rows), case["sort_channels"], [SORT_ORDER[o] for o in case["sort_orders"]])
     assert [[rows[i][ch] for ch in case["output_channels"]] for i in pos] == case["expect_rows"]
+
+
+# ---- outer joins and join filter functions: T/operator/TestHashJoinOperator.java:714-1021 ------------------------------------------
+def _filter_program(pkg_expr, case, n_build_channels, probe_types):
+    E = pkg_expr
+    if case["source"].startswith("T/operator/TestHashJoinOperator.java:714"):
+        return E.FlatProgram(E.field(n_build_channels + 1, BIGINT) >= 1025, [])
+    vals = case["filter_probe_values"]
+    f = E.field(n_build_channels + 0, VARCHAR)
+    e = f.eq(vals[0])
+    for v in vals[1:]:
+        e = E.or_(e, f.eq(v))
+    return E.FlatProgram(e, [])
+
+
+@pytest.mark.parametrize("name", ["testProbeOuterJoinWithFilterFunction", "testOuterJoinWithNullProbe", "testOuterJoinWithNullProbeAndFilterFunction",
+                                  "testOuterJoinWithNullBuild", "testOuterJoinWithNullBuildAndFilterFunction", "testOuterJoinWithNullOnBothSides",
+                                  "testOuterJoinWithNullOnBothSidesAndFilterFunction"])
+def test_outer_joins_and_join_filter_function_golden(oracle, name):
+    import importlib
+    E = importlib.import_module("presto-1_amd").expressions
+    case = GOLD["hash_join"][name]
+    if isinstance(case["build"], str):
+        T = [VARCHAR, BIGINT, BIGINT]
+        bvals, pvals = sequence_page(T, 10, 20, 30, 40), sequence_page(T, 15, 20, 1020, 2020)
+    else:
+        T = [VARCHAR]
+        bvals, pvals = [case["build"]], [case["probe"]]
+    bcols = [oracle.Col(t, v) for t, v in zip(T, bvals)]
+    pcols = [oracle.Col(t, v) for t, v in zip(T, pvals)]
+    ph = oracle.PagesHash([bcols[0]])
+    if case["filter"]:
+        prog = _filter_program(E, case, len(T), T)
+        op, ob = oracle.probe_with_filter(ph, [pcols[0]], bcols, pcols, prog.nodes, prog.filter_root, bytes(prog.pool), probe_outer=True)
+    else:
+        op, ob = ph.probe([pcols[0]], probe_outer=True)
+    rows = []
+    for p, b in zip(op, ob):
+        row = [list(v)[p] if not isinstance(v, np.ndarray) else v[p].item() for v in pvals]
+        row += [None] * len(T) if b < 0 else [list(v)[b] if not isinstance(v, np.ndarray) else v[b].item() for v in bvals]
+        rows.append(row)
+    assert rows == case["expect_rows"]
