@@ -145,6 +145,7 @@ EXTRA_SYMBOLS = {
     "tgpu_page_processor_source": (i64, [i32, P(i32), P(PageProcessorSpec), cp, i64]),
     "tgpu_group_by_hash_rehash_count": (i32, [vp]),
     "tgpu_debug_bind_count": (C.c_longlong, []),
+    "tgpu_debug_dictionary_pages": (i64, [vp]),
     "tgpu_precompile_fused_probe": (i32, [i32, P(i32), P(PageProcessorSpec), i32, i32, P(i32)]),
     "tgpu_precompile_fused_aggregation": (i32, [i32, P(i32), P(PageProcessorSpec), i32, P(AggSpec), i32, P(i32)]),
 }

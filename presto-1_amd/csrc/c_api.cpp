@@ -504,6 +504,17 @@ int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
     });
 }
 
+/* diagnostics: input pages a FilterAndProjectOperator processed once per dictionary entry (DictionaryAwarePageFilter / -Projection path) */
+int64_t tgpu_debug_dictionary_pages(tgpu_operator *op)
+{
+    int64_t v = 0;
+    int32_t rc = guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        v = filter_project_dictionary_pages(op->op.get());
+    });
+    return rc == TGPU_OK ? v : rc;
+}
+
 int32_t tgpu_operator_finish(tgpu_operator *op)
 {
     return guard_on(ctx_of(op), [&] {

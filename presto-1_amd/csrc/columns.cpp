@@ -141,6 +141,31 @@ static DeviceColumn ingest_block_raw(Context *ctx, const tgpu_block *b)
     return c;
 }
 
+// DictionaryBlock / RunLengthEncodedBlock kept as (flat dictionary, device ids) instead of being flattened: the dictionary-aware
+// operators evaluate once per dictionary entry (M/operator/project/DictionaryAwarePageFilter.java:56-110).  RLE = one entry, ids all 0.
+void ingest_dictionary(Context *ctx, const tgpu_block *b, DeviceColumn &dictionary, BufferPtr &ids)
+{
+    check_block(b);
+    TG_CHECK_ARG(b->encoding != TGPU_FLAT && b->dictionary != nullptr, "not a dictionary / RLE block");
+    const int64_t n = b->position_count;
+    dictionary = ingest_block(ctx, b->dictionary);
+    TG_CHECK_ARG(dictionary.type == b->type, "dictionary type mismatch");
+    ids = ctx->alloc((size_t)(n > 0 ? n : 1) * 4);
+    if (b->encoding == TGPU_RLE) {
+        TG_CHECK_ARG(dictionary.n == 1, "RLE value block must have exactly one position");
+        if (n > 0) k::fill_i32(ctx, ids->as<int32_t>(), 0, n);
+        return;
+    }
+    TG_CHECK_ARG(b->ids != nullptr || n == 0, "dictionary block without ids");
+    if (n == 0) return;
+    if (b->memory == TGPU_HOST) {
+        for (int64_t i = 0; i < n; i++) TG_CHECK_ARG(b->ids[i] >= 0 && b->ids[i] < dictionary.n, "dictionary id out of range");
+        ctx->upload(ids->ptr(), b->ids, (size_t)n * 4);
+        ctx->sync();   // the caller's ids array is only valid during the call
+    }
+    else HIP_CHECK(hipMemcpyAsync(ids->ptr(), b->ids, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream()));
+}
+
 // A column that borrows caller memory (a device-resident input block: no owning buffers) is only valid during the call; an operator
 // that lets such a column out again (an identity projection, a page passing through) gives it buffers of its own first.
 void own_borrowed_columns(Context *ctx, DevicePage &page)

@@ -248,6 +248,8 @@ inline KeyCols key_cols_of(const std::vector<const DeviceColumn *> &cols)
 // ingest: tgpu_page (host or device memory, any encoding) -> flat device columns.  columns.cpp
 DevicePage ingest_page(Context *ctx, const tgpu_page *page);
 DeviceColumn ingest_block(Context *ctx, const tgpu_block *block);
+// a DICTIONARY / RLE block as (flat dictionary column, device ids) -- not flattened (dictionary-aware processing)
+void ingest_dictionary(Context *ctx, const tgpu_block *block, DeviceColumn &dictionary, BufferPtr &ids);
 // gives every column of `page` that still borrows caller memory (device-resident input) buffers of its own (a device copy)
 void own_borrowed_columns(Context *ctx, DevicePage &page);
 

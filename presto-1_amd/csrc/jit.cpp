@@ -686,9 +686,48 @@ PageProcessorGpu::PageProcessorGpu(std::vector<int32_t> input_types, const tgpu_
     proj_roots_.assign(spec->projection_roots, spec->projection_roots + spec->projection_count);
     for (int32_t t : input_types_) TG_CHECK_ARG(valid_type(t), "unknown input type");
     generate();
+    // which input channels do the computed expressions read?
+    std::set<int> read;
+    std::function<void(int)> walk = [&](int idx) {
+        if (idx < 0 || idx >= (int)nodes_.size()) return;
+        const tgpu_expr_node &nd = nodes_[(size_t)idx];
+        if (nd.kind == TGPU_EX_INPUT) read.insert(nd.op);
+        if (nd.kind == TGPU_EX_CALL || nd.kind == TGPU_EX_SPECIAL)
+            for (int k = 0; k < nd.n_args && k < 3; k++) walk(nd.args[k]);
+    };
+    if (filter_root_ >= 0) walk(filter_root_);
+    for (size_t i = 0; i < projs_.size(); i++)
+        if (projs_[i].kind == ProjKind::COMPUTED) walk(proj_roots_[i]);
+    single_input_ = read.size() == 1 ? *read.begin() : -1;
 }
 
 PageProcessorGpu::~PageProcessorGpu() {}
+
+void PageProcessorGpu::process_dictionary(Context *ctx, const DeviceColumn &dictionary, DevicePage &out)
+{
+    TG_CHECK_STATE(single_input_ >= 0, "the processor's expressions do not read a single channel");
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!dict_processor_) {
+            // the same node array with every input reference pointing at channel 0; no filter; projections = [filter, computed...]
+            std::vector<tgpu_expr_node> nodes = nodes_;
+            for (auto &nd : nodes)
+                if (nd.kind == TGPU_EX_INPUT) nd.op = 0;
+            std::vector<int32_t> roots;
+            if (filter_root_ >= 0) roots.push_back(filter_root_);
+            std::vector<int32_t> by_slot((size_t)computed_count_, -1);
+            for (size_t i = 0; i < projs_.size(); i++)
+                if (projs_[i].kind == ProjKind::COMPUTED) by_slot[(size_t)projs_[i].slot] = proj_roots_[i];
+            for (int32_t r : by_slot) roots.push_back(r);
+            tgpu_page_processor_spec spec{nodes.data(), (int32_t)nodes.size(), pool_.data(), (int32_t)pool_.size(), -1, (int32_t)roots.size(), roots.data()};
+            dict_processor_ = PageProcessorGpu::shared({input_types_[(size_t)single_input_]}, &spec);
+        }
+    }
+    DevicePage in;
+    in.n = dictionary.n;
+    in.cols.push_back(dictionary);
+    dict_processor_->process(ctx, in, out);
+}
 
 void PageProcessorGpu::generate()
 {

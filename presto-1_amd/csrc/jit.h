@@ -41,6 +41,20 @@ public:
     bool process(Context *ctx, const DevicePage &in, DevicePage &out);
     const std::vector<int32_t> &output_types() const { return output_types_; }
     const std::string &source() const { return source_; }
+    // Dictionary-aware processing (M/operator/project/DictionaryAwarePageFilter.java:56-110, DictionaryAwarePageProjection.java,
+    // PageFunctionCompiler.java:176-212): the input channel every computed expression (filter and non-identity projections) reads
+    // when they all read the same single one, else -1.
+    int single_input_channel() const { return single_input_; }
+    // The processor evaluated once per DICTIONARY ENTRY: `dictionary` stands for channel single_input_channel(); returns one row per
+    // entry: [the filter's verdict as BOOLEAN (only when there is a filter), every computed projection in slot order].
+    // Throws like process() when an entry raises (the caller then falls back to the flat path: only selected rows may raise).
+    void process_dictionary(Context *ctx, const DeviceColumn &dictionary, DevicePage &out);
+    bool has_filter() const { return filter_root_ >= 0; }
+    // per projection: -1 = computed (its slot via computed_slot), else the input channel it passes through
+    int identity_channel(int projection) const { return projs_[(size_t)projection].kind == ProjKind::IDENTITY ? projs_[(size_t)projection].channel : -1; }
+    bool is_null_constant(int projection) const { return projs_[(size_t)projection].kind == ProjKind::CONSTANT_NULL; }
+    int computed_slot(int projection) const { return projs_[(size_t)projection].slot; }
+    int projection_count() const { return (int)projs_.size(); }
 
 private:
     enum class ProjKind { COMPUTED, IDENTITY, CONSTANT_NULL };
@@ -65,6 +79,8 @@ private:
     std::string source_;
     std::shared_ptr<JitModule> module_;
     hipFunction_t fn_count_ = nullptr, fn_emit_ = nullptr;
+    int single_input_ = -1;
+    std::shared_ptr<PageProcessorGpu> dict_processor_;   // lazily: the same expressions over the one-channel dictionary page
 };
 
 // ---- operator fusion by codegen ---------------------------------------------------------------------------------------

@@ -18,6 +18,25 @@ namespace tgpu {
 // at least one row; MergePages (M/operator/project/MergePages.java) is not applied (page boundaries are not part of the
 // operator's contract: the reference's tests compare rows, T/operator/OperatorAssertion.java).
 // =====================================================================================================================
+namespace {
+// dictionary-aware selection: row r is selected iff the verdict of its dictionary entry is a non-null true
+__global__ void __launch_bounds__(256) dict_select_kernel(const uint8_t *verdict, const uint8_t *verdict_nulls, const int32_t *ids, int64_t n, int32_t *flags)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const int32_t e = ids[r];
+        flags[r] = (verdict[e] != 0 && !(verdict_nulls && verdict_nulls[e])) ? 1 : 0;
+    }
+}
+__global__ void __launch_bounds__(256) dict_compact_kernel(const int32_t *flags, const int32_t *rank, const int32_t *ids, int64_t n, int32_t *positions, int32_t *sel_ids)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256)
+        if (flags[r]) {
+            positions[rank[r]] = (int32_t)r;
+            sel_ids[rank[r]] = ids[r];
+        }
+}
+}  // namespace
+
 class FilterAndProjectOperator : public Operator {
 public:
     FilterAndProjectOperator(Context *ctx, int32_t id, std::shared_ptr<PageProcessorGpu> p) : Operator(ctx, id), processor_(std::move(p)) {}
@@ -28,8 +47,81 @@ public:
     {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
         TG_CHECK_STATE(!pending_, "Operator still has pending output");
+        if (try_dictionary(page)) return;
         run(ingest_page(ctx_, page));
     }
+
+    // Dictionary-aware processing (M/operator/project/DictionaryAwarePageFilter.java:56-110, DictionaryAwarePageProjection.java:60-160,
+    // selected by PageFunctionCompiler.java:176-212 for deterministic single-channel expressions): when every computed expression reads
+    // the same channel and that channel arrives as a DictionaryBlock or RunLengthEncodedBlock, the filter and the projections are
+    // evaluated once per dictionary entry (once in all for RLE) and mapped through the ids -- same rows, same values as the flat path.
+    // An entry that raises (overflow, division by zero) may belong to no selected row: like the reference (which catches and
+    // re-processes the block the normal way, DictionaryAwarePageProjection.java:139-152) the page then takes the flat path.
+    bool try_dictionary(const tgpu_page *page)
+    {
+        const int c = processor_->single_input_channel();
+        if (c < 0 || page == nullptr || c >= page->channel_count || getenv("TGPU_DISABLE_DICTIONARY_AWARE")) return false;
+        const tgpu_block &blk = page->blocks[c];
+        if (blk.encoding == TGPU_FLAT || blk.dictionary == nullptr || blk.dictionary->encoding != TGPU_FLAT) return false;
+        const int64_t n = page->position_count;
+        if (n == 0 || (int64_t)blk.dictionary->position_count * 2 > n) return false;   // a dictionary about as long as the page: nothing to gain
+        for (int32_t ch = 0; ch < page->channel_count; ch++) TG_CHECK_ARG(page->blocks[ch].position_count == page->position_count, "block position count differs from the page's");
+        DeviceColumn dict;
+        BufferPtr ids;
+        ingest_dictionary(ctx_, &blk, dict, ids);
+        DevicePage per_entry;
+        try {
+            ProfileScope ps(ctx_, "dictionary_entries");
+            processor_->process_dictionary(ctx_, dict, per_entry);
+        }
+        catch (const Error &e) {
+            if (e.code == TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE || e.code == TGPU_ERR_DIVISION_BY_ZERO || e.code == TGPU_ERR_INVALID_CAST_ARGUMENT) return false;
+            throw;
+        }
+        dictionary_pages_++;
+        const bool has_filter = processor_->has_filter();
+        const int first_slot = has_filter ? 1 : 0;
+        int64_t n_sel = n;
+        BufferPtr positions, sel_ids = ids;
+        if (has_filter) {
+            const DeviceColumn &verdict = per_entry.cols[0];
+            BufferPtr flags = ctx_->alloc((size_t)n * 4), rank = ctx_->alloc((size_t)n * 4), total = ctx_->alloc(8);
+            const int g = (int)std::min<int64_t>(ceil_div(n, 256), (int64_t)ctx_->cu_count() * 8);
+            ProfileScope ps(ctx_, "dictionary_select");
+            dict_select_kernel<<<g, 256, 0, ctx_->stream()>>>((const uint8_t *)verdict.values, verdict.nulls, ids->as<int32_t>(), n, flags->as<int32_t>());
+            k::exclusive_scan_i32(ctx_, flags->as<int32_t>(), rank->as<int32_t>(), n, total->as<int64_t>());
+            n_sel = ctx_->read_scalar(total->as<int64_t>());
+            if (n_sel == 0) return true;   // no output page (PageProcessor.java:122-124)
+            if (n_sel < n) {
+                positions = ctx_->alloc((size_t)n_sel * 4);
+                sel_ids = ctx_->alloc((size_t)n_sel * 4);
+                dict_compact_kernel<<<g, 256, 0, ctx_->stream()>>>(flags->as<int32_t>(), rank->as<int32_t>(), ids->as<int32_t>(), n, positions->as<int32_t>(), sel_ids->as<int32_t>());
+                check_launch("dict_compact");
+            }
+        }
+        DevicePage out;
+        out.n = n_sel;
+        std::vector<DeviceColumn> flat((size_t)page->channel_count);   // other channels are ingested only when a projection passes them through
+        std::vector<bool> have((size_t)page->channel_count, false);
+        for (int p = 0; p < processor_->projection_count(); p++) {
+            const int ident = processor_->identity_channel(p);
+            if (ident < 0) out.cols.push_back(k::gather_column(ctx_, per_entry.cols[(size_t)(first_slot + processor_->computed_slot(p))], sel_ids->as<int32_t>(), n_sel, false));
+            else if (ident == c) out.cols.push_back(k::gather_column(ctx_, dict, sel_ids->as<int32_t>(), n_sel, false));
+            else {
+                if (!have[(size_t)ident]) {
+                    flat[(size_t)ident] = ingest_block(ctx_, &page->blocks[ident]);
+                    have[(size_t)ident] = true;
+                }
+                if (positions) out.cols.push_back(k::gather_column(ctx_, flat[(size_t)ident], positions->as<int32_t>(), n_sel, false));
+                else out.cols.push_back(flat[(size_t)ident]);
+            }
+        }
+        ctx_->sync();   // host blocks ingested above are only valid during the call
+        own_borrowed_columns(ctx_, out);
+        pending_ = wrap(std::move(out));
+        return true;
+    }
+    int64_t dictionary_pages() const { return dictionary_pages_; }
     // a page of this library: identity projections that pass a block through share its (reference counted) buffers
     void add_input_owned(const DevicePage &page) override
     {
@@ -57,8 +149,17 @@ private:
 
     std::shared_ptr<PageProcessorGpu> processor_;
     std::unique_ptr<OutputPage> pending_;
+    int64_t dictionary_pages_ = 0;   // input pages that took the dictionary-aware path
     bool finishing_ = false;
 };
+
+// how many input pages of a FilterAndProjectOperator were processed once per dictionary entry (tests, stats)
+int64_t filter_project_dictionary_pages(Operator *op)
+{
+    auto *p = dynamic_cast<FilterAndProjectOperator *>(op);
+    TG_CHECK_ARG(p != nullptr, "not a FilterAndProjectOperator");
+    return p->dictionary_pages();
+}
 
 FilterAndProjectOperatorFactory::FilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types,
                                                                  const tgpu_page_processor_spec *spec)

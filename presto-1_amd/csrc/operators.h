@@ -62,6 +62,8 @@ private:
     std::shared_ptr<PageProcessorGpu> processor_;
 };
 
+int64_t filter_project_dictionary_pages(Operator *op);
+
 // ---- HashAggregationOperator (M/operator/HashAggregationOperator.java:54-262,367-518) -----------------------------
 struct HashAggregationConfig {
     std::vector<int32_t> group_by_types, group_by_channels;

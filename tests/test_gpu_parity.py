@@ -1784,3 +1784,72 @@ def test_join_filter_function_random_vs_oracle(pkg, ctx, oracle, join_type):
         outer_rows = [r for pg in pkg.to_pages(of.createOperator(), []) for r in pg.rows()]
         visited = set(int(q) for q in ob if q >= 0)
         assert outer_rows == [(None, None, bk[q], bv[q]) for q in range(nb) if q not in visited]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# F7: dictionary-aware filter / projection (M/operator/project/DictionaryAwarePageFilter.java:56-110, DictionaryAwarePageProjection.java)
+# ---------------------------------------------------------------------------------------------------------------------
+def _run_fp_counting(pkg, ctx, pages, types, filt, projs):
+    fac = pkg.FilterAndProjectOperatorFactory(ctx, 0, types, filt, projs)
+    op = fac.createOperator()
+    outs = []
+    for pg in pages:
+        op.addInput(pg)
+        o = op.getOutput()
+        if o is not None:
+            outs.append(o.to_host())
+            o.release()
+    dict_pages = pkg._lib.lib().tgpu_debug_dictionary_pages(op.handle)
+    op.finish()
+    op.close()
+    return [r for pg in outs for r in pg.rows()], dict_pages
+
+
+def test_dictionary_aware_filter_project_equals_flat_path(pkg, ctx, monkeypatch):
+    rng = np.random.default_rng(12)
+    n = 50_000
+    B, V, D = pkg.BIGINT, pkg.VARCHAR, pkg.DOUBLE
+    f, c = pkg.field, pkg.constant
+    # dictionaries with a null entry and with DUPLICATE entries (a DictionaryBlock's dictionary need not be distinct)
+    sdict = pkg.Block(V, ["AUTOMOBILE", "BUILDING", None, "FURNITURE", "BUILDING", "HOUSEHOLD", "MACHINERY"])
+    sids = rng.integers(0, 7, n).astype(np.int32)
+    bdict = pkg.Block(B, [5, -3, None, 2**40, 7, 5])
+    bids = rng.integers(0, 6, n).astype(np.int32)
+    other = pkg.Block(D, rng.standard_normal(n), (rng.random(n) < 0.1).astype(np.uint8))
+    cases = [
+        ([V, D], [pkg.DictionaryBlock(sdict, sids), other], f(0, V).eq("BUILDING"), [f(0, V), f(1, D), f(0, V) < c("C", V)]),
+        ([V, D], [pkg.DictionaryBlock(sdict, sids), other], pkg.or_(pkg.is_null(f(0, V)), f(0, V) >= c("H", V)), [f(1, D), pkg.is_null(f(0, V))]),
+        ([B, D], [pkg.DictionaryBlock(bdict, bids), other], f(0, B) > 0, [f(0, B) * 3 + 1, f(0, B), f(1, D), pkg.cast(f(0, B), D)]),
+        ([B, D], [pkg.DictionaryBlock(bdict, bids), other], None, [f(0, B) % 4, f(1, D)]),
+        ([B, D], [pkg.RunLengthEncodedBlock(pkg.Block(B, [42]), n), other], f(0, B).eq(42), [f(0, B) + 1, f(1, D)]),
+        ([B, D], [pkg.RunLengthEncodedBlock(pkg.Block(B, [42]), n), other], f(0, B).eq(41), [f(0, B) + 1]),
+        ([B, D], [pkg.RunLengthEncodedBlock(pkg.Block(B, [None]), n), other], pkg.is_null(f(0, B)), [pkg.coalesce(f(0, B), c(9, B)), f(1, D)]),
+    ]
+    for types, blocks, filt, projs in cases:
+        page = pkg.Page(*blocks)
+        got, dict_pages = _run_fp_counting(pkg, ctx, [page, page], types, filt, projs)
+        assert dict_pages == 2                      # both pages took the per-dictionary-entry path
+        monkeypatch.setenv("TGPU_DISABLE_DICTIONARY_AWARE", "1")
+        want, flat_pages = _run_fp_counting(pkg, ctx, [page, page], types, filt, projs)
+        monkeypatch.delenv("TGPU_DISABLE_DICTIONARY_AWARE")
+        assert flat_pages == 0
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert all((x == y) or (isinstance(x, float) and isinstance(y, float) and np.isnan(x) and np.isnan(y)) for x, y in zip(g, w)), (g, w)
+
+
+def test_dictionary_aware_path_falls_back_when_an_entry_raises(pkg, ctx):
+    """DictionaryAwarePageProjection.java:139-152: a dictionary entry whose projection raises may belong to no selected row; the block
+    is then processed the normal way, and the error surfaces only if a SELECTED row raises"""
+    B = pkg.BIGINT
+    f = pkg.field
+    n = 10_000
+    d = pkg.Block(B, [1, 2, 2**62, 3])
+    ids = (np.arange(n) % 2).astype(np.int32)                 # only entries 0 and 1 are referenced
+    sel = pkg.Block(B, np.ones(n, dtype=np.int64))
+    rows, dict_pages = _run_fp_counting(pkg, ctx, [pkg.Page(pkg.DictionaryBlock(d, ids), sel)], [B, B], None, [f(0, B) * 4])
+    assert dict_pages == 0 and [r[0] for r in rows[:4]] == [4, 8, 4, 8]
+    ids2 = (np.arange(n) % 3).astype(np.int32)                # entry 2 (overflows) is referenced: the reference's error
+    with pytest.raises(pkg.TgpuError) as e:
+        _run_fp_counting(pkg, ctx, [pkg.Page(pkg.DictionaryBlock(d, ids2), sel)], [B, B], None, [f(0, B) * 4])
+    assert e.value.code == -2
