@@ -1781,7 +1781,11 @@ def test_join_filter_function_random_vs_oracle(pkg, ctx, oracle, join_type):
     if join_type in ("LOOKUP_OUTER", "FULL_OUTER"):
         jf.noMoreOperators()
         of = pkg.LookupOuterOperatorFactory(ctx, 2, bf.lookup_source_factory, [B, B])
-        outer_rows = [r for pg in pkg.to_pages(of.createOperator(), []) for r in pg.rows()]
+        outer_op = of.createOperator()
+        assert not outer_op.isBlocked()          # every probe operator is finished and no more will be created
+        o = outer_op.getOutput()                 # a source operator: its page comes without a finish() call (LookupOuterOperator.java:175-221)
+        outer_rows = o.to_host().rows() if o is not None else []
+        assert outer_op.isFinished()
         visited = set(int(q) for q in ob if q >= 0)
         assert outer_rows == [(None, None, bk[q], bv[q]) for q in range(nb) if q not in visited]
 
