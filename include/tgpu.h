@@ -49,6 +49,7 @@ extern "C" {
 
 /* ---- status codes: 0 ok, >0 informational, <0 error mirroring io.trino.spi.StandardErrorCode ---- */
 #define TGPU_OK 0
+#define TGPU_WOULD_BLOCK 1                          /* tgpu_operator_get_output: no page yet and the operator's isBlocked() future is not done */
 #define TGPU_ERR_INVALID_ARGUMENT (-1)              /* GENERIC_INTERNAL_ERROR / IllegalArgumentException */
 #define TGPU_ERR_NUMERIC_VALUE_OUT_OF_RANGE (-2)    /* M/type/BigintOperators.java:47-79 */
 #define TGPU_ERR_INSUFFICIENT_RESOURCES (-3)        /* GENERIC_INSUFFICIENT_RESOURCES: BigintGroupByHash.java:264-267, PagesIndex.java:234-236 */
@@ -283,13 +284,23 @@ int32_t tgpu_order_by_factory_create(tgpu_context *ctx, int32_t operator_id, int
 /* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory);
+/* OperatorFactory.duplicate() (M/operator/OperatorFactory.java:49): another factory of the same operator; probe-side join factories share
+ * the join bridge (the probes are complete once EVERY duplicate has seen noMoreOperators); a hash builder cannot be duplicated
+ * (TGPU_ERR_NOT_SUPPORTED, HashBuilderOperator.java:150-152) */
+int32_t tgpu_operator_factory_duplicate(tgpu_operator_factory *factory, tgpu_operator_factory **out);
 void tgpu_operator_factory_destroy(tgpu_operator_factory *factory);
 
 /* ---- Operator (M/operator/Operator.java:20-102).  Boolean queries return 1/0, or <0 on error. ---- */
 int32_t tgpu_operator_needs_input(tgpu_operator *op);
 int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page);
-/* *out = NULL when no page is available (Operator.getOutput() == null) */
+/* *out = NULL when no page is available (Operator.getOutput() == null); returns TGPU_WOULD_BLOCK instead of TGPU_OK when, in addition,
+ * the operator is blocked (a probe waiting for its build side, the outer operator waiting for the probes): the driver should park the
+ * pipeline on tgpu_operator_is_blocked instead of spinning (Operator.java:32-35, Driver.java:367-400) */
 int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out);
+/* Operator.startMemoryRevoke() / finishMemoryRevoke() (M/operator/Operator.java:53-79): nothing is revocable (state lives in HBM and is
+ * reported through tgpu_operator_memory_bytes as user memory); both return TGPU_OK at once */
+int32_t tgpu_operator_start_memory_revoke(tgpu_operator *op);
+int32_t tgpu_operator_finish_memory_revoke(tgpu_operator *op);
 int32_t tgpu_operator_finish(tgpu_operator *op);
 int32_t tgpu_operator_is_finished(tgpu_operator *op);
 /* addInput with a page another operator of this library produced: the buffers are shared (reference counted), so an operator that keeps

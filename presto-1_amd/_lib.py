@@ -93,6 +93,9 @@ SYMBOLS = {
     "tgpu_filter_project_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, P(vp)]),
     "tgpu_operator_factory_create_operator": (i32, [vp, P(vp)]),
     "tgpu_operator_factory_no_more_operators": (i32, [vp]),
+    "tgpu_operator_factory_duplicate": (i32, [vp, P(vp)]),
+    "tgpu_operator_start_memory_revoke": (i32, [vp]),
+    "tgpu_operator_finish_memory_revoke": (i32, [vp]),
     "tgpu_operator_factory_destroy": (None, [vp]),
     "tgpu_operator_needs_input": (i32, [vp]),
     "tgpu_operator_add_input": (i32, [vp, P(Page)]),

@@ -455,6 +455,18 @@ int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tg
     });
 }
 
+int32_t tgpu_operator_factory_duplicate(tgpu_operator_factory *factory, tgpu_operator_factory **out)
+{
+    return guard_on(ctx_of(factory), [&] {
+        TG_CHECK_ARG(factory && out, "null argument");
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = factory->f->duplicate();
+        f->ctx = factory->ctx;
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
 int32_t tgpu_operator_factory_no_more_operators(tgpu_operator_factory *factory)
 {
     return guard_on(ctx_of(factory), [&] {
@@ -496,12 +508,27 @@ int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page)
 
 int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
 {
-    return guard_on(ctx_of(op), [&] {
+    bool would_block = false;
+    int32_t rc = guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op != nullptr && op->op && out, "null argument");
         *out = nullptr;
         std::unique_ptr<OutputPage> p = op->op->get_output();
         if (p) *out = release_output(std::move(p));
+        else would_block = op->op->is_blocked();   // no page AND an unfinished isBlocked() future (Operator.java:32-35): come back later
     });
+    return rc == TGPU_OK && would_block ? TGPU_WOULD_BLOCK : rc;
+}
+
+// Operator.startMemoryRevoke / finishMemoryRevoke (M/operator/Operator.java:53-79): the GPU operators hold their state in HBM and
+// report it as non-revocable user memory (tgpu_operator_memory_bytes), so there is never anything to revoke: the "future" is done at once
+int32_t tgpu_operator_start_memory_revoke(tgpu_operator *op)
+{
+    return guard_on(ctx_of(op), [&] { TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed"); });
+}
+
+int32_t tgpu_operator_finish_memory_revoke(tgpu_operator *op)
+{
+    return guard_on(ctx_of(op), [&] { TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed"); });
 }
 
 /* diagnostics: input pages a FilterAndProjectOperator processed once per dictionary entry (DictionaryAwarePageFilter / -Projection path) */

@@ -173,6 +173,11 @@ std::unique_ptr<Operator> FilterAndProjectOperatorFactory::create_operator()
     return std::make_unique<FilterAndProjectOperator>(ctx_, operator_id_, processor_);
 }
 
+std::unique_ptr<OperatorFactory> FilterAndProjectOperatorFactory::duplicate()
+{
+    return std::unique_ptr<OperatorFactory>(new FilterAndProjectOperatorFactory(*this));   // shares the compiled page processor
+}
+
 // =====================================================================================================================
 // HashAggregationOperator + InMemoryHashAggregationBuilder
 // =====================================================================================================================
@@ -322,6 +327,8 @@ std::unique_ptr<Operator> HashAggregationOperatorFactory::create_operator()
     TG_CHECK_STATE(!closed_, "Factory is already closed");
     return std::make_unique<HashAggregationOperator>(ctx_, operator_id_, cfg_);
 }
+
+std::unique_ptr<OperatorFactory> HashAggregationOperatorFactory::duplicate() { return std::make_unique<HashAggregationOperatorFactory>(ctx_, operator_id_, cfg_); }
 
 // =====================================================================================================================
 // HashBuilderOperator (M/operator/HashBuilderOperator.java:155-191 state machine, spill states omitted: the GPU path reports
@@ -619,6 +626,7 @@ LookupJoinOperatorFactory::LookupJoinOperatorFactory(Context *ctx, int32_t opera
     TG_CHECK_ARG(cfg_.probe_hash_channel < nt, "probe hash channel out of range");
     TG_CHECK_ARG(cfg_.join_type >= TGPU_JOIN_INNER && cfg_.join_type <= TGPU_JOIN_FULL_OUTER, "unknown join type");
     if (cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER) bridge_->outer_expected();   // LookupJoinOperatorFactory.java:88-103
+    bridge_->probe_factory_created();
 }
 
 std::unique_ptr<Operator> LookupJoinOperatorFactory::create_operator()
@@ -627,8 +635,11 @@ std::unique_ptr<Operator> LookupJoinOperatorFactory::create_operator()
     return std::make_unique<LookupJoinOperator>(ctx_, operator_id_, cfg_, bridge_);
 }
 
+std::unique_ptr<OperatorFactory> LookupJoinOperatorFactory::duplicate() { return std::make_unique<LookupJoinOperatorFactory>(ctx_, operator_id_, cfg_, bridge_); }
+
 void LookupJoinOperatorFactory::no_more_operators()
 {
+    if (closed_) return;
     closed_ = true;
     bridge_->no_more_probes();
 }
@@ -815,6 +826,7 @@ FusedFilterProjectJoinOperatorFactory::FusedFilterProjectJoinOperatorFactory(Con
     TG_CHECK_ARG(cfg_.join_type >= TGPU_JOIN_INNER && cfg_.join_type <= TGPU_JOIN_FULL_OUTER, "unknown join type");
     if (cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER) bridge_->outer_expected();
     fused_ = FusedProbeGpu::shared(input_types, spec, cfg_.probe_join_channels[0], cfg_.probe_output_channels);
+    bridge_->probe_factory_created();
 }
 
 std::unique_ptr<Operator> FusedFilterProjectJoinOperatorFactory::create_operator()
@@ -823,8 +835,17 @@ std::unique_ptr<Operator> FusedFilterProjectJoinOperatorFactory::create_operator
     return std::make_unique<FusedFilterProjectJoinOperator>(ctx_, operator_id_, cfg_, bridge_, processor_, fused_);
 }
 
+std::unique_ptr<OperatorFactory> FusedFilterProjectJoinOperatorFactory::duplicate()
+{
+    auto f = std::unique_ptr<FusedFilterProjectJoinOperatorFactory>(new FusedFilterProjectJoinOperatorFactory(*this));
+    f->closed_ = false;
+    bridge_->probe_factory_created();
+    return f;
+}
+
 void FusedFilterProjectJoinOperatorFactory::no_more_operators()
 {
+    if (closed_) return;
     closed_ = true;
     bridge_->no_more_probes();
 }
@@ -891,6 +912,11 @@ std::unique_ptr<Operator> FusedFilterProjectAggregationOperatorFactory::create_o
     return std::make_unique<FusedFilterProjectAggregationOperator>(ctx_, operator_id_, cfg_, processor_, fused_);
 }
 
+std::unique_ptr<OperatorFactory> FusedFilterProjectAggregationOperatorFactory::duplicate()
+{
+    return std::unique_ptr<OperatorFactory>(new FusedFilterProjectAggregationOperatorFactory(*this));
+}
+
 // =====================================================================================================================
 // TopNOperator (M/operator/TopNOperator.java:135-225 over TopNProcessor.java:45-105): consumes pages until finish(), then emits
 // the n first rows in sort order as one page
@@ -945,6 +971,8 @@ std::unique_ptr<Operator> TopNOperatorFactory::create_operator()
     TG_CHECK_STATE(!closed_, "Factory is already closed");
     return std::make_unique<TopNOperator>(ctx_, operator_id_, types_, n_, sort_channels_, sort_orders_);
 }
+
+std::unique_ptr<OperatorFactory> TopNOperatorFactory::duplicate() { return std::make_unique<TopNOperatorFactory>(ctx_, operator_id_, types_, n_, sort_channels_, sort_orders_); }
 
 // =====================================================================================================================
 // OrderByOperator (M/operator/OrderByOperator.java:160-300): PagesIndex.addPage per input page, one sort at finish()
@@ -1008,6 +1036,11 @@ std::unique_ptr<Operator> OrderByOperatorFactory::create_operator()
 {
     TG_CHECK_STATE(!closed_, "Factory is already closed");
     return std::make_unique<OrderByOperator>(ctx_, operator_id_, types_, output_channels_, sort_channels_, sort_orders_);
+}
+
+std::unique_ptr<OperatorFactory> OrderByOperatorFactory::duplicate()
+{
+    return std::make_unique<OrderByOperatorFactory>(ctx_, operator_id_, types_, output_channels_, sort_channels_, sort_orders_);
 }
 
 
@@ -1246,6 +1279,12 @@ std::unique_ptr<Operator> DynamicFilterSourceOperatorFactory::create_operator()
     return std::make_unique<DynamicFilterSourceOperator>(ctx_, operator_id_, types_, channels_, max_distinct_, max_size_, min_max_limit_);
 }
 
+std::unique_ptr<OperatorFactory> DynamicFilterSourceOperatorFactory::duplicate()
+{
+    // DynamicFilterSourceOperator.java:131-135: "duplicate() is not supported for DynamicFilterSourceOperatorFactory"
+    fail(TGPU_ERR_NOT_SUPPORTED, "duplicate() is not supported for DynamicFilterSourceOperatorFactory");
+}
+
 void dynamic_filter_result(Operator *op, int32_t k, int32_t *kind, std::unique_ptr<OutputPage> *values, int64_t *min, int64_t *max)
 {
     auto *p = dynamic_cast<DynamicFilterSourceOperator *>(op);
@@ -1401,6 +1440,11 @@ std::unique_ptr<Operator> MergePagesOperatorFactory::create_operator()
     return std::make_unique<MergePagesOperator>(ctx_, operator_id_, types_, min_page_size_, min_row_count_, max_page_size_);
 }
 
+std::unique_ptr<OperatorFactory> MergePagesOperatorFactory::duplicate()
+{
+    return std::make_unique<MergePagesOperatorFactory>(ctx_, operator_id_, types_, min_page_size_, min_row_count_, max_page_size_);
+}
+
 // =====================================================================================================================
 // PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java; PagePartitioner.partitionPage :406-426)
 //   position -> every partition when (replicatesAnyRow and no row has been replicated yet) or the null channel is null there,
@@ -1535,6 +1579,11 @@ std::unique_ptr<Operator> PartitionedOutputOperatorFactory::create_operator()
     TG_CHECK_STATE(!closed_, "Factory is already closed");
     return std::make_unique<PartitionedOutputOperator>(ctx_, operator_id_, types_, partition_channels_, hash_channel_, partition_count_, replicates_any_row_, null_channel_,
                                                        local_function_);
+}
+
+std::unique_ptr<OperatorFactory> PartitionedOutputOperatorFactory::duplicate()
+{
+    return std::unique_ptr<OperatorFactory>(new PartitionedOutputOperatorFactory(*this));
 }
 
 bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<OutputPage> *out)

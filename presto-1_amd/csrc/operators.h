@@ -45,6 +45,9 @@ public:
     virtual ~OperatorFactory() {}
     virtual std::unique_ptr<Operator> create_operator() = 0;
     virtual void no_more_operators() { closed_ = true; }
+    // OperatorFactory.duplicate() (M/operator/OperatorFactory.java:49): an independent factory of the same operator for another
+    // pipeline instance; a hash build cannot be duplicated (HashBuilderOperator.java:150-152 throws UnsupportedOperationException)
+    virtual std::unique_ptr<OperatorFactory> duplicate() { fail(TGPU_ERR_NOT_SUPPORTED, "this operator factory cannot be duplicated"); }
 
 protected:
     bool closed_ = false;
@@ -55,6 +58,7 @@ class FilterAndProjectOperatorFactory : public OperatorFactory {
 public:
     FilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -79,6 +83,7 @@ class HashAggregationOperatorFactory : public OperatorFactory {
 public:
     HashAggregationOperatorFactory(Context *ctx, int32_t operator_id, HashAggregationConfig cfg);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -122,10 +127,18 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         live_probes_--;
     }
+    // every probe-side factory of the join (the original and its duplicate()s) registers; the probes are complete when the last
+    // of them has seen noMoreOperators (JoinBridgeManager's probe factory reference counting, M/operator/JoinBridgeManager.java)
+    void probe_factory_created()
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        probe_factories_++;
+    }
     void no_more_probes()
     {
         std::lock_guard<std::mutex> lk(mu_);
-        no_more_probes_ = true;
+        if (probe_factories_ > 0) probe_factories_--;
+        if (probe_factories_ == 0) no_more_probes_ = true;
     }
     // every probe operator is done: the outer position iterator becomes available (PartitionedLookupSourceFactory.java:259-297)
     bool probes_finished() const
@@ -167,7 +180,7 @@ private:
     mutable std::mutex mu_;
     std::shared_ptr<const JoinFilter> filter_;
     std::shared_ptr<LookupSourceGpu> source_;
-    int live_probes_ = 0;
+    int live_probes_ = 0, probe_factories_ = 0;
     bool any_probe_ = false, no_more_probes_ = false, outer_expected_ = false, outer_done_ = false;
 };
 
@@ -200,6 +213,7 @@ class LookupJoinOperatorFactory : public OperatorFactory {
 public:
     LookupJoinOperatorFactory(Context *ctx, int32_t operator_id, LookupJoinConfig cfg, std::shared_ptr<LookupSourceFactory> bridge);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
     void no_more_operators() override;
 
 private:
@@ -230,6 +244,7 @@ public:
     FusedFilterProjectJoinOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec,
                                           LookupJoinConfig cfg, std::shared_ptr<LookupSourceFactory> bridge);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
     void no_more_operators() override;
 
 private:
@@ -247,6 +262,7 @@ public:
     FusedFilterProjectAggregationOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> input_types, const tgpu_page_processor_spec *spec,
                                                  HashAggregationConfig cfg);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -262,6 +278,7 @@ public:
     TopNOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, int64_t n, std::vector<int32_t> sort_channels,
                         std::vector<int32_t> sort_orders);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -276,6 +293,7 @@ public:
     OrderByOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> output_channels, std::vector<int32_t> sort_channels,
                            std::vector<int32_t> sort_orders);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -290,6 +308,7 @@ public:
     DynamicFilterSourceOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> channels, int32_t max_distinct_values,
                                        int64_t max_filter_size_in_bytes, int32_t min_max_collection_limit);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -308,6 +327,7 @@ public:
     MergePagesOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, int64_t min_page_size_in_bytes, int32_t min_row_count,
                               int64_t max_page_size_in_bytes);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;
@@ -326,6 +346,7 @@ public:
     PartitionedOutputOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, std::vector<int32_t> partition_channels, int32_t hash_channel,
                                      int32_t partition_count, bool replicates_any_row, int32_t null_channel, int32_t partition_function);
     std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
 
 private:
     Context *ctx_;

@@ -113,8 +113,14 @@ class Operator:
 
     def getOutput(self):
         out = C.c_void_p()
-        _lib.check(_lib.lib().tgpu_operator_get_output(self.handle, C.byref(out)))
+        self.last_get_output_status = _lib.check(_lib.lib().tgpu_operator_get_output(self.handle, C.byref(out)))   # 1 = TGPU_WOULD_BLOCK
         return OutputPage(out) if out.value else None
+
+    def startMemoryRevoke(self):
+        _lib.check(_lib.lib().tgpu_operator_start_memory_revoke(self.handle))
+
+    def finishMemoryRevoke(self):
+        _lib.check(_lib.lib().tgpu_operator_finish_memory_revoke(self.handle))
 
     def finish(self):
         _lib.check(_lib.lib().tgpu_operator_finish(self.handle))
@@ -152,6 +158,17 @@ class OperatorFactory:
 
     def noMoreOperators(self):
         _lib.check(_lib.lib().tgpu_operator_factory_no_more_operators(self.handle))
+
+    def duplicate(self):
+        """OperatorFactory.duplicate() (M/operator/OperatorFactory.java:49)"""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_operator_factory_duplicate(self.handle, C.byref(h)))
+        dup = type(self).__new__(type(self))
+        OperatorFactory.__init__(dup, h, self._keep)
+        for k, v in self.__dict__.items():
+            if k not in ("handle", "_keep"):
+                setattr(dup, k, v)
+        return dup
 
     def close(self):
         if self.handle:

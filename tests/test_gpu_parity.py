@@ -1857,3 +1857,47 @@ def test_dictionary_aware_path_falls_back_when_an_entry_raises(pkg, ctx):
     with pytest.raises(pkg.TgpuError) as e:
         _run_fp_counting(pkg, ctx, [pkg.Page(pkg.DictionaryBlock(d, ids2), sel)], [B, B], None, [f(0, B) * 4])
     assert e.value.code == -2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# boundary protocol: would-block, duplicate(), memory revoke
+# ---------------------------------------------------------------------------------------------------------------------
+def test_would_block_duplicate_and_revoke_protocol(pkg, ctx, oracle):
+    B = pkg.BIGINT
+    bk = np.arange(0, 2000, 2, dtype=np.int64)
+    bf = pkg.HashBuilderOperatorFactory(ctx, 0, [B], [0], [0])
+    jf = pkg.LookupJoinOperatorFactory(ctx, 1, bf.lookup_source_factory, [B], [0])
+    with pytest.raises(pkg.TgpuError) as e:          # HashBuilderOperator.java:150-152: "Parallel hash build cannot be duplicated"
+        bf.duplicate()
+    assert e.value.code == -8
+    jf2 = jf.duplicate()                             # a second probe pipeline over the same join bridge
+    p1, p2 = jf.createOperator(), jf2.createOperator()
+    # the build side has not lent its table: no page AND blocked -> TGPU_WOULD_BLOCK (Operator.java:32-35)
+    assert p1.isBlocked() and not p1.needsInput()
+    assert p1.getOutput() is None and p1.last_get_output_status == 1
+    b = bf.createOperator()
+    b.addInput(pkg.Page(pkg.Block(B, bk)))
+    b.startMemoryRevoke()                            # nothing revocable: done at once (Operator.java:53-79)
+    b.finishMemoryRevoke()
+    b.finish()
+    assert not p1.isBlocked() and p1.needsInput()
+    assert p1.getOutput() is None and p1.last_get_output_status == 0     # nothing to hand out, but not blocked either
+    probe = np.arange(0, 3000, 3, dtype=np.int64)
+    want_p, want_b = oracle.PagesHash([oracle.Col(B, bk)]).probe([oracle.Col(B, probe)])
+    want = [(int(probe[i]), int(bk[j])) for i, j in zip(want_p, want_b)]
+    for op in (p1, p2):
+        assert [r for pg in pkg.to_pages(op, [pkg.Page(pkg.Block(B, probe))]) for r in pg.rows()] == want
+    # the build operator stays blocked until EVERY probe factory (the duplicate too) has seen noMoreOperators
+    jf.noMoreOperators()
+    assert b.isBlocked()
+    jf2.noMoreOperators()
+    assert not b.isBlocked() and b.isFinished()
+    # other factories duplicate into independent ones
+    f = pkg.field
+    fp = pkg.FilterAndProjectOperatorFactory(ctx, 2, [B], f(0, B) > 5, [f(0, B) * 2])
+    fp2 = fp.duplicate()
+    fp.noMoreOperators()
+    with pytest.raises(pkg.TgpuError):
+        fp.createOperator()
+    out = pkg.to_pages(fp2.createOperator(), [pkg.Page(pkg.Block(B, np.arange(10, dtype=np.int64)))])
+    assert out[0].getBlock(0).to_list() == [12, 14, 16, 18]
