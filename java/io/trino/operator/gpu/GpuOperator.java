@@ -1,0 +1,147 @@
+package io.trino.operator.gpu;
+
+import com.google.common.util.concurrent.ListenableFuture;
+import com.google.common.util.concurrent.SettableFuture;
+import io.trino.memory.context.LocalMemoryContext;
+import io.trino.operator.Operator;
+import io.trino.operator.OperatorContext;
+import io.trino.spi.Page;
+
+import java.util.concurrent.ScheduledExecutorService;
+import java.util.concurrent.TimeUnit;
+
+/**
+ * io.trino.operator.Operator (core/trino-main/src/main/java/io/trino/operator/Operator.java:20-102) over a tgpu_operator handle.
+ * Same call protocol and error behaviour as the Java operator it replaces; one thread at a time per instance (Driver.java:55-62).
+ */
+public class GpuOperator
+        implements Operator
+{
+    private final OperatorContext operatorContext;
+    private final LocalMemoryContext memory;
+    private final ScheduledExecutorService poller;
+    private long handle;                                   // tgpu_operator*
+    private final boolean[] wouldBlock = new boolean[1];
+
+    private final int[] inputTypes;                        // tgpu_type of every input channel
+
+    public GpuOperator(OperatorContext operatorContext, long handle, int[] inputTypes, ScheduledExecutorService poller)
+    {
+        this.inputTypes = inputTypes;
+        this.operatorContext = operatorContext;
+        this.memory = operatorContext.localUserMemoryContext();
+        this.handle = handle;
+        this.poller = poller;
+    }
+
+    @Override
+    public OperatorContext getOperatorContext()
+    {
+        return operatorContext;
+    }
+
+    /** the build -> probe dependency (LookupJoinOperator.java:235-243) and probes -> outer operator: polled, the driver thread never blocks */
+    @Override
+    public ListenableFuture<?> isBlocked()
+    {
+        if (!call(() -> GpuNative.isBlocked(handle))) {
+            return NOT_BLOCKED;
+        }
+        SettableFuture<?> unblocked = SettableFuture.create();
+        Runnable check = new Runnable()
+        {
+            @Override
+            public void run()
+            {
+                if (handle == 0 || !GpuNative.isBlocked(handle)) {
+                    unblocked.set(null);
+                }
+                else {
+                    poller.schedule(this, 1, TimeUnit.MILLISECONDS);
+                }
+            }
+        };
+        poller.schedule(check, 1, TimeUnit.MILLISECONDS);
+        return unblocked;
+    }
+
+    @Override
+    public boolean needsInput()
+    {
+        return call(() -> GpuNative.needsInput(handle));
+    }
+
+    @Override
+    public void addInput(Page page)
+    {
+        try {
+            if (page instanceof GpuPages.DeviceResidentPage) {
+                // the producer was a GPU operator: the page never left HBM (tgpu_operator_add_input_output_page)
+                GpuNative.addInputDevicePage(handle, ((GpuPages.DeviceResidentPage) page).handle());
+            }
+            else {
+                GpuPages.addInput(handle, page.getLoadedPage(), inputTypes);
+            }
+        }
+        catch (GpuNative.NativeError e) {
+            throw GpuNative.toTrinoException(e);
+        }
+        memory.setBytes(GpuNative.memoryBytes(handle));   // OperatorContext.java:263-275
+    }
+
+    @Override
+    public Page getOutput()
+    {
+        try {
+            long page = GpuNative.getOutput(handle, wouldBlock);
+            return page == 0 ? null : GpuPages.deviceResident(page);
+        }
+        catch (GpuNative.NativeError e) {
+            throw GpuNative.toTrinoException(e);
+        }
+    }
+
+    @Override
+    public void finish()
+    {
+        try {
+            GpuNative.finish(handle);
+        }
+        catch (GpuNative.NativeError e) {
+            throw GpuNative.toTrinoException(e);
+        }
+    }
+
+    @Override
+    public boolean isFinished()
+    {
+        return call(() -> GpuNative.isFinished(handle));
+    }
+
+    // startMemoryRevoke / finishMemoryRevoke keep the interface defaults: the GPU operators report non-revocable user memory and never spill
+
+    @Override
+    public void close()
+    {
+        if (handle != 0) {
+            GpuNative.close(handle);
+            handle = 0;
+            memory.setBytes(0);
+        }
+    }
+
+    private interface BooleanCall
+    {
+        boolean get();
+    }
+
+    private static boolean call(BooleanCall c)
+    {
+        try {
+            return c.get();
+        }
+        catch (GpuNative.NativeError e) {
+            throw GpuNative.toTrinoException(e);
+        }
+    }
+}

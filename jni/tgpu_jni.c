@@ -1,0 +1,327 @@
+/*
+ * tgpu_jni.c -- the JNI shim between core/trino-main and libtgpu.so: one JNIEXPORT per C-ABI entry point the Java glue
+ * (the classes under java/io/trino/operator/gpu) calls.  Plain C over include/tgpu.h; nothing here computes.
+ *
+ * Compiled only where a JDK is present (the build image has none: `java`, `javac`, `jni.h` are absent, so on this image the file
+ * compiles to an empty translation unit -- `gcc -fsyntax-only jni/tgpu_jni.c` is part of build()):
+ *     gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jni/tgpu_jni.c -Lpresto-1_amd -ltgpu -o libtgpu_jni.so
+ *
+ * Ownership (tgpu.h): Java arrays are pinned with GetPrimitiveArrayCritical for the duration of one call only -- the library has
+ * uploaded what it keeps when it returns -- and released in reverse order with no JNI call in between.  Errors: a negative status
+ * becomes io.trino.operator.gpu.GpuNative$NativeError(code, message), which the glue maps to TrinoException(StandardErrorCode).
+ */
+#if defined(__has_include)
+#if __has_include(<jni.h>)
+#define TGPU_HAVE_JNI 1
+#endif
+#endif
+
+#ifdef TGPU_HAVE_JNI
+#include <jni.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/tgpu.h"
+
+#define H(type, handle) ((type *)(intptr_t)(handle))
+
+static void throw_native(JNIEnv *env, int32_t rc)
+{
+    jclass cls = (*env)->FindClass(env, "io/trino/operator/gpu/GpuNative$NativeError");
+    if (!cls) return;
+    jmethodID ctor = (*env)->GetMethodID(env, cls, "<init>", "(ILjava/lang/String;)V");
+    jstring msg = (*env)->NewStringUTF(env, tgpu_last_error());
+    jobject ex = (*env)->NewObject(env, cls, ctor, (jint)rc, msg);
+    if (ex) (*env)->Throw(env, (jthrowable)ex);
+}
+
+/* ---- context ---- */
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createContext(JNIEnv *env, jclass c, jint device)
+{
+    tgpu_context *ctx = NULL;
+    int32_t rc = tgpu_context_create(device, NULL, &ctx);
+    if (rc < 0) throw_native(env, rc);
+    return (jlong)(intptr_t)ctx;
+}
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_destroyContext(JNIEnv *env, jclass c, jlong ctx) { tgpu_context_destroy(H(tgpu_context, ctx)); }
+
+/* ---- pages: a flat block = the block's own primitive arrays (LongArrayBlock: long[] values + boolean[] valueIsNull + arrayOffset,
+ * S/block/LongArrayBlock.java:38-75; VariableWidthBlock: byte[] of the Slice + int[] offsets, S/block/VariableWidthBlock.java:38-83);
+ * DictionaryBlock / RunLengthEncodedBlock: ids + the (flat) dictionary / value block, passed as a second set of arrays ---- */
+typedef struct {
+    jarray values, nulls, offsets, ids, dvalues, dnulls, doffsets;
+    void *pv, *pn, *po, *pi, *pdv, *pdn, *pdo;
+} pinned_block;
+
+static void *pin(JNIEnv *env, jarray a) { return a ? (*env)->GetPrimitiveArrayCritical(env, a, NULL) : NULL; }
+static void unpin(JNIEnv *env, jarray a, void *p) { if (a && p) (*env)->ReleasePrimitiveArrayCritical(env, a, p, JNI_ABORT); }
+static int width_of(jint t) { return t == TGPU_BIGINT || t == TGPU_DOUBLE ? 8 : (t == TGPU_INTEGER || t == TGPU_DATE ? 4 : 1); }
+
+/* GpuPages.flatten() hands every channel as parallel arrays: per channel i
+ *   types[i], encodings[i] (TGPU_FLAT / TGPU_DICTIONARY / TGPU_RLE), arrayOffsets[i], dictionaryPositions[i],
+ *   values[i] / nulls[i] / offsets[i]          the flat block's arrays (FLAT), or null
+ *   ids[i]                                     int[] ids (DICTIONARY)
+ *   dvalues[i] / dnulls[i] / doffsets[i]       the dictionary's / the RLE value block's arrays */
+static int32_t with_page(JNIEnv *env, jint positions, jintArray types, jintArray encodings, jintArray arrayOffsets, jintArray dictPositions, jobjectArray values,
+                         jobjectArray nulls, jobjectArray offsets, jobjectArray ids, jobjectArray dvalues, jobjectArray dnulls, jobjectArray doffsets,
+                         int32_t (*call)(void *arg, const tgpu_page *page), void *arg)
+{
+    const jsize n = (*env)->GetArrayLength(env, types);
+    tgpu_block *blocks = (tgpu_block *)calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_block));
+    tgpu_block *dicts = (tgpu_block *)calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_block));
+    pinned_block *pins = (pinned_block *)calloc((size_t)(n > 0 ? n : 1), sizeof(pinned_block));
+    jint *t = (*env)->GetIntArrayElements(env, types, NULL), *enc = (*env)->GetIntArrayElements(env, encodings, NULL);
+    jint *ao = (*env)->GetIntArrayElements(env, arrayOffsets, NULL), *dp = (*env)->GetIntArrayElements(env, dictPositions, NULL);
+    for (jsize i = 0; i < n; i++) {   /* object fetches first: no JNI calls are allowed once the first array is pinned */
+        pins[i].values = (jarray)(*env)->GetObjectArrayElement(env, values, i);
+        pins[i].nulls = (jarray)(*env)->GetObjectArrayElement(env, nulls, i);
+        pins[i].offsets = (jarray)(*env)->GetObjectArrayElement(env, offsets, i);
+        pins[i].ids = (jarray)(*env)->GetObjectArrayElement(env, ids, i);
+        pins[i].dvalues = (jarray)(*env)->GetObjectArrayElement(env, dvalues, i);
+        pins[i].dnulls = (jarray)(*env)->GetObjectArrayElement(env, dnulls, i);
+        pins[i].doffsets = (jarray)(*env)->GetObjectArrayElement(env, doffsets, i);
+    }
+    for (jsize i = 0; i < n; i++) {
+        pinned_block *p = &pins[i];
+        p->pv = pin(env, p->values); p->pn = pin(env, p->nulls); p->po = pin(env, p->offsets); p->pi = pin(env, p->ids);
+        p->pdv = pin(env, p->dvalues); p->pdn = pin(env, p->dnulls); p->pdo = pin(env, p->doffsets);
+        const int w = width_of(t[i]);
+        tgpu_block *b = &blocks[i];
+        b->type = t[i]; b->encoding = enc[i]; b->memory = TGPU_HOST; b->position_count = positions;
+        if (enc[i] == TGPU_FLAT) {
+            b->values = t[i] == TGPU_VARCHAR ? p->pv : (const char *)p->pv + (size_t)ao[i] * (size_t)w;
+            b->nulls = p->pn ? (const uint8_t *)p->pn + ao[i] : NULL;            /* Java boolean[] = one byte per position */
+            b->offsets = p->po ? (const int32_t *)p->po + ao[i] : NULL;
+        }
+        else {
+            tgpu_block *d = &dicts[i];
+            d->type = t[i]; d->encoding = TGPU_FLAT; d->memory = TGPU_HOST; d->position_count = dp[i];
+            d->values = p->pdv; d->nulls = (const uint8_t *)p->pdn; d->offsets = (const int32_t *)p->pdo;
+            b->ids = p->pi ? (const int32_t *)p->pi + ao[i] : NULL;
+            b->dictionary = d;
+        }
+    }
+    tgpu_page page = {positions, n, blocks};
+    const int32_t rc = call(arg, &page);    /* the library copies to HBM before it returns: nothing of the heap arrays is retained */
+    for (jsize i = n; i-- > 0;) {
+        pinned_block *p = &pins[i];
+        unpin(env, p->doffsets, p->pdo); unpin(env, p->dnulls, p->pdn); unpin(env, p->dvalues, p->pdv); unpin(env, p->ids, p->pi);
+        unpin(env, p->offsets, p->po); unpin(env, p->nulls, p->pn); unpin(env, p->values, p->pv);
+    }
+    (*env)->ReleaseIntArrayElements(env, dictPositions, dp, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, arrayOffsets, ao, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, encodings, enc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    free(pins); free(dicts); free(blocks);
+    return rc;
+}
+
+static int32_t call_add_input(void *op, const tgpu_page *page) { return tgpu_operator_add_input((tgpu_operator *)op, page); }
+
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_addInput(JNIEnv *env, jclass c, jlong op, jint positions, jintArray types, jintArray encodings,
+        jintArray arrayOffsets, jintArray dictPositions, jobjectArray values, jobjectArray nulls, jobjectArray offsets, jobjectArray ids, jobjectArray dvalues,
+        jobjectArray dnulls, jobjectArray doffsets)
+{
+    int32_t rc = with_page(env, positions, types, encodings, arrayOffsets, dictPositions, values, nulls, offsets, ids, dvalues, dnulls, doffsets, call_add_input,
+                           H(tgpu_operator, op));
+    if (rc < 0) throw_native(env, rc);
+}
+
+/* chaining two GPU operators: the page never leaves HBM (tgpu_operator_add_input_output_page) */
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_addInputDevicePage(JNIEnv *env, jclass c, jlong op, jlong page)
+{
+    int32_t rc = tgpu_operator_add_input_output_page(H(tgpu_operator, op), H(tgpu_output_page, page));
+    if (rc < 0) throw_native(env, rc);
+}
+
+/* ---- Operator protocol (M/operator/Operator.java:20-102) ---- */
+#define BOOL_CALL(jname, cfn)                                                                                         \
+    JNIEXPORT jboolean JNICALL Java_io_trino_operator_gpu_GpuNative_##jname(JNIEnv *env, jclass c, jlong op)         \
+    { int32_t r = cfn(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); return r == 1; }
+BOOL_CALL(needsInput, tgpu_operator_needs_input)
+BOOL_CALL(isFinished, tgpu_operator_is_finished)
+BOOL_CALL(isBlocked, tgpu_operator_is_blocked)
+
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_finish(JNIEnv *env, jclass c, jlong op)
+{ int32_t r = tgpu_operator_finish(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_memoryBytes(JNIEnv *env, jclass c, jlong op) { return tgpu_operator_memory_bytes(H(tgpu_operator, op)); }
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_close(JNIEnv *env, jclass c, jlong op) { tgpu_operator_close(H(tgpu_operator, op)); }
+
+/* returns the output-page handle, 0 = no page; wouldBlock[0] = 1 when the operator is blocked as well (TGPU_WOULD_BLOCK) */
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_getOutput(JNIEnv *env, jclass c, jlong op, jbooleanArray wouldBlock)
+{
+    tgpu_output_page *p = NULL;
+    int32_t r = tgpu_operator_get_output(H(tgpu_operator, op), &p);
+    if (r < 0) { throw_native(env, r); return 0; }
+    jboolean wb = r == TGPU_WOULD_BLOCK;
+    if (wouldBlock) (*env)->SetBooleanArrayRegion(env, wouldBlock, 0, 1, &wb);
+    return (jlong)(intptr_t)p;
+}
+
+/* ---- output pages -> heap blocks (S/Page.java:33-73) ---- */
+JNIEXPORT jint JNICALL Java_io_trino_operator_gpu_GpuNative_pagePositionCount(JNIEnv *env, jclass c, jlong page) { return tgpu_output_page_position_count(H(tgpu_output_page, page)); }
+JNIEXPORT jint JNICALL Java_io_trino_operator_gpu_GpuNative_pageChannelCount(JNIEnv *env, jclass c, jlong page) { return tgpu_output_page_channel_count(H(tgpu_output_page, page)); }
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_releasePage(JNIEnv *env, jclass c, jlong page) { tgpu_output_page_release(H(tgpu_output_page, page)); }
+
+/* info[0] = type, info[1] = value bytes (VARCHAR: byte pool size), info[2] = may have nulls */
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_blockInfo(JNIEnv *env, jclass c, jlong page, jint channel, jlongArray info)
+{
+    int32_t type = 0, may = 0;
+    int64_t bytes = 0;
+    int32_t r = tgpu_output_page_block_info(H(tgpu_output_page, page), channel, &type, &bytes, &may);
+    if (r < 0) { throw_native(env, r); return; }
+    jlong v[3] = {type, bytes, may};
+    (*env)->SetLongArrayRegion(env, info, 0, 3, v);
+}
+
+/* every channel in ONE call (one stream synchronisation per page): values[i] is long[] / int[] / byte[] of the size blockInfo gave,
+ * nulls[i] boolean[positionCount] or null, offsets[i] int[positionCount + 1] for VARCHAR */
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_copyBlocks(JNIEnv *env, jclass c, jlong page, jobjectArray values, jobjectArray nulls, jobjectArray offsets)
+{
+    const jsize n = (*env)->GetArrayLength(env, values);
+    jarray *av = calloc((size_t)(3 * n + 1), sizeof(jarray));
+    void **pv = calloc((size_t)(3 * n + 1), sizeof(void *));
+    for (jsize i = 0; i < n; i++) {
+        av[i] = (jarray)(*env)->GetObjectArrayElement(env, values, i);
+        av[n + i] = (jarray)(*env)->GetObjectArrayElement(env, nulls, i);
+        av[2 * n + i] = (jarray)(*env)->GetObjectArrayElement(env, offsets, i);
+    }
+    for (jsize i = 0; i < 3 * n; i++) pv[i] = pin(env, av[i]);
+    int32_t r = tgpu_output_page_copy_blocks(H(tgpu_output_page, page), n, (void *const *)pv, (uint8_t *const *)(pv + n), (int32_t *const *)(pv + 2 * n));
+    for (jsize i = 3 * n; i-- > 0;)
+        if (av[i] && pv[i]) (*env)->ReleasePrimitiveArrayCritical(env, av[i], pv[i], 0);   /* 0: copy back / commit */
+    free(pv); free(av);
+    if (r < 0) throw_native(env, r);
+}
+
+/* ---- factories ---- */
+static jlong factory_result(JNIEnv *env, int32_t rc, tgpu_operator_factory *f) { if (rc < 0) { throw_native(env, rc); return 0; } return (jlong)(intptr_t)f; }
+
+/* nodes: int[node][9] = {kind, type, op, n_args, arg0, arg1, arg2, is_null, slen}; ivals / dvals per node; pool = the VARCHAR constants */
+static tgpu_expr_node *read_nodes(JNIEnv *env, jobjectArray nodes, jlongArray ivals, jdoubleArray dvals, jsize *count)
+{
+    const jsize n = (*env)->GetArrayLength(env, nodes);
+    tgpu_expr_node *out = calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_expr_node));
+    jlong *iv = (*env)->GetLongArrayElements(env, ivals, NULL);
+    jdouble *dv = (*env)->GetDoubleArrayElements(env, dvals, NULL);
+    for (jsize i = 0; i < n; i++) {
+        jintArray row = (jintArray)(*env)->GetObjectArrayElement(env, nodes, i);
+        jint f[9];
+        (*env)->GetIntArrayRegion(env, row, 0, 9, f);
+        out[i].kind = f[0]; out[i].type = f[1]; out[i].op = f[2]; out[i].n_args = f[3];
+        out[i].args[0] = f[4]; out[i].args[1] = f[5]; out[i].args[2] = f[6]; out[i].is_null = f[7]; out[i].slen = f[8];
+        out[i].ival = iv[i]; out[i].dval = dv[i];
+        (*env)->DeleteLocalRef(env, row);
+    }
+    (*env)->ReleaseDoubleArrayElements(env, dvals, dv, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, ivals, iv, JNI_ABORT);
+    *count = n;
+    return out;
+}
+
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createFilterProjectFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray inputTypes,
+        jobjectArray nodes, jlongArray ivals, jdoubleArray dvals, jbyteArray pool, jint filterRoot, jintArray projectionRoots)
+{
+    jsize n_nodes = 0;
+    tgpu_expr_node *nd = read_nodes(env, nodes, ivals, dvals, &n_nodes);
+    jint *types = (*env)->GetIntArrayElements(env, inputTypes, NULL), *roots = (*env)->GetIntArrayElements(env, projectionRoots, NULL);
+    jbyte *pl = (*env)->GetByteArrayElements(env, pool, NULL);
+    tgpu_page_processor_spec spec = {nd, n_nodes, (const char *)pl, (*env)->GetArrayLength(env, pool), filterRoot, (*env)->GetArrayLength(env, projectionRoots),
+                                     (const int32_t *)roots};
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_filter_project_factory_create(H(tgpu_context, ctx), operatorId, (*env)->GetArrayLength(env, inputTypes), (const int32_t *)types, &spec, &f);
+    (*env)->ReleaseByteArrayElements(env, pool, pl, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, projectionRoots, roots, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, inputTypes, types, JNI_ABORT);
+    free(nd);
+    return factory_result(env, rc, f);
+}
+
+/* aggregates: int[agg][3] = {function, input channel, mask channel} flattened */
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createHashAggregationFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray groupByTypes,
+        jintArray groupByChannels, jint hashChannel, jint step, jintArray aggregates, jint expectedGroups, jboolean produceDefaultOutput)
+{
+    jint *gt = (*env)->GetIntArrayElements(env, groupByTypes, NULL), *gc = (*env)->GetIntArrayElements(env, groupByChannels, NULL);
+    jint *ag = (*env)->GetIntArrayElements(env, aggregates, NULL);
+    const jsize n_agg = (*env)->GetArrayLength(env, aggregates) / 3;
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_hash_aggregation_factory_create(H(tgpu_context, ctx), operatorId, (*env)->GetArrayLength(env, groupByTypes), (const int32_t *)gt, (const int32_t *)gc,
+                                                      hashChannel, step, n_agg, (const tgpu_agg_spec *)ag, expectedGroups, produceDefaultOutput, &f);
+    (*env)->ReleaseIntArrayElements(env, aggregates, ag, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, groupByChannels, gc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, groupByTypes, gt, JNI_ABORT);
+    return factory_result(env, rc, f);
+}
+
+/* returns {factory, bridge} */
+JNIEXPORT jlongArray JNICALL Java_io_trino_operator_gpu_GpuNative_createHashBuilderFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types,
+        jintArray outputChannels, jintArray hashChannels, jint precomputedHashChannel, jint expectedPositions)
+{
+    jint *t = (*env)->GetIntArrayElements(env, types, NULL), *oc = (*env)->GetIntArrayElements(env, outputChannels, NULL), *hc = (*env)->GetIntArrayElements(env, hashChannels, NULL);
+    tgpu_lookup_source_factory *bridge = NULL;
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_hash_builder_factory_create(H(tgpu_context, ctx), operatorId, (*env)->GetArrayLength(env, types), (const int32_t *)t, (*env)->GetArrayLength(env, outputChannels),
+                                                  (const int32_t *)oc, (*env)->GetArrayLength(env, hashChannels), (const int32_t *)hc, precomputedHashChannel, expectedPositions, &bridge, &f);
+    (*env)->ReleaseIntArrayElements(env, hashChannels, hc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, outputChannels, oc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    if (rc < 0) { throw_native(env, rc); return NULL; }
+    jlong v[2] = {(jlong)(intptr_t)f, (jlong)(intptr_t)bridge};
+    jlongArray out = (*env)->NewLongArray(env, 2);
+    (*env)->SetLongArrayRegion(env, out, 0, 2, v);
+    return out;
+}
+
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createLookupJoinFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray probeTypes,
+        jintArray probeJoinChannels, jint probeHashChannel, jintArray probeOutputChannels, jint joinType)
+{
+    jint *t = (*env)->GetIntArrayElements(env, probeTypes, NULL), *jc = (*env)->GetIntArrayElements(env, probeJoinChannels, NULL);
+    jint *oc = (*env)->GetIntArrayElements(env, probeOutputChannels, NULL);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_lookup_join_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), (*env)->GetArrayLength(env, probeTypes), (const int32_t *)t,
+                                                 (*env)->GetArrayLength(env, probeJoinChannels), (const int32_t *)jc, probeHashChannel,
+                                                 (*env)->GetArrayLength(env, probeOutputChannels), (const int32_t *)oc, joinType, &f);
+    (*env)->ReleaseIntArrayElements(env, probeOutputChannels, oc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, probeJoinChannels, jc, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, probeTypes, t, JNI_ABORT);
+    return factory_result(env, rc, f);
+}
+
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createLookupOuterFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray probeOutputTypes)
+{
+    jint *t = (*env)->GetIntArrayElements(env, probeOutputTypes, NULL);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_lookup_outer_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), (*env)->GetArrayLength(env, probeOutputTypes), (const int32_t *)t, &f);
+    (*env)->ReleaseIntArrayElements(env, probeOutputTypes, t, JNI_ABORT);
+    return factory_result(env, rc, f);
+}
+
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_destroyBridge(JNIEnv *env, jclass c, jlong bridge) { tgpu_lookup_source_factory_destroy(H(tgpu_lookup_source_factory, bridge)); }
+
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createOperator(JNIEnv *env, jclass c, jlong factory)
+{
+    tgpu_operator *op = NULL;
+    int32_t rc = tgpu_operator_factory_create_operator(H(tgpu_operator_factory, factory), &op);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)op;
+}
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_noMoreOperators(JNIEnv *env, jclass c, jlong factory)
+{ int32_t rc = tgpu_operator_factory_no_more_operators(H(tgpu_operator_factory, factory)); if (rc < 0) throw_native(env, rc); }
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_duplicateFactory(JNIEnv *env, jclass c, jlong factory)
+{
+    tgpu_operator_factory *f = NULL;
+    return factory_result(env, tgpu_operator_factory_duplicate(H(tgpu_operator_factory, factory), &f), f);
+}
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_destroyFactory(JNIEnv *env, jclass c, jlong factory) { tgpu_operator_factory_destroy(H(tgpu_operator_factory, factory)); }
+
+/* ---- SerializedPage bytes straight into HBM (M/execution/buffer/PagesSerde.java:117-160) ---- */
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_deserializePage(JNIEnv *env, jclass c, jlong ctx, jbyteArray bytes, jint offset, jint length, jintArray types)
+{
+    jint *t = (*env)->GetIntArrayElements(env, types, NULL);
+    const jsize nt = (*env)->GetArrayLength(env, types);
+    jbyte *p = (*env)->GetPrimitiveArrayCritical(env, bytes, NULL);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_deserialize_page(H(tgpu_context, ctx), p + offset, length, nt, (const int32_t *)t, &out);
+    (*env)->ReleasePrimitiveArrayCritical(env, bytes, p, JNI_ABORT);   /* the library has consumed the bytes when it returns */
+    (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)out;
+}
+#endif /* TGPU_HAVE_JNI */
+
+/* keeps the translation unit non-empty (ISO C) where no JDK is installed */
+typedef int tgpu_jni_translation_unit;
