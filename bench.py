@@ -568,17 +568,117 @@ class Bench:
         t = self.q1 = gen_q1(self.dev, n, self.rank)
         pp = self.entry.bench_page_processors(p)
         V, D, DT = p.VARCHAR, p.DOUBLE, p.DATE
-        self.q1_page = p.Page(self.dblock(V, t["returnflag"], t["off"]), self.dblock(V, t["linestatus"], t["off"]), self.dblock(D, t["quantity"]),
+        self.q1_page_ = p.Page(self.dblock(V, t["returnflag"], t["off"]), self.dblock(V, t["linestatus"], t["off"]), self.dblock(D, t["quantity"]),
                               self.dblock(D, t["extendedprice"]), self.dblock(D, t["discount"]), self.dblock(D, t["tax"]), self.dblock(DT, t["shipdate"]))
         # HandTpchQuery1.java:60-133: scan filter/project fused into the hash aggregation (group by returnflag, linestatus)
         self.q1_agg = p.FilterProjectHashAggregationOperatorFactory(self.ctx, 21, *pp["q1"], [V, V], [0, 1], self.entry.q1_aggregates(p), expected_groups=16)
 
     def step_q1(self):
         aop = self.q1_agg.createOperator()
-        aop.addInput(self.q1_page)
+        aop.addInput(self.q1_page_)
         outs = self.finish(aop)
         self.q1_result = [o.to_host().rows() for o in outs]
         aop.close()
+
+    def q1_page(self, a, z):
+        """rows [a, z) of the Q1 input as a device page (zero-copy views of the generated columns)"""
+        p, t = self.pkg, self.q1
+        V, D, DT = p.VARCHAR, p.DOUBLE, p.DATE
+        m = z - a
+        vb = lambda key: p.DeviceBlock(V, m, t[key], None, t["off"][a:z + 1])
+        db = lambda ty, key: p.DeviceBlock(ty, m, t[key][a:z])
+        return p.Page(vb("returnflag"), vb("linestatus"), db(D, "quantity"), db(D, "extendedprice"), db(D, "discount"), db(D, "tax"), db(DT, "shipdate"), position_count=m)
+
+    def q1_paged(self, steps, warmup, page_rows, merge_mb=None):
+        """Q1 fed as pages of `page_rows` rows (the engine hands pages, not tables): directly, or through a MergePagesOperator with
+        `merge_mb` MB thresholds in front (DESIGN.md "Page granularity")"""
+        p, ctx = self.pkg, self.ctx
+        n = int(self.q1["quantity"].numel())
+        pages = [self.q1_page(a, min(a + page_rows, n)) for a in range(0, n, page_rows)]
+        cpages = [pg.to_c() for pg in pages]     # marshalled once: the timed loop is the library's work, not ctypes struct building
+        types = [p.VARCHAR, p.VARCHAR, p.DOUBLE, p.DOUBLE, p.DOUBLE, p.DOUBLE, p.DATE]
+        mfac = p.MergePagesOperatorFactory(ctx, 20, types, merge_mb << 20, 1 << 27, (merge_mb << 20) * 2) if merge_mb else None
+        L = p._lib.lib()
+        import ctypes as C
+        res = {}
+
+        def step():
+            aop = self.q1_agg.createOperator()
+            if mfac is None:
+                for cp, keep in cpages:
+                    p._lib.check(L.tgpu_operator_add_input(aop.handle, C.byref(cp)))
+            else:
+                m = mfac.createOperator()
+
+                def drain():
+                    while True:
+                        o = m.getOutput()
+                        if o is None:
+                            return
+                        aop.addInput(o)        # a library-owned page: buffers shared, nothing copied
+                        o.release()
+                for cp, keep in cpages:
+                    p._lib.check(L.tgpu_operator_add_input(m.handle, C.byref(cp)))
+                    drain()
+                m.finish()
+                drain()
+                m.close()
+            outs = self.finish(aop)
+            res["rows"] = [o.to_host().rows() for o in outs]
+            aop.close()
+
+        step_s, prof = self.timed(step, steps, warmup)
+        self.q1_result = res["rows"]
+        ok = self.check_q1()["ok"]
+        return {"page_rows": page_rows, "pages": len(pages), "through_merge_pages_mb": merge_mb, "ms_per_step": step_s * 1e3, "rows_per_sec": n / step_s,
+                "readbacks_per_page": self.last_readbacks_per_step / max(len(pages), 1), "ok": ok}
+
+    def q1_pcie_inclusive(self, steps, warmup, n, page_rows, pinned):
+        """Q1 with every input byte crossing PCIe inside the timed region: the columns live in host memory (pinned = hipHostMalloc'ed
+        through tgpu_pinned_alloc, else pageable numpy arrays), fed as pages of `page_rows` rows; every add_input stages its arrays
+        through the double-buffered ingest ring on the copy stream while the kernels of the previous page run"""
+        p, ctx = self.pkg, self.ctx
+        t = gen_q1(self.dev, n, self.rank)
+        V, D, DT = p.VARCHAR, p.DOUBLE, p.DATE
+        host, holders = {}, []
+        for key in ("returnflag", "linestatus", "quantity", "extendedprice", "discount", "tax", "shipdate"):
+            src = t[key].cpu().numpy()
+            if pinned:
+                arr, holder = ctx.pinned_array(src.dtype, src.size)
+                np.copyto(arr, src)
+                holders.append(holder)
+                host[key] = arr
+            else:
+                host[key] = src
+        del t
+        torch.cuda.empty_cache()
+        off0 = np.arange(page_rows + 1, dtype=np.int32)
+        pages = []
+        for a in range(0, n, page_rows):
+            z = min(a + page_rows, n)
+            m = z - a
+            vb = lambda key: p.Block(V, host[key][a:z], None, off0[:m + 1])
+            fb = lambda ty, key: p.Block(ty, host[key][a:z])
+            pages.append(p.Page(vb("returnflag"), vb("linestatus"), fb(D, "quantity"), fb(D, "extendedprice"), fb(D, "discount"), fb(D, "tax"), fb(DT, "shipdate")))
+        cpages = [pg.to_c() for pg in pages]
+        L = p._lib.lib()
+        import ctypes as C
+        res = {}
+
+        def step():
+            aop = self.q1_agg.createOperator()
+            for cp, keep in cpages:
+                p._lib.check(L.tgpu_operator_add_input(aop.handle, C.byref(cp)))
+            outs = self.finish(aop)
+            res["rows"] = [o.to_host().rows() for o in outs]
+            aop.close()
+
+        step_s, prof = self.timed(step, steps, warmup)
+        groups = sum(len(r) for r in res["rows"])
+        for h in holders:
+            h.free()
+        return {"rows": n, "pages": len(pages), "page_rows": page_rows, "host_memory": "pinned (tgpu_pinned_alloc)" if pinned else "pageable", "ms_per_step": step_s * 1e3,
+                "rows_per_sec": n / step_s, "host_to_hbm_GBps": 46.0 * n / step_s / 1e9, "groups": groups, "ok": groups == 4}
 
     def check_q1(self, java_order_distance=False):
         t = self.q1
@@ -1027,7 +1127,12 @@ def main():
         out["q1"]["roofline"] = dominant(p1, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
                                          {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
-        del b.q1, b.q1_page
+        if b.world == 1 and "sub" in only:
+            # the engine hands over pages, not tables: the same program fed as 2^20-row pages (573 of them at SF100) directly and through MergePages
+            out["q1"]["paged"] = {"direct_2^20": b.q1_paged(args.steps, args.warmup, 1 << 20), "merged_2^20_1GB": b.q1_paged(args.steps, args.warmup, 1 << 20, merge_mb=1024),
+                                  "direct_2^24": b.q1_paged(args.steps, args.warmup, 1 << 24)}
+            out["checks"]["q1_paged"] = all(v["ok"] for v in out["q1"]["paged"].values())
+        del b.q1, b.q1_page_
         b.q1_result = None
         torch.cuda.empty_cache()
 
@@ -1049,6 +1154,13 @@ def main():
         b.c2_out = None
         torch.cuda.empty_cache()
 
+    if b.world == 1 and "sub" in only and "q1" in only:
+        # PCIe-inclusive Q1 on a bounded sample (every input byte host -> HBM inside the timed region; never `value`)
+        n_pcie = int(6_000_379.02 * min(args.sf, 20.0))
+        b.setup_q1(1024)   # (re)creates the factory
+        out["q1"]["pcie_inclusive"] = {"pinned": b.q1_pcie_inclusive(args.steps, args.warmup, n_pcie, 1 << 24, True),
+                                       "pageable": b.q1_pcie_inclusive(args.steps, args.warmup, n_pcie, 1 << 24, False)}
+        del b.q1, b.q1_page_
     if b.world == 1 and "sub" in only:
         torch.cuda.empty_cache()
         sub = {}

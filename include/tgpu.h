@@ -118,6 +118,12 @@ int32_t tgpu_set_resource_dir(const char *dir);
 typedef enum tgpu_double_sum_order { TGPU_SUM_ORDER_EXACT = 0, TGPU_SUM_ORDER_JAVA = 1 } tgpu_double_sum_order;
 int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order);
 
+/* Pinned (page-locked) host memory for hosts that fill their own receive buffers (an exchange client, a file reader): blocks whose arrays
+ * live in such memory are transferred by asynchronous DMA.  Every tgpu_operator_add_input of a host page stages its arrays through a
+ * double-buffered ring on a second HIP stream, so the transfer of page i + 1 runs under the kernels of page i (DESIGN.md "Ingest"). */
+int32_t tgpu_pinned_alloc(tgpu_context *ctx, int64_t bytes, void **out);
+int32_t tgpu_pinned_free(tgpu_context *ctx, void *ptr);
+
 /* per-kernel HIP-event timing on the context's stream (bench.py's roofline leg) */
 int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled);
 int32_t tgpu_profile_reset(tgpu_context *ctx);

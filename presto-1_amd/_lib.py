@@ -77,6 +77,8 @@ SYMBOLS = {
     "tgpu_version": (cp, []),
     "tgpu_set_resource_dir": (i32, [cp]),
     "tgpu_context_set_double_sum_order": (i32, [vp, i32]),
+    "tgpu_pinned_alloc": (i32, [vp, i64, P(vp)]),
+    "tgpu_pinned_free": (i32, [vp, vp]),
     "tgpu_profile_enable": (i32, [vp, i32]),
     "tgpu_profile_reset": (i32, [vp]),
     "tgpu_profile_dump": (i64, [vp, cp, i64]),

@@ -168,6 +168,22 @@ int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order)
     });
 }
 
+int32_t tgpu_pinned_alloc(tgpu_context *ctx, int64_t bytes, void **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && bytes >= 0, "bad argument");
+        *out = ctx->ctx->pinned_alloc((size_t)bytes);
+    });
+}
+
+int32_t tgpu_pinned_free(tgpu_context *ctx, void *ptr)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        ctx->ctx->pinned_free(ptr);
+    });
+}
+
 int32_t tgpu_profile_enable(tgpu_context *ctx, int32_t enabled)
 {
     return guard_on(ctx_of(ctx), [&] {

@@ -197,10 +197,28 @@ DevicePage ingest_page(Context *ctx, const tgpu_page *page)
     out.n = page->position_count;
     out.cols.reserve((size_t)page->channel_count);
     bool any_host = false;
+    size_t host_bytes = 0;   // what the flat host blocks of the page upload: staged through the double-buffered ingest ring when sizeable
     for (int32_t c = 0; c < page->channel_count; c++) {
-        TG_CHECK_ARG(page->blocks[c].position_count == page->position_count, "block position count differs from the page's");
-        any_host |= page->blocks[c].memory == TGPU_HOST;
-        out.cols.push_back(ingest_block_raw(ctx, &page->blocks[c]));
+        const tgpu_block &b = page->blocks[c];
+        TG_CHECK_ARG(b.position_count == page->position_count, "block position count differs from the page's");
+        any_host |= b.memory == TGPU_HOST;
+        if (b.memory == TGPU_HOST && b.encoding == TGPU_FLAT && valid_type(b.type) && b.position_count > 0) {
+            const size_t n = (size_t)b.position_count;
+            if (b.type == TGPU_VARCHAR) host_bytes += (b.offsets ? (size_t)(b.offsets[n] - b.offsets[0]) : 0) + (n + 1) * 4;
+            else host_bytes += n * (size_t)type_width(b.type);
+            if (b.nulls) host_bytes += n;
+        }
+    }
+    struct IngestScope {   // end_ingest also on the error path (it releases the context's ingest lock)
+        Context *c;
+        bool on;
+        ~IngestScope() { if (on) c->end_ingest(); }
+    } scope{ctx, any_host && ctx->begin_ingest(host_bytes)};
+    const bool ringed = scope.on;
+    for (int32_t c = 0; c < page->channel_count; c++) out.cols.push_back(ingest_block_raw(ctx, &page->blocks[c]));
+    if (scope.on) {
+        scope.on = false;
+        ctx->end_ingest();   // waits for the transfers only: the kernels of the previous page keep running on the compute stream
     }
     std::vector<DeviceColumn *> unresolved;
     for (DeviceColumn &c : out.cols)
@@ -208,7 +226,7 @@ DevicePage ingest_page(Context *ctx, const tgpu_page *page)
     resolve_varchar_ends(ctx, unresolved);
     // ownership rule: the caller's (Java heap) arrays are only valid during the call, so the H2D copies must have
     // consumed them before we return (the batched read above has already waited for the stream)
-    if (any_host && unresolved.empty()) ctx->sync();
+    if (any_host && unresolved.empty() && !ringed) ctx->sync();
     return out;
 }
 

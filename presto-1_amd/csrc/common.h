@@ -105,7 +105,17 @@ public:
 
     // pinned host staging (uploads / small readbacks)
     void *pinned(size_t bytes);
-    void upload(void *dst, const void *src, size_t bytes);          // async H2D through pinned staging when small
+    void upload(void *dst, const void *src, size_t bytes);          // H2D; inside an ingest scope: staged through the slab ring on the copy stream
+    // Double-buffered page ingest (north_star: "pinned and streamed to HBM"): between begin_ingest and end_ingest every upload() goes
+    // host -> one of two device staging slabs on a SECOND stream, so that the transfer of page i + 1 runs under the kernels of page i
+    // (which occupy the context's stream); end_ingest waits for the transfer (the caller's arrays are only valid during the call), lets
+    // the compute stream wait on it and moves the bytes into their stream-ordered buffers with device-to-device copies.  A slab is
+    // reused only after the compute stream has drained it (event).  Hosts that hand over hipHostMalloc'ed (pinned) arrays get a true
+    // asynchronous DMA; pageable arrays are staged by the runtime.  Returns false (plain path) for pages larger than the slabs may grow.
+    bool begin_ingest(size_t total_bytes);
+    void end_ingest();
+    void *pinned_alloc(size_t bytes);    // hipHostMalloc for the embedding host (tgpu_pinned_alloc): e.g. the exchange client's receive buffers
+    void pinned_free(void *p);
     void download(void *dst, const void *src, size_t bytes);        // D2H + sync
     // many small D2H copies with ONE synchronisation: staged through pinned memory, then scattered to the destinations
     struct Transfer { void *dst; const void *src; size_t bytes; };
@@ -162,6 +172,14 @@ private:
     std::map<std::string, KernelStat> stats_;
     const char *cur_name_ = nullptr;
     hipEvent_t cur_a_ = nullptr;
+    struct Slab { void *dev = nullptr; size_t cap = 0; hipEvent_t drained = nullptr; };
+    struct PendingCopy { void *dst; const void *src; size_t bytes; };
+    hipStream_t copy_stream_ = nullptr;
+    hipEvent_t copy_done_ = nullptr;
+    Slab slabs_[2];
+    int next_slab_ = 0, active_slab_ = -1;
+    size_t slab_used_ = 0;
+    std::vector<PendingCopy> pending_copies_;
     std::mutex mu_;
     std::recursive_mutex io_mu_;   // the pinned staging buffer, the polling event and the profile lists: shared by every handle of the context
 };

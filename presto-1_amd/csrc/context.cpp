@@ -47,6 +47,12 @@ Context::~Context()
     for (auto &kv : free_) hipFree(kv.second);
     for (auto &p : pending_) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto ev : event_pool_) hipEventDestroy(ev);
+    for (Slab &sl : slabs_) {
+        if (sl.dev) hipFree(sl.dev);
+        if (sl.drained) hipEventDestroy(sl.drained);
+    }
+    if (copy_done_) hipEventDestroy(copy_done_);
+    if (copy_stream_) hipStreamDestroy(copy_stream_);
     if (pinned_) hipHostFree(pinned_);
     if (wait_event_) hipEventDestroy(wait_event_);
 }
@@ -165,9 +171,91 @@ void *Context::pinned(size_t bytes)
     return pinned_;
 }
 
+bool Context::begin_ingest(size_t total_bytes)
+{
+    static const bool disabled = getenv("TGPU_DISABLE_INGEST_RING") != nullptr;
+    if (disabled || total_bytes < (256u << 10) || total_bytes > (4ull << 30)) return false;   // tiny pages: latency matters more than overlap
+    io_mu_.lock();   // one ingest at a time per context (released by end_ingest)
+    try {
+        if (!copy_stream_) {
+            HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&copy_done_, hipEventDisableTiming));
+        }
+        Slab &sl = slabs_[next_slab_];
+        const size_t need = total_bytes + 256 * 64;   // per-upload alignment slack
+        if (sl.cap < need) {
+            if (sl.dev) {
+                HIP_CHECK(hipEventSynchronize(sl.drained));
+                HIP_CHECK(hipFree(sl.dev));
+                sl.dev = nullptr;
+                sl.cap = 0;
+            }
+            size_t cap = 64u << 20;
+            while (cap < need) cap <<= 1;
+            HIP_CHECK(hipMalloc(&sl.dev, cap));
+            sl.cap = cap;
+            if (!sl.drained) HIP_CHECK(hipEventCreateWithFlags(&sl.drained, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(sl.drained, stream_));
+        }
+        HIP_CHECK(hipStreamWaitEvent(copy_stream_, sl.drained, 0));   // the compute stream has read the slab's previous page out
+        active_slab_ = next_slab_;
+        next_slab_ ^= 1;
+        slab_used_ = 0;
+        pending_copies_.clear();
+    }
+    catch (...) {
+        io_mu_.unlock();
+        throw;
+    }
+    return true;
+}
+
+void Context::end_ingest()
+{
+    if (active_slab_ < 0) return;
+    Slab &sl = slabs_[active_slab_];
+    active_slab_ = -1;
+    try {
+        HIP_CHECK(hipEventRecord(copy_done_, copy_stream_));
+        HIP_CHECK(hipEventSynchronize(copy_done_));                   // the caller's arrays have been consumed (pinned sources are real async DMA)
+        for (const PendingCopy &c : pending_copies_) HIP_CHECK(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, stream_));
+        HIP_CHECK(hipEventRecord(sl.drained, stream_));
+        pending_copies_.clear();
+    }
+    catch (...) {
+        io_mu_.unlock();
+        throw;
+    }
+    io_mu_.unlock();
+}
+
+void *Context::pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    HIP_CHECK(hipSetDevice(device_));
+    HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    return p;
+}
+
+void Context::pinned_free(void *p)
+{
+    if (p) HIP_CHECK(hipHostFree(p));
+}
+
 void Context::upload(void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
+    if (active_slab_ >= 0) {
+        Slab &sl = slabs_[active_slab_];
+        const size_t at = (slab_used_ + 255) / 256 * 256;
+        if (at + bytes <= sl.cap) {
+            void *stage = (uint8_t *)sl.dev + at;
+            HIP_CHECK(hipMemcpyAsync(stage, src, bytes, hipMemcpyHostToDevice, copy_stream_));
+            pending_copies_.push_back({dst, stage, bytes});
+            slab_used_ = at + bytes;
+            return;
+        }
+    }
     // Java heap arrays are pageable; hipMemcpyAsync from pageable memory stages internally and returns once the
     // source has been consumed, which is what the ownership rule needs (the caller may reuse src after the call).
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));

@@ -38,6 +38,27 @@ class Context:
     def synchronize(self):
         _lib.check(_lib.lib().tgpu_context_synchronize(self.handle))
 
+    def pinned_array(self, dtype, count):
+        """a numpy array over page-locked host memory (tgpu_pinned_alloc): blocks built on it are transferred by asynchronous DMA;
+        the array keeps the allocation alive and frees it with the context still open (call .base.free() or let it be collected)"""
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_pinned_alloc(self.handle, int(count) * dt.itemsize, C.byref(p)))
+        ctx_handle = self.handle
+
+        class _Pinned:
+            def __init__(self):
+                self.ptr = p.value
+                self.__array_interface__ = {"shape": (int(count),), "typestr": dt.str, "data": (p.value, False), "version": 3}
+
+            def free(self):
+                if self.ptr:
+                    _lib.lib().tgpu_pinned_free(ctx_handle, self.ptr)
+                    self.ptr = None
+
+        holder = _Pinned()
+        return np.asarray(holder), holder
+
     def set_double_sum_order(self, order):
         """SUM_ORDER_EXACT (default) or SUM_ORDER_JAVA for the aggregation operators created from now on (tgpu.h)"""
         _lib.check(_lib.lib().tgpu_context_set_double_sum_order(self.handle, order))

@@ -205,6 +205,6 @@ def test_full_size_sf100_properties(bench_mod, bench):
     bench.step_q1()
     chk = bench.check_q1()
     assert chk["ok"], chk
-    del bench.q1, bench.q1_page
+    del bench.q1, bench.q1_page_
     bench.q1_result = None
     torch.cuda.empty_cache()
