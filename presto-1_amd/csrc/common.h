@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -12,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -177,7 +179,9 @@ private:
     hipStream_t copy_stream_ = nullptr;
     hipEvent_t copy_done_ = nullptr;
     Slab slabs_[2];
-    int next_slab_ = 0, active_slab_ = -1;
+    int next_slab_ = 0;
+    std::atomic<int> active_slab_{-1};
+    std::thread::id ingest_owner_;   // the ring serves the thread that opened the ingest scope; other threads' uploads take the plain path
     size_t slab_used_ = 0;
     std::vector<PendingCopy> pending_copies_;
     std::mutex mu_;

@@ -198,6 +198,7 @@ bool Context::begin_ingest(size_t total_bytes)
             HIP_CHECK(hipEventRecord(sl.drained, stream_));
         }
         HIP_CHECK(hipStreamWaitEvent(copy_stream_, sl.drained, 0));   // the compute stream has read the slab's previous page out
+        ingest_owner_ = std::this_thread::get_id();
         active_slab_ = next_slab_;
         next_slab_ ^= 1;
         slab_used_ = 0;
@@ -245,7 +246,7 @@ void Context::pinned_free(void *p)
 void Context::upload(void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
-    if (active_slab_ >= 0) {
+    if (active_slab_ >= 0 && ingest_owner_ == std::this_thread::get_id()) {
         Slab &sl = slabs_[active_slab_];
         const size_t at = (slab_used_ + 255) / 256 * 256;
         if (at + bytes <= sl.cap) {
