@@ -208,6 +208,20 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
                                          int32_t hash_channel_count, const int32_t *hash_channels /* join key channels */,
                                          int32_t precomputed_hash_channel /* -1 = none */, int32_t expected_positions,
                                          tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out);
+/* The build side as `partition_count` HashBuilderOperators (PartitionedLookupSourceFactory.java:110-124: one per build driver; each receives
+ * the rows a LocalExchange with the LocalPartitionGenerator function -- TGPU_PARTITION_LOCAL below -- routes to its partition).
+ * tgpu_operator_factory_create_operator may then be called partition_count times; the probes stay blocked until every build operator has
+ * finished (lendPartitionLookupSource).  The partitions are concatenated in partition order into ONE table in HBM (the reference keeps P
+ * tables to parallelise a CPU build); results equal PartitionedLookupSource's (PartitionedLookupSource.java:87-153): a key's matches
+ * newest -> oldest within its partition, unmatched outer rows partition by partition (:233-262).  partition_count: a power of two. */
+int32_t tgpu_partitioned_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types,
+                                                     int32_t output_channel_count, const int32_t *output_channels, int32_t hash_channel_count,
+                                                     const int32_t *hash_channels, int32_t precomputed_hash_channel, int32_t expected_positions,
+                                                     int32_t partition_count, tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out);
+/* PartitionedLookupSource's join-position encoding (PartitionedLookupSource.java:212-226): (joinPosition << shiftSize) | partition with
+ * shiftSize = numberOfTrailingZeros(partitionCount) + 1; for shims that must hand such positions to Java code */
+int64_t tgpu_partitioned_join_position_encode(int32_t partition, int32_t join_position, int32_t partition_count);
+int32_t tgpu_partitioned_join_position_decode(int64_t partitioned_join_position, int32_t partition_count, int32_t *partition, int32_t *join_position);
 void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge);
 /* JoinFilterFunction (M/operator/JoinHash.java:44-47,82-130; M/sql/gen/JoinFilterFunctionCompiler.java; handed to the build side like
  * JoinHashSupplier.java:54-70): a predicate over (build row, probe row) that a join position must pass besides key equality.  `spec`'s

@@ -85,6 +85,9 @@ SYMBOLS = {
     "tgpu_filter_project_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), P(vp)]),
     "tgpu_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, i32, P(vp)]),
     "tgpu_hash_builder_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, P(i32), i32, i32, P(vp), P(vp)]),
+    "tgpu_partitioned_hash_builder_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, P(i32), i32, i32, i32, P(vp), P(vp)]),
+    "tgpu_partitioned_join_position_encode": (i64, [i32, i32, i32]),
+    "tgpu_partitioned_join_position_decode": (i32, [i64, i32, P(i32), P(i32)]),
     "tgpu_lookup_source_factory_destroy": (None, [vp]),
     "tgpu_lookup_source_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     "tgpu_lookup_source_factory_set_join_filter": (i32, [vp, i32, P(i32), P(PageProcessorSpec)]),

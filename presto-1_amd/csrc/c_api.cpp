@@ -277,6 +277,31 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
                                          const int32_t *hash_channels, int32_t precomputed_hash_channel, int32_t expected_positions,
                                          tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out)
 {
+    return tgpu_partitioned_hash_builder_factory_create(ctx, operator_id, type_count, types, output_channel_count, output_channels, hash_channel_count, hash_channels,
+                                                        precomputed_hash_channel, expected_positions, 1, bridge_out, out);
+}
+
+int64_t tgpu_partitioned_join_position_encode(int32_t partition, int32_t join_position, int32_t partition_count)
+{
+    // PartitionedLookupSource.java:101-102,222-226: shiftSize = numberOfTrailingZeros(partitions) + 1
+    const int shift = __builtin_ctz((unsigned)partition_count) + 1;
+    return ((int64_t)join_position << shift) | (int64_t)partition;
+}
+
+int32_t tgpu_partitioned_join_position_decode(int64_t partitioned_join_position, int32_t partition_count, int32_t *partition, int32_t *join_position)
+{
+    if (partition_count <= 0 || (partition_count & (partition_count - 1)) || !partition || !join_position) return TGPU_ERR_INVALID_ARGUMENT;
+    const int shift = __builtin_ctz((unsigned)partition_count) + 1;
+    *partition = (int32_t)(partitioned_join_position & (partition_count - 1));             // :212-216
+    *join_position = (int32_t)((uint64_t)partitioned_join_position >> shift);               // :218-221
+    return TGPU_OK;
+}
+
+int32_t tgpu_partitioned_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types,
+                                                     int32_t output_channel_count, const int32_t *output_channels, int32_t hash_channel_count,
+                                                     const int32_t *hash_channels, int32_t precomputed_hash_channel, int32_t expected_positions,
+                                                     int32_t partition_count, tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out)
+{
     return guard_on(ctx_of(ctx), [&] {
         TG_CHECK_ARG(ctx && out && bridge_out, "null argument");
         HashBuilderConfig cfg;
@@ -285,6 +310,7 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
         cfg.hash_channels = vec(hash_channels, hash_channel_count);
         cfg.precomputed_hash_channel = precomputed_hash_channel;
         cfg.expected_positions = expected_positions;
+        cfg.partition_count = partition_count;
         auto bridge = std::make_unique<tgpu_lookup_source_factory>();
         bridge->bridge = std::make_shared<LookupSourceFactory>();
         auto f = std::make_unique<tgpu_operator_factory>();

@@ -338,8 +338,8 @@ class HashBuilderOperator : public Operator {
 public:
     enum class State { CONSUMING_INPUT, LOOKUP_SOURCE_BUILT, CLOSED };
 
-    HashBuilderOperator(Context *ctx, int32_t id, const HashBuilderConfig &cfg, std::shared_ptr<LookupSourceFactory> bridge)
-        : Operator(ctx, id), cfg_(cfg), bridge_(std::move(bridge)), index_(std::make_shared<PagesIndexGpu>(ctx, cfg.types))
+    HashBuilderOperator(Context *ctx, int32_t id, const HashBuilderConfig &cfg, std::shared_ptr<LookupSourceFactory> bridge, int partition)
+        : Operator(ctx, id), cfg_(cfg), bridge_(std::move(bridge)), index_(std::make_shared<PagesIndexGpu>(ctx, cfg.types)), partition_(partition)
     {
     }
 
@@ -359,10 +359,9 @@ public:
     void finish() override
     {
         if (state_ != State::CONSUMING_INPUT) return;
-        auto source = std::make_shared<LookupSourceGpu>(ctx_, index_, cfg_.hash_channels, cfg_.precomputed_hash_channel, cfg_.output_channels);
-        source->build();
-        source_ = source;
-        bridge_->lend(source);
+        index_bytes_ = index_->estimated_size();
+        bridge_->lend_partition(partition_, index_);   // the last partition to arrive builds the table (lendPartitionLookupSource)
+        index_.reset();
         state_ = State::LOOKUP_SOURCE_BUILT;
     }
 
@@ -375,19 +374,22 @@ public:
         return state_ == State::CLOSED;
     }
 
-    int64_t memory_bytes() override { return source_ ? source_->estimated_size() : index_->estimated_size(); }
-
-    void close() override
+    int64_t memory_bytes() override
     {
-        state_ = State::CLOSED;
-        source_.reset();
+        if (index_) return index_->estimated_size();
+        if (state_ == State::CLOSED) return 0;
+        std::shared_ptr<LookupSourceGpu> s = bridge_->lookup_source();
+        return s && partition_ == 0 ? s->estimated_size() : index_bytes_;   // the merged table is accounted once, on partition 0
     }
+
+    void close() override { state_ = State::CLOSED; }
 
 private:
     HashBuilderConfig cfg_;
     std::shared_ptr<LookupSourceFactory> bridge_;
     std::shared_ptr<PagesIndexGpu> index_;
-    std::shared_ptr<LookupSourceGpu> source_;
+    int partition_;
+    int64_t index_bytes_ = 0;
     State state_ = State::CONSUMING_INPUT;
 };
 
@@ -402,14 +404,35 @@ HashBuilderOperatorFactory::HashBuilderOperatorFactory(Context *ctx, int32_t ope
     TG_CHECK_ARG(cfg_.precomputed_hash_channel < nt, "hash channel out of range");
     for (int32_t ch : cfg_.output_channels) bridge_->build_output_types.push_back(cfg_.types[(size_t)ch]);
     bridge_->build_types = cfg_.types;
+    TG_CHECK_ARG(cfg_.partition_count >= 1 && cfg_.partition_count <= 1024 && (cfg_.partition_count & (cfg_.partition_count - 1)) == 0,
+                 "the build partition count must be a power of two (LocalPartitionGenerator.java:45-52)");
+    const HashBuilderConfig config = cfg_;
+    Context *c = ctx_;
+    bridge_->set_partitioning(cfg_.partition_count, [config, c](std::vector<std::shared_ptr<PagesIndexGpu>> &parts) {
+        const HashBuilderConfig &cfg = config;
+        std::shared_ptr<PagesIndexGpu> index = parts[0];
+        if (parts.size() > 1) {   // concatenation in partition order
+            index = std::make_shared<PagesIndexGpu>(c, cfg.types);
+            for (auto &part : parts) {
+                if (!part || part->position_count() == 0) continue;
+                DevicePage pg;
+                pg.n = part->position_count();
+                for (size_t i = 0; i < cfg.types.size(); i++) pg.cols.push_back(part->column((int)i));
+                index->add_page(pg);
+                part.reset();   // the partition's own copy goes back to the allocator as soon as it is merged
+            }
+        }
+        auto source = std::make_shared<LookupSourceGpu>(c, index, cfg.hash_channels, cfg.precomputed_hash_channel, cfg.output_channels);
+        source->build();
+        return source;
+    });
 }
 
 std::unique_ptr<Operator> HashBuilderOperatorFactory::create_operator()
 {
     TG_CHECK_STATE(!closed_, "Factory is already closed");
-    TG_CHECK_STATE(!created_, "one build operator per lookup source partition (one partition per GPU)");
-    created_ = true;
-    return std::make_unique<HashBuilderOperator>(ctx_, operator_id_, cfg_, bridge_);
+    TG_CHECK_STATE(created_ < cfg_.partition_count, "one build operator per lookup source partition");
+    return std::make_unique<HashBuilderOperator>(ctx_, operator_id_, cfg_, bridge_, created_++);
 }
 
 // ---- join filter function: the candidate pairs of a probe page, filtered --------------------------------------------------------

@@ -3,6 +3,8 @@
 #pragma once
 
 #include "agg.h"
+#include <functional>
+
 #include "common.h"
 #include "groupby.h"
 #include "jit.h"
@@ -116,6 +118,32 @@ public:
         std::lock_guard<std::mutex> lk(mu_);
         source_ = std::move(s);
     }
+    // PartitionedLookupSourceFactory.lendPartitionLookupSource (M/operator/PartitionedLookupSourceFactory.java:110-124, 146-205): the build
+    // side may run as P HashBuilderOperators (one per local-exchange partition); the probes stay blocked until every partition has been
+    // lent.  On the GPU the P partitions exist to feed the build, not to be probed separately: the last lender concatenates them in
+    // partition order into ONE index and builds ONE table (`make_source`) -- the chip builds and probes a single table faster than P
+    // small ones.  Observable behaviour equals PartitionedLookupSource's (PartitionedLookupSource.java:87-153): all rows of a key sit in
+    // one partition, so a key's chain (newest -> oldest) is that partition's; the outer iterator walks partition 0's positions, then
+    // partition 1's ... (:233-262) = ascending positions of the concatenation.  Returns true for the call that completed the set.
+    void set_partitioning(int partitions, std::function<std::shared_ptr<LookupSourceGpu>(std::vector<std::shared_ptr<PagesIndexGpu>> &)> make_source)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        partitions_.assign((size_t)partitions, nullptr);
+        lent_.assign((size_t)partitions, false);
+        make_source_ = std::move(make_source);
+    }
+    bool lend_partition(int partition, std::shared_ptr<PagesIndexGpu> index)
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        TG_CHECK_STATE(partition >= 0 && partition < (int)partitions_.size() && !lent_[(size_t)partition], "partition already lent");
+        partitions_[(size_t)partition] = std::move(index);
+        lent_[(size_t)partition] = true;
+        for (bool b : lent_)
+            if (!b) return false;
+        source_ = make_source_(partitions_);
+        partitions_.clear();
+        return true;
+    }
     void probe_created()
     {
         std::lock_guard<std::mutex> lk(mu_);
@@ -178,6 +206,9 @@ public:
 
 private:
     mutable std::mutex mu_;
+    std::vector<std::shared_ptr<PagesIndexGpu>> partitions_;
+    std::vector<bool> lent_;
+    std::function<std::shared_ptr<LookupSourceGpu>(std::vector<std::shared_ptr<PagesIndexGpu>> &)> make_source_;
     std::shared_ptr<const JoinFilter> filter_;
     std::shared_ptr<LookupSourceGpu> source_;
     int live_probes_ = 0, probe_factories_ = 0;
@@ -188,6 +219,7 @@ struct HashBuilderConfig {
     std::vector<int32_t> types, output_channels, hash_channels;
     int32_t precomputed_hash_channel = -1;
     int32_t expected_positions = 0;
+    int32_t partition_count = 1;   // HashBuilderOperators the factory hands out (LocalExecutionPlanner.java:2129 partitionCount = build driver instances)
 };
 
 class HashBuilderOperatorFactory : public OperatorFactory {
@@ -200,7 +232,7 @@ private:
     int32_t operator_id_;
     HashBuilderConfig cfg_;
     std::shared_ptr<LookupSourceFactory> bridge_;
-    bool created_ = false;
+    int created_ = 0;
 };
 
 struct LookupJoinConfig {

@@ -285,13 +285,15 @@ class LookupSourceFactory:
 class HashBuilderOperatorFactory(OperatorFactory):
     """M/operator/HashBuilderOperator.java:54-152.  `lookup_source_factory` is the bridge to hand to the probe factory."""
 
-    def __init__(self, ctx: Context, operator_id, types, output_channels, hash_channels, precomputed_hash_channel=-1, expected_positions=100):
+    def __init__(self, ctx: Context, operator_id, types, output_channels, hash_channels, precomputed_hash_channel=-1, expected_positions=100, partition_count=1):
+        """partition_count > 1: createOperator() hands out that many build operators, one per local-exchange partition
+        (PartitionedLookupSourceFactory.java:110-124)"""
         t, nt = _i32(types)
         oc, no = _i32(output_channels)
         hc, nh = _i32(hash_channels)
         bridge, h = C.c_void_p(), C.c_void_p()
-        _lib.check(_lib.lib().tgpu_hash_builder_factory_create(ctx.handle, operator_id, nt, t, no, oc, nh, hc, precomputed_hash_channel,
-                                                               expected_positions, C.byref(bridge), C.byref(h)))
+        _lib.check(_lib.lib().tgpu_partitioned_hash_builder_factory_create(ctx.handle, operator_id, nt, t, no, oc, nh, hc, precomputed_hash_channel,
+                                                                           expected_positions, partition_count, C.byref(bridge), C.byref(h)))
         super().__init__(h)
         self.lookup_source_factory = LookupSourceFactory(bridge)
 

@@ -1901,3 +1901,75 @@ def test_would_block_duplicate_and_revoke_protocol(pkg, ctx, oracle):
         fp.createOperator()
     out = pkg.to_pages(fp2.createOperator(), [pkg.Page(pkg.Block(B, np.arange(10, dtype=np.int64)))])
     assert out[0].getBlock(0).to_list() == [12, 14, 16, 18]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# J12: the build side as P HashBuilderOperators behind a local exchange (PartitionedLookupSourceFactory.java:110-124,
+# PartitionedLookupSource.java:87-153,212-262)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("join_type", ["INNER", "FULL_OUTER"])
+def test_partitioned_lookup_source_factory(pkg, ctx, oracle, join_type):
+    rng = np.random.default_rng(55)
+    P = 4
+    B, V = pkg.BIGINT, pkg.VARCHAR
+    nb, npr = 6000, 20_000
+    build_pages = []
+    for k in range(3):                                  # several build pages, duplicate keys, nulls
+        build_pages.append(pkg.Page(rand_block(pkg, rng, B, nb // 3, 0.03, (0, 900)), rand_block(pkg, rng, V, nb // 3, 0.1, (0, 50))))
+    probe = pkg.Page(rand_block(pkg, rng, B, npr, 0.03, (0, 1100)))
+    bf = pkg.HashBuilderOperatorFactory(ctx, 0, [B, V], [0, 1], [0], partition_count=P)
+    jt = getattr(pkg, join_type)
+    jf = pkg.LookupJoinOperatorFactory(ctx, 1, bf.lookup_source_factory, [B], [0], join_type=jt)
+    builders = [bf.createOperator() for _ in range(P)]
+    with pytest.raises(pkg.TgpuError):
+        bf.createOperator()                             # one build operator per partition
+    probe_op = jf.createOperator()
+    # the local exchange in front of the build: LocalPartitionGenerator on the key's raw hash (TGPU_PARTITION_LOCAL)
+    ex = pkg.PartitionedOutputOperatorFactory(ctx, 2, [B, V], [0], P, local=True).createOperator()
+    parts = [[] for _ in range(P)]
+    for pg in build_pages:
+        ex.addInput(pg)
+        while True:
+            polled = ex.poll()
+            if polled is None:
+                break
+            part, out = polled
+            parts[part].append(out.to_host())
+            builders[part].addInput(out)
+            out.release()
+    for k, b in enumerate(builders):
+        assert probe_op.isBlocked()                     # until EVERY partition has been lent (PartitionedLookupSourceFactory.java:146-205)
+        b.finish()
+    assert not probe_op.isBlocked()
+    # what the reference's PartitionedLookupSource yields = one PagesHash per partition; all rows of a key sit in one partition, so the pairs
+    # equal those of a single table over the partition-major concatenation of the build rows
+    cat_keys = [v for part in parts for pg in part for v in pg.getBlock(0).to_list()]
+    cat_vals = [v for part in parts for pg in part for v in pg.getBlock(1).to_list()]
+    kblock = pkg.Block(B, cat_keys)
+    for part_no, part in enumerate(parts):              # the exchange routed every non-null key by the oracle's local partition function
+        for pg in part:
+            blk = pg.getBlock(0)
+            nn = [i for i in range(blk.position_count) if not blk.isNull(i)]
+            if nn:
+                sub = pkg.Block(B, [blk.get(i) for i in nn])
+                assert set(oracle.partition_local(oracle.hash_rows([ocol(oracle, sub)]), P).tolist()) == {part_no}
+    ph = oracle.PagesHash([ocol(oracle, kblock)])
+    outer = join_type == "FULL_OUTER"
+    op, ob = ph.probe([ocol(oracle, probe.getBlock(0))], probe_outer=outer)
+    pk = probe.getBlock(0).to_list()
+    want = [(pk[p],) + ((None, None) if q < 0 else (cat_keys[q], cat_vals[q])) for p, q in zip(op, ob)]
+    got = [r for pg in pkg.to_pages(probe_op, [probe]) for r in pg.rows()]
+    assert got == want
+    if outer:
+        jf.noMoreOperators()
+        oo = pkg.LookupOuterOperatorFactory(ctx, 3, bf.lookup_source_factory, [B]).createOperator()
+        o = oo.getOutput()
+        visited = set(int(q) for q in ob if q >= 0)
+        assert o.to_host().rows() == [(None, cat_keys[q], cat_vals[q]) for q in range(len(cat_keys)) if q not in visited]   # partition by partition (:233-262)
+    L = pkg._lib.lib()
+    import ctypes as C
+    for partition, pos in [(0, 0), (3, 12345), (1, 2**30)]:
+        enc = L.tgpu_partitioned_join_position_encode(partition, pos, P)
+        assert enc == (pos << 3) | partition            # shiftSize = numberOfTrailingZeros(4) + 1 = 3 (PartitionedLookupSource.java:101-102,222-226)
+        a, b_ = C.c_int32(), C.c_int32()
+        assert L.tgpu_partitioned_join_position_decode(enc, P, C.byref(a), C.byref(b_)) == 0 and (a.value, b_.value) == (partition, pos)
