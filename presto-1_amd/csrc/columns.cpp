@@ -105,6 +105,7 @@ static DeviceColumn ingest_block_raw(Context *ctx, const tgpu_block *b)
             }
             else ids = b->ids;   // device-resident ids are trusted (the producer was a kernel of this library)
         }
+        ctx->flush_ingest();     // the dictionary and the ids must be in place before the gather reads them
         return k::gather_column(ctx, dict, ids, n, false);
     }
     if (b->memory == TGPU_DEVICE) {

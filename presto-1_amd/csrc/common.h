@@ -116,6 +116,7 @@ public:
     // asynchronous DMA; pageable arrays are staged by the runtime.  Returns false (plain path) for pages larger than the slabs may grow.
     bool begin_ingest(size_t total_bytes);
     void end_ingest();
+    void flush_ingest();   // inside a scope: what has been uploaded so far is in place for kernels enqueued from now on (dictionary flattening)
     void *pinned_alloc(size_t bytes);    // hipHostMalloc for the embedding host (tgpu_pinned_alloc): e.g. the exchange client's receive buffers
     void pinned_free(void *p);
     void download(void *dst, const void *src, size_t bytes);        // D2H + sync

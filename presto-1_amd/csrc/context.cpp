@@ -211,19 +211,29 @@ bool Context::begin_ingest(size_t total_bytes)
     return true;
 }
 
+void Context::flush_ingest()
+{
+    if (active_slab_ < 0 || ingest_owner_ != std::this_thread::get_id() || pending_copies_.empty()) return;
+    HIP_CHECK(hipEventRecord(copy_done_, copy_stream_));
+    HIP_CHECK(hipEventSynchronize(copy_done_));
+    for (const PendingCopy &c : pending_copies_) HIP_CHECK(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, stream_));
+    pending_copies_.clear();
+}
+
 void Context::end_ingest()
 {
     if (active_slab_ < 0) return;
     Slab &sl = slabs_[active_slab_];
-    active_slab_ = -1;
     try {
         HIP_CHECK(hipEventRecord(copy_done_, copy_stream_));
         HIP_CHECK(hipEventSynchronize(copy_done_));                   // the caller's arrays have been consumed (pinned sources are real async DMA)
         for (const PendingCopy &c : pending_copies_) HIP_CHECK(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToDevice, stream_));
         HIP_CHECK(hipEventRecord(sl.drained, stream_));
         pending_copies_.clear();
+        active_slab_ = -1;
     }
     catch (...) {
+        active_slab_ = -1;
         io_mu_.unlock();
         throw;
     }
