@@ -115,6 +115,12 @@ int32_t tgpu_set_resource_dir(const char *dir);
  *   JAVA:            always in row order, one group's rows after another -- the loop of DoubleSumAggregation.java:34-38 /
  *                    AccumulatorCompiler.java:487-566, bit-identical to the Java operator for any input, at the price of a
  *                    sequential chain per group (meant for page-sized inputs and strict-parity runs). */
+/* Output page size.  The reference's operators cut their output at PageBuilder.isFull (1 MB, S/block/PageBuilderStatus.java:49-60;
+ * LookupJoinPageBuilder.java:51-56, OrderByOperator.java:270-296); the GPU operators produce one page per call, which is what downstream
+ * GPU operators want.  In front of Java operators set limits: tgpu_operator_get_output then hands a larger page out as consecutive
+ * zero-copy regions of at most max_rows rows and about max_bytes bytes (Java block accounting); 0 = no limit (the default). */
+int32_t tgpu_context_set_max_output_page(tgpu_context *ctx, int64_t max_bytes, int64_t max_rows);
+
 typedef enum tgpu_double_sum_order { TGPU_SUM_ORDER_EXACT = 0, TGPU_SUM_ORDER_JAVA = 1 } tgpu_double_sum_order;
 int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order);
 

@@ -159,6 +159,14 @@ int32_t tgpu_set_resource_dir(const char *dir)
     });
 }
 
+int32_t tgpu_context_set_max_output_page(tgpu_context *ctx, int64_t max_bytes, int64_t max_rows)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx != nullptr && max_bytes >= 0 && max_rows >= 0, "bad argument");
+        ctx->ctx->set_max_output_page(max_bytes, max_rows);
+    });
+}
+
 int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order)
 {
     return guard_on(ctx_of(ctx), [&] {
@@ -534,8 +542,9 @@ void tgpu_operator_factory_destroy(tgpu_operator_factory *factory)
     });                                                          \
     return rc == TGPU_OK ? result : rc;
 
-int32_t tgpu_operator_needs_input(tgpu_operator *op) { OP_BOOL(op->op->needs_input()) }
-int32_t tgpu_operator_is_finished(tgpu_operator *op) { OP_BOOL(op->op->is_finished()) }
+// (regions of a cut output page still waiting to be handed out count as pending output)
+int32_t tgpu_operator_needs_input(tgpu_operator *op) { OP_BOOL(op->cut_pages.empty() && op->op->needs_input()) }
+int32_t tgpu_operator_is_finished(tgpu_operator *op) { OP_BOOL(op->cut_pages.empty() && op->op->is_finished()) }
 int32_t tgpu_operator_is_blocked(tgpu_operator *op) { OP_BOOL(op->op->is_blocked()) }
 
 int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page)
@@ -548,13 +557,53 @@ int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page)
     });
 }
 
+// PageBuilder.isFull (S/PageBuilder.java:126-129, PageBuilderStatus.java:49-60: DEFAULT_MAX_PAGE_SIZE_IN_BYTES = 1 MB) is what cuts the output
+// of the reference's operators into pages (LookupJoinPageBuilder.java:51-56, HashAggregationOperator's buildResult, OrderByOperator.java:270-296).
+// The GPU operators produce one page per call; with tgpu_context_set_max_output_page they hand it out as consecutive regions of at most
+// `rows` rows and about `bytes` bytes (the page's Java-accounted size spread evenly over its rows) -- zero-copy views of the same buffers.
+static void cut_output_page(tgpu_operator *op, std::unique_ptr<OutputPage> &p)
+{
+    Context *c = op->ctx;
+    const int64_t max_bytes = c->max_output_page_bytes(), max_rows = c->max_output_page_rows();
+    const int64_t n = p->page.n;
+    if ((max_bytes <= 0 && max_rows <= 0) || n <= 1) return;
+    int64_t per = n;
+    if (max_rows > 0) per = std::min(per, max_rows);
+    if (max_bytes > 0) {
+        int64_t size = 0;   // Page.getSizeInBytes of flat blocks: (width + 1) per fixed-width cell, length + 5 per VARCHAR cell
+        for (auto &col : p->page.cols) size += col.type == TGPU_VARCHAR ? col.pool_bytes + 5 * n : (int64_t)(type_width(col.type) + 1) * n;
+        if (size > max_bytes) per = std::min<int64_t>(per, std::max<int64_t>(1, (int64_t)((double)n * (double)max_bytes / (double)size)));
+    }
+    if (per >= n) return;
+    std::unique_ptr<OutputPage> whole = std::move(p);
+    for (int64_t at = 0; at < n; at += per) {
+        const int64_t len = std::min(per, n - at);
+        DevicePage part;
+        part.n = len;
+        for (auto &col : whole->page.cols) part.cols.push_back(k::region_of(c, col, at, len));
+        auto o = std::make_unique<OutputPage>();
+        o->ctx = c;
+        o->page = std::move(part);
+        if (at == 0) p = std::move(o);
+        else op->cut_pages.push_back(std::move(o));
+    }
+}
+
 int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
 {
     bool would_block = false;
     int32_t rc = guard_on(ctx_of(op), [&] {
         TG_CHECK_ARG(op != nullptr && op->op && out, "null argument");
         *out = nullptr;
-        std::unique_ptr<OutputPage> p = op->op->get_output();
+        std::unique_ptr<OutputPage> p;
+        if (!op->cut_pages.empty()) {
+            p = std::move(op->cut_pages.front());
+            op->cut_pages.pop_front();
+        }
+        else {
+            p = op->op->get_output();
+            if (p) cut_output_page(op, p);
+        }
         if (p) *out = release_output(std::move(p));
         else would_block = op->op->is_blocked();   // no page AND an unfinished isBlocked() future (Operator.java:32-35): come back later
     });

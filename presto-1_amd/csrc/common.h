@@ -141,6 +141,10 @@ public:
 
     int cu_count() const { return cu_count_; }
     // tgpu_context_set_double_sum_order: read by the aggregation operators when they create their accumulators
+    // tgpu_context_set_max_output_page: 0 = no limit
+    int64_t max_output_page_bytes() const { return max_out_bytes_; }
+    int64_t max_output_page_rows() const { return max_out_rows_; }
+    void set_max_output_page(int64_t bytes, int64_t rows) { max_out_bytes_ = bytes; max_out_rows_ = rows; }
     int double_sum_order() const { return double_sum_order_; }
     void set_double_sum_order(int order) { double_sum_order_ = order; }
 
@@ -162,6 +166,7 @@ private:
     bool own_stream_ = false;
     int cu_count_ = 256;
     int double_sum_order_ = 0;
+    int64_t max_out_bytes_ = 0, max_out_rows_ = 0;
     std::multimap<size_t, void *> free_;
     size_t in_use_ = 0, cached_ = 0;
     void *pinned_ = nullptr;

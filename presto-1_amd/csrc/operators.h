@@ -3,6 +3,7 @@
 #pragma once
 
 #include "agg.h"
+#include <deque>
 #include <functional>
 
 #include "common.h"
@@ -403,6 +404,8 @@ struct tgpu_operator_factory {
 struct tgpu_operator {
     std::unique_ptr<tgpu::Operator> op;
     tgpu::Context *ctx = nullptr;
+    // tgpu_context_set_max_output_page: an output page larger than the limits is handed out as consecutive regions (shared buffers)
+    std::deque<std::unique_ptr<tgpu::OutputPage>> cut_pages;
 };
 struct tgpu_lookup_source_factory {
     std::shared_ptr<tgpu::LookupSourceFactory> bridge;

@@ -59,6 +59,10 @@ class Context:
         holder = _Pinned()
         return np.asarray(holder), holder
 
+    def set_max_output_page(self, max_bytes=0, max_rows=0):
+        """operators hand pages larger than this out as consecutive regions (PageBuilder.isFull granularity for Java consumers); 0 = no limit"""
+        _lib.check(_lib.lib().tgpu_context_set_max_output_page(self.handle, int(max_bytes), int(max_rows)))
+
     def set_double_sum_order(self, order):
         """SUM_ORDER_EXACT (default) or SUM_ORDER_JAVA for the aggregation operators created from now on (tgpu.h)"""
         _lib.check(_lib.lib().tgpu_context_set_double_sum_order(self.handle, order))

@@ -1973,3 +1973,41 @@ def test_partitioned_lookup_source_factory(pkg, ctx, oracle, join_type):
         assert enc == (pos << 3) | partition            # shiftSize = numberOfTrailingZeros(4) + 1 = 3 (PartitionedLookupSource.java:101-102,222-226)
         a, b_ = C.c_int32(), C.c_int32()
         assert L.tgpu_partitioned_join_position_decode(enc, P, C.byref(a), C.byref(b_)) == 0 and (a.value, b_.value) == (partition, pos)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# D5: output pages cut at the reference's page-full granularity (S/PageBuilder.java:126-129, PageBuilderStatus.java:49-60)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_output_page_cuts_multi_slice_aggregation_golden(pkg):
+    """T/operator/TestHashAggregationOperator.java:478-511 testMultiSliceAggregationOutput: 1.5 pages worth of groups come out as 2 pages"""
+    case = GOLD["hash_aggregation"]["testMultiSliceAggregationOutput"]
+    c = pkg.Context(0)
+    c.set_max_output_page(max_bytes=case["max_page_size_bytes"])
+    n = case["rows"]
+    B = pkg.BIGINT
+    page = pkg.Page(*blocks_of(pkg, [B, B], sequence_page([B, B], n, 0, 0)))
+    fac = pkg.HashAggregationOperatorFactory(c, 0, [B], [1], [(pkg.COUNT_COLUMN, 0), (pkg.AVG_BIGINT, 1)], expected_groups=100_000)
+    op = fac.createOperator()
+    op.addInput(page)
+    op.finish()
+    pages = []
+    while not op.isFinished():
+        assert not op.needsInput()
+        o = op.getOutput()
+        if o is not None:
+            pages.append(o.to_host())
+            o.release()
+    assert len(pages) == case["expect_output_pages"]
+    rows = [r for pg in pages for r in pg.rows()]
+    assert rows == [(i, 1, float(i)) for i in range(n)]
+    # row limit: a join's output in pages of at most 8192 rows, order kept across the cuts
+    c.set_max_output_page(max_rows=8192)
+    bf = pkg.HashBuilderOperatorFactory(c, 1, [B], [0], [0])
+    b = bf.createOperator()
+    b.addInput(pkg.Page(pkg.Block(B, np.arange(30_000, dtype=np.int64))))
+    b.finish()
+    jf = pkg.LookupJoinOperatorFactory(c, 2, bf.lookup_source_factory, [B], [0])
+    outs = pkg.to_pages(jf.createOperator(), [pkg.Page(pkg.Block(B, np.arange(0, 60_000, 2, dtype=np.int64)))])
+    assert [o.position_count for o in outs] == [8192, 6808] and [r[0] for o in outs for r in o.rows()] == list(range(0, 30_000, 2))
+    op.close(); b.close(); fac.close(); bf.close(); jf.close()
+    c.close()
