@@ -70,7 +70,10 @@ typedef enum tgpu_type {
     TGPU_VARCHAR = 6   /* VariableWidthBlock: byte pool + int32 offsets[n+1] */
 } tgpu_type;
 
-typedef enum tgpu_encoding { TGPU_FLAT = 0, TGPU_DICTIONARY = 1, TGPU_RLE = 2 } tgpu_encoding;
+typedef enum tgpu_encoding {
+    TGPU_FLAT = 0, TGPU_DICTIONARY = 1, TGPU_RLE = 2,
+    TGPU_LAZY = 3   /* S/block/LazyBlock.java: not loaded yet; only in pages a tgpu_page_source hands out (loaded through its load_block) */
+} tgpu_encoding;
 typedef enum tgpu_memory { TGPU_HOST = 0, TGPU_DEVICE = 1 } tgpu_memory;
 
 /* One Block.  All pointers of one block live in the same memory space (`memory`). */
@@ -306,6 +309,31 @@ int32_t tgpu_order_by_factory_create(tgpu_context *ctx, int32_t operator_id, int
                                      int32_t output_channel_count, const int32_t *output_channels, int32_t expected_positions,
                                      int32_t sort_channel_count, const int32_t *sort_channels, const int32_t *sort_orders,
                                      tgpu_operator_factory **out);
+
+/* ---- ScanFilterAndProjectOperator (M/operator/ScanFilterAndProjectOperator.java:66-447): a SOURCE operator that pulls pages from the split's
+ * ConnectorPageSource (S/connector/ConnectorPageSource.java; here callbacks) and runs the page processor over them ---- */
+typedef struct tgpu_page_source {
+    void *user;
+    /* ConnectorPageSource.getNextPage: 1 = *page filled (its arrays stay valid until the next call on this source), 0 = no page right now, < 0 error.
+     * Channels may be TGPU_LAZY blocks (only type and position_count set). */
+    int32_t (*get_next_page)(void *user, tgpu_page *page);
+    int32_t (*is_finished)(void *user);                                        /* ConnectorPageSource.isFinished */
+    int32_t (*is_blocked)(void *user);                                         /* isBlocked() future not done; NULL = never blocked */
+    /* LazyBlock.getLoadedBlock for channel `channel` of the page get_next_page returned last: fills *block with a FLAT / DICTIONARY / RLE block.
+     * Called at most once per channel and page, only for channels the filter reads and -- when the filter selected at least one row -- the
+     * channels the projections read (PageProcessor.java:111-137; T/operator/project/TestPageProcessor.java:156-184,219-253). */
+    int32_t (*load_block)(void *user, int32_t channel, tgpu_block *block);
+    void (*close)(void *user);                                                 /* ConnectorPageSource.close; NULL = nothing to do */
+} tgpu_page_source;
+/* ScanFilterAndProjectOperatorFactory (:449-560) over the page-source flavour (processPageSource :275-287); `types` = the channels the
+ * page source produces.  The operator takes no input: tgpu_operator_add_input fails. */
+int32_t tgpu_scan_filter_project_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types,
+                                                const tgpu_page_processor_spec *spec, tgpu_operator_factory **out);
+/* SourceOperator.addSplit (:232-263: the split's page source; one at a time, the next one after the current is finished) / noMoreSplits */
+int32_t tgpu_scan_operator_add_page_source(tgpu_operator *op, const tgpu_page_source *source);
+int32_t tgpu_scan_operator_no_more_splits(tgpu_operator *op);
+/* OperatorStats the scan side feeds (:354-397): positions pulled from the page sources, lazy blocks loaded / skipped */
+int32_t tgpu_scan_operator_stats(tgpu_operator *op, int64_t *processed_positions, int64_t *lazy_blocks_loaded, int64_t *lazy_blocks_skipped);
 
 /* OperatorFactory.createOperator / noMoreOperators (M/operator/OperatorFactory.java:18-50) */
 int32_t tgpu_operator_factory_create_operator(tgpu_operator_factory *factory, tgpu_operator **out);

@@ -60,6 +60,17 @@ class ExchangeTransport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_to_all_meta", TRANSPORT_META_FN), ("all_to_all_v", TRANSPORT_V_FN)]
 
 
+SOURCE_NEXT_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(Page))
+SOURCE_FLAG_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+SOURCE_LOAD_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(Block))
+SOURCE_CLOSE_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class PageSource(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("get_next_page", SOURCE_NEXT_FN), ("is_finished", SOURCE_FLAG_FN), ("is_blocked", SOURCE_FLAG_FN), ("load_block", SOURCE_LOAD_FN),
+                ("close", SOURCE_CLOSE_FN)]
+
+
 class AggSpec(C.Structure):
     _fields_ = [("function", C.c_int32), ("input_channel", C.c_int32), ("mask_channel", C.c_int32)]
 
@@ -97,6 +108,10 @@ SYMBOLS = {
     "tgpu_order_by_factory_create": (i32, [vp, i32, i32, P(i32), i32, P(i32), i32, i32, P(i32), P(i32), P(vp)]),
     "tgpu_filter_project_lookup_join_factory_create": (i32, [vp, i32, vp, i32, P(i32), P(PageProcessorSpec), i32, P(i32), i32, i32, P(i32), i32, P(vp)]),
     "tgpu_filter_project_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, P(vp)]),
+    "tgpu_scan_filter_project_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), P(vp)]),
+    "tgpu_scan_operator_add_page_source": (i32, [vp, P(PageSource)]),
+    "tgpu_scan_operator_no_more_splits": (i32, [vp]),
+    "tgpu_scan_operator_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     "tgpu_operator_factory_create_operator": (i32, [vp, P(vp)]),
     "tgpu_operator_factory_no_more_operators": (i32, [vp]),
     "tgpu_operator_factory_duplicate": (i32, [vp, P(vp)]),

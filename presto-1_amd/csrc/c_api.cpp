@@ -234,6 +234,43 @@ int32_t tgpu_filter_project_factory_create(tgpu_context *ctx, int32_t operator_i
     });
 }
 
+int32_t tgpu_scan_filter_project_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, const tgpu_page_processor_spec *spec,
+                                                tgpu_operator_factory **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && spec, "null argument");
+        auto f = std::make_unique<tgpu_operator_factory>();
+        f->f = std::make_unique<ScanFilterAndProjectOperatorFactory>(ctx->ctx.get(), operator_id, vec(types, type_count), spec);
+        f->ctx = ctx->ctx.get();
+        retain(f->ctx);
+        *out = f.release();
+    });
+}
+
+int32_t tgpu_scan_operator_add_page_source(tgpu_operator *op, const tgpu_page_source *source)
+{
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op && source, "null argument");
+        scan_add_page_source(op->op.get(), source);
+    });
+}
+
+int32_t tgpu_scan_operator_no_more_splits(tgpu_operator *op)
+{
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        scan_no_more_splits(op->op.get());
+    });
+}
+
+int32_t tgpu_scan_operator_stats(tgpu_operator *op, int64_t *processed_positions, int64_t *lazy_blocks_loaded, int64_t *lazy_blocks_skipped)
+{
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op && processed_positions && lazy_blocks_loaded && lazy_blocks_skipped, "null argument");
+        scan_stats(op->op.get(), processed_positions, lazy_blocks_loaded, lazy_blocks_skipped);
+    });
+}
+
 // compile-only entry (no GPU needed): lets build() pre-warm the on-disk kernel cache
 int32_t tgpu_precompile_page_processor(int32_t input_type_count, const int32_t *input_types, const tgpu_page_processor_spec *spec)
 {

@@ -22,7 +22,8 @@ void check_block(const tgpu_block *b)
     TG_CHECK_ARG(b != nullptr, "block is null");
     TG_CHECK_ARG(valid_type(b->type), "unknown block type");
     TG_CHECK_ARG(b->position_count >= 0, "negative position count");
-    TG_CHECK_ARG(b->encoding >= TGPU_FLAT && b->encoding <= TGPU_RLE, "unknown block encoding");
+    TG_CHECK_ARG(b->encoding >= TGPU_FLAT && b->encoding <= TGPU_LAZY, "unknown block encoding");
+    if (b->encoding == TGPU_LAZY) fail(TGPU_ERR_NOT_SUPPORTED, "a lazy block outside a page source: load it first (Page.getLoadedPage)");
 }
 
 DeviceColumn upload_flat(Context *ctx, int32_t type, int64_t n, const void *values, int64_t value_bytes, const uint8_t *nulls, const int32_t *offsets)

@@ -696,9 +696,24 @@ PageProcessorGpu::PageProcessorGpu(std::vector<int32_t> input_types, const tgpu_
             for (int k = 0; k < nd.n_args && k < 3; k++) walk(nd.args[k]);
     };
     if (filter_root_ >= 0) walk(filter_root_);
+    filter_channels_.assign(read.begin(), read.end());
     for (size_t i = 0; i < projs_.size(); i++)
         if (projs_[i].kind == ProjKind::COMPUTED) walk(proj_roots_[i]);
     single_input_ = read.size() == 1 ? *read.begin() : -1;
+    std::set<int> pread;
+    std::swap(read, pread);
+    for (size_t i = 0; i < projs_.size(); i++) walk(proj_roots_[i]);
+    projection_channels_.assign(read.begin(), read.end());
+}
+
+std::shared_ptr<PageProcessorGpu> PageProcessorGpu::filter_only()
+{
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!filter_only_) {
+        tgpu_page_processor_spec spec{nodes_.data(), (int32_t)nodes_.size(), pool_.data(), (int32_t)pool_.size(), filter_root_, 0, nullptr};
+        filter_only_ = PageProcessorGpu::shared(input_types_, &spec);
+    }
+    return filter_only_;
 }
 
 PageProcessorGpu::~PageProcessorGpu() {}

@@ -45,6 +45,11 @@ public:
     // PageFunctionCompiler.java:176-212): the input channel every computed expression (filter and non-identity projections) reads
     // when they all read the same single one, else -1.
     int single_input_channel() const { return single_input_; }
+    // input channels the filter reads / the projections (computed or identity) read: what a lazy page has to load, and when
+    const std::vector<int> &filter_channels() const { return filter_channels_; }
+    const std::vector<int> &projection_channels() const { return projection_channels_; }
+    // the same filter without projections (lazy pages: decides whether the projection-only channels are loaded at all)
+    std::shared_ptr<PageProcessorGpu> filter_only();
     // The processor evaluated once per DICTIONARY ENTRY: `dictionary` stands for channel single_input_channel(); returns one row per
     // entry: [the filter's verdict as BOOLEAN (only when there is a filter), every computed projection in slot order].
     // Throws like process() when an entry raises (the caller then falls back to the flat path: only selected rows may raise).
@@ -80,6 +85,8 @@ private:
     std::shared_ptr<JitModule> module_;
     hipFunction_t fn_count_ = nullptr, fn_emit_ = nullptr;
     int single_input_ = -1;
+    std::vector<int> filter_channels_, projection_channels_;
+    std::shared_ptr<PageProcessorGpu> filter_only_;
     std::shared_ptr<PageProcessorGpu> dict_processor_;   // lazily: the same expressions over the one-channel dictionary page
 };
 

@@ -2,6 +2,7 @@
 // the reference's Java operators; the work inside addInput / getOutput runs in the gfx950 kernels).
 #include "operators.h"
 
+#include <algorithm>
 #include <array>
 #include <deque>
 #include <set>
@@ -177,6 +178,183 @@ std::unique_ptr<OperatorFactory> FilterAndProjectOperatorFactory::duplicate()
 {
     return std::unique_ptr<OperatorFactory>(new FilterAndProjectOperatorFactory(*this));   // shares the compiled page processor
 }
+
+// =====================================================================================================================
+// ScanFilterAndProjectOperator, page-source flavour (M/operator/ScanFilterAndProjectOperator.java:232-287,354-397): a source operator.
+// addSplit hands it the split's ConnectorPageSource; getOutput pulls the next page (ConnectorPageSourceToPages.process :368-397:
+// finished / blocked / null page = yield) and runs the page processor over it.  LazyBlocks are loaded on demand, in the order the
+// reference's PageProcessor touches them (PageProcessor.java:111-137): the channels the filter reads first; the channels only the
+// projections read when -- and only when -- the filter selected a row (T/operator/project/TestPageProcessor.java:156-184,219-253).
+// =====================================================================================================================
+class ScanFilterAndProjectOperator : public Operator {
+public:
+    ScanFilterAndProjectOperator(Context *ctx, int32_t id, std::vector<int32_t> types, std::shared_ptr<PageProcessorGpu> p)
+        : Operator(ctx, id), types_(std::move(types)), processor_(std::move(p))
+    {
+    }
+    ~ScanFilterAndProjectOperator() override { close(); }
+
+    bool needs_input() override { return false; }                                                                    // :188-191
+    void add_input(const tgpu_page *) override { fail(TGPU_ERR_NOT_SUPPORTED, "ScanFilterAndProjectOperator is a source operator"); }
+
+    void add_page_source(const tgpu_page_source *src)
+    {
+        TG_CHECK_ARG(src && src->get_next_page && src->is_finished, "page source callbacks are null");
+        TG_CHECK_STATE(!no_more_splits_ && !closed_, "no more splits can be added");
+        TG_CHECK_STATE(!have_source_, "Table scan split already set");                                               // :235
+        source_ = *src;
+        have_source_ = true;
+    }
+    void no_more_splits() { no_more_splits_ = true; }
+
+    // waiting for a split, or for the page source (:214-230)
+    bool is_blocked() override
+    {
+        if (closed_ || finishing_) return false;
+        if (!have_source_) return !no_more_splits_;
+        return source_.is_blocked && source_.is_blocked(source_.user) == 1;
+    }
+
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (closed_ || finishing_ || !have_source_ || is_blocked()) return nullptr;
+        if (source_.is_finished(source_.user) == 1) {
+            release_source();
+            return nullptr;
+        }
+        tgpu_page page{};
+        const int32_t rc = source_.get_next_page(source_.user, &page);
+        if (rc < 0) fail(TGPU_ERR_INTERNAL, "the page source failed");
+        if (rc == 0) {                                                                                             // null page: finished or yield (:381-388)
+            if (source_.is_finished(source_.user) == 1) release_source();
+            return nullptr;
+        }
+        processed_positions_ += page.position_count;
+        DevicePage out;
+        if (!process(page, out)) return nullptr;
+        own_borrowed_columns(ctx_, out);
+        return wrap(std::move(out));
+    }
+
+    void finish() override
+    {
+        finishing_ = true;
+        release_source();
+    }
+    bool is_finished() override { return closed_ || finishing_ || (no_more_splits_ && !have_source_); }
+    void close() override
+    {
+        release_source();
+        closed_ = true;
+    }
+    void stats(int64_t *positions, int64_t *loaded, int64_t *skipped) const
+    {
+        *positions = processed_positions_;
+        *loaded = lazy_loaded_;
+        *skipped = lazy_skipped_;
+    }
+
+private:
+    void release_source()
+    {
+        if (have_source_ && source_.close) source_.close(source_.user);
+        have_source_ = false;
+    }
+
+    DeviceColumn load_channel(const tgpu_page &page, int ch)
+    {
+        const tgpu_block &b = page.blocks[ch];
+        if (b.encoding != TGPU_LAZY) return ingest_block(ctx_, &b);
+        TG_CHECK_ARG(source_.load_block != nullptr, "the page has lazy blocks but the page source has no load_block");
+        tgpu_block loaded{};
+        if (source_.load_block(source_.user, ch, &loaded) < 0) fail(TGPU_ERR_INTERNAL, "the page source failed to load a lazy block");
+        TG_CHECK_ARG(loaded.encoding != TGPU_LAZY && loaded.position_count == page.position_count && loaded.type == types_[(size_t)ch], "bad loaded block");
+        lazy_loaded_++;
+        return ingest_block(ctx_, &loaded);
+    }
+
+    bool process(const tgpu_page &page, DevicePage &out)
+    {
+        TG_CHECK_ARG(page.channel_count == (int32_t)types_.size(), "page channel count differs from the scan's types");
+        const int64_t n = page.position_count;
+        if (n == 0) return false;
+        int lazy = 0;
+        for (int32_t ch = 0; ch < page.channel_count; ch++) {
+            TG_CHECK_ARG(page.blocks[ch].position_count == page.position_count && page.blocks[ch].type == types_[(size_t)ch], "bad block in the scanned page");
+            lazy += page.blocks[ch].encoding == TGPU_LAZY ? 1 : 0;
+        }
+        DevicePage in;
+        in.n = n;
+        in.cols.resize(types_.size());
+        std::vector<bool> have(types_.size(), false);
+        for (size_t i = 0; i < types_.size(); i++) {   // placeholders: a channel no expression reads is never dereferenced
+            in.cols[i].type = types_[i];
+            in.cols[i].n = n;
+        }
+        auto need = [&](int ch) {
+            if (have[(size_t)ch]) return;
+            in.cols[(size_t)ch] = load_channel(page, ch);
+            have[(size_t)ch] = true;
+        };
+        for (int ch : processor_->filter_channels()) need(ch);
+        bool projection_only_lazy = false;
+        for (int ch : processor_->projection_channels()) projection_only_lazy = projection_only_lazy || (!have[(size_t)ch] && page.blocks[ch].encoding == TGPU_LAZY);
+        if (processor_->has_filter() && projection_only_lazy) {
+            // would any row survive?  Only then are the projections' lazy blocks loaded (the filter runs again with them in place)
+            DevicePage none;
+            if (!processor_->filter_only()->process(ctx_, in, none)) {
+                for (int ch : processor_->projection_channels())
+                    if (!have[(size_t)ch] && page.blocks[ch].encoding == TGPU_LAZY) lazy_skipped_++;
+                count_unread(page, have, lazy);
+                return false;
+            }
+        }
+        for (int ch : processor_->projection_channels()) need(ch);
+        count_unread(page, have, lazy);
+        ctx_->sync();   // the source's arrays are valid until its next call; the uploads have consumed them now
+        return processor_->process(ctx_, in, out);
+    }
+
+    void count_unread(const tgpu_page &page, const std::vector<bool> &have, int lazy)
+    {
+        if (!lazy) return;
+        const std::vector<int> &pc = processor_->projection_channels();
+        for (int32_t ch = 0; ch < page.channel_count; ch++)   // lazy channels nobody reads at all
+            if (page.blocks[ch].encoding == TGPU_LAZY && !have[(size_t)ch] && std::find(pc.begin(), pc.end(), (int)ch) == pc.end()) lazy_skipped_++;
+    }
+
+    std::vector<int32_t> types_;
+    std::shared_ptr<PageProcessorGpu> processor_;
+    tgpu_page_source source_{};
+    bool have_source_ = false, no_more_splits_ = false, finishing_ = false, closed_ = false;
+    int64_t processed_positions_ = 0, lazy_loaded_ = 0, lazy_skipped_ = 0;
+};
+
+ScanFilterAndProjectOperatorFactory::ScanFilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, const tgpu_page_processor_spec *spec)
+    : ctx_(ctx), operator_id_(operator_id), types_(std::move(types)), processor_(PageProcessorGpu::shared(types_, spec))
+{
+}
+
+std::unique_ptr<Operator> ScanFilterAndProjectOperatorFactory::create_operator()
+{
+    TG_CHECK_STATE(!closed_, "Factory is already closed");
+    return std::make_unique<ScanFilterAndProjectOperator>(ctx_, operator_id_, types_, processor_);
+}
+
+std::unique_ptr<OperatorFactory> ScanFilterAndProjectOperatorFactory::duplicate()
+{
+    return std::unique_ptr<OperatorFactory>(new ScanFilterAndProjectOperatorFactory(*this));
+}
+
+static ScanFilterAndProjectOperator *as_scan(Operator *op)
+{
+    auto *p = dynamic_cast<ScanFilterAndProjectOperator *>(op);
+    TG_CHECK_ARG(p != nullptr, "not a ScanFilterAndProjectOperator");
+    return p;
+}
+void scan_add_page_source(Operator *op, const tgpu_page_source *source) { as_scan(op)->add_page_source(source); }
+void scan_no_more_splits(Operator *op) { as_scan(op)->no_more_splits(); }
+void scan_stats(Operator *op, int64_t *processed_positions, int64_t *lazy_loaded, int64_t *lazy_skipped) { as_scan(op)->stats(processed_positions, lazy_loaded, lazy_skipped); }
 
 // =====================================================================================================================
 // HashAggregationOperator + InMemoryHashAggregationBuilder

@@ -71,6 +71,23 @@ private:
 
 int64_t filter_project_dictionary_pages(Operator *op);
 
+// ---- ScanFilterAndProjectOperator (M/operator/ScanFilterAndProjectOperator.java:66-447), page-source flavour ------------------------
+class ScanFilterAndProjectOperatorFactory : public OperatorFactory {
+public:
+    ScanFilterAndProjectOperatorFactory(Context *ctx, int32_t operator_id, std::vector<int32_t> types, const tgpu_page_processor_spec *spec);
+    std::unique_ptr<Operator> create_operator() override;
+    std::unique_ptr<OperatorFactory> duplicate() override;
+
+private:
+    Context *ctx_;
+    int32_t operator_id_;
+    std::vector<int32_t> types_;
+    std::shared_ptr<PageProcessorGpu> processor_;
+};
+void scan_add_page_source(Operator *op, const tgpu_page_source *source);
+void scan_no_more_splits(Operator *op);
+void scan_stats(Operator *op, int64_t *processed_positions, int64_t *lazy_loaded, int64_t *lazy_skipped);
+
 // ---- HashAggregationOperator (M/operator/HashAggregationOperator.java:54-262,367-518) -----------------------------
 struct HashAggregationConfig {
     std::vector<int32_t> group_by_types, group_by_channels;

@@ -220,6 +220,89 @@ class FilterAndProjectOperatorFactory(OperatorFactory):
         super().__init__(h, keep)
 
 
+class PageSource:
+    """a ConnectorPageSource (S/connector/ConnectorPageSource.java) over Python pages, as the callbacks of tgpu_page_source"""
+
+    def __init__(self, pages, blocked_polls=0):
+        self.pages = list(pages)
+        self.at = 0
+        self.blocked_polls = blocked_polls      # isBlocked() reports "not done" this many times first
+        self.current = None
+        self.closed = False
+        self._keep = None
+        self._load_keep = []
+        self.error = None
+        self.struct = _lib.PageSource(None, _lib.SOURCE_NEXT_FN(self._next), _lib.SOURCE_FLAG_FN(self._finished), _lib.SOURCE_FLAG_FN(self._blocked),
+                                      _lib.SOURCE_LOAD_FN(self._load), _lib.SOURCE_CLOSE_FN(self._close))
+
+    def _next(self, user, out):
+        try:
+            if self.at >= len(self.pages):
+                return 0
+            self.current = self.pages[self.at]
+            self.at += 1
+            self._load_keep = []
+            cp, self._keep = self.current.to_c()   # valid until the next call
+            out[0].position_count, out[0].channel_count, out[0].blocks = cp.position_count, cp.channel_count, cp.blocks
+            return 1
+        except Exception as e:   # must not unwind through the C frames
+            self.error = e
+            return -1
+
+    def _finished(self, user):
+        return 1 if self.at >= len(self.pages) else 0
+
+    def _blocked(self, user):
+        if self.blocked_polls > 0:
+            self.blocked_polls -= 1
+            return 1
+        return 0
+
+    def _load(self, user, channel, out):
+        try:
+            blk = self.current.blocks[channel].load()
+            blk._fill(out[0], self._load_keep)
+            return 0
+        except Exception as e:
+            self.error = e
+            return -1
+
+    def _close(self, user):
+        self.closed = True
+
+
+class ScanOperator(Operator):
+    def addSplit(self, page_source: PageSource):
+        """SourceOperator.addSplit: the split's page source"""
+        self._sources = getattr(self, "_sources", []) + [page_source]
+        _lib.check(_lib.lib().tgpu_scan_operator_add_page_source(self.handle, C.byref(page_source.struct)))
+
+    def noMoreSplits(self):
+        _lib.check(_lib.lib().tgpu_scan_operator_no_more_splits(self.handle))
+
+    def stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().tgpu_scan_operator_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"processedPositions": a.value, "lazyBlocksLoaded": b.value, "lazyBlocksSkipped": c.value}
+
+
+class ScanFilterAndProjectOperatorFactory(OperatorFactory):
+    """ScanFilterAndProjectOperator.ScanFilterAndProjectOperatorFactory (M/operator/ScanFilterAndProjectOperator.java:449-560), page-source flavour"""
+
+    def __init__(self, ctx: Context, operator_id, types, filter_expr, projections):
+        self.program = FlatProgram(filter_expr, projections)
+        spec, keep = self.program.to_c()
+        t, n = _i32(types)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_scan_filter_project_factory_create(ctx.handle, operator_id, n, t, C.byref(spec), C.byref(h)))
+        super().__init__(h, keep)
+
+    def createOperator(self):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().tgpu_operator_factory_create_operator(self.handle, C.byref(h)))
+        return ScanOperator(h)
+
+
 def precompile_page_processor(input_types, filter_expr, projections):
     """Compile the kernels of a page processor into the on-disk cache (no GPU needed)."""
     prog = FlatProgram(filter_expr, projections)

@@ -149,6 +149,33 @@ class RunLengthEncodedBlock:
         keep.append(self)
 
 
+class LazyBlock:
+    """io.trino.spi.block.LazyBlock (S/block/LazyBlock.java): `loader()` returns the loaded block; only meaningful in pages a page source hands to a
+    ScanFilterAndProjectOperator (tgpu_page_source.load_block)"""
+
+    encoding = 3   # TGPU_LAZY
+
+    def __init__(self, type_id, position_count, loader):
+        self.type, self.position_count, self.loader = type_id, position_count, loader
+        self.loaded = None
+
+    def getPositionCount(self):
+        return self.position_count
+
+    def isLoaded(self):
+        return self.loaded is not None
+
+    def load(self):
+        if self.loaded is None:
+            self.loaded = self.loader()
+        return self.loaded
+
+    def _fill(self, s, keep):
+        s.type, s.encoding, s.memory, s.position_count = self.type, 3, HOST, self.position_count
+        s.values = s.nulls = s.offsets = s.ids = None
+        keep.append(self)
+
+
 class DeviceBlock:
     """A flat block whose arrays already live in HBM.  `values`/`nulls`/`offsets` are objects exposing data_ptr()
     (torch tensors) or plain integer device addresses; the owner keeps them alive."""

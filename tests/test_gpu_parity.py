@@ -2011,3 +2011,89 @@ def test_output_page_cuts_multi_slice_aggregation_golden(pkg):
     assert [o.position_count for o in outs] == [8192, 6808] and [r[0] for o in outs for r in o.rows()] == list(range(0, 30_000, 2))
     op.close(); b.close(); fac.close(); bf.close(); jf.close()
     c.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# F2: ScanFilterAndProjectOperator over a page source, lazy blocks (M/operator/ScanFilterAndProjectOperator.java:232-287,354-397)
+# ---------------------------------------------------------------------------------------------------------------------
+def _drain_source_operator(op):
+    """T/operator/OperatorAssertion.toPages for a source operator: getOutput until finished (blocked polls are just retried)"""
+    pages, spins = [], 0
+    while not op.isFinished() and spins < 100_000:
+        spins += 1
+        o = op.getOutput()
+        if o is not None:
+            pages.append(o.to_host())
+            o.release()
+    assert op.isFinished()
+    return pages
+
+
+def test_scan_filter_project_page_source_golden(pkg, ctx):
+    # T/operator/TestScanFilterAndProjectOperator.java:98-130 testPageSource: one VARCHAR sequence page of 10 000 rows, projection field(0)
+    V, B = pkg.VARCHAR, pkg.BIGINT
+    f = pkg.field
+    vals = sequence_values(V, 0, 10_000)
+    fac = pkg.ScanFilterAndProjectOperatorFactory(ctx, 0, [V], None, [f(0, V)])
+    op = fac.createOperator()
+    assert not op.needsInput() and op.isBlocked()                 # waiting for its split
+    assert op.getOutput() is None and op.last_get_output_status == 1
+    src = pkg.PageSource([pkg.Page(pkg.Block(V, vals))], blocked_polls=2)
+    op.addSplit(src)
+    op.noMoreSplits()
+    pages = _drain_source_operator(op)
+    assert [r[0] for pg in pages for r in pg.rows()] == vals
+    assert src.closed and op.stats()["processedPositions"] == 10_000
+    with pytest.raises(pkg.TgpuError):
+        op.addInput(pkg.Page(pkg.Block(V, ["x"])))
+    # :133-179 testPageSourceMergeOutput: 4 pages of 100 rows, filter field(0) = 10, projection field(0) -> the four matching rows
+    pgs = [pkg.Page(pkg.Block(B, np.arange(100, dtype=np.int64))) for _ in range(4)]
+    fac2 = pkg.ScanFilterAndProjectOperatorFactory(ctx, 1, [B], f(0, B).eq(10), [f(0, B)])
+    op2 = fac2.createOperator()
+    op2.addSplit(pkg.PageSource(pgs))
+    op2.noMoreSplits()
+    assert [r[0] for pg in _drain_source_operator(op2) for r in pg.rows()] == [10, 10, 10, 10]
+
+
+def test_scan_filter_project_lazy_blocks(pkg, ctx):
+    """T/operator/project/TestPageProcessor.java:156-184 (SelectAll: filter block loaded, projection block loaded for the output),
+    :219-234 testSelectNoneFilterLazyLoad (a projection-only lazy channel is NOT loaded when the filter selects nothing),
+    :236-253 testProjectLazyLoad (a channel nobody reads is never loaded); T/operator/TestScanFilterAndProjectOperator.java:182-218"""
+    B = pkg.BIGINT
+    f = pkg.field
+    n = 100
+    loads = []
+
+    def lazy(name, values):
+        def load():
+            loads.append(name)
+            return pkg.Block(B, values)
+        return pkg.LazyBlock(B, n, load)
+
+    def run(filt, projs, blocks):
+        fac = pkg.ScanFilterAndProjectOperatorFactory(ctx, 0, [B, B], filt, projs)
+        op = fac.createOperator()
+        op.addSplit(pkg.PageSource([pkg.Page(*blocks)]))
+        op.noMoreSplits()
+        pages = _drain_source_operator(op)
+        return [r for pg in pages for r in pg.rows()], op.stats()
+
+    a, b = np.arange(0, 100, dtype=np.int64), np.arange(100, 200, dtype=np.int64)
+    # select all: both blocks end up loaded, the filter's first
+    loads.clear()
+    rows, st = run(f(0, B) >= 0, [f(0, B), f(1, B)], [lazy("filter", a), lazy("projection", b)])
+    assert rows == list(zip(a.tolist(), b.tolist())) and loads == ["filter", "projection"] and st["lazyBlocksLoaded"] == 2
+    # select none: the projection-only channel is never loaded ("Lazy block should not be loaded")
+    loads.clear()
+
+    def must_not_load():
+        raise AssertionError("Lazy block should not be loaded")
+    rows, st = run(f(0, B) < 0, [f(1, B)], [pkg.Block(B, a), pkg.LazyBlock(B, n, must_not_load)])
+    assert rows == [] and st["lazyBlocksSkipped"] == 1 and st["lazyBlocksLoaded"] == 0
+    # a projection that does not read channel 1: never loaded
+    rows, st = run(f(0, B) >= 0, [f(0, B) + 1], [pkg.Block(B, a), pkg.LazyBlock(B, n, must_not_load)])
+    assert [r[0] for r in rows] == (a + 1).tolist() and st["lazyBlocksSkipped"] == 1
+    # a partial filter with a lazy projection channel: loaded because rows survive
+    loads.clear()
+    rows, st = run(pkg.between(f(0, B), 25, 74), [f(1, B) * 2], [pkg.Block(B, a), lazy("projection", b)])
+    assert [r[0] for r in rows] == (b[25:75] * 2).tolist() and loads == ["projection"]
