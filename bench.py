@@ -1018,7 +1018,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--sf", type=float, default=100.0, help="TPCH scale factor per GPU")
-    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2,sub (default: all at N=1, q3 only at N>1)")
+    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2,sub,paged (default at N=1: q3,q1,cfg2,sub; q3 only at N>1); paged = Q1 fed as 2^20-row pages and PCIe-inclusive Q1 (kept out of the default run so that a profiler's per-kernel averages of that run are those of the headline launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-sf", type=float, default=20.0, help="scale factor of the bounded sample the CPU baseline runs (~10-25 s of CPU work)")
     args = ap.parse_args()
@@ -1127,7 +1127,7 @@ def main():
         out["q1"]["roofline"] = dominant(p1, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
                                          {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
-        if b.world == 1 and "sub" in only:
+        if b.world == 1 and "paged" in only:
             # the engine hands over pages, not tables: the same program fed as 2^20-row pages (573 of them at SF100) directly and through MergePages
             out["q1"]["paged"] = {"direct_2^20": b.q1_paged(args.steps, args.warmup, 1 << 20), "merged_2^20_1GB": b.q1_paged(args.steps, args.warmup, 1 << 20, merge_mb=1024),
                                   "direct_2^24": b.q1_paged(args.steps, args.warmup, 1 << 24)}
@@ -1154,7 +1154,7 @@ def main():
         b.c2_out = None
         torch.cuda.empty_cache()
 
-    if b.world == 1 and "sub" in only and "q1" in only:
+    if b.world == 1 and "paged" in only and "q1" in only:
         # PCIe-inclusive Q1 on a bounded sample (every input byte host -> HBM inside the timed region; never `value`)
         n_pcie = int(6_000_379.02 * min(args.sf, 20.0))
         b.setup_q1(1024)   # (re)creates the factory

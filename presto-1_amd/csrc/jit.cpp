@@ -1505,7 +1505,12 @@ void FusedProbeGpu::generate()
 // x pages with / without null vectors (FJ_NO_NULLS: the null loads and tests fold away)
 static std::string prefilter_source(const std::string &src, int variant)
 {
-    return "#define FJ_PF " + std::to_string(variant % 4) + "\n#define FJ_NO_NULLS " + std::to_string(variant / 4) + "\n" + src;
+    // the kernels carry their table layout in their name (fj_probe_direct, ..._bitmap, ..._bloom, ..._plain): a profiler's per-kernel
+    // statistics then keep the DIRECT-layout launches (TPCH keys) apart from the open-address ones
+    static const char *layout[4] = {"plain", "bitmap", "bloom", "direct"};
+    const std::string l = layout[variant % 4];
+    return "#define FJ_PF " + std::to_string(variant % 4) + "\n#define FJ_NO_NULLS " + std::to_string(variant / 4) + "\n#define fj_probe fj_probe_" + l +
+           "\n#define fj_emit fj_emit_" + l + "\n" + src;
 }
 
 void FusedProbeGpu::precompile()
@@ -1559,7 +1564,10 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.tiles = ceil_div(n, tile_rows);
     TG_CHECK_ARG(n <= 0x7fffffffLL && J.tiles <= 0x7fffffffLL, "page too large");
     // persistent workgroups: exactly as many as are resident at once (a second round of workgroups would only add a tail)
-    const int64_t resident = (int64_t)ctx->cu_count() * module->blocks_per_cu("fj_probe");
+    const int pf_kind = tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0));
+    static const char *probe_names[4] = {"fj_probe_plain", "fj_probe_bitmap", "fj_probe_bloom", "fj_probe_direct"};
+    static const char *emit_names[4] = {"fj_emit_plain", "fj_emit_bitmap", "fj_emit_bloom", "fj_emit_direct"};
+    const int64_t resident = (int64_t)ctx->cu_count() * module->blocks_per_cu(probe_names[pf_kind]);
     // chunks of consecutive tiles per workgroup (fj_probe): up to 64 tiles, but at least ~4 chunks per resident workgroup
     int chunk_shift = 0;
     const int max_chunk_shift = getenv("TGPU_FJ_CHUNK_SHIFT") ? atoi(getenv("TGPU_FJ_CHUNK_SHIFT")) : 6;
@@ -1583,7 +1591,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     J.pair_build = pair_build->as<int32_t>();
     {
         ProfileScope ps(ctx, "fused_filter_probe");
-        launch_args(module->fn("fj_probe"), (int)grid1, J, ctx->stream());
+        launch_args(module->fn(probe_names[pf_kind]), (int)grid1, J, ctx->stream());
     }
     {
         ProfileScope ps(ctx, "fused_probe_scan");
@@ -1620,7 +1628,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     {
         ProfileScope ps(ctx, "fused_probe_emit");
         int64_t blocks = std::min<int64_t>(chunks, (int64_t)ctx->cu_count() * 8);
-        launch_args(module->fn("fj_emit"), (int)blocks, J, ctx->stream());
+        launch_args(module->fn(emit_names[pf_kind]), (int)blocks, J, ctx->stream());
     }
     // no second error read-back: the projections evaluated by pass 2 cannot raise (the constructor keeps anything with checked
     // integer arithmetic on the unfused path), and pass 1's filter / key errors were raised above

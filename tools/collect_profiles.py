@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("fj_", "fg_", "fa_", "fp_", "tgpu::", "void tgpu::")   # rocPRIM kernels (scan / radix sort) are shared with torch: left out
-PROFILE_NAME = {"fj_probe": "fused_filter_probe", "fj_emit": "fused_probe_emit", "fg_probe": "fused_filter_group_probe",
+PROFILE_NAME = {"fj_probe_direct": "fused_filter_probe", "fj_emit_direct": "fused_probe_emit", "fg_probe": "fused_filter_group_probe",
                 "fa_accumulate_lowcard": "fused_project_accumulate_lowcard", "fp_count": "filter_count", "fp_emit": "filter_project_emit"}
 
 

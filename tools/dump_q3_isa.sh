@@ -12,5 +12,5 @@ pkg.precompile_fused_probe(*pp["q3_lineitem"], 0, [0, 1])
 PY
 for f in presto-1_amd/_kcache/*.hip; do if head -2 $f | tr "\n" " " | grep -q "FJ_PF ${1:-1} #define FJ_NO_NULLS ${2:-1}"; then (echo '#include <hip/hip_runtime.h>'; cat $f) > /tmp/fj.hip; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S /tmp/fj.hip -o /tmp/fj.s -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A12 "Function Name: fj_" | grep -E "Name|VGPRs:|Scratch|Occupancy"
-awk '/^fj_probe:/,/s_endpgm/' /tmp/fj.s > /tmp/fj_p.s
+awk '/^fj_probe[a-z_]*:/,/s_endpgm/' /tmp/fj.s > /tmp/fj_p.s
 wc -l /tmp/fj_p.s
