@@ -462,7 +462,8 @@ int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out,
 /* PagesSerde.deserialize (PagesSerde.java:117-160) of one uncompressed, unencrypted SerializedPage in host memory, straight into a
  * device-resident page: LONG_ARRAY / INT_ARRAY / BYTE_ARRAY / VARIABLE_WIDTH blocks, RLE and DICTIONARY (RunLengthBlockEncoding.java:31-53,
  * DictionaryBlockEncoding.java:33-80) flattened on the device.  `types` = the tgpu_type of every channel (the encodings do not tell
- * BIGINT from DOUBLE, INTEGER from DATE).  COMPRESSED / ENCRYPTED markers: TGPU_ERR_NOT_SUPPORTED. */
+ * BIGINT from DOUBLE, INTEGER from DATE).  A COMPRESSED page (exchange.compression-enabled: one LZ4 block, PagesSerde.java:73-93,153-165) is
+ * inflated on the device first; ENCRYPTED: TGPU_ERR_NOT_SUPPORTED.  (tgpu_serialize_page always writes uncompressed pages, which every reader accepts.) */
 int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len, int32_t type_count, const int32_t *types, tgpu_output_page **out);
 
 /* ---- exchange between the GPUs of one node ---- */

@@ -750,3 +750,94 @@ def probe_with_filter(pages_hash, probe_key_cols, build_cols, probe_cols, flat_n
             out_p.append(r)
             out_b.append(-1)
     return np.array(out_p, dtype=np.int32), np.array(out_b, dtype=np.int32)
+
+
+# ---- LZ4 block format (what PagesSerde's Lz4Compressor / Lz4Decompressor exchange; io.airlift:aircompressor, un-vendored) -----------
+def lz4_block_compress(src: bytes) -> bytes:
+    """a plain greedy LZ4 block compressor (test infrastructure: produces valid blocks, not the reference's exact bytes): 4-byte
+    hash table, matches extended forwards, the format's end-of-block rules kept (last 5 bytes literals, no match within 12 of the end)"""
+    n = len(src)
+    out = bytearray()
+    anchor = 0
+
+    def emit(lit_end, match_len, offset):
+        lit = lit_end - anchor
+        token_l = min(lit, 15)
+        token_m = 0 if match_len is None else min(match_len - 4, 15)
+        out.append((token_l << 4) | token_m)
+        if lit >= 15:
+            rest = lit - 15
+            while rest >= 255:
+                out.append(255)
+                rest -= 255
+            out.append(rest)
+        out.extend(src[anchor:lit_end])
+        if match_len is not None:
+            out.append(offset & 0xFF)
+            out.append(offset >> 8)
+            if match_len - 4 >= 15:
+                rest = match_len - 4 - 15
+                while rest >= 255:
+                    out.append(255)
+                    rest -= 255
+                out.append(rest)
+
+    table = {}
+    i = 0
+    limit = n - 12
+    while i < limit:
+        key = src[i:i + 4]
+        cand = table.get(key)
+        table[key] = i
+        if cand is not None and i - cand <= 65535:
+            m = 4
+            while i + m < n - 5 and src[cand + m] == src[i + m]:
+                m += 1
+            emit(i, m, i - cand)
+            i += m
+            anchor = i
+        else:
+            i += 1
+    emit(n, None, 0)
+    return bytes(out)
+
+
+def lz4_block_decompress(src: bytes, n: int) -> bytes:
+    out = bytearray()
+    ip = 0
+    while ip < len(src):
+        token = src[ip]; ip += 1
+        lit = token >> 4
+        if lit == 15:
+            while True:
+                b = src[ip]; ip += 1
+                lit += b
+                if b != 255:
+                    break
+        out += src[ip:ip + lit]
+        ip += lit
+        if ip >= len(src):
+            break
+        offset = src[ip] | (src[ip + 1] << 8); ip += 2
+        ml = token & 15
+        if ml == 15:
+            while True:
+                b = src[ip]; ip += 1
+                ml += b
+                if b != 255:
+                    break
+        ml += 4
+        for _ in range(ml):
+            out.append(out[-offset])
+    assert len(out) == n
+    return bytes(out)
+
+
+def compress_serialized_page(page: bytes) -> bytes:
+    """PagesSerde.serialize with a compressor (PagesSerde.java:73-93): the payload as one LZ4 block, COMPRESSED marker set, sizeInBytes =
+    compressed size, uncompressedSize kept -- whatever the ratio (the reference keeps the page uncompressed above 0.8)"""
+    positions, markers = page[:4], page[4]
+    uncompressed = int.from_bytes(page[5:9], "little")
+    payload = page[13:13 + uncompressed]
+    comp = lz4_block_compress(payload)
+    return positions + bytes([markers | 1]) + _i32le(uncompressed) + _i32le(len(comp)) + comp

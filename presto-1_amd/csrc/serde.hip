@@ -289,6 +289,93 @@ const char *encoding_name(int32_t type)
     }
 }
 
+// LZ4 block decode (the format io.airlift.compress.lz4.Lz4Decompressor reads; M/execution/buffer/PagesSerde.java:153-165): a page's
+// payload is ONE block = a sequence of (token, literal run, 2-byte little-endian offset, match length) records.  The records depend on
+// each other, so one wave decodes the block: the token and the length bytes are read by all lanes alike (wave-uniform control flow), the
+// literal and match copies run across the 64 lanes.  A match may overlap its own output (offset < length): every 64-byte chunk of it
+// reads the `offset` bytes in front of the chunk, periodically repeated, which were written before the chunk -- through a 128 KB window
+// of the most recent output in LDS (offsets are < 64 KB), so no lane ever reads global memory another lane has just written.
+// status: 0 ok, 1 malformed input / output overrun.
+constexpr int kLz4Window = 128 * 1024;
+__global__ void __launch_bounds__(64) lz4_decode_kernel(const uint8_t *__restrict__ src, long long src_len, uint8_t *__restrict__ dst, long long dst_len, int *status)
+{
+    extern __shared__ uint8_t window[];
+    const int lane = threadIdx.x;
+    long long ip = 0, op = 0;
+    int bad = 0;
+    while (ip < src_len && !bad) {
+        const unsigned token = src[ip++];
+        long long lit = token >> 4;
+        if (lit == 15) {
+            unsigned b;
+            do {
+                if (ip >= src_len) { bad = 1; break; }
+                b = src[ip++];
+                lit += b;
+            } while (b == 255);
+        }
+        if (bad || ip + lit > src_len || op + lit > dst_len) { bad = 1; break; }
+        for (long long i = lane; i < lit; i += 64) {
+            const uint8_t v = src[ip + i];
+            dst[op + i] = v;
+            window[(op + i) & (kLz4Window - 1)] = v;
+        }
+        ip += lit;
+        op += lit;
+        __syncthreads();
+        if (ip >= src_len) break;   // the last record of a block has no match part
+        if (ip + 2 > src_len) { bad = 1; break; }
+        const long long offset = (long long)src[ip] | ((long long)src[ip + 1] << 8);
+        ip += 2;
+        long long ml = token & 15;
+        if (ml == 15) {
+            unsigned b;
+            do {
+                if (ip >= src_len) { bad = 1; break; }
+                b = src[ip++];
+                ml += b;
+            } while (b == 255);
+        }
+        ml += 4;
+        if (bad || offset == 0 || offset > op || op + ml > dst_len) { bad = 1; break; }
+        for (long long cs = 0; cs < ml; cs += 64) {
+            const long long i = cs + lane;
+            uint8_t v = 0;
+            if (i < ml) v = window[(op + cs - offset + (long long)(lane % offset)) & (kLz4Window - 1)];
+            __syncthreads();
+            if (i < ml) {
+                dst[op + i] = v;
+                window[(op + i) & (kLz4Window - 1)] = v;
+            }
+            __syncthreads();
+        }
+        op += ml;
+    }
+    if (lane == 0) *status = (bad || op != dst_len) ? 1 : 0;
+}
+
+// decompresses an LZ4 block on the device and returns the payload in host memory (the block headers are parsed on the host)
+std::vector<uint8_t> lz4_decode_on_device(Context *ctx, const uint8_t *compressed, int64_t compressed_len, int64_t uncompressed_len)
+{
+    TG_CHECK_ARG(uncompressed_len >= 0 && uncompressed_len <= 0x7fffffffLL, "bad uncompressed size");
+    std::vector<uint8_t> out((size_t)uncompressed_len);
+    if (uncompressed_len == 0) return out;
+    BufferPtr src = upload_section(ctx, compressed, compressed_len), dst = ctx->alloc((size_t)uncompressed_len), status = ctx->alloc_zero(4);
+    static bool configured = false;
+    if (!configured) {
+        HIP_CHECK(hipFuncSetAttribute((const void *)lz4_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLz4Window));
+        configured = true;
+    }
+    {
+        ProfileScope ps(ctx, "lz4_decode");
+        lz4_decode_kernel<<<1, 64, kLz4Window, ctx->stream()>>>(src->as<uint8_t>(), compressed_len, dst->as<uint8_t>(), uncompressed_len, status->as<int>());
+        check_launch("lz4_decode");
+    }
+    TG_CHECK_ARG(ctx->read_scalar(status->as<int>()) == 0, "malformed LZ4 block in a compressed serialized page");
+    ctx->download(out.data(), dst->ptr(), (size_t)uncompressed_len);
+    return out;
+}
+
 }  // namespace
 
 DevicePage deserialize(Context *ctx, const uint8_t *bytes, int64_t len, const int32_t *types, int32_t type_count)
@@ -299,10 +386,18 @@ DevicePage deserialize(Context *ctx, const uint8_t *bytes, int64_t len, const in
     const uint8_t markers = h.u8();
     const int32_t uncompressed = h.i32(), size = h.i32();
     TG_CHECK_ARG(positions >= 0 && size >= 0 && (int64_t)kHeaderBytes + size <= len, "serialized page is truncated");
-    if (markers & 1) fail(TGPU_ERR_NOT_SUPPORTED, "compressed serialized pages are not supported (exchange.compression-enabled=false)");
     if (markers & 2) fail(TGPU_ERR_NOT_SUPPORTED, "encrypted serialized pages are not supported");
-    TG_CHECK_ARG(uncompressed == size, "uncompressed size differs from the payload size of an uncompressed page");
-    Reader r{bytes + kHeaderBytes, size};
+    std::vector<uint8_t> inflated;
+    const uint8_t *payload = bytes + kHeaderBytes;
+    int64_t payload_len = size;
+    if (markers & 1) {   // COMPRESSED (PagesSerde.java:153-165): the payload is one LZ4 block of `uncompressed` bytes
+        TG_CHECK_ARG(uncompressed >= 0, "negative uncompressed size");
+        inflated = lz4_decode_on_device(ctx, payload, size, uncompressed);
+        payload = inflated.data();
+        payload_len = uncompressed;
+    }
+    else TG_CHECK_ARG(uncompressed == size, "uncompressed size differs from the payload size of an uncompressed page");
+    Reader r{payload, payload_len};
     const int32_t channels = r.i32();
     TG_CHECK_ARG(channels == type_count, "serialized page has a different channel count than the expected types");
     DevicePage page;
@@ -315,6 +410,7 @@ DevicePage deserialize(Context *ctx, const uint8_t *bytes, int64_t len, const in
     TG_CHECK_ARG(r.at == r.len, "trailing bytes after the last block");
     // the uploads read the caller's buffer asynchronously only until hipMemcpyAsync returns (pageable source); kernels may still
     // be running, but they only touch library-owned buffers: nothing to wait for here
+    if (!inflated.empty()) ctx->sync();   // (the inflated payload is ours and dies with this frame)
     return page;
 }
 

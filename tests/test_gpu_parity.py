@@ -1048,9 +1048,38 @@ def test_deserialize_rle_and_dictionary_blocks(pkg, ctx, oracle):
     out.release()
 
 
+def test_deserialize_lz4_compressed_pages(pkg, ctx, oracle):
+    """exchange.compression-enabled: the payload of a SerializedPage is one LZ4 block (M/execution/buffer/PagesSerde.java:73-93,153-165),
+    inflated on the device.  Blocks come from the oracle's greedy compressor (valid LZ4, checked against its own decompressor): long
+    literal runs, long and overlapping matches (runs of equal bytes: offset 1), matches at the 64 KB offset limit, incompressible data."""
+    rng = np.random.default_rng(23)
+    n = 40_000
+    cases = [
+        [pkg.Block(pkg.BIGINT, np.zeros(n, dtype=np.int64))],                                                   # one long overlapping match
+        [pkg.Block(pkg.BIGINT, np.arange(n, dtype=np.int64)), pkg.Block(pkg.VARCHAR, ["row%d" % (i % 13) for i in range(n)])],
+        [rand_block(pkg, rng, pkg.BIGINT, n, 0.1, (0, 7)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.0), rand_block(pkg, rng, pkg.VARCHAR, n, 0.2, (0, 30))],
+        [pkg.Block(pkg.BIGINT, np.tile(rng.integers(-2**62, 2**62, 8192), 5)[:n].astype(np.int64))],              # matches 65 536 bytes back
+        [pkg.Block(pkg.BIGINT, np.array([], dtype=np.int64))],
+    ]
+    for blocks in cases:
+        page = pkg.Page(*blocks)
+        plain = oracle.serialize_page([ocol(oracle, b) for b in blocks])
+        packed = oracle.compress_serialized_page(plain)
+        assert packed[4] == 1 and oracle.lz4_block_decompress(packed[13:], int.from_bytes(packed[5:9], "little")) == plain[13:]
+        got = ctx.deserialize_page(packed, [b.type for b in blocks]).to_host()
+        assert got.rows() == page.rows()
+    # a corrupt block (an offset reaching before the start of the output) fails cleanly
+    bad = bytearray(oracle.compress_serialized_page(oracle.serialize_page([oracle.Col(oracle.BIGINT, np.zeros(1000, dtype=np.int64))])))
+    at = 13 + 1 + (bad[13] >> 4)        # the first record's offset field
+    bad[at:at + 2] = (60000).to_bytes(2, "little")
+    with pytest.raises(pkg.TgpuError) as e:
+        ctx.deserialize_page(bytes(bad), [pkg.BIGINT])
+    assert e.value.code == -1
+
+
 def test_deserialize_rejects_what_it_cannot_read(pkg, ctx, oracle):
     data = bytearray(oracle.serialize_page([oracle.Col(oracle.BIGINT, [1, 2, 3])]))
-    for marker in (1, 2):   # PageCodecMarker.java:24-25 COMPRESSED, ENCRYPTED
+    for marker in (2, 3):   # PageCodecMarker.java:24-25 ENCRYPTED (alone, or with COMPRESSED)
         bad = bytearray(data)
         bad[4] = marker
         with pytest.raises(pkg.TgpuError) as e:

@@ -66,3 +66,15 @@ def test_null_bit_order(oracle):
     body = blk[4 + len(b"BYTE_ARRAY") + 4:]
     assert body[0] == 1 and body[1] == 0b10000001 and body[2] == 0b01000000
     assert int.from_bytes(body[3:7], "little") == 8   # non-null positions
+
+
+def test_lz4_block_round_trip(oracle):
+    """the oracle's LZ4 block compressor / decompressor (test infrastructure for the compressed-page ingest): valid blocks, exact round trip"""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for data in [b"", b"x", b"abc" * 700, bytes(70_000), rng.integers(0, 3, 20_000, dtype=np.uint8).tobytes(), rng.integers(0, 256, 5_000, dtype=np.uint8).tobytes()]:
+        packed = oracle.lz4_block_compress(data)
+        assert oracle.lz4_block_decompress(packed, len(data)) == data
+    page = oracle.serialize_page([oracle.Col(oracle.BIGINT, np.zeros(5000, dtype=np.int64))])
+    packed = oracle.compress_serialized_page(page)
+    assert packed[4] == 1 and len(packed) < len(page) // 10 and int.from_bytes(packed[5:9], "little") == len(page) - 13
