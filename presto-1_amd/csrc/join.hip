@@ -87,6 +87,45 @@ __device__ __forceinline__ long long int_key_at(const ColView &c, int64_t r)
     return c.type == TGPU_BIGINT ? ((const long long *)c.values)[r] : (long long)((const int *)c.values)[r];
 }
 
+// PagesIndex.addPage / MergePages' appendPage as ONE launch: every buffer of the page (values and null vectors of all channels, VARCHAR
+// byte ranges) and every VARCHAR channel's rebased offsets.  A per-buffer hipMemcpyAsync costs ~5 us of host time each -- nine of them per
+// 7-channel page were most of MergePages' per-page cost (DESIGN.md "Page granularity").
+struct AppendJob {
+    const uint8_t *src;
+    uint8_t *dst;
+    long long bytes;        // plain copy; for an offsets job: the row count
+    int src_base, dst_base; // offsets job (kind 1): dst[i + 1] = dst_base + (src[i + 1] - src_base)
+    int kind, pad;
+};
+constexpr int kMaxAppendJobs = 40;
+struct AppendJobs {
+    AppendJob j[kMaxAppendJobs];
+};
+__global__ void __launch_bounds__(kBlock) append_page_kernel(AppendJobs jobs)
+{
+    // the job of this blockIdx.y, selected without indexing the by-value argument at run time (that would copy it to scratch)
+    AppendJob job = jobs.j[0];
+#pragma unroll
+    for (int k = 1; k < kMaxAppendJobs; k++)
+        if ((int)blockIdx.y == k) job = jobs.j[k];
+    const long long tid = (long long)blockIdx.x * kBlock + threadIdx.x, stride = (long long)gridDim.x * kBlock;
+    if (job.kind == 1) {
+        const int *src = (const int *)job.src;
+        int *dst = (int *)job.dst;
+        for (long long i = tid; i < job.bytes; i += stride) dst[i + 1] = job.dst_base + (src[i + 1] - job.src_base);
+        return;
+    }
+    if ((((unsigned long long)job.src | (unsigned long long)job.dst) & 15ull) == 0) {
+        const long long n16 = job.bytes >> 4;
+        const uint4 *s = (const uint4 *)job.src;
+        uint4 *d = (uint4 *)job.dst;
+        for (long long i = tid; i < n16; i += stride) d[i] = s[i];
+        for (long long i = (n16 << 4) + tid; i < job.bytes; i += stride) job.dst[i] = job.src[i];
+    }
+    else
+        for (long long i = tid; i < job.bytes; i += stride) job.dst[i] = job.src[i];
+}
+
 __global__ void __launch_bounds__(kBlock) append_offsets_kernel(const int32_t *__restrict__ src, int64_t n, int32_t src_base, int32_t dst_base,
                                                                  int32_t *__restrict__ dst)
 {
@@ -488,13 +527,30 @@ void PagesIndexGpu::add_page(const DevicePage &page, const std::vector<std::arra
     if (page.n == 0) return;
     if (n_ + page.n > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "Size of pages index cannot exceed 2 billion entries");  // PagesIndex.java:234-236
     reserve(n_ + page.n);
+    AppendJobs jobs{};
+    int n_jobs = 0;
+    long long most = 0;
+    auto launch_jobs = [&]() {
+        if (n_jobs == 0) return;
+        dim3 grid((unsigned)std::min<long long>(std::max<long long>(ceil_div(most / 16 + 1, kBlock), 1), (long long)ctx_->cu_count() * 4), (unsigned)n_jobs);
+        append_page_kernel<<<grid, kBlock, 0, ctx_->stream()>>>(jobs);
+        check_launch("append_page");
+        n_jobs = 0;
+        most = 0;
+    };
+    auto add_job = [&](const void *src, void *dst, long long bytes, int kind = 0, int src_base = 0, int dst_base = 0) {
+        if (bytes <= 0) return;
+        if (n_jobs == kMaxAppendJobs) launch_jobs();
+        jobs.j[n_jobs++] = AppendJob{(const uint8_t *)src, (uint8_t *)dst, bytes, src_base, dst_base, kind, 0};
+        most = std::max(most, kind == 1 ? bytes * 16 : bytes);
+    };
     for (size_t i = 0; i < cols_.size(); i++) {
         Store &c = cols_[i];
         const DeviceColumn &src = page.cols[i];
         TG_CHECK_ARG(src.type == c.type, "page channel type does not match the index");
         if (src.nulls) {
             if (!c.nulls) c.nulls = ctx_->alloc_zero((size_t)c.cap);
-            HIP_CHECK(hipMemcpyAsync(c.nulls->as<uint8_t>() + n_, src.nulls, (size_t)page.n, hipMemcpyDeviceToDevice, ctx_->stream()));
+            add_job(src.nulls, c.nulls->as<uint8_t>() + n_, page.n);
             c.has_nulls = true;
         }
         if (c.type == TGPU_VARCHAR) {
@@ -521,16 +577,16 @@ void PagesIndexGpu::add_page(const DevicePage &page, const std::vector<std::arra
                 c.values = nv;
                 c.pool_cap = cap;
             }
-            if (bytes) HIP_CHECK(hipMemcpyAsync(c.values->as<uint8_t>() + c.pool_used, (const uint8_t *)src.values + a, (size_t)bytes, hipMemcpyDeviceToDevice, ctx_->stream()));
-            append_offsets_kernel<<<grid_for(ctx_, page.n), kBlock, 0, ctx_->stream()>>>(src.offsets, page.n, a, (int32_t)c.pool_used, c.offsets->as<int32_t>() + n_);
-            check_launch("append_offsets");
+            add_job((const uint8_t *)src.values + a, c.values->as<uint8_t>() + c.pool_used, bytes);
+            add_job(src.offsets, c.offsets->as<int32_t>() + n_, page.n, 1, a, (int32_t)c.pool_used);
             c.pool_used += bytes;
         }
         else {
             const int w = type_width(c.type);
-            HIP_CHECK(hipMemcpyAsync(c.values->as<uint8_t>() + n_ * w, src.values, (size_t)page.n * w, hipMemcpyDeviceToDevice, ctx_->stream()));
+            add_job(src.values, c.values->as<uint8_t>() + n_ * w, (long long)page.n * w);
         }
     }
+    launch_jobs();
     n_ += page.n;
 }
 
