@@ -1070,7 +1070,14 @@ def test_deserialize_lz4_compressed_pages(pkg, ctx, oracle):
         assert got.rows() == page.rows()
     # a corrupt block (an offset reaching before the start of the output) fails cleanly
     bad = bytearray(oracle.compress_serialized_page(oracle.serialize_page([oracle.Col(oracle.BIGINT, np.zeros(1000, dtype=np.int64))])))
-    at = 13 + 1 + (bad[13] >> 4)        # the first record's offset field
+    at, lit = 14, bad[13] >> 4                       # the first record: token, [length bytes], literals, then the 2-byte offset
+    if lit == 15:
+        while True:
+            lit += bad[at]
+            at += 1
+            if bad[at - 1] != 255:
+                break
+    at += lit
     bad[at:at + 2] = (60000).to_bytes(2, "little")
     with pytest.raises(pkg.TgpuError) as e:
         ctx.deserialize_page(bytes(bad), [pkg.BIGINT])
