@@ -631,7 +631,9 @@ class Bench:
         self.q1_result = res["rows"]
         ok = self.check_q1()["ok"]
         return {"page_rows": page_rows, "pages": len(pages), "through_merge_pages_mb": merge_mb, "ms_per_step": step_s * 1e3, "rows_per_sec": n / step_s,
-                "readbacks_per_page": self.last_readbacks_per_step / max(len(pages), 1), "ok": ok}
+                "readbacks_per_page": self.last_readbacks_per_step / max(len(pages), 1),
+                "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:6]},
+                "kernel_launches_per_page": sum(v["count"] for v in prof.values()) / steps / max(len(pages), 1), "ok": ok}
 
     def q1_pcie_inclusive(self, steps, warmup, n, page_rows, pinned):
         """Q1 with every input byte crossing PCIe inside the timed region: the columns live in host memory (pinned = hipHostMalloc'ed

@@ -53,6 +53,14 @@ public:
     bool force_ordered() const { return force_ordered_ && allow_ordered_; }
     bool ordered() const { return mode_ == Mode::ORDERED; }
     DeviceState device_state(int k) const;
+    // folded partials of the low-cardinality launches (device_agg.h TgFoldScratch): one row per workgroup, `group_capacity` x
+    // aggregates items per row; the launches add to them, flush_fold() adds them exactly into the states (evaluate does it)
+    struct FoldScratch {
+        unsigned long long *partials;
+        int32_t stride;
+    };
+    FoldScratch fold_scratch(int64_t blocks, int64_t group_capacity);
+    void flush_fold();
     const std::vector<tgpu_agg_spec> specs() const;
     int output_channel_count() const;
     int intermediate_channel_count() const;
@@ -78,6 +86,9 @@ private:
     std::vector<State> states_;
     int32_t step_;
     BufferPtr error_;  // device uint32
+    BufferPtr fold_partials_;
+    int64_t fold_rows_ = 0, fold_stride_ = 0;
+    bool fold_dirty_ = false;
 };
 
 }  // namespace tgpu

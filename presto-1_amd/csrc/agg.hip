@@ -164,7 +164,8 @@ struct LowCardStates {
     TgAggState st[kMaxAggs];
 };
 
-__global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCardStates states, LowCardPlan plan, const int32_t *__restrict__ gids, int64_t n)
+__global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCardStates states, LowCardPlan plan, const int32_t *__restrict__ gids, int64_t n,
+                                                              TgFoldScratch fold)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     tg_lc_zero(lds, plan);
@@ -192,7 +193,12 @@ __global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCa
             tg_lc_add_double(hi_base, lo_base, w, v);
         }
     }
-    tg_lc_fold(lds, plan, states.st);
+    tg_lc_fold(lds, plan, states.st, fold);
+}
+
+__global__ void __launch_bounds__(kBlock) agg_fold_flush_kernel(TgFoldScratch fs, int rows, int n_aggs, LowCardStates states)
+{
+    tg_fold_flush(fs, rows, n_aggs, states.st);
 }
 
 // limbs -> correctly rounded double (round half to even).  One pass over the limbs with O(1) state: the carry-normalised
@@ -374,6 +380,40 @@ GroupedAccumulators::GroupedAccumulators(Context *ctx, std::vector<tgpu_agg_spec
     error_ = ctx_->alloc_zero(4);
 }
 
+GroupedAccumulators::FoldScratch GroupedAccumulators::fold_scratch(int64_t blocks, int64_t group_capacity)
+{
+    const int64_t stride = group_capacity * (int64_t)states_.size();
+    if (!fold_partials_ || stride != fold_stride_ || blocks > fold_rows_) {
+        flush_fold();   // (into the states, before the rows change shape)
+        fold_rows_ = std::max<int64_t>(blocks, fold_rows_);
+        fold_stride_ = stride;
+        fold_partials_ = ctx_->alloc_zero((size_t)fold_rows_ * (size_t)stride * 24);
+    }
+    ensure(group_capacity);   // the flush addresses the states of every group a row has room for
+    fold_dirty_ = true;
+    return {fold_partials_->as<unsigned long long>(), (int32_t)stride};
+}
+
+void GroupedAccumulators::flush_fold()
+{
+    if (!fold_dirty_) return;
+    fold_dirty_ = false;
+    LowCardStates states{};
+    for (size_t k = 0; k < states_.size(); k++) {
+        const DeviceState d = device_state((int)k);
+        states.st[k].function = d.function;
+        states.st[k].counts = d.counts;
+        states.st[k].limbs = d.limbs;
+        states.st[k].special = d.special;
+        states.st[k].i128 = d.i128;
+        states.st[k].dsum = nullptr;
+    }
+    ProfileScope ps(ctx_, "agg_fold_flush");
+    agg_fold_flush_kernel<<<(int)ceil_div(fold_stride_, kBlock / 64), kBlock, 0, ctx_->stream()>>>(TgFoldScratch{fold_partials_->as<unsigned long long>(), (int)fold_stride_},
+                                                                                                (int)fold_rows_, (int)states_.size(), states);
+    check_launch("agg_fold_flush");
+}
+
 GroupedAccumulators::DeviceState GroupedAccumulators::device_state(int k) const
 {
     const State &st = states_[(size_t)k];
@@ -512,7 +552,13 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
     }
     if (gids) decide_mode(group_count > 0 ? group_count : 1, (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1));
     else if (mode_ == Mode::UNDECIDED) mode_ = Mode::EXACT;
-    ensure(group_count > 0 ? group_count : 1);
+    {
+        // a low-cardinality launch leaves folded partials for every group its LDS has room for (fold_scratch): reserve those states
+        // now, before the argument block below takes their addresses
+        const int64_t lowcard_capacity = (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1);
+        const int64_t g = group_count > 0 ? group_count : 1;
+        ensure(mode_ == Mode::EXACT && g <= lowcard_capacity ? lowcard_capacity : g);
+    }
     AggArgs args{};
     args.n_aggs = (int32_t)states_.size();
     for (size_t k = 0; k < states_.size(); k++) {
@@ -580,7 +626,8 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
             states.st[k].i128 = args.a[k].i128;
             states.st[k].dsum = nullptr;
         }
-        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, states, plan, gids, n);
+        const FoldScratch fs = fold_scratch(blocks, (160 * 1024) / plan.per_group_bytes);   // (states reserved above: nothing moves)
+        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, states, plan, gids, n, TgFoldScratch{fs.partials, fs.stride});
         check_launch("agg_accumulate_lowcard");
         return;
     }
@@ -639,6 +686,7 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
 {
     if (states_.empty()) return;
     ensure(groups > 0 ? groups : 1);
+    flush_fold();
     EvalArgs args{};
     args.n_aggs = (int32_t)states_.size();
     const bool partial = step_ == TGPU_STEP_PARTIAL;

@@ -69,6 +69,14 @@ static void resolve_varchar_ends(Context *ctx, std::vector<DeviceColumn *> cols)
     }
 }
 
+void resolve_varchar_ends(Context *ctx, DevicePage &page)
+{
+    std::vector<DeviceColumn *> unresolved;
+    for (DeviceColumn &c : page.cols)
+        if (c.type == TGPU_VARCHAR && !c.pool_exact) unresolved.push_back(&c);
+    resolve_varchar_ends(ctx, unresolved);
+}
+
 static DeviceColumn ingest_block_raw(Context *ctx, const tgpu_block *b);
 
 DeviceColumn ingest_block(Context *ctx, const tgpu_block *b)
@@ -191,7 +199,7 @@ void own_borrowed_columns(Context *ctx, DevicePage &page)
     }
 }
 
-DevicePage ingest_page(Context *ctx, const tgpu_page *page)
+DevicePage ingest_page(Context *ctx, const tgpu_page *page, bool resolve_varchar)
 {
     TG_CHECK_ARG(page != nullptr, "page is null");
     TG_CHECK_ARG(page->position_count >= 0 && page->channel_count >= 0, "bad page header");
@@ -224,7 +232,7 @@ DevicePage ingest_page(Context *ctx, const tgpu_page *page)
     }
     std::vector<DeviceColumn *> unresolved;
     for (DeviceColumn &c : out.cols)
-        if (c.type == TGPU_VARCHAR && !c.pool_exact) unresolved.push_back(&c);
+        if (resolve_varchar && c.type == TGPU_VARCHAR && !c.pool_exact) unresolved.push_back(&c);
     resolve_varchar_ends(ctx, unresolved);
     // ownership rule: the caller's (Java heap) arrays are only valid during the call, so the H2D copies must have
     // consumed them before we return (the batched read above has already waited for the stream)

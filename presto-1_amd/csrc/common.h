@@ -274,7 +274,10 @@ inline KeyCols key_cols_of(const std::vector<const DeviceColumn *> &cols)
 }
 
 // ingest: tgpu_page (host or device memory, any encoding) -> flat device columns.  columns.cpp
-DevicePage ingest_page(Context *ctx, const tgpu_page *page);
+// resolve_varchar = false leaves the byte ranges of borrowed device-resident VARCHAR columns unread (pool_exact == false: no
+// round trip to the device); a consumer that needs them calls resolve_varchar_ends
+DevicePage ingest_page(Context *ctx, const tgpu_page *page, bool resolve_varchar = true);
+void resolve_varchar_ends(Context *ctx, DevicePage &page);
 DeviceColumn ingest_block(Context *ctx, const tgpu_block *block);
 // a DICTIONARY / RLE block as (flat dictionary column, device ids) -- not flattened (dictionary-aware processing)
 void ingest_dictionary(Context *ctx, const tgpu_block *block, DeviceColumn &dictionary, BufferPtr &ids);

@@ -127,45 +127,125 @@ __device__ inline void tg_flag_special(unsigned int *special, double v)
     atomicOr(special, (bits & 0xfffffffffffffULL) ? 1u : ((bits >> 63) ? 4u : 2u));
 }
 
-// end of block: fold the 256 lane partials of each (group, aggregate) and add them EXACTLY into the global state
-__device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, const TgAggState *st)
+// Folded partials of the low-cardinality launches: workgroup b owns slot row b -- `stride` (group, aggregate) items of 3 words: count,
+// and the (hi, lo) double-double sum or the (low, high) words of a 128-bit bigint sum -- and ADDS each launch's block total to it
+// (plain read-modify-write: the launches of an operator are ordered on the stream and a row has one owner per launch).  Nothing
+// crosses workgroups per page; tg_fold_flush adds the rows EXACTLY into the global state when the state is read (evaluate).
+// (Round 1 had every wave add its partials to the global state with atomics at the end of each launch: ~7 atomics per wave and
+// (group, aggregate) onto the same few cache lines = ~100 us per launch whatever the page size; a last-workgroup reduction inside
+// the launch was no better -- device-scope fences write back / invalidate the XCD's L2, remote partials arrive one latency at a
+// time, and the cold reduction code is fetched at instruction-cache-miss speed.)
+struct TgFoldScratch {
+    unsigned long long *partials;   // [workgroups][stride][3]
+    int stride;                     // items per row = group capacity x n_aggs
+};
+
+// a += b for a (hi, lo) double-double pair, or for the (low, high) words of a 128-bit integer
+__device__ inline void tg_fold_pair(bool bigint, unsigned long long &a0, unsigned long long &a1, unsigned long long b0, unsigned long long b1)
+{
+    if (bigint) {
+        const unsigned long long s = a0 + b0;
+        a1 += b1 + (s < a0 ? 1ULL : 0ULL);
+        a0 = s;
+    }
+    else {
+        double hi = __longlong_as_double((long long)a0), lo = __longlong_as_double((long long)a1);
+        tg_dd_add(hi, lo, __longlong_as_double((long long)b0), __longlong_as_double((long long)b1));
+        a0 = (unsigned long long)__double_as_longlong(hi);
+        a1 = (unsigned long long)__double_as_longlong(lo);
+    }
+}
+
+__device__ inline void tg_fold_wave(bool bigint, unsigned long long &c, unsigned long long &a0, unsigned long long &a1)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        c += __shfl_down(c, d, 64);
+        const unsigned long long b0 = __shfl_down(a0, d, 64), b1 = __shfl_down(a1, d, 64);
+        tg_fold_pair(bigint, a0, a1, b0, b1);
+    }
+}
+
+// end of block: one wave per (group, aggregate) item folds the 256 lane partials; lane j of the wave keeps the wave's j-th item and
+// adds it to the block's slot -- the slots' loads are all in flight together, no atomics, no cross-workgroup traffic
+__device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, const TgAggState *st, TgFoldScratch fs)
 {
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    for (int g = 0; g < p.n_groups; g++) {
-        double *hi_base = tg_lc_hi(lds, p, g), *lo_base = tg_lc_lo(lds, p, g);
-        unsigned int *cnt_base = tg_lc_cnt(lds, p, g);
-        for (int k = 0; k < p.n_aggs; k++) {
-            const TgAggState &a = st[k];
-            unsigned long long c = cnt_base[(p.count_from_rows[k] ? p.rows_slot : p.cnt_slot[k]) * TG_AGG_BLOCK + threadIdx.x];
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
-            const bool any = __shfl(c, 0, 64) != 0;
-            if (!any) continue;
-            if (lane == 0) atomicAdd((unsigned long long *)&a.counts[g], c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int items = p.n_groups * p.n_aggs;
+    unsigned long long *mine = fs.partials + (size_t)blockIdx.x * fs.stride * 3;
+    for (int base = 0; base < items; base += 64 * (TG_AGG_BLOCK / 64)) {
+        unsigned long long kc = 0, k0 = 0, k1 = 0;   // lane j: item base + wave + 4 j
+        for (int j = 0; j < 64; j++) {
+            const int it = base + wave + j * (TG_AGG_BLOCK / 64);
+            if (it >= items) break;
+            const int g = it / p.n_aggs, k = it - g * p.n_aggs;
+            const unsigned int *cnt = tg_lc_cnt(lds, p, g) + (p.count_from_rows[k] ? p.rows_slot : p.cnt_slot[k]) * TG_AGG_BLOCK;
             const int w = p.wide_slot[k];
-            if (w < 0) continue;
-            if (a.function == TG_AGG_SUM_BIGINT) {
-                const unsigned long long lo64 = *(unsigned long long *)&hi_base[w * TG_AGG_BLOCK + threadIdx.x];
-                const long long hi64 = *(long long *)&lo_base[w * TG_AGG_BLOCK + threadIdx.x];
-                if (lo64 || hi64) {
-                    const unsigned long long old = atomicAdd(&a.i128[g * 2], lo64);
-                    const unsigned long long carry = (old + lo64) < old ? 1ULL : 0ULL;
-                    const unsigned long long add_hi = (unsigned long long)hi64 + carry;
-                    if (add_hi) atomicAdd(&a.i128[g * 2 + 1], add_hi);
-                }
-                continue;
-            }
-            double hi = hi_base[w * TG_AGG_BLOCK + threadIdx.x], lo = lo_base[w * TG_AGG_BLOCK + threadIdx.x];
+            const bool bigint = st[k].function == TG_AGG_SUM_BIGINT;
+            unsigned long long c = 0, a0 = 0, a1 = 0;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const double h2 = __shfl_down(hi, d, 64), l2 = __shfl_down(lo, d, 64);
-                tg_dd_add(hi, lo, h2, l2);
+            for (int q = 0; q < TG_AGG_BLOCK / 64; q++) {
+                c += cnt[lane + 64 * q];
+                if (w >= 0) {
+                    const unsigned long long b0 = ((const unsigned long long *)tg_lc_hi(lds, p, g))[w * TG_AGG_BLOCK + lane + 64 * q];
+                    const unsigned long long b1 = ((const unsigned long long *)tg_lc_lo(lds, p, g))[w * TG_AGG_BLOCK + lane + 64 * q];
+                    if (q == 0) { a0 = b0; a1 = b1; }
+                    else tg_fold_pair(bigint, a0, a1, b0, b1);
+                }
             }
-            if (lane == 0) {
-                tg_kulisch_add(&a.limbs[(size_t)g * TG_LIMBS], &a.special[g], hi);
-                tg_kulisch_add(&a.limbs[(size_t)g * TG_LIMBS], &a.special[g], lo);
+            tg_fold_wave(bigint, c, a0, a1);
+            c = __shfl(c, 0, 64);
+            a0 = __shfl(a0, 0, 64);
+            a1 = __shfl(a1, 0, 64);
+            if (lane == j) { kc = c; k0 = a0; k1 = a1; }
+        }
+        const int it = base + wave + lane * (TG_AGG_BLOCK / 64);
+        if (it < items && kc != 0) {
+            const int k = it % p.n_aggs;
+            unsigned long long *slot = mine + (size_t)it * 3;
+            unsigned long long s0 = slot[1], s1 = slot[2];
+            slot[0] += kc;
+            if (p.wide_slot[k] >= 0) {
+                tg_fold_pair(st[k].function == TG_AGG_SUM_BIGINT, s0, s1, k0, k1);
+                slot[1] = s0;
+                slot[2] = s1;
             }
         }
     }
+}
+
+// one wave per item: folds the item's slot of every workgroup row (in row order: deterministic), adds the total exactly into the
+// global state and clears the slots
+__device__ inline void tg_fold_flush(TgFoldScratch fs, int rows, int n_aggs, const TgAggState *st)
+{
+    const int lane = threadIdx.x & 63;
+    const int it = blockIdx.x * (TG_AGG_BLOCK / 64) + (threadIdx.x >> 6);
+    if (it >= fs.stride) return;
+    const int g = it / n_aggs, k = it - g * n_aggs;
+    const TgAggState &a = st[k];
+    const bool bigint = a.function == TG_AGG_SUM_BIGINT;
+    unsigned long long c = 0, a0 = 0, a1 = 0;
+    for (int b = lane; b < rows; b += 64) {
+        unsigned long long *slot = fs.partials + ((size_t)b * fs.stride + it) * 3;
+        const unsigned long long v = slot[0];
+        if (v == 0) continue;
+        c += v;
+        tg_fold_pair(bigint, a0, a1, slot[1], slot[2]);
+        slot[0] = slot[1] = slot[2] = 0;
+    }
+    tg_fold_wave(bigint, c, a0, a1);
+    if (lane != 0 || c == 0) return;
+    atomicAdd((unsigned long long *)&a.counts[g], c);
+    if (a.function == TG_AGG_COUNT_ALL || a.function == TG_AGG_COUNT_COLUMN) return;
+    if (bigint) {
+        if (a0 || a1) {
+            const unsigned long long old = atomicAdd(&a.i128[g * 2], a0);
+            const unsigned long long add_hi = a1 + ((old + a0) < old ? 1ULL : 0ULL);
+            if (add_hi) atomicAdd(&a.i128[g * 2 + 1], add_hi);
+        }
+        return;
+    }
+    tg_kulisch_add(&a.limbs[(size_t)g * TG_LIMBS], &a.special[g], __longlong_as_double((long long)a0));
+    tg_kulisch_add(&a.limbs[(size_t)g * TG_LIMBS], &a.special[g], __longlong_as_double((long long)a1));
 }

@@ -1661,6 +1661,7 @@ struct FaArgs {
   const unsigned int* ord_keys;   // ORDERED mode: (group id + 1) of the page's rows in (group, row) order, 0 = filtered row
   const int* ord_rows;            //               and their row numbers
   const unsigned char* gids8;     // compact group ids (id + 1, 0 = filtered row) instead of gids
+  TgFoldScratch fold;             // low-cardinality launches: the workgroups' folded partials
 };
 // group id of a row: compact byte ids when the group-by table delivered them, else int32 ids, else the single global group
 // (FA_GID8 is a compile-time variant: a run-time choice would put branches around the pipelined loads)
@@ -1733,9 +1734,12 @@ template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, un
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_lowcard(FaArgs F) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[FA_LDS_BYTES];
-  tg_lc_zero(lds, F.plan);
-  fa_accumulate_body<true>(F, lds);
-  tg_lc_fold(lds, F.plan, F.st);
+#ifndef FA_DEBUG_SKIP
+#define FA_DEBUG_SKIP 0
+#endif
+  if (!(FA_DEBUG_SKIP & 1)) tg_lc_zero(lds, F.plan);
+  if (!(FA_DEBUG_SKIP & 2)) fa_accumulate_body<true>(F, lds);
+  if (!(FA_DEBUG_SKIP & 4)) tg_lc_fold(lds, F.plan, F.st, F.fold);
 }
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F) {
@@ -1781,6 +1785,10 @@ struct FaArgsHost {
     const unsigned int *ord_keys;
     const int *ord_rows;
     const unsigned char *gids8;
+    struct {
+        unsigned long long *partials;
+        int32_t stride;
+    } fold;
 };
 
 }  // namespace
@@ -2037,7 +2045,8 @@ void FusedAggGpu::generate()
     if (const char *exp = getenv("TGPU_FG_EXP")) src << "#define FG_EXP_" << exp << " 1\n";  // kernel-study switch, never set in production
     if (const char *st = getenv("TGPU_FG_STRIPES")) src << "#define FG_STRIPES " << std::max(1, std::min(16, atoi(st))) << "\n";  // rows per lane per tile of fg_probe
     src << device_header("device_hash.h") << device_header("device_agg.h") << gm.consts.str() << gr.consts.str();
-    src << "#define FA_LDS_BYTES " << std::max(64, max_groups_ * per_group_bytes_) << "\n";
+    if (getenv("TGPU_FA_DEBUG_SKIP")) src << "#define FA_DEBUG_SKIP " << atoi(getenv("TGPU_FA_DEBUG_SKIP")) << "\n";   // kernel study only
+    src << "#define FA_LDS_BYTES " << std::max(2048, max_groups_ * per_group_bytes_) << "\n";   // >= the fold's exchange area (device_agg.h)
     // FA_NO_NULLS 1: the specialisation for pages without null vectors (null loads and per-aggregate count slots fold away)
     src << "#ifndef FA_NO_NULLS\n#define FA_NO_NULLS 0\n#endif\n";
     src << "struct TgRow {\n";
@@ -2582,7 +2591,8 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     JitModule *module = module_for(in, gids8 != nullptr);
     BufferPtr ord_keys, ord_rows;
     const bool ordered = accs.begin_ordered(gids, in.n, groups, max_groups_, ord_keys, ord_rows);
-    if (!ordered) accs.reserve(groups);
+    // (low-cardinality launches: the states of every group the folded partials have room for, see GroupedAccumulators::fold_scratch)
+    if (!ordered) accs.reserve(groups <= max_groups_ ? max_groups_ : groups);
     FaArgsHost F{};
     fill_fp_cols(F.fp, in);
     BufferPtr err = ctx->alloc(8);
@@ -2630,6 +2640,11 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     // the LDS array is static (sized for max_groups_), so one block per CU is resident; the 8-stripe software pipeline keeps
     // ~8 x row-bytes in flight per lane, which is what saturates HBM at 4 waves per CU
     const int64_t blocks = std::min<int64_t>(F.tiles, (int64_t)ctx->cu_count() * (F.lowcard ? 1 : 4));
+    if (F.lowcard) {
+        const GroupedAccumulators::FoldScratch fs = accs.fold_scratch(blocks, max_groups_);
+        F.fold.partials = fs.partials;
+        F.fold.stride = fs.stride;
+    }
     {
         ProfileScope ps(ctx, F.lowcard ? "fused_project_accumulate_lowcard" : "fused_project_accumulate");
         launch_args(module->fn(F.lowcard ? "fa_accumulate_lowcard" : "fa_accumulate_global"), (int)blocks, F, ctx->stream());

@@ -1066,9 +1066,10 @@ public:
     void add_input(const tgpu_page *page) override
     {
         begin_input();
-        DevicePage in = ingest_page(ctx_, page);
-        if (in.n == 0) return;
         const bool fused_ok = fused_->supported() && gbh_ && !fused_->key_inputs().empty() && cfg_.step != TGPU_STEP_FINAL && getenv("TGPU_DISABLE_FUSION") == nullptr;
+        // the fused kernels address VARCHAR bytes through the offsets alone: the byte ranges of borrowed device columns stay unread
+        DevicePage in = ingest_page(ctx_, page, /*resolve_varchar=*/!fused_ok);
+        if (in.n == 0) return;
         if (!fused_ok) {
             // unfused composition: FilterAndProject, then the aggregation
             DevicePage mid;
