@@ -346,6 +346,12 @@ void tgpu_operator_factory_destroy(tgpu_operator_factory *factory);
 
 /* ---- Operator (M/operator/Operator.java:20-102).  Boolean queries return 1/0, or <0 on error. ---- */
 int32_t tgpu_operator_needs_input(tgpu_operator *op);
+/* Lifetime of `page`: TGPU_HOST arrays have been consumed when the call returns (Java heap arrays are only pinned for the JNI call).
+ * TGPU_DEVICE arrays are read by kernels on the context's stream, some of which may still be queued when the call returns (the
+ * aggregation's accumulate launch is enqueued behind its group-by probe and not waited for): the caller may overwrite or free them in
+ * STREAM ORDER -- by work on that stream, hipFreeAsync on it, hipFree (which synchronises), or after tgpu_context_synchronize -- the
+ * rule of any stream-ordered device buffer.  An operator that keeps rows beyond the call copies them or shares the owner
+ * (tgpu_operator_add_input_output_page). */
 int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page);
 /* *out = NULL when no page is available (Operator.getOutput() == null); returns TGPU_WOULD_BLOCK instead of TGPU_OK when, in addition,
  * the operator is blocked (a probe waiting for its build side, the outer operator waiting for the probes): the driver should park the

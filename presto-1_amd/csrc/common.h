@@ -120,6 +120,14 @@ public:
     void *pinned_alloc(size_t bytes);    // hipHostMalloc for the embedding host (tgpu_pinned_alloc): e.g. the exchange client's receive buffers
     void pinned_free(void *p);
     void download(void *dst, const void *src, size_t bytes);        // D2H + sync
+    // A small read-back the caller keeps enqueueing work behind: begin_read copies `bytes` (<= 256) into a pinned slot and marks the
+    // stream; finish_read waits for THAT point only (the kernels enqueued after begin_read keep running) and copies the bytes out.
+    struct AsyncRead {
+        int slot = -1;
+        size_t bytes = 0;
+    };
+    AsyncRead begin_read(const void *src, size_t bytes);
+    void finish_read(const AsyncRead &r, void *dst);
     // many small D2H copies with ONE synchronisation: staged through pinned memory, then scattered to the destinations
     struct Transfer { void *dst; const void *src; size_t bytes; };
     void download_batch(const std::vector<Transfer> &transfers);
@@ -171,6 +179,10 @@ private:
     size_t in_use_ = 0, cached_ = 0;
     void *pinned_ = nullptr;
     size_t pinned_bytes_ = 0;
+    static constexpr int kReadSlots = 4;
+    void *read_slots_ = nullptr;          // kReadSlots x 256 B pinned
+    void *read_events_[kReadSlots] = {};  // hipEvent_t
+    int next_read_slot_ = 0;
     bool profiling_ = false;
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending_;

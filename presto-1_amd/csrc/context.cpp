@@ -55,6 +55,11 @@ Context::~Context()
     if (copy_stream_) hipStreamDestroy(copy_stream_);
     if (pinned_) hipHostFree(pinned_);
     if (wait_event_) hipEventDestroy(wait_event_);
+    if (read_slots_) {
+        hipHostFree(read_slots_);
+        for (void *e : read_events_)
+            if (e) hipEventDestroy(static_cast<hipEvent_t>(e));
+    }
 }
 
 void Context::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
@@ -289,6 +294,43 @@ void Context::download(void *dst, const void *src, size_t bytes)
     }
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
+{
+    TG_CHECK_STATE(bytes > 0 && bytes <= 256, "asynchronous read-backs are at most 256 bytes");
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
+    readbacks_++;
+    if (!read_slots_) {
+        HIP_CHECK(hipHostMalloc(&read_slots_, (size_t)kReadSlots * 256, hipHostMallocDefault));
+        for (int i = 0; i < kReadSlots; i++) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            read_events_[i] = e;
+        }
+    }
+    AsyncRead r;
+    r.slot = next_read_slot_;
+    r.bytes = bytes;
+    next_read_slot_ = (next_read_slot_ + 1) % kReadSlots;   // (a slot is reused kReadSlots reads later: every caller finishes its read within its call)
+    HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * 256, src, bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(read_events_[r.slot]), stream_));
+    return r;
+}
+
+void Context::finish_read(const AsyncRead &r, void *dst)
+{
+    TG_CHECK_STATE(r.slot >= 0 && r.slot < kReadSlots, "no read-back in flight");
+    hipEvent_t e = static_cast<hipEvent_t>(read_events_[r.slot]);
+    static const bool blocking = getenv("TGPU_BLOCKING_WAIT") != nullptr;
+    if (blocking) HIP_CHECK(hipEventSynchronize(e));
+    else
+        for (;;) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIP_CHECK(q);
+        }
+    memcpy(dst, static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * 256, r.bytes);
 }
 
 void Context::download_batch(const std::vector<Transfer> &transfers)

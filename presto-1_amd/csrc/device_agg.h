@@ -5,6 +5,7 @@
 #define TG_LIMBS 68          // 32-bit limbs (held in int64 words) covering 2^-1074 .. 2^2101
 #define TG_AGG_BLOCK 256
 #define TG_MAX_AGGS 16
+#define TG_FOLD_ILP 4
 
 // aggregate function codes = tgpu_agg_function
 #define TG_AGG_COUNT_ALL 1
@@ -176,29 +177,48 @@ __device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, co
     unsigned long long *mine = fs.partials + (size_t)blockIdx.x * fs.stride * 3;
     for (int base = 0; base < items; base += 64 * (TG_AGG_BLOCK / 64)) {
         unsigned long long kc = 0, k0 = 0, k1 = 0;   // lane j: item base + wave + 4 j
-        for (int j = 0; j < 64; j++) {
-            const int it = base + wave + j * (TG_AGG_BLOCK / 64);
-            if (it >= items) break;
-            const int g = it / p.n_aggs, k = it - g * p.n_aggs;
-            const unsigned int *cnt = tg_lc_cnt(lds, p, g) + (p.count_from_rows[k] ? p.rows_slot : p.cnt_slot[k]) * TG_AGG_BLOCK;
-            const int w = p.wide_slot[k];
-            const bool bigint = st[k].function == TG_AGG_SUM_BIGINT;
-            unsigned long long c = 0, a0 = 0, a1 = 0;
+        // TG_FOLD_ILP items at a time: their shuffle / double-double chains are independent and interleave (one chain at a time
+        // leaves the wave -- the only one on its SIMD -- waiting out every latency)
+        for (int j0 = 0; j0 < 64; j0 += TG_FOLD_ILP) {
+            if (base + wave + j0 * (TG_AGG_BLOCK / 64) >= items) break;
+            unsigned long long c[TG_FOLD_ILP], a0[TG_FOLD_ILP], a1[TG_FOLD_ILP];
+            bool bigint[TG_FOLD_ILP];
 #pragma unroll
-            for (int q = 0; q < TG_AGG_BLOCK / 64; q++) {
-                c += cnt[lane + 64 * q];
-                if (w >= 0) {
-                    const unsigned long long b0 = ((const unsigned long long *)tg_lc_hi(lds, p, g))[w * TG_AGG_BLOCK + lane + 64 * q];
-                    const unsigned long long b1 = ((const unsigned long long *)tg_lc_lo(lds, p, g))[w * TG_AGG_BLOCK + lane + 64 * q];
-                    if (q == 0) { a0 = b0; a1 = b1; }
-                    else tg_fold_pair(bigint, a0, a1, b0, b1);
+            for (int u = 0; u < TG_FOLD_ILP; u++) {
+                int it = base + wave + (j0 + u) * (TG_AGG_BLOCK / 64);
+                const bool live = it < items;
+                it = live ? it : 0;
+                const int g = it / p.n_aggs, k = it - g * p.n_aggs;
+                const unsigned int *cnt = tg_lc_cnt(lds, p, g) + (p.count_from_rows[k] ? p.rows_slot : p.cnt_slot[k]) * TG_AGG_BLOCK;
+                const int w = p.wide_slot[k];
+                bigint[u] = st[k].function == TG_AGG_SUM_BIGINT;
+                c[u] = a0[u] = a1[u] = 0;
+#pragma unroll
+                for (int q = 0; q < TG_AGG_BLOCK / 64; q++) {
+                    c[u] += cnt[lane + 64 * q];
+                    if (w >= 0) {
+                        const unsigned long long b0 = ((const unsigned long long *)tg_lc_hi(lds, p, g))[w * TG_AGG_BLOCK + lane + 64 * q];
+                        const unsigned long long b1 = ((const unsigned long long *)tg_lc_lo(lds, p, g))[w * TG_AGG_BLOCK + lane + 64 * q];
+                        if (q == 0) { a0[u] = b0; a1[u] = b1; }
+                        else tg_fold_pair(bigint[u], a0[u], a1[u], b0, b1);
+                    }
+                }
+                if (!live) c[u] = a0[u] = a1[u] = 0;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+                for (int u = 0; u < TG_FOLD_ILP; u++) {
+                    c[u] += __shfl_down(c[u], d, 64);
+                    const unsigned long long b0 = __shfl_down(a0[u], d, 64), b1 = __shfl_down(a1[u], d, 64);
+                    tg_fold_pair(bigint[u], a0[u], a1[u], b0, b1);
                 }
             }
-            tg_fold_wave(bigint, c, a0, a1);
-            c = __shfl(c, 0, 64);
-            a0 = __shfl(a0, 0, 64);
-            a1 = __shfl(a1, 0, 64);
-            if (lane == j) { kc = c; k0 = a0; k1 = a1; }
+#pragma unroll
+            for (int u = 0; u < TG_FOLD_ILP; u++) {
+                const unsigned long long tc = __shfl(c[u], 0, 64), t0 = __shfl(a0[u], 0, 64), t1 = __shfl(a1[u], 0, 64);
+                if (lane == j0 + u) { kc = tc; k0 = t0; k1 = t1; }
+            }
         }
         const int it = base + wave + lane * (TG_AGG_BLOCK / 64);
         if (it < items && kc != 0) {

@@ -24,9 +24,15 @@ struct GbhProbeLaunch {
     uint8_t *out8 = nullptr;
 };
 using GbhProbeFn = std::function<void(const GbhProbeLaunch &)>;
+// Speculation hook of the compact mode: called between the probe launch of a sub-batch that covers the WHOLE page and the wait for its
+// counters, with the device address of those counters.  The caller enqueues the page's consumer there (the fused accumulate kernel),
+// gated on the counters being clean ([0] == 0 no row met a new group, [2] == 0 no table overflow, [7] == ~0 no expression error): in the
+// steady state of low-cardinality inputs the wait for the counters then overlaps the consumer instead of idling the device.
+using GbhSpeculateFn = std::function<void(const unsigned long long *counters)>;
 
 class GroupByHashGpu {
 public:
+    static constexpr int kCounterSets = 64;   // counter sets per initialising launch (fresh_counters)
     GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool has_input_hash, int32_t expected_size);
 
     // group id (int32, device) of each of the n rows; new keys get ids in first-seen order.
@@ -37,8 +43,11 @@ public:
     // out_gids8 (optional, with an external probe kernel): while the table holds fewer than 250 groups the ids are delivered as one
     // byte per row (group id + 1, 0 = excluded row) instead of four -- on TPCH Q1's shape that is a tenth of the whole
     // pipeline's HBM traffic.  Returns true when out_gids8 holds the page's ids (out_gids untouched), false when out_gids does.
+    // speculate / *speculated (optional, compact mode): see GbhSpeculateFn; *speculated = the hook ran AND the counters came back clean
+    // (what it enqueued took effect); false = it did not run, or ran and -- by its gate -- did nothing.
     bool get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
-                       const uint8_t *row_mask = nullptr, bool inline_hash = false, const GbhProbeFn *probe = nullptr, uint8_t *out_gids8 = nullptr);
+                       const uint8_t *row_mask = nullptr, bool inline_hash = false, const GbhProbeFn *probe = nullptr, uint8_t *out_gids8 = nullptr,
+                       const GbhSpeculateFn *speculate = nullptr, bool *speculated = nullptr);
     // lookup only (GroupByHash.contains): out[i] = group id or -1
     void lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids);
 
@@ -85,7 +94,9 @@ private:
     int64_t sub_batch_;
     int64_t last_new_groups_ = 0;   // new groups of the previous sub-batch (decides whether the next one ranks eagerly)
     int64_t next_sub_ = 0;   // size of the next sub-batch (ramps up, see get_group_ids)
-    BufferPtr counters_;  // [0] pending rows, [1] new groups (scan total), [2] error flag, [3] scratch total
+    BufferPtr counters_;  // ring of counter sets: [0] pending rows, [1] new groups (scan total), [2] error flag, [3] scratch total, [7] expression error
+    int next_counter_set_ = 0;
+    unsigned long long *fresh_counters();
 };
 
 }  // namespace tgpu

@@ -233,7 +233,7 @@ GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool ha
     // first sub-batch: small when few groups are expected (see get_group_ids), a full one when the planner expects many
     const char *first = getenv("TGPU_GBH_FIRST_SUB");
     next_sub_ = std::min<int64_t>(sub_batch_, std::max<int64_t>(first ? atoll(first) : (1ll << 14), (int64_t)expected_size * 16));
-    counters_ = ctx_->alloc_zero(8 * 8);
+    counters_ = ctx_->alloc_zero((size_t)GroupByHashGpu::kCounterSets * 8 * 8);
 }
 
 int64_t GroupByHashGpu::estimated_size() const
@@ -341,10 +341,22 @@ KeyCols GroupByHashGpu::store_view() const
     return k;
 }
 
-// one launch instead of two memsets: the eight counter words of a sub-batch, the last one being an error word whose "none" is ~0
+// the eight counter words of a sub-batch, the last one being an error word whose "none" is ~0: a ring of kCounterSets sets is
+// initialised by ONE launch and handed out set by set (a launch per sub-batch was a tenth of a 2^20-row page's device time)
 static __global__ void init_counters_kernel(unsigned long long *ctr)
 {
-    if (threadIdx.x < 8) ctr[threadIdx.x] = threadIdx.x == 7 ? ~0ull : 0ull;
+    for (int i = threadIdx.x; i < GroupByHashGpu::kCounterSets * 8; i += blockDim.x) ctr[i] = (i & 7) == 7 ? ~0ull : 0ull;
+}
+
+unsigned long long *GroupByHashGpu::fresh_counters()
+{
+    if (next_counter_set_ % kCounterSets == 0) {
+        // every earlier user of the ring is in front of this launch on the stream
+        init_counters_kernel<<<1, 256, 0, ctx_->stream()>>>(counters_->as<unsigned long long>());
+        check_launch("init_counters");
+        next_counter_set_ = 0;
+    }
+    return counters_->as<unsigned long long>() + 8 * (next_counter_set_++);
 }
 
 bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hashes, const uint8_t *row_mask, int64_t row0, int64_t n, int32_t *out,
@@ -354,8 +366,7 @@ bool GroupByHashGpu::process_sub_batch(const KeyCols &batch, const int64_t *hash
     // room for every row of a normal sub-batch to be a new group; larger (optimistic) sub-batches rely on overflow detection
     ensure_table(groups_ + std::min<int64_t>(n, sub_batch_));
     ensure_store(groups_ > 0 ? groups_ : 1);  // the store view must be addressable for OLD slots
-    unsigned long long *ctr = counters_->as<unsigned long long>();
-    init_counters_kernel<<<1, 64, 0, ctx_->stream()>>>(ctr);   // [0..6] = 0, [7] (expression-error word of a fused probe kernel) = ~0
+    unsigned long long *ctr = fresh_counters();   // [0..6] = 0, [7] (expression-error word of a fused probe kernel) = ~0
     const int g = grid_for(ctx_, n);
     if (probe) {
         GbhProbeLaunch l{row0, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out, ctr};
@@ -450,8 +461,10 @@ void GroupByHashGpu::rebuild_table(int64_t min_capacity)
 }
 
 bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids,
-                                   const uint8_t *row_mask, bool inline_hash, const GbhProbeFn *probe, uint8_t *out_gids8)
+                                   const uint8_t *row_mask, bool inline_hash, const GbhProbeFn *probe, uint8_t *out_gids8, const GbhSpeculateFn *speculate,
+                                   bool *speculated)
 {
+    if (speculated) *speculated = false;
     TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
     for (size_t i = 0; i < keys.size(); i++) TG_CHECK_ARG(keys[i]->type == types_[i], "group-by key channel type mismatch");
     if (n <= 0) return false;
@@ -502,13 +515,16 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             // sub-batch are only counted
             ensure_table(groups_ + std::min<int64_t>(len, sub_batch_));
             ensure_store(groups_ > 0 ? groups_ : 1);
-            unsigned long long *ctr = counters_->as<unsigned long long>();
-            init_counters_kernel<<<1, 64, 0, ctx_->stream()>>>(ctr);
+            unsigned long long *ctr = fresh_counters();
             GbhProbeLaunch l{start, len, words_->as<uint64_t>(), (uint64_t)capacity_ - 1, store_view(), (int32_t)std::min<int64_t>(groups_, 1 << 20), nullptr, ctr,
                              out_gids8 + start};
             (*probe)(l);
             unsigned long long host_ctr[8];
-            ctx_->download(host_ctr, ctr, sizeof(host_ctr));
+            const Context::AsyncRead rd = ctx_->begin_read(ctr, sizeof(host_ctr));
+            const bool hooked = speculate != nullptr && start == 0 && len == n;
+            if (hooked) (*speculate)(ctr);   // the page's consumer, gated on these counters: runs while the host waits for them
+            ctx_->finish_read(rd, host_ctr);
+            if (hooked && speculated) *speculated = host_ctr[0] == 0 && host_ctr[2] == 0 && host_ctr[7] == ~0ull;
             raise_expression_error(host_ctr[7]);
             ok = host_ctr[2] == 0;
             if (ok && host_ctr[0] != 0) {
@@ -563,7 +579,7 @@ void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const
     BufferPtr dbatch = device_keys(key_cols_of(keys)), dstore = device_keys(store_view());
     gbh_probe_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(dbatch->as<KeyCols>(), hashes, nullptr, n, words_->as<uint64_t>(), (uint64_t)capacity_ - 1,
                                                                               dstore->as<KeyCols>(), (int32_t)std::min<int64_t>(groups_, 1 << 20), out_gids,
-                                                                              counters_->as<unsigned long long>());
+                                                                              fresh_counters());
     check_launch("gbh_lookup");
 }
 

@@ -1662,7 +1662,10 @@ struct FaArgs {
   const int* ord_rows;            //               and their row numbers
   const unsigned char* gids8;     // compact group ids (id + 1, 0 = filtered row) instead of gids
   TgFoldScratch fold;             // low-cardinality launches: the workgroups' folded partials
+  const unsigned long long* gate; // speculative launch behind a group-by probe: its counters; anything but clean = do nothing
 };
+// clean = no row met a new group ([0]), no table overflow ([2]), no expression error ([7] == ~0): groupby.h GbhSpeculateFn
+#define FA_GATE_CLOSED(F) ((F).gate && (((F).gate[0] | (F).gate[2] | ~(F).gate[7]) != 0ULL))
 // group id of a row: compact byte ids when the group-by table delivered them, else int32 ids, else the single global group
 // (FA_GID8 is a compile-time variant: a run-time choice would put branches around the pipelined loads)
 #ifndef FA_GID8
@@ -1734,6 +1737,7 @@ template <bool LC> __device__ inline void fa_accumulate_body(const FaArgs& F, un
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_lowcard(FaArgs F) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[FA_LDS_BYTES];
+  if (FA_GATE_CLOSED(F)) return;
 #ifndef FA_DEBUG_SKIP
 #define FA_DEBUG_SKIP 0
 #endif
@@ -1743,11 +1747,13 @@ extern "C" __global__ void __launch_bounds__(256) fa_accumulate_lowcard(FaArgs F
 }
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F) {
+  if (FA_GATE_CLOSED(F)) return;
   fa_accumulate_body<false>(F, (unsigned char*)0);
 }
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_ordered(FaArgs F) {
   const FpArgs& A = F.fp;
+  if (FA_GATE_CLOSED(F)) return;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < A.n; i += (long long)gridDim.x * 256) {
     const unsigned int key = F.ord_keys[i];
     if (key == 0 || (i > 0 && F.ord_keys[i - 1] == key)) continue;
@@ -1789,6 +1795,7 @@ struct FaArgsHost {
         unsigned long long *partials;
         int32_t stride;
     } fold;
+    const unsigned long long *gate;
 };
 
 }  // namespace
@@ -2576,7 +2583,8 @@ static __global__ void __launch_bounds__(256) widen_gids_kernel(const unsigned c
     for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < n; r += (long long)gridDim.x * 256) gids[r] = (int)gids8[r] - 1;
 }
 
-void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs)
+void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs,
+                             const unsigned long long *gate)
 {
     TG_CHECK_STATE(supported_, "fused aggregation not supported for this configuration");
     if (in.n == 0) return;
@@ -2600,6 +2608,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     F.fp.error = err->as<unsigned long long>();
     F.gids = gids;
     F.gids8 = gids8;
+    F.gate = gate;
     for (size_t k = 0; k < aggs_.size(); k++) {
         GroupedAccumulators::DeviceState d = accs.device_state((int)k);
         F.st[k].function = d.function;

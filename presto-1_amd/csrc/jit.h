@@ -180,7 +180,11 @@ public:
     void filter_mask(Context *ctx, const DevicePage &in, uint8_t *mask_out);
     // state[gid[row]] (+)= aggregate inputs of every row with gid >= 0
     // gids8 (optional, instead of gids): compact ids, one byte per row = group id + 1 (GroupByHashGpu::get_group_ids)
-    void accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs);
+    // gate (optional): device counters of the group-by probe launch in front (GbhSpeculateFn): the kernels do nothing unless they are clean
+    void accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs,
+                    const unsigned long long *gate = nullptr);
+    // the accumulate launch can be enqueued speculatively behind a probe launch (no error read-back of its own, lane-private LDS states)
+    bool can_speculate(int64_t groups) const { return supported_ && !accumulate_can_raise_ && groups > 0 && groups <= max_groups_; }
 
 private:
     void generate();

@@ -1083,7 +1083,17 @@ public:
         // few groups: the ids travel as one byte per row between the two fused kernels (int32 only if the table outgrows a byte)
         BufferPtr gids = ctx_->alloc((size_t)in.n * 4), gids8 = ctx_->alloc((size_t)in.n);
         GbhProbeFn probe = [&](const GbhProbeLaunch &l) { fused_->probe_groups(ctx_, in, l); };
-        const bool compact = gbh_->get_group_ids(keys, nullptr, in.n, gids->as<int32_t>(), nullptr, /*inline_hash=*/true, &probe, gids8->as<uint8_t>());
+        // steady state (every group of the page exists already, few groups): the accumulate launch goes out behind the probe launch,
+        // gated on the probe's counters, and runs while the host waits for them (groupby.h GbhSpeculateFn)
+        const int64_t groups_before = gbh_->group_count();
+        const bool may_speculate = fused_->can_speculate(groups_before) && !accs_->force_ordered() && getenv("TGPU_DISABLE_SPECULATION") == nullptr;
+        GbhSpeculateFn speculate = [&](const unsigned long long *counters) {
+            fused_->accumulate(ctx_, in, nullptr, gids8->as<uint8_t>(), groups_before, *accs_, counters);
+        };
+        bool speculated = false;
+        const bool compact = gbh_->get_group_ids(keys, nullptr, in.n, gids->as<int32_t>(), nullptr, /*inline_hash=*/true, &probe, gids8->as<uint8_t>(),
+                                                 may_speculate ? &speculate : nullptr, &speculated);
+        if (speculated) return;
         fused_->accumulate(ctx_, in, compact ? nullptr : gids->as<int32_t>(), compact ? gids8->as<uint8_t>() : nullptr, gbh_->group_count(), *accs_);
     }
 

@@ -2133,3 +2133,57 @@ def test_scan_filter_project_lazy_blocks(pkg, ctx):
     loads.clear()
     rows, st = run(pkg.between(f(0, B), 25, 74), [f(1, B) * 2], [pkg.Block(B, a), lazy("projection", b)])
     assert [r[0] for r in rows] == (b[25:75] * 2).tolist() and loads == ["projection"]
+
+
+@pytest.mark.parametrize("speculation", [True, False])
+def test_fused_aggregation_speculative_accumulate_falls_back_on_new_groups_and_errors(pkg, oracle, monkeypatch, speculation):
+    """steady-state pages of the fused aggregation enqueue their accumulate launch behind the group probe, gated on the probe's counters
+    (groupby.h GbhSpeculateFn).  A page that brings a NEW group closes the gate: the speculative launch does nothing and the page is
+    accumulated after the insert protocol -- counts and exact sums equal the oracle's, with and without speculation; an expression
+    error of the fused filter on a speculated page is raised as on any other."""
+    if not speculation:
+        monkeypatch.setenv("TGPU_DISABLE_SPECULATION", "1")
+    rng = np.random.default_rng(61)
+    n = 40_000
+    T = [pkg.BIGINT, pkg.DOUBLE, pkg.BIGINT]
+    f, c = pkg.field, pkg.constant
+
+    def make(keys):
+        return pkg.Page(pkg.Block(pkg.BIGINT, rng.choice(np.array(keys, dtype=np.int64), n)), pkg.Block(pkg.DOUBLE, rng.uniform(-1e6, 1e6, n)),
+                        pkg.Block(pkg.BIGINT, rng.integers(1, 100, n)))
+    pages = [make([7, 9]), make([7, 9]), make([9, 7]), make([7, 9, 11]), make([11, 7, 9]), make([7])]
+    filt = (c(1000, pkg.BIGINT) / f(2, pkg.BIGINT)) >= 11          # selects divisor <= 90; divisor 0 raises DIVISION_BY_ZERO
+    projs = [f(0, pkg.BIGINT), f(1, pkg.DOUBLE) * c(0.5, pkg.DOUBLE)]
+    aggs = [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, -1), (pkg.AVG_DOUBLE, 1)]
+    ctx = pkg.Context(0)
+    ctx.profile_enable(True)
+    fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.BIGINT], [0], aggs)
+    rows = [r for p in pkg.to_pages(fac.createOperator(), pages) for r in p.rows()]
+    prof = ctx.profile()
+    # one accumulate launch per page, plus the gated one of the page that brought group 11 (page 0 meets an empty table: no speculation)
+    assert prof["fused_project_accumulate_lowcard"]["count"] == len(pages) + (1 if speculation else 0)
+    keys = np.concatenate([np.asarray(p.getBlock(0).to_list(), dtype=np.int64) for p in pages])
+    vals = np.concatenate([np.asarray(p.getBlock(1).to_list()) for p in pages]) * 0.5
+    div = np.concatenate([np.asarray(p.getBlock(2).to_list(), dtype=np.int64) for p in pages])
+    sel = (1000 // div) >= 11
+    og = oracle.BigintGroupByHash(100)
+    gids = og.get_group_ids(ocol(oracle, pkg.Block(pkg.BIGINT, keys[sel])))
+    assert [r[0] for r in rows] == [int(k) for k in og.values()[0]]      # first-seen order
+    assert sorted(r[0] for r in rows) == [7, 9, 11]
+    cnt, total = oracle.agg_double_sum_exact(gids, vals[sel], og.group_count)
+    assert [r[2] for r in rows] == list(cnt)
+    assert ulp_diff(np.array([r[1] for r in rows]), total).max() == 0
+    assert ulp_diff(np.array([r[3] for r in rows]), total / cnt).max() == 0
+    # the error path: a steady-state (speculated) page whose filter divides by zero on one row
+    op = fac.createOperator()
+    op.addInput(pages[0])
+    op.addInput(pages[1])
+    bad = make([7, 9])
+    bad_div = np.asarray(bad.getBlock(2).to_list(), dtype=np.int64)
+    bad_div[n // 2] = 0
+    bad = pkg.Page(bad.getBlock(0), bad.getBlock(1), pkg.Block(pkg.BIGINT, bad_div))
+    with pytest.raises(pkg.TgpuError) as e:
+        op.addInput(bad)
+    assert e.value.code == -7
+    op.close()
+    ctx.close()
