@@ -2051,8 +2051,8 @@ void FusedAggGpu::generate()
     src << kPrelude;
     if (const char *exp = getenv("TGPU_FG_EXP")) src << "#define FG_EXP_" << exp << " 1\n";  // kernel-study switch, never set in production
     if (const char *st = getenv("TGPU_FG_STRIPES")) src << "#define FG_STRIPES " << std::max(1, std::min(16, atoi(st))) << "\n";  // rows per lane per tile of fg_probe
-    src << device_header("device_hash.h") << device_header("device_agg.h") << gm.consts.str() << gr.consts.str();
     if (getenv("TGPU_FA_DEBUG_SKIP")) src << "#define FA_DEBUG_SKIP " << atoi(getenv("TGPU_FA_DEBUG_SKIP")) << "\n";   // kernel study only
+    src << device_header("device_hash.h") << device_header("device_agg.h") << gm.consts.str() << gr.consts.str();
     src << "#define FA_LDS_BYTES " << std::max(2048, max_groups_ * per_group_bytes_) << "\n";   // >= the fold's exchange area (device_agg.h)
     // FA_NO_NULLS 1: the specialisation for pages without null vectors (null loads and per-aggregate count slots fold away)
     src << "#ifndef FA_NO_NULLS\n#define FA_NO_NULLS 0\n#endif\n";
