@@ -272,9 +272,11 @@ class Bench:
         obuild.close()
         aop.close()
 
-    def q3_paged(self, steps, warmup, page_rows):
+    def q3_paged(self, steps, warmup, page_rows, merge_mb=None):
         """Q3 with every table fed as pages of `page_rows` rows (the engine hands pages, not tables): each probe page's join output goes
-        straight into the next hash build / the aggregation as a library-owned page (buffers shared, nothing copied)"""
+        straight into the next hash build / the aggregation as a library-owned page (buffers shared, nothing copied); with `merge_mb`
+        the (small: 0.5 - 10 % of the probe page) join output pages are coalesced by a MergePagesOperator in front of the aggregation,
+        the reference's remedy for small pages (M/operator/project/MergePages.java)"""
         p, ctx, f, t = self.pkg, self.ctx, self.q3_fac, self.q3
         B, D, DT, V, I = p.BIGINT, p.DOUBLE, p.DATE, p.VARCHAR, p.INTEGER
         import ctypes as C
@@ -321,7 +323,29 @@ class Bench:
             lj = p.FilterProjectLookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, *pp["q3_lineitem"], [0], probe_output_channels=[0, 1])
             agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
             ljoin, aop = lj.createOperator(), agg.createOperator()
-            st["lineitem_join_rows"] = pump(ljoin, "lineitem", aop)
+            if merge_mb:
+                class Coalesced:   # MergePages in front of the aggregation
+                    def __init__(self, ctx):
+                        self.m = p.MergePagesOperatorFactory(ctx, 15, [B, D, DT, I], merge_mb << 20, 1 << 22, (merge_mb << 20) * 2).createOperator()
+
+                    def drain(self):
+                        while True:
+                            o = self.m.getOutput()
+                            if o is None:
+                                return
+                            aop.addInput(o)
+                            o.release()
+
+                    def addInput(self, page):
+                        self.m.addInput(page)
+                        self.drain()
+                sink = Coalesced(ctx)
+                st["lineitem_join_rows"] = pump(ljoin, "lineitem", sink)
+                sink.m.finish()
+                sink.drain()
+                sink.m.close()
+            else:
+                st["lineitem_join_rows"] = pump(ljoin, "lineitem", aop)
             outs = self.finish(aop)
             st["groups"] = sum(o.position_count for o in outs)
             for o in (self.q3_result or []):
@@ -337,7 +361,8 @@ class Bench:
         probe_rows = self.q3_stats["lineitem_probe_rows"]
         self.q3_stats = keep
         n_pages = len(cust) + len(orders) + len(lineitem)
-        return {"page_rows": page_rows, "pages": {"customer": len(cust), "orders": len(orders), "lineitem": len(lineitem)}, "ms_per_step": step_s * 1e3,
+        return {"page_rows": page_rows, "pages": {"customer": len(cust), "orders": len(orders), "lineitem": len(lineitem)}, "merge_pages_before_aggregation_mb": merge_mb,
+                "ms_per_step": step_s * 1e3,
                 "probe_rows_per_sec": probe_rows / step_s, "readbacks_per_page": self.last_readbacks_per_step / n_pages,
                 "kernel_launches_per_page": sum(v["count"] for v in prof.values()) / steps / n_pages,
                 "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}, "ok": chk["ok"]}
@@ -1184,7 +1209,8 @@ def main():
     extra["q3_kernel_launch_min_max_ms"] = {k: [v["min_ms"], v["max_ms"], v["count"]] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
     if b.world == 1 and "paged" in only:
         # the engine hands over pages, not tables: the same three-table pipeline fed as 2^20- and 2^24-row pages
-        extra["q3_paged"] = {"direct_2^20": b.q3_paged(args.steps, args.warmup, 1 << 20), "direct_2^24": b.q3_paged(args.steps, args.warmup, 1 << 24)}
+        extra["q3_paged"] = {"direct_2^20": b.q3_paged(args.steps, args.warmup, 1 << 20), "merged_2^20_16MB": b.q3_paged(args.steps, args.warmup, 1 << 20, merge_mb=16),
+                             "direct_2^24": b.q3_paged(args.steps, args.warmup, 1 << 24)}
         out["checks"]["q3_paged"] = all(v["ok"] for v in extra["q3_paged"].values())
     for o in (b.q3_result or []):
         o.release()

@@ -110,10 +110,38 @@ __global__ void __launch_bounds__(kBlock) scan_small_i64(const int64_t *__restri
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
+// one tile: sums, prefix and scan in a single launch (the per-page scans of the join's chunk counts are a few hundred elements;
+// three launches cost 11 us there, several times the kernels' work)
+__global__ void __launch_bounds__(kBlock) scan_one_tile_i32(const int32_t *__restrict__ in, int32_t *__restrict__ out, int64_t n, int64_t *total_out)
+{
+    __shared__ int64_t lds[kWaves + 1];
+    const int64_t base = (int64_t)threadIdx.x * kScanItems;
+    int32_t v[kScanItems];
+    int64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        v[i] = base + i < n ? in[base + i] : 0;
+        s += v[i];
+    }
+    int64_t total;
+    int64_t prefix = block_exclusive_scan<int64_t>(s, &total, lds);
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) {
+        if (base + i < n) out[base + i] = (int32_t)prefix;
+        prefix += v[i];
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = total;
+}
+
 void exclusive_scan_i32(Context *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total_dev)
 {
     if (n <= 0) {
         if (total_dev) HIP_CHECK(hipMemsetAsync(total_dev, 0, 8, ctx->stream()));
+        return;
+    }
+    if (n <= kScanTile) {
+        scan_one_tile_i32<<<1, kBlock, 0, ctx->stream()>>>(in, out, n, total_dev);
+        check_launch("exclusive_scan_i32");
         return;
     }
     int64_t tiles = ceil_div(n, kScanTile);
