@@ -1075,6 +1075,9 @@ struct FjArgs {
   int outer;                // bit 0: PROBE_OUTER / FULL_OUTER rows; bit 1: nobody reads the build positions (no build output channels,
                             // no outer tracking): the DIRECT layout then skips the rank and position lookups
   int chunk_shift;          // a workgroup takes 2^chunk_shift consecutive tiles at a time
+  struct { const void* values; const unsigned char* nulls; void* out_values; unsigned char* out_nulls; int width; int pad; } bcol[4];   // build-side
+  int n_bcol;               // output channels pass 2 gathers itself (fixed width)
+  int pad2;
 };
 #define FJ_STRIPES @FJ_STRIPES@
 #define FJ_TILE (FJ_STRIPES * 256)
@@ -1364,6 +1367,18 @@ extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
 #else
       if (!(J.outer & 2)) J.out_build[dst + i] = J.pair_build[src + i];
 #endif
+      if (J.n_bcol > 0) {
+        const int pos = J.out_build[dst + i];   // (written by this lane just above)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (k >= J.n_bcol) break;
+          const bool nl = pos < 0 || (J.bcol[k].nulls && J.bcol[k].nulls[pos]);
+          if (J.bcol[k].out_nulls) J.bcol[k].out_nulls[dst + i] = nl ? 1 : 0;
+          if (J.bcol[k].width == 8) ((long long*)J.bcol[k].out_values)[dst + i] = pos < 0 ? 0LL : ((const long long*)J.bcol[k].values)[pos];
+          else if (J.bcol[k].width == 4) ((int*)J.bcol[k].out_values)[dst + i] = pos < 0 ? 0 : ((const int*)J.bcol[k].values)[pos];
+          else ((unsigned char*)J.bcol[k].out_values)[dst + i] = pos < 0 ? (unsigned char)0 : ((const unsigned char*)J.bcol[k].values)[pos];
+        }
+      }
       tg_emit_outputs(A, row, dst + i);
     }
   }
@@ -1538,7 +1553,8 @@ JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls)
 }
 
 void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions,
-                            std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count, int64_t &selected_rows)
+                            std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count, int64_t &selected_rows,
+                            const std::vector<DeviceColumn> *build_cols, std::vector<DeviceColumn> *build_out)
 {
     TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
@@ -1637,6 +1653,29 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
         J.fp.out_values[i] = c.values_buf->ptr();
         J.fp.out_nulls[i] = null_free ? nullptr : c.nulls_buf->as<uint8_t>();
         probe_out.push_back(c);
+    }
+    J.n_bcol = 0;
+    if (build_cols && build_out && need_build_positions) {
+        TG_CHECK_ARG((int)build_cols->size() <= kFjMaxBuildCols, "too many build channels for the fused gather");
+        for (const DeviceColumn &src : *build_cols) {
+            TG_CHECK_ARG(src.type != TGPU_VARCHAR, "the fused gather takes fixed-width build channels");
+            DeviceColumn c;
+            c.type = src.type;
+            c.n = count;
+            c.values_buf = ctx->alloc((size_t)count * type_width(c.type));
+            c.values = c.values_buf->ptr();
+            if (src.nulls != nullptr || outer) {
+                c.nulls_buf = ctx->alloc((size_t)count);
+                c.nulls = c.nulls_buf->as<uint8_t>();
+            }
+            FjArgs::BuildCol &b = J.bcol[J.n_bcol++];
+            b.values = src.values;
+            b.nulls = src.nulls;
+            b.out_values = c.values_buf->ptr();
+            b.out_nulls = c.nulls_buf ? c.nulls_buf->as<uint8_t>() : nullptr;
+            b.width = type_width(c.type);
+            build_out->push_back(c);
+        }
     }
     {
         ProfileScope ps(ctx, "fused_probe_emit");

@@ -117,7 +117,19 @@ struct FjArgs {  // must match the generated struct
     long long grid1;
     int32_t outer;
     int32_t chunk_shift;
+    // build-side output channels gathered by pass 2 itself (fixed-width columns; one launch instead of one more per channel)
+    struct BuildCol {
+        const void *values;
+        const uint8_t *nulls;
+        void *out_values;
+        uint8_t *out_nulls;
+        int32_t width;
+        int32_t pad;
+    } bcol[4];
+    int32_t n_bcol;
+    int32_t pad2;
 };
+constexpr int kFjMaxBuildCols = 4;
 
 class LookupSourceGpu;
 
@@ -134,8 +146,11 @@ public:
     // probes `in` against the lookup source's int-key table; returns the probe-side output columns + build positions
     // need_build_positions = false (no build output channels, no outer tracking): build_idx is left undefined and the DIRECT
     // layout skips its rank / position lookups
+    // build_cols / build_out (optional): the lookup source's fixed-width output channels, gathered by the emit pass itself into
+    // build_out (null vector policy of k::gather_column: only when the source has one or unmatched outer rows can occur)
     void process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, std::vector<DeviceColumn> &probe_out,
-                 BufferPtr &build_idx, int64_t &count, int64_t &selected_rows);
+                 BufferPtr &build_idx, int64_t &count, int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols = nullptr,
+                 std::vector<DeviceColumn> *build_out = nullptr);
     const std::string &source() const { return source_; }
 
 private:

@@ -69,6 +69,8 @@ public:
     // each probe row's matches newest build position first); build position -1 = PROBE_OUTER row without a match.
     void probe(const std::vector<const DeviceColumn *> &probe_keys, const int64_t *probe_hashes, int64_t n_probe, bool probe_outer,
                BufferPtr &out_probe_idx, BufferPtr &out_build_idx, int64_t &out_count);
+    // the build side's output channel out_idx as stored in the index (all build rows)
+    DeviceColumn build_column(int out_idx) const;
     DeviceColumn gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const;
     // any channel of the build side (a join filter function may read channels that are not output channels)
     DeviceColumn gather_index_channel(int channel, const int32_t *build_positions, int64_t n) const;

@@ -927,6 +927,8 @@ DeviceColumn LookupSourceGpu::gather_index_channel(int channel, const int32_t *b
     return k::gather_column(ctx_, index_->column(channel), build_positions, n, false);
 }
 
+DeviceColumn LookupSourceGpu::build_column(int out_idx) const { return index_->column(output_channels_[out_idx]); }
+
 DeviceColumn LookupSourceGpu::gather_build(int out_idx, const int32_t *build_positions, int64_t n, bool negative_is_null) const
 {
     DeviceColumn src = index_->column(output_channels_[out_idx]);

@@ -964,16 +964,27 @@ public:
             BufferPtr build_idx;
             int64_t count = 0, selected = 0;
             const bool need_positions = track || !source->output_channels().empty();
-            fused_->process(ctx_, in, *source, outer, need_positions, probe_out, build_idx, count, selected);
+            // fixed-width build output channels are gathered by the probe's emit pass itself (no launch of their own)
+            const int nb = (int)source->output_channels().size();
+            std::vector<DeviceColumn> build_cols, build_out;
+            bool gather_fused = nb > 0 && nb <= kFjMaxBuildCols;
+            for (int i = 0; i < nb && gather_fused; i++) {
+                build_cols.push_back(source->build_column(i));
+                gather_fused = build_cols.back().type != TGPU_VARCHAR && build_cols.back().values != nullptr;
+            }
+            fused_->process(ctx_, in, *source, outer, need_positions, probe_out, build_idx, count, selected, gather_fused ? &build_cols : nullptr,
+                            gather_fused ? &build_out : nullptr);
             probe_rows_ += selected;
             if (count == 0) return;
             if (track) source->mark_visited(build_idx->as<int32_t>(), count);
             DevicePage out;
             out.n = count;
             out.cols = std::move(probe_out);
-            ProfileScope ps(ctx_, "join_gather");
-            const int nb = (int)source->output_channels().size();
-            for (int i = 0; i < nb; i++) out.cols.push_back(source->gather_build(i, build_idx->as<int32_t>(), count, outer));
+            if (gather_fused) for (DeviceColumn &c : build_out) out.cols.push_back(std::move(c));
+            else {
+                ProfileScope ps(ctx_, "join_gather");
+                for (int i = 0; i < nb; i++) out.cols.push_back(source->gather_build(i, build_idx->as<int32_t>(), count, outer));
+            }
             pending_ = wrap(std::move(out));
             return;
         }
