@@ -2187,3 +2187,86 @@ def test_fused_aggregation_speculative_accumulate_falls_back_on_new_groups_and_e
     assert e.value.code == -7
     op.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("join_type", [0, 1])
+def test_fused_join_gathers_fixed_width_build_channels_in_the_emit_pass(pkg, monkeypatch, join_type):
+    """the fused probe's emit pass gathers the build side's fixed-width output channels itself (8 / 4 / 1 byte wide, with and without
+    null vectors; unmatched PROBE_OUTER rows come out null): same rows as the unfused composition with its per-channel gathers"""
+    rng = np.random.default_rng(83)
+    nb, n = 30_000, 200_000
+    bkeys = rng.permutation(90_000)[:nb].astype(np.int64)
+    build = pkg.Page(pkg.Block(pkg.BIGINT, bkeys), rand_block(pkg, rng, pkg.BIGINT, nb, 0.1), rand_block(pkg, rng, pkg.INTEGER, nb, 0.0, (-5, 5)),
+                     rand_block(pkg, rng, pkg.BOOLEAN, nb, 0.2), rand_block(pkg, rng, pkg.DOUBLE, nb, 0.0), rand_block(pkg, rng, pkg.DATE, nb, 0.3, (0, 20000)))
+    BT = [pkg.BIGINT, pkg.BIGINT, pkg.INTEGER, pkg.BOOLEAN, pkg.DOUBLE, pkg.DATE]
+    T = [pkg.BIGINT, pkg.DATE]
+    probe = pkg.Page(rand_block(pkg, rng, pkg.BIGINT, n, 0.02, (0, 90_000)), rand_block(pkg, rng, pkg.DATE, n, 0.0, (9000, 9400)))
+    f = pkg.field
+    results = {}
+    for mode in ("fused", "unfused"):
+        if mode == "unfused":
+            monkeypatch.setenv("TGPU_DISABLE_FUSION", "1")
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        for out_b in ([1, 2, 3, 4], [5, 3]):
+            bf = pkg.HashBuilderOperatorFactory(ctx, 1, BT, out_b, [0])
+            jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, T, f(1, pkg.DATE) > 9100, [f(0, pkg.BIGINT), f(1, pkg.DATE)], [0],
+                                                            probe_output_channels=[1, 0], join_type=join_type)
+            b = bf.createOperator()
+            b.addInput(build)
+            b.finish()
+            op = jf.createOperator()
+            out = pkg.to_pages(op, [probe, probe])
+            results[(mode, tuple(out_b))] = [r for p in out for r in p.rows()]
+            op.close(); b.close()
+        prof = ctx.profile()
+        assert ("fused_filter_probe" in prof) == (mode == "fused")
+        if mode == "fused":
+            assert "join_gather" not in prof and "gather" not in prof     # no gather launches of their own
+        ctx.close()
+    for out_b in ((1, 2, 3, 4), (5, 3)):
+        a, b = results[("fused", out_b)], results[("unfused", out_b)]
+        assert len(a) > 50_000 and a == b
+        if join_type == 1:
+            assert any(r[2] is None and r[3] is None for r in a)       # unmatched probe rows: build channels null
+
+
+def test_fused_aggregation_low_cardinality_fold_many_items_growing_groups(pkg, oracle):
+    """the low-cardinality accumulate keeps per-workgroup folded partials across pages and flushes them at the end (device_agg.h
+    tg_lc_fold / tg_fold_flush): 20 groups x 3 aggregates = 60 (group, aggregate) items (two fold passes), groups appearing page by
+    page, 128-bit bigint sums with carries in both directions, double sums exact"""
+    rng = np.random.default_rng(97)
+    n = 70_000
+    T = [pkg.BIGINT, pkg.BIGINT, pkg.DOUBLE]
+    f = pkg.field
+    pages, allk, allv, alld = [], [], [], []
+    for p_i in range(5):
+        k = np.repeat(rng.integers(0, 4 * (p_i + 1), n // 2), 2).astype(np.int64)   # 4, 8, ... 20 distinct keys; rows 2j, 2j + 1 share a key
+        big = rng.choice(np.array([2**62, 2**63 - 1000, 2**61], dtype=np.int64), n // 2)
+        v = np.empty(n, dtype=np.int64)
+        v[0::2] = big + rng.integers(-100, 100, n // 2)                             # +B and -B of a pair cancel: a group's total is small, but a
+        v[1::2] = -big + rng.integers(-100, 100, n // 2)                            # lane sees one sign only and runs far beyond 64 bits
+        d = rng.uniform(-1e9, 1e9, n) * 10.0 ** rng.integers(-6, 7, n)
+        pages.append(pkg.Page(pkg.Block(pkg.BIGINT, k), pkg.Block(pkg.BIGINT, v), pkg.Block(pkg.DOUBLE, d)))
+        allk.append(k); allv.append(v); alld.append(d)
+    ctx = pkg.Context(0)
+    ctx.profile_enable(True)
+    fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, None, [f(0, pkg.BIGINT), f(1, pkg.BIGINT), f(2, pkg.DOUBLE)], [pkg.BIGINT], [0],
+                                                          [(pkg.SUM_BIGINT, 1), (pkg.COUNT_ALL, -1), (pkg.SUM_DOUBLE, 2)])
+    rows = [r for p in pkg.to_pages(fac.createOperator(), pages) for r in p.rows()]
+    prof = ctx.profile()
+    assert prof["fused_project_accumulate_lowcard"]["count"] >= len(pages) and "agg_fold_flush" in prof
+    ctx.close()
+    k, v, d = np.concatenate(allk), np.concatenate(allv), np.concatenate(alld)
+    og = oracle.BigintGroupByHash(100)
+    gids = og.get_group_ids(ocol(oracle, pkg.Block(pkg.BIGINT, k)))
+    ng = og.group_count
+    assert ng == 20 and [r[0] for r in rows] == [int(x) for x in og.values()[0]]
+    isum = [0] * ng
+    for g, x in zip(gids.tolist(), v.tolist()):
+        isum[g] += x
+    cnt, dsum = oracle.agg_double_sum_exact(gids, d, ng)
+    assert [r[2] for r in rows] == list(cnt)
+    assert ulp_diff(np.array([r[3] for r in rows]), dsum).max() == 0
+    assert all(-(2**63) <= s < 2**63 for s in isum)
+    assert [r[1] for r in rows] == isum
