@@ -1112,8 +1112,8 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sf", type=float, default=100.0, help="TPCH scale factor per GPU")
     ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2,sub,paged (default at N=1: q3,q1,cfg2,sub; q3 only at N>1); paged = Q1 fed as 2^20-row pages and PCIe-inclusive Q1 (kept out of the default run so that a profiler's per-kernel averages of that run are those of the headline launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
