@@ -357,10 +357,24 @@ int32_t tgpu_operator_add_input(tgpu_operator *op, const tgpu_page *page);
  * the operator is blocked (a probe waiting for its build side, the outer operator waiting for the probes): the driver should park the
  * pipeline on tgpu_operator_is_blocked instead of spinning (Operator.java:32-35, Driver.java:367-400) */
 int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out);
-/* Operator.startMemoryRevoke() / finishMemoryRevoke() (M/operator/Operator.java:53-79): nothing is revocable (state lives in HBM and is
- * reported through tgpu_operator_memory_bytes as user memory); both return TGPU_OK at once */
+/* Operator.startMemoryRevoke() / finishMemoryRevoke() (M/operator/Operator.java:53-79).  Only a spill-enabled SINGLE / FINAL hash
+ * aggregation holds revocable memory: startMemoryRevoke moves its groups out of HBM (below) and has finished when it returns (the
+ * reference's future is done); for every other operator state is user memory (tgpu_operator_memory_bytes) and both calls do nothing. */
 int32_t tgpu_operator_start_memory_revoke(tgpu_operator *op);
 int32_t tgpu_operator_finish_memory_revoke(tgpu_operator *op);
+/* OperatorContext.getReservedRevocableBytes(): what startMemoryRevoke would free (the driver revokes while this is > 0,
+ * T/operator/OperatorAssertion.java:150-156) */
+int64_t tgpu_operator_revocable_memory_bytes(tgpu_operator *op);
+/* HashAggregationOperatorFactory(..., spillEnabled, ...) (M/operator/HashAggregationOperator.java:133-154,389-425;
+ * M/operator/aggregation/builder/SpillableHashAggregationBuilder.java:47-351), for operators created afterwards, SINGLE and FINAL steps:
+ * startMemoryRevoke parks the builder's groups -- keys, raw hashes and the exact accumulator state -- in host memory as one run and
+ * starts an empty builder (spillToDisk :283-299); when the output is built the runs are merged through a fresh group-by table, their
+ * states added exactly (mergeFromDisk :229-240), and the groups come out in raw-hash order like the reference's merged result
+ * (M/operator/MergeHashSort.java).  Accepted by tgpu_hash_aggregation_factory_create and
+ * tgpu_filter_project_hash_aggregation_factory_create factories, TGPU_ERR_NOT_SUPPORTED otherwise. */
+int32_t tgpu_hash_aggregation_factory_set_spill_enabled(tgpu_operator_factory *factory, int32_t enabled);
+/* spills so far (DummySpillerFactory.getSpillsCount in the reference's tests) and the host bytes they hold or held */
+int32_t tgpu_operator_spill_stats(tgpu_operator *op, int64_t *spill_count, int64_t *spilled_bytes);
 int32_t tgpu_operator_finish(tgpu_operator *op);
 int32_t tgpu_operator_is_finished(tgpu_operator *op);
 /* addInput with a page another operator of this library produced: the buffers are shared (reference counted), so an operator that keeps

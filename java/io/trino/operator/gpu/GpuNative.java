@@ -58,6 +58,10 @@ public final class GpuNative
     public static native void finish(long operator);
     public static native long memoryBytes(long operator);
     public static native void close(long operator);
+    public static native long revocableMemoryBytes(long operator);
+    public static native void startMemoryRevoke(long operator);
+    public static native void finishMemoryRevoke(long operator);
+    public static native void setSpillEnabled(long factory, boolean enabled);
     public static native long getOutput(long operator, boolean[] wouldBlock);
 
     // output pages

@@ -19,6 +19,7 @@ public class GpuOperator
 {
     private final OperatorContext operatorContext;
     private final LocalMemoryContext memory;
+    private final LocalMemoryContext revocableMemory;
     private final ScheduledExecutorService poller;
     private long handle;                                   // tgpu_operator*
     private final boolean[] wouldBlock = new boolean[1];
@@ -30,6 +31,7 @@ public class GpuOperator
         this.inputTypes = inputTypes;
         this.operatorContext = operatorContext;
         this.memory = operatorContext.localUserMemoryContext();
+        this.revocableMemory = operatorContext.localRevocableMemoryContext();
         this.handle = handle;
         this.poller = poller;
     }
@@ -86,7 +88,14 @@ public class GpuOperator
         catch (GpuNative.NativeError e) {
             throw GpuNative.toTrinoException(e);
         }
-        memory.setBytes(GpuNative.memoryBytes(handle));   // OperatorContext.java:263-275
+        updateMemory();
+    }
+
+    // OperatorContext.java:263-275; SpillableHashAggregationBuilder.updateMemory :117-128 (user vs revocable)
+    private void updateMemory()
+    {
+        memory.setBytes(GpuNative.memoryBytes(handle));
+        revocableMemory.setBytes(GpuNative.revocableMemoryBytes(handle));
     }
 
     @Override
@@ -118,7 +127,26 @@ public class GpuOperator
         return call(() -> GpuNative.isFinished(handle));
     }
 
-    // startMemoryRevoke / finishMemoryRevoke keep the interface defaults: the GPU operators report non-revocable user memory and never spill
+    // Only a spill-enabled SINGLE / FINAL hash aggregation holds revocable memory (GpuNative.setSpillEnabled on its factory): the revoke moves
+    // its groups to host memory and is complete when the native call returns (SpillableHashAggregationBuilder.startMemoryRevoke)
+    @Override
+    public ListenableFuture<?> startMemoryRevoke()
+    {
+        try {
+            GpuNative.startMemoryRevoke(handle);
+        }
+        catch (GpuNative.NativeError e) {
+            throw GpuNative.toTrinoException(e);
+        }
+        return NOT_BLOCKED;
+    }
+
+    @Override
+    public void finishMemoryRevoke()
+    {
+        GpuNative.finishMemoryRevoke(handle);
+        updateMemory();
+    }
 
     @Override
     public void close()
@@ -127,6 +155,7 @@ public class GpuOperator
             GpuNative.close(handle);
             handle = 0;
             memory.setBytes(0);
+            revocableMemory.setBytes(0);
         }
     }
 

@@ -144,6 +144,14 @@ JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_finish(JNIEnv *env, 
 { int32_t r = tgpu_operator_finish(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
 JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_memoryBytes(JNIEnv *env, jclass c, jlong op) { return tgpu_operator_memory_bytes(H(tgpu_operator, op)); }
 JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_close(JNIEnv *env, jclass c, jlong op) { tgpu_operator_close(H(tgpu_operator, op)); }
+/* Operator.startMemoryRevoke / finishMemoryRevoke, OperatorContext.getReservedRevocableBytes (spill-enabled hash aggregations) */
+JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_revocableMemoryBytes(JNIEnv *env, jclass c, jlong op) { return tgpu_operator_revocable_memory_bytes(H(tgpu_operator, op)); }
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_startMemoryRevoke(JNIEnv *env, jclass c, jlong op)
+{ int32_t r = tgpu_operator_start_memory_revoke(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_finishMemoryRevoke(JNIEnv *env, jclass c, jlong op)
+{ int32_t r = tgpu_operator_finish_memory_revoke(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_setSpillEnabled(JNIEnv *env, jclass c, jlong factory, jboolean enabled)
+{ int32_t r = tgpu_hash_aggregation_factory_set_spill_enabled(H(tgpu_operator_factory, factory), enabled ? 1 : 0); if (r < 0) throw_native(env, r); }
 
 /* returns the output-page handle, 0 = no page; wouldBlock[0] = 1 when the operator is blocked as well (TGPU_WOULD_BLOCK) */
 JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_getOutput(JNIEnv *env, jclass c, jlong op, jbooleanArray wouldBlock)

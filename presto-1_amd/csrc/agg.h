@@ -61,6 +61,24 @@ public:
     };
     FoldScratch fold_scratch(int64_t blocks, int64_t group_capacity);
     void flush_fold();
+    // Spill support (SpillableHashAggregationBuilder.java:283-299): the accumulator state of groups [0, groups) in host memory -- the
+    // EXACT state itself (counts, limb accumulators, NaN / inf flags, 128-bit bigint sums; ORDERED mode: the running double sums), not a
+    // rounded intermediate value, so that merging runs loses nothing.
+    struct HostStates {
+        int64_t groups = 0;
+        struct Agg {
+            std::vector<long long> counts, limbs;
+            std::vector<unsigned int> special;
+            std::vector<unsigned long long> i128;
+            std::vector<double> dsum;
+        };
+        std::vector<Agg> aggs;
+        int64_t bytes() const;
+    };
+    HostStates dump(int64_t groups);
+    // adds run group i's state to group gids[i] (gids == nullptr: group 0, a global aggregation); this accumulator runs in EXACT mode
+    // from then on (a run's running double sums are added exactly, as one addend each)
+    void merge(const int32_t *gids, const HostStates &run, int64_t live_groups);
     const std::vector<tgpu_agg_spec> specs() const;
     int output_channel_count() const;
     int intermediate_channel_count() const;

@@ -414,6 +414,129 @@ void GroupedAccumulators::flush_fold()
     check_launch("agg_fold_flush");
 }
 
+int64_t GroupedAccumulators::HostStates::bytes() const
+{
+    int64_t b = 0;
+    for (const Agg &a : aggs) b += (int64_t)(a.counts.size() * 8 + a.limbs.size() * 8 + a.special.size() * 4 + a.i128.size() * 8 + a.dsum.size() * 8);
+    return b;
+}
+
+GroupedAccumulators::HostStates GroupedAccumulators::dump(int64_t groups)
+{
+    HostStates h;
+    h.groups = groups;
+    if (groups <= 0) return h;
+    ensure(groups);
+    flush_fold();
+    for (State &st : states_) {
+        HostStates::Agg a;
+        a.counts.resize((size_t)groups);
+        ctx_->download(a.counts.data(), st.counts->ptr(), (size_t)groups * 8);
+        if (st.limbs) {
+            a.limbs.resize((size_t)groups * kLimbs);
+            ctx_->download(a.limbs.data(), st.limbs->ptr(), (size_t)groups * kLimbs * 8);
+            a.special.resize((size_t)groups);
+            ctx_->download(a.special.data(), st.special->ptr(), (size_t)groups * 4);
+        }
+        if (st.dsum) {
+            a.dsum.resize((size_t)groups);
+            ctx_->download(a.dsum.data(), st.dsum->ptr(), (size_t)groups * 8);
+        }
+        if (st.i128) {
+            a.i128.resize((size_t)groups * 2);
+            ctx_->download(a.i128.data(), st.i128->ptr(), (size_t)groups * 16);
+        }
+        h.aggs.push_back(std::move(a));
+    }
+    return h;
+}
+
+namespace {
+struct MergeArgs {
+    int32_t n_aggs;
+    struct A {
+        int32_t function, pad;
+        long long *counts, *limbs;
+        unsigned int *special;
+        unsigned long long *i128;
+        const long long *r_counts, *r_limbs;
+        const unsigned int *r_special;
+        const unsigned long long *r_i128;
+        const double *r_dsum;
+    } a[kMaxAggs];
+};
+
+// one thread per (run group, limb): the run's limbs stream in, the live group's limbs are contiguous.  A live group receives at most
+// one run group per launch (the keys of a run are distinct), so plain adds suffice.
+__global__ void __launch_bounds__(kBlock) agg_merge_states_kernel(MergeArgs args, const int32_t *__restrict__ gids, int64_t n)
+{
+    const int64_t total = n * kLimbs;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t i = idx / kLimbs;
+        const int l = (int)(idx - i * kLimbs);
+        const int64_t g = gids ? gids[i] : 0;
+        for (int k = 0; k < args.n_aggs; k++) {
+            const MergeArgs::A &a = args.a[k];
+            if (a.r_limbs) a.limbs[g * kLimbs + l] += a.r_limbs[idx];
+            if (l != 0) continue;
+            a.counts[g] += a.r_counts[i];
+            if (a.r_special) a.special[g] |= a.r_special[i];
+            if (a.r_dsum && a.limbs) {
+                const double v = a.r_dsum[i];
+                if (!(fabs(v) <= 1.7976931348623157e308)) tg_flag_special(&a.special[g], v);
+                else tg_kulisch_add(&a.limbs[g * kLimbs], &a.special[g], v);   // (atomic adds: lane l == 0 of this group races with the limb lanes above)
+            }
+            if (a.r_i128) {
+                const unsigned long long lo = a.i128[g * 2], add = a.r_i128[i * 2];
+                a.i128[g * 2] = lo + add;
+                a.i128[g * 2 + 1] += a.r_i128[i * 2 + 1] + ((lo + add) < lo ? 1ULL : 0ULL);
+            }
+        }
+    }
+}
+}  // namespace
+
+void GroupedAccumulators::merge(const int32_t *gids, const HostStates &run, int64_t live_groups)
+{
+    if (states_.empty() || run.groups <= 0) return;
+    TG_CHECK_STATE(run.aggs.size() == states_.size(), "spilled run has a different number of aggregates");
+    TG_CHECK_STATE(mode_ != Mode::ORDERED, "runs are merged into exact accumulators");
+    mode_ = Mode::EXACT;
+    ensure(live_groups > 0 ? live_groups : 1);
+    // an aggregate of a run carries either limbs (EXACT run) or running double sums (ORDERED run), never both: the plain limb adds and
+    // the atomic adds of a double never meet on one group's limbs
+    MergeArgs args{};
+    args.n_aggs = (int32_t)states_.size();
+    std::vector<BufferPtr> keep;
+    auto up = [&](const void *src, size_t bytes) -> void * {
+        if (!bytes) return nullptr;
+        BufferPtr b = ctx_->alloc(bytes);
+        ctx_->upload(b->ptr(), src, bytes);
+        keep.push_back(b);
+        return b->ptr();
+    };
+    for (size_t k = 0; k < states_.size(); k++) {
+        State &st = states_[k];
+        const HostStates::Agg &r = run.aggs[k];
+        MergeArgs::A &a = args.a[k];
+        a.function = st.spec.function;
+        a.counts = st.counts->as<long long>();
+        a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
+        a.special = st.special ? st.special->as<unsigned int>() : nullptr;
+        a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+        a.r_counts = (const long long *)up(r.counts.data(), r.counts.size() * 8);
+        a.r_limbs = (const long long *)up(r.limbs.data(), r.limbs.size() * 8);
+        a.r_special = (const unsigned int *)up(r.special.data(), r.special.size() * 4);
+        a.r_i128 = (const unsigned long long *)up(r.i128.data(), r.i128.size() * 8);
+        a.r_dsum = (const double *)up(r.dsum.data(), r.dsum.size() * 8);
+    }
+    ctx_->sync();   // the uploads read host vectors owned by the caller
+    ProfileScope ps(ctx_, "agg_merge_states");
+    agg_merge_states_kernel<<<grid_for(ctx_, run.groups * kLimbs), kBlock, 0, ctx_->stream()>>>(args, gids, run.groups);
+    check_launch("agg_merge_states");
+    ctx_->sync();
+}
+
 GroupedAccumulators::DeviceState GroupedAccumulators::device_state(int k) const
 {
     const State &st = states_[(size_t)k];

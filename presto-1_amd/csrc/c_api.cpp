@@ -647,16 +647,54 @@ int32_t tgpu_operator_get_output(tgpu_operator *op, tgpu_output_page **out)
     return rc == TGPU_OK && would_block ? TGPU_WOULD_BLOCK : rc;
 }
 
-// Operator.startMemoryRevoke / finishMemoryRevoke (M/operator/Operator.java:53-79): the GPU operators hold their state in HBM and
-// report it as non-revocable user memory (tgpu_operator_memory_bytes), so there is never anything to revoke: the "future" is done at once
+// Operator.startMemoryRevoke / finishMemoryRevoke (M/operator/Operator.java:53-79).  Only a spill-enabled SINGLE / FINAL hash aggregation
+// holds revocable memory (tgpu_operator_revocable_memory_bytes): startMemoryRevoke moves its groups to host memory as one run, and the
+// "future" is done when the call returns.  Every other operator reports non-revocable user memory: nothing to do.
 int32_t tgpu_operator_start_memory_revoke(tgpu_operator *op)
 {
-    return guard_on(ctx_of(op), [&] { TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed"); });
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        op->op->start_memory_revoke();
+    });
 }
 
 int32_t tgpu_operator_finish_memory_revoke(tgpu_operator *op)
 {
-    return guard_on(ctx_of(op), [&] { TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed"); });
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        op->op->finish_memory_revoke();
+    });
+}
+
+int64_t tgpu_operator_revocable_memory_bytes(tgpu_operator *op)
+{
+    int64_t v = -1;
+    guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        v = op->op->revocable_memory_bytes();
+    });
+    return v;
+}
+
+int32_t tgpu_operator_spill_stats(tgpu_operator *op, int64_t *spill_count, int64_t *spilled_bytes)
+{
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op, "operator is null or closed");
+        int64_t c = 0, b = 0;
+        op->op->spill_stats(c, b);
+        if (spill_count) *spill_count = c;
+        if (spilled_bytes) *spilled_bytes = b;
+    });
+}
+
+int32_t tgpu_hash_aggregation_factory_set_spill_enabled(tgpu_operator_factory *factory, int32_t enabled)
+{
+    return guard_on(ctx_of(factory), [&] {
+        TG_CHECK_ARG(factory != nullptr && factory->f, "factory is null");
+        if (auto *f = dynamic_cast<HashAggregationOperatorFactory *>(factory->f.get())) f->set_spill_enabled(enabled != 0);
+        else if (auto *g = dynamic_cast<FusedFilterProjectAggregationOperatorFactory *>(factory->f.get())) g->set_spill_enabled(enabled != 0);
+        else fail(TGPU_ERR_NOT_SUPPORTED, "only hash aggregation factories can spill");
+    });
 }
 
 /* diagnostics: input pages a FilterAndProjectOperator processed once per dictionary entry (DictionaryAwarePageFilter / -Projection path) */

@@ -240,4 +240,58 @@ DevicePage ingest_page(Context *ctx, const tgpu_page *page, bool resolve_varchar
     return out;
 }
 
+HostColumn download_column(Context *ctx, const DeviceColumn &c)
+{
+    HostColumn h;
+    h.type = c.type;
+    h.n = c.n;
+    h.has_nulls = c.nulls != nullptr;
+    if (c.n <= 0) {
+        if (c.type == TGPU_VARCHAR) h.offsets.assign(1, 0);
+        return h;
+    }
+    if (c.nulls) {
+        h.nulls.resize((size_t)c.n);
+        ctx->download(h.nulls.data(), c.nulls, (size_t)c.n);
+    }
+    if (c.type == TGPU_VARCHAR) {
+        h.offsets.resize((size_t)c.n + 1);
+        ctx->download(h.offsets.data(), c.offsets, ((size_t)c.n + 1) * 4);
+        const int32_t first = h.offsets[0], last = h.offsets[(size_t)c.n];
+        h.values.resize((size_t)(last - first));
+        if (last > first) ctx->download(h.values.data(), (const uint8_t *)c.values + first, (size_t)(last - first));
+        for (int32_t &o : h.offsets) o -= first;
+    }
+    else {
+        h.values.resize((size_t)c.n * type_width(c.type));
+        ctx->download(h.values.data(), c.values, h.values.size());
+    }
+    return h;
+}
+
+DeviceColumn upload_column(Context *ctx, const HostColumn &h)
+{
+    DeviceColumn c;
+    c.type = h.type;
+    c.n = h.n;
+    c.values_buf = ctx->alloc(h.values.empty() ? 8 : h.values.size());
+    c.values = c.values_buf->ptr();
+    if (!h.values.empty()) ctx->upload(c.values_buf->ptr(), h.values.data(), h.values.size());
+    if (h.has_nulls && h.n > 0) {
+        c.nulls_buf = ctx->alloc((size_t)h.n);
+        c.nulls = c.nulls_buf->as<uint8_t>();
+        ctx->upload(c.nulls_buf->ptr(), h.nulls.data(), (size_t)h.n);
+    }
+    if (h.type == TGPU_VARCHAR) {
+        c.offsets_buf = ctx->alloc(h.offsets.size() * 4);
+        c.offsets = c.offsets_buf->as<int32_t>();
+        ctx->upload(c.offsets_buf->ptr(), h.offsets.data(), h.offsets.size() * 4);
+        c.pool_first = 0;
+        c.pool_bytes = (int64_t)h.values.size();
+        c.pool_exact = true;
+    }
+    ctx->sync();   // the uploads read the caller's vectors
+    return c;
+}
+
 }  // namespace tgpu

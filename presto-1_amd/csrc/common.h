@@ -286,6 +286,18 @@ inline KeyCols key_cols_of(const std::vector<const DeviceColumn *> &cols)
 }
 
 // ingest: tgpu_page (host or device memory, any encoding) -> flat device columns.  columns.cpp
+// a device column parked in host memory (the aggregation's spilled runs) and its way back into owned device buffers
+struct HostColumn {
+    int32_t type = 0;
+    int64_t n = 0;
+    bool has_nulls = false;
+    std::vector<uint8_t> values, nulls;
+    std::vector<int32_t> offsets;   // VARCHAR: n + 1, rebased to 0
+    int64_t bytes() const { return (int64_t)(values.size() + nulls.size() + offsets.size() * 4); }
+};
+HostColumn download_column(Context *ctx, const DeviceColumn &c);
+DeviceColumn upload_column(Context *ctx, const HostColumn &h);
+
 // resolve_varchar = false leaves the byte ranges of borrowed device-resident VARCHAR columns unread (pool_exact == false: no
 // round trip to the device); a consumer that needs them calls resolve_varchar_ends
 DevicePage ingest_page(Context *ctx, const tgpu_page *page, bool resolve_varchar = true);

@@ -428,6 +428,8 @@ public:
                 ensure_builder();
             }
             finished_ = true;
+            producing_output_ = true;
+            if (!runs_.empty()) merge_runs();   // SpillableHashAggregationBuilder.buildResult :193-240
             if (!builder_) return nullptr;
             std::unique_ptr<OutputPage> out = build_result();
             reset_builder();
@@ -441,9 +443,79 @@ public:
 
     void finish() override { finishing_ = true; }
     bool is_finished() override { return finished_; }
-    int64_t memory_bytes() override { return (gbh_ ? gbh_->estimated_size() : 0) + (accs_ ? accs_->estimated_size() : 0); }
+    // SpillableHashAggregationBuilder.updateMemory :117-128: until output is produced the builder's memory is revocable
+    int64_t memory_bytes() override { return revocable() ? 0 : builder_bytes(); }
+    int64_t revocable_memory_bytes() override { return revocable() ? builder_bytes() : 0; }
+
+    // startMemoryRevoke -> spillToDisk (:160-168, :283-299): the builder's groups leave HBM as one run -- keys, raw hashes and the
+    // EXACT accumulator state (GroupedAccumulators::dump), parked in host memory -- and an empty builder takes over.  The reference
+    // sorts a run by hash for its merge of bounded memory; here the runs are merged through the group-by table when the output is
+    // built (288 GB of HBM: the merge itself is not what memory pressure is about), and the output comes out in raw-hash order like
+    // the reference's merged result.
+    void start_memory_revoke() override
+    {
+        if (!revocable() || !builder_) return;
+        spill_run();
+    }
+    void spill_stats(int64_t &spill_count, int64_t &spilled_bytes) override
+    {
+        spill_count = spill_count_;
+        spilled_bytes = spilled_bytes_;
+    }
 
 protected:
+    int64_t builder_bytes() const { return (gbh_ ? gbh_->estimated_size() : 0) + (accs_ ? accs_->estimated_size() : 0); }
+    bool spillable() const { return cfg_.spill_enabled && (cfg_.step == TGPU_STEP_SINGLE || cfg_.step == TGPU_STEP_FINAL); }   // HashAggregationOperator.java:390
+    bool revocable() const { return spillable() && !producing_output_; }
+    struct SpilledRun {
+        int64_t groups = 0;
+        std::vector<HostColumn> keys;   // group-by channels, then the raw hash of every group
+        GroupedAccumulators::HostStates states;
+    };
+    void spill_run()
+    {
+        const int64_t groups = gbh_ ? gbh_->group_count() : (input_processed_ ? 1 : 0);
+        if (groups > 0) {
+            SpilledRun run;
+            run.groups = groups;
+            if (gbh_) {
+                DevicePage keys = gbh_->key_page(true);
+                for (const DeviceColumn &c : keys.cols) run.keys.push_back(download_column(ctx_, c));
+            }
+            run.states = accs_->dump(groups);
+            spill_count_++;
+            spilled_bytes_ += run.states.bytes();
+            for (const HostColumn &h : run.keys) spilled_bytes_ += h.bytes();
+            runs_.push_back(std::move(run));
+        }
+        reset_builder();   // rebuildHashAggregationBuilder :331-351
+    }
+    // mergeFromDisk :229-240 (after spilling what is still in memory, like the reference does when memory is short): every run's
+    // groups are looked up / inserted in a fresh table, their states added exactly
+    void merge_runs()
+    {
+        if (builder_) spill_run();
+        ensure_builder();
+        accs_->set_allow_ordered(false);
+        for (const SpilledRun &run : runs_) {
+            BufferPtr gid_buf;
+            const int32_t *gids = nullptr;
+            if (gbh_) {
+                std::vector<DeviceColumn> cols;
+                for (const HostColumn &h : run.keys) cols.push_back(upload_column(ctx_, h));
+                std::vector<const DeviceColumn *> keys;
+                for (size_t i = 0; i + 1 < cols.size(); i++) keys.push_back(&cols[i]);
+                const int64_t *hashes = cfg_.hash_channel >= 0 ? (const int64_t *)cols.back().values : nullptr;
+                gid_buf = ctx_->alloc((size_t)run.groups * 4);
+                gbh_->get_group_ids(keys, hashes, run.groups, gid_buf->as<int32_t>());
+                gids = gid_buf->as<int32_t>();
+            }
+            accs_->merge(gids, run.states, gbh_ ? gbh_->group_count() : 1);
+        }
+        runs_.clear();
+        hash_sorted_output_ = gbh_ != nullptr;
+    }
+
     void ensure_builder()
     {
         if (builder_) return;
@@ -481,6 +553,19 @@ protected:
         out.n = groups;
         accs_->evaluate(groups, out.cols);
         if (groups == 0) return nullptr;
+        if (hash_sorted_output_ && groups > 1) {
+            // merged runs come out in raw-hash order (MergeHashSort.java:58-101: Long.compare of the hashes; equal hashes keep the
+            // order in which the runs brought them)
+            DevicePage hp;
+            hp.n = groups;
+            hp.cols.push_back(gbh_->key_page(true).cols.back());
+            int64_t count = 0;
+            BufferPtr order = TopNGpu::sorted_positions(ctx_, hp, {0}, {TGPU_SORT_ASC_NULLS_LAST}, groups, count);
+            DevicePage sorted;
+            sorted.n = groups;
+            for (const DeviceColumn &c : out.cols) sorted.cols.push_back(k::gather_column(ctx_, c, order->as<int32_t>(), groups, false));
+            out = std::move(sorted);
+        }
         return wrap(std::move(out));
     }
 
@@ -488,6 +573,9 @@ protected:
     std::unique_ptr<GroupByHashGpu> gbh_;
     std::unique_ptr<GroupedAccumulators> accs_;
     bool builder_ = false, finishing_ = false, finished_ = false, input_processed_ = false;
+    std::vector<SpilledRun> runs_;
+    bool producing_output_ = false, hash_sorted_output_ = false;
+    int64_t spill_count_ = 0, spilled_bytes_ = 0;
 };
 
 HashAggregationOperatorFactory::HashAggregationOperatorFactory(Context *ctx, int32_t operator_id, HashAggregationConfig cfg)

@@ -28,6 +28,12 @@ public:
     virtual bool is_finished() = 0;
     virtual bool is_blocked() { return false; }
     virtual int64_t memory_bytes() { return 0; }
+    // Operator.startMemoryRevoke / finishMemoryRevoke (M/operator/Operator.java:53-79) and OperatorContext.getReservedRevocableBytes:
+    // only a spill-enabled hash aggregation holds revocable memory
+    virtual void start_memory_revoke() {}
+    virtual void finish_memory_revoke() {}
+    virtual int64_t revocable_memory_bytes() { return 0; }
+    virtual void spill_stats(int64_t &spill_count, int64_t &spilled_bytes) { spill_count = 0; spilled_bytes = 0; }
     virtual void close() {}
     Context *context() const { return ctx_; }
 
@@ -97,6 +103,7 @@ struct HashAggregationConfig {
     int32_t expected_groups = 1024;
     bool produce_default_output = false;
     int64_t max_partial_memory = 16ll << 20;  // TaskManagerConfig.java:47 (max_partial_aggregation_memory)
+    bool spill_enabled = false;               // HashAggregationOperator.java:133,389-425: SINGLE / FINAL steps get the spillable builder
 };
 
 class HashAggregationOperatorFactory : public OperatorFactory {
@@ -104,6 +111,7 @@ public:
     HashAggregationOperatorFactory(Context *ctx, int32_t operator_id, HashAggregationConfig cfg);
     std::unique_ptr<Operator> create_operator() override;
     std::unique_ptr<OperatorFactory> duplicate() override;
+    void set_spill_enabled(bool on) { cfg_.spill_enabled = on; }
 
 private:
     Context *ctx_;
@@ -313,6 +321,7 @@ public:
                                                  HashAggregationConfig cfg);
     std::unique_ptr<Operator> create_operator() override;
     std::unique_ptr<OperatorFactory> duplicate() override;
+    void set_spill_enabled(bool on) { cfg_.spill_enabled = on; }
 
 private:
     Context *ctx_;

@@ -147,6 +147,16 @@ class Operator:
     def finishMemoryRevoke(self):
         _lib.check(_lib.lib().tgpu_operator_finish_memory_revoke(self.handle))
 
+    def revocableMemoryBytes(self):
+        """OperatorContext.getReservedRevocableBytes()"""
+        return int(_lib.lib().tgpu_operator_revocable_memory_bytes(self.handle))
+
+    def spillStats(self):
+        """(spills so far, host bytes spilled)"""
+        n, b = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().tgpu_operator_spill_stats(self.handle, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
     def finish(self):
         _lib.check(_lib.lib().tgpu_operator_finish(self.handle))
 
@@ -183,6 +193,11 @@ class OperatorFactory:
 
     def noMoreOperators(self):
         _lib.check(_lib.lib().tgpu_operator_factory_no_more_operators(self.handle))
+
+    def setSpillEnabled(self, on=True):
+        """spillEnabled of HashAggregationOperatorFactory (M/operator/HashAggregationOperator.java:133), for operators created afterwards;
+        hash aggregation factories only (NOT_SUPPORTED otherwise)"""
+        _lib.check(_lib.lib().tgpu_hash_aggregation_factory_set_spill_enabled(self.handle, int(on)))
 
     def duplicate(self):
         """OperatorFactory.duplicate() (M/operator/OperatorFactory.java:49)"""
@@ -326,7 +341,7 @@ class HashAggregationOperatorFactory(OperatorFactory):
     """M/operator/HashAggregationOperator.java:54-262.  aggs: list of (function, input_channel, mask_channel)."""
 
     def __init__(self, ctx: Context, operator_id, group_by_types, group_by_channels, aggs, step=SINGLE, hash_channel=-1,
-                 expected_groups=10_000, produce_default_output=False):
+                 expected_groups=10_000, produce_default_output=False, spill_enabled=False):
         gt, ng = _i32(group_by_types)
         gc, _ = _i32(group_by_channels)
         arr = (_lib.AggSpec * max(1, len(aggs)))()
@@ -337,6 +352,8 @@ class HashAggregationOperatorFactory(OperatorFactory):
         _lib.check(_lib.lib().tgpu_hash_aggregation_factory_create(ctx.handle, operator_id, ng, gt, gc, hash_channel, step, len(aggs), arr,
                                                                    expected_groups, int(produce_default_output), C.byref(h)))
         super().__init__(h)
+        if spill_enabled:
+            self.setSpillEnabled(True)
 
 
 class LookupSourceFactory:

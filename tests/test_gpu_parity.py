@@ -2270,3 +2270,172 @@ def test_fused_aggregation_low_cardinality_fold_many_items_growing_groups(pkg, o
     assert ulp_diff(np.array([r[3] for r in rows]), dsum).max() == 0
     assert all(-(2**63) <= s < 2**63 for s in isum)
     assert [r[1] for r in rows] == isum
+
+
+def _drive_with_revokes(op, pages, revoke):
+    """T/operator/OperatorAssertion.java:84-156 (toPagesPartial + finishOperator with revokeMemory): before every addInput and after
+    every getOutput the driver revokes whatever the operator holds as revocable memory"""
+    out = []
+
+    def revoke_all():
+        if revoke and op.revocableMemoryBytes() > 0:
+            op.startMemoryRevoke()
+            op.finishMemoryRevoke()
+    for pg in pages:
+        revoke_all()
+        assert op.needsInput()
+        op.addInput(pg)
+        o = op.getOutput()
+        assert o is None
+    op.finish()
+    for _ in range(1000):
+        if op.isFinished():
+            break
+        o = op.getOutput()
+        if o is not None:
+            out.append(o.to_host())
+            o.release()
+        revoke_all()
+    assert op.isFinished() and not op.needsInput()
+    return [r for p in out for r in p.rows()]
+
+
+@pytest.mark.parametrize("hash_enabled,spill_enabled,revoke", [(True, True, True), (True, True, False), (False, False, False), (False, True, True), (False, True, False)])
+def test_hash_aggregation_golden_with_spill(pkg, oracle, hash_enabled, spill_enabled, revoke):
+    """T/operator/TestHashAggregationOperator.java:138-220 testHashAggregation over its data provider (hashEnabled, spillEnabled,
+    revokeMemoryWhenAddingPages): the same rows whatever was spilled, compared ignoring order like assertOperatorEqualsIgnoreOrder; the
+    spill state is what :219 asserts (spills happen iff spilling is enabled and the driver revokes -- or, without revokes, never here:
+    this library has no internal memory limit that would force one)"""
+    n = GOLD["hash_aggregation"]["testHashAggregation"]["rows"]
+    types = [pkg.VARCHAR, pkg.VARCHAR, pkg.VARCHAR, pkg.BIGINT, pkg.BOOLEAN]
+    pages = []
+    for base in (100_000, 200_000, 300_000):
+        blocks = blocks_of(pkg, types, sequence_page(types, n, 100, 0, base, 0, 500))
+        if hash_enabled:
+            blocks = blocks + [pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, blocks[1])]))]
+        pages.append(pkg.Page(*blocks))
+    aggs = [(pkg.COUNT_ALL, -1), (pkg.SUM_BIGINT, 3), (pkg.AVG_BIGINT, 3), (pkg.COUNT_COLUMN, 0), (pkg.COUNT_COLUMN, 4)]
+    ctx = pkg.Context(0)
+    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.VARCHAR], [1], aggs, hash_channel=5 if hash_enabled else -1, expected_groups=100_000,
+                                             spill_enabled=spill_enabled)
+    op = fac.createOperator()
+    rows = _drive_with_revokes(op, pages, revoke)
+    spills, spilled_bytes = op.spillStats()
+    assert (spills > 0) == (spill_enabled and revoke)
+    if spill_enabled and revoke:
+        assert spills == 3 and spilled_bytes > n * 3 * 8     # every page's groups left HBM once (the last run when the output was built)
+    op.close()
+    ctx.close()
+    assert len(rows) == n
+    off = 2 if hash_enabled else 1
+    want = sorted((str(i), 3, 3 * i, float(i), 3, 3) for i in range(n))
+    assert sorted((r[0],) + tuple(r[off:]) for r in rows) == want
+    if spill_enabled and revoke:
+        # merged runs come out in raw-hash order (MergeHashSort)
+        hk = oracle.hash_rows([oracle.Col(pkg.VARCHAR, [r[0] for r in rows])])
+        assert np.all(np.diff(hk.astype(np.int64)) >= 0)
+
+
+@pytest.mark.parametrize("groups", [5, 40_000])
+def test_hash_aggregation_spill_merges_exact_states(pkg, oracle, groups):
+    """spilled runs carry the exact accumulator state: after any number of revokes double sums are still the correctly rounded exact sums
+    (few groups; many groups: each run's row-order sums, added exactly), bigint sums and counts exact, varchar + bigint keys with nulls"""
+    rng = np.random.default_rng(101)
+    n = 60_000
+    pages, K1, K2, V, D = [], [], [], [], []
+    for _ in range(4):
+        k1 = rand_block(pkg, rng, pkg.VARCHAR, n, 0.02, (0, 2 if groups == 5 else 400))                  # few groups: {null, "0", "1"} x {0, 1}: the exact
+        k2 = rand_block(pkg, rng, pkg.BIGINT, n, 0.0 if groups == 5 else 0.01, (0, 2 if groups == 5 else 100))   # (low-cardinality) accumulators
+        v = rand_block(pkg, rng, pkg.BIGINT, n, 0.1, (-10**12, 10**12))
+        d = pkg.Block(pkg.DOUBLE, rng.standard_normal(n) * 10.0 ** rng.integers(-8, 9, n), (rng.random(n) < 0.05).astype(np.uint8))
+        pages.append(pkg.Page(k1, k2, v, d))
+    aggs = [(pkg.COUNT_ALL, -1), (pkg.SUM_BIGINT, 2), (pkg.SUM_DOUBLE, 3), (pkg.AVG_DOUBLE, 3), (pkg.COUNT_COLUMN, 3)]
+    results = {}
+    for spill in (False, True):
+        ctx = pkg.Context(0)
+        fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.VARCHAR, pkg.BIGINT], [0, 1], aggs, expected_groups=1000, spill_enabled=spill)
+        op = fac.createOperator()
+        rows = _drive_with_revokes(op, pages, spill)
+        assert (op.spillStats()[0] == 4) == spill
+        results[spill] = {(r[0], r[1]): r[2:] for r in rows}
+        assert len(results[spill]) == len(rows)
+        op.close()
+        ctx.close()
+    a, b = results[False], results[True]
+    assert a.keys() == b.keys() and (len(a) == 6 if groups == 5 else len(a) > 20_000)
+    for key in a:
+        ra, rb = a[key], b[key]
+        assert ra[0] == rb[0] and ra[1] == rb[1] and ra[4] == rb[4]
+    sa = np.array([[np.nan if x is None else x for x in a[k][2:4]] for k in a])
+    sb = np.array([[np.nan if x is None else x for x in b[k][2:4]] for k in a])
+    if groups == 5:
+        assert ulp_diff(sa[:, 0], sb[:, 0]).max() == 0 and ulp_diff(sa[:, 1], sb[:, 1]).max() == 0       # exact either way
+    else:
+        # many groups: every run (= one page here) holds row-order (Java-order) sums; the merge adds the runs' sums exactly and rounds
+        # once.  Restated with the oracle: per-page Java-order sums per group, then the exact sum of those addends -- bit-identical.
+        og = oracle.MultiChannelGroupByHash([pkg.VARCHAR, pkg.BIGINT], 1000)
+        per_page, key_of = [], {}
+        for pg in pages:
+            gids = og.get_group_ids([ocol(oracle, pg.getBlock(0)), ocol(oracle, pg.getBlock(1))])
+            per_page.append((gids, pg.getBlock(3)))
+            first = np.unique(gids, return_index=True)
+            for g, row in zip(first[0].tolist(), first[1].tolist()):
+                key_of.setdefault(g, (pg.getBlock(0).get(row), pg.getBlock(1).get(row)))
+        ng = og.group_count
+        addends, owners = [], []
+        for gids, blk in per_page:
+            cnt, js = oracle.agg_double_sum(gids, blk.values, ng, nulls=blk.nulls)
+            addends.append(np.where(cnt > 0, js, 0.0))
+            owners.append(np.arange(ng, dtype=np.int64))
+        _, want = oracle.agg_double_sum_exact(np.concatenate(owners), np.concatenate(addends), ng)
+        got = np.array([np.nan if b[key_of[i]][2] is None else b[key_of[i]][2] for i in range(ng)])
+        has = ~np.isnan(got)
+        assert has.sum() > 20_000 and ulp_diff(got[has], want[has]).max() == 0
+
+
+def test_spill_fused_aggregation_final_step_and_unsupported_factories(pkg, ctx, oracle):
+    """the fused filter / project + aggregation operator spills like the plain one (same result as without revokes); a FINAL aggregation
+    spills its merged intermediate states; PARTIAL steps and other operators hold nothing revocable"""
+    rng = np.random.default_rng(107)
+    n = 50_000
+    T = [pkg.BIGINT, pkg.DOUBLE, pkg.DATE]
+    f, c = pkg.field, pkg.constant
+    pages = [pkg.Page(rand_block(pkg, rng, pkg.BIGINT, n, 0.0, (0, 5)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.02), rand_block(pkg, rng, pkg.DATE, n, 0.0, (9000, 9400))) for _ in range(3)]
+    aggs = [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, -1), (pkg.AVG_DOUBLE, 1)]
+    got = {}
+    for spill in (False, True):
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, f(2, pkg.DATE) > 9100, [f(0, pkg.BIGINT), f(1, pkg.DOUBLE) * c(3.0, pkg.DOUBLE)], [pkg.BIGINT], [0], aggs)
+        if spill:
+            fac.setSpillEnabled(True)
+        op = fac.createOperator()
+        got[spill] = sorted(_drive_with_revokes(op, pages, spill))
+        assert (op.spillStats()[0] > 0) == spill
+        op.close()
+    assert len(got[True]) == 5 and got[True] == got[False]          # exact accumulators: bit-identical with and without spills
+    # PARTIAL -> FINAL with the FINAL step spilling
+    part = pkg.HashAggregationOperatorFactory(ctx, 1, [pkg.BIGINT], [0], [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, -1)], step=pkg.PARTIAL, spill_enabled=True)
+    p_op = part.createOperator()
+    assert p_op.revocableMemoryBytes() == 0
+    inter = []
+    for pg in pages:
+        p_op.addInput(pg)
+        assert p_op.revocableMemoryBytes() == 0                      # output-partial steps get the in-memory builder (HashAggregationOperator.java:390)
+        p_op.startMemoryRevoke()
+    p_op.finish()
+    while not p_op.isFinished():
+        o = p_op.getOutput()
+        if o is not None:
+            inter.append(o.to_host())
+    assert p_op.spillStats() == (0, 0)
+    fin = {}
+    for spill in (False, True):
+        ff = pkg.HashAggregationOperatorFactory(ctx, 2, [pkg.BIGINT], [0], [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, 3)], step=pkg.FINAL, spill_enabled=spill)
+        op = ff.createOperator()
+        fin[spill] = sorted(_drive_with_revokes(op, inter + inter, spill))
+        assert (op.spillStats()[0] > 0) == spill
+        op.close()
+    assert len(fin[True]) == 5 and [r[0] for r in fin[True]] == [r[0] for r in fin[False]] and [r[2] for r in fin[True]] == [r[2] for r in fin[False]]
+    assert ulp_diff(np.array([r[1] for r in fin[True]]), np.array([r[1] for r in fin[False]])).max() == 0
+    with pytest.raises(pkg.TgpuError) as e:
+        pkg.FilterAndProjectOperatorFactory(ctx, 3, T, None, [f(0, pkg.BIGINT)]).setSpillEnabled(True)
+    assert e.value.code == -8
