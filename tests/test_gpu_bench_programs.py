@@ -208,3 +208,38 @@ def test_full_size_sf100_properties(bench_mod, bench):
     del bench.q1, bench.q1_page_
     bench.q1_result = None
     torch.cuda.empty_cache()
+
+
+def test_paged_feeding_gives_the_single_page_results_bit_for_bit(bench):
+    """bench.py's page-granularity sub-lines (`--only paged`): Q1 and Q3 fed as many small pages -- the speculative accumulate launch
+    behind the group probe, per-workgroup folded partials kept across pages, MergePages in front of the aggregation, the emit pass's
+    build-channel gather -- must give exactly the rows of the one-page-per-table run (exact double sums are order independent; the
+    many-group sums of Q3 are added in row order either way: pages do not change the row order)"""
+    n = 2_400_011
+    bench.setup_q1(n)
+    bench.step_q1()
+    single = [r for pg in bench.q1_result for r in pg]
+    for merge in (None, 8):
+        res = bench.q1_paged(1, 0, 1 << 16, merge_mb=merge)
+        assert res["ok"] and res["pages"] == 37
+        assert [r for pg in bench.q1_result for r in pg] == single
+    del bench.q1, bench.q1_page_
+    bench.q1_result = None
+    bench.setup_q3(0.5)
+    bench.step_q3()
+    want_stats = dict(bench.q3_stats)
+    single = [r for o in bench.q3_result for r in o.to_host().rows()]
+    for o in bench.q3_result:
+        o.release()
+    bench.q3_result = None
+    for merge in (None, 1):
+        res = bench.q3_paged(1, 0, 1 << 16, merge_mb=merge)
+        assert res["ok"] and res["pages"]["lineitem"] == 46
+        got = [r for o in bench.q3_result for r in o.to_host().rows()]
+        assert got == single
+        for o in bench.q3_result:
+            o.release()
+        bench.q3_result = None
+    assert want_stats["groups"] == len(single)
+    del bench.q3, bench.q3_pages
+    torch.cuda.empty_cache()
