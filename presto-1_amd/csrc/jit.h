@@ -128,6 +128,8 @@ struct FjArgs {  // must match the generated struct
     } bcol[4];
     int32_t n_bcol;
     int32_t pad2;
+    void *carry[4];         // carry variant: block-private regions of the probe-side output values, one per output channel
+    uint8_t *carry_nulls;   //                and of their null bits (nullptr: no output can be null)
 };
 constexpr int kFjMaxBuildCols = 4;
 
@@ -155,7 +157,7 @@ public:
 
 private:
     void generate();
-    struct JitModule *module_for(int prefilter_kind, bool no_nulls);
+    struct JitModule *module_for(int prefilter_kind, bool no_nulls, bool carry);
     std::mutex mu_;
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
@@ -165,7 +167,8 @@ private:
     int32_t join_channel_;
     bool supported_ = false;
     std::string source_;
-    std::shared_ptr<JitModule> modules_[8];
+    std::shared_ptr<JitModule> modules_[16];   // layout (4) x no-null-vectors (2) x carry (2)
+    bool carry_supported_ = false;
 };
 
 // FilterAndProject feeding a HashAggregation: the filter becomes a row mask in front of the group-by table (no row is

@@ -609,6 +609,41 @@ def test_fused_filter_project_join_matches_unfused_and_oracle(pkg, oracle, monke
     assert results["fused"] == want + want
 
 
+def test_fused_join_carry_variant_matches_the_two_pass_gather(pkg, monkeypatch):
+    """TGPU_FJ_CARRY=1: the probe pass evaluates the probe-side outputs from its row registers and stores them with the pairs, the emit
+    pass moves them (jit.cpp FJ_CARRY; opt-in): same rows as the default two-pass gather, null outputs included, on the
+    bitmap and the DIRECT table layouts"""
+    rng = np.random.default_rng(89)
+    nb, n = 40_000, 300_000
+    T = [pkg.BIGINT, pkg.DOUBLE, pkg.DOUBLE, pkg.DATE, pkg.INTEGER]
+    probe = pkg.Page(rand_block(pkg, rng, pkg.BIGINT, n, 0.03, (0, 100_000)), rand_block(pkg, rng, pkg.DOUBLE, n, 0.05), rand_block(pkg, rng, pkg.DOUBLE, n, 0.0),
+                     rand_block(pkg, rng, pkg.DATE, n, 0.02, (9000, 9400)), rand_block(pkg, rng, pkg.INTEGER, n, 0.1, (-5, 5)))
+    f, c = pkg.field, pkg.constant
+    filt = f(3, pkg.DATE) > 9150
+    projs = [f(0, pkg.BIGINT), f(1, pkg.DOUBLE) * (c(1.0, pkg.DOUBLE) - f(2, pkg.DOUBLE)), f(3, pkg.DATE), f(4, pkg.INTEGER)]
+    for dup in (False, True):     # unique ascending keys -> DIRECT layout; a repeated key -> hash table + exact bitmap
+        bkeys = np.sort(rng.permutation(100_000)[:nb]).astype(np.int64)
+        if dup:
+            bkeys[7] = bkeys[6]
+        build = pkg.Page(pkg.Block(pkg.BIGINT, bkeys), pkg.Block(pkg.BIGINT, np.arange(nb, dtype=np.int64)))
+        got = {}
+        for carry in ("0", "1"):
+            monkeypatch.setenv("TGPU_FJ_CARRY", carry)
+            ctx = pkg.Context(0)
+            ctx.profile_enable(True)
+            bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT, pkg.BIGINT], [1], [0])
+            jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, T, filt, projs, [0], probe_output_channels=[1, 0, 3, 2])
+            b = bf.createOperator()
+            b.addInput(build)
+            b.finish()
+            op = jf.createOperator()
+            got[carry] = [r for p in pkg.to_pages(op, [probe, probe]) for r in p.rows()]
+            assert "fused_filter_probe" in ctx.profile() or dup       # (duplicate build keys: position links -> unfused composition)
+            op.close(); b.close(); ctx.close()
+        assert len(got["1"]) > 50_000 and got["1"] == got["0"]
+        assert any(r[0] is None for r in got["1"]) and any(r[2] is None for r in got["1"])
+
+
 def test_fused_join_falls_back_when_projection_can_raise(pkg, ctx):
     # a checked BIGINT projection must still raise for selected rows that do NOT match (FilterAndProject semantics)
     build = pkg.Page(pkg.Block(pkg.BIGINT, np.array([1, 2], dtype=np.int64)))
