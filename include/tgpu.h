@@ -373,6 +373,10 @@ int64_t tgpu_operator_revocable_memory_bytes(tgpu_operator *op);
  * (M/operator/MergeHashSort.java).  Accepted by tgpu_hash_aggregation_factory_create and
  * tgpu_filter_project_hash_aggregation_factory_create factories, TGPU_ERR_NOT_SUPPORTED otherwise. */
 int32_t tgpu_hash_aggregation_factory_set_spill_enabled(tgpu_operator_factory *factory, int32_t enabled);
+/* maxPartialMemory of HashAggregationOperatorFactory (M/operator/HashAggregationOperator.java:128-131; default 16 MB =
+ * TaskManagerConfig max_partial_aggregation_memory), for operators created afterwards: a PARTIAL aggregation whose builder is full stops
+ * taking input and flushes its groups as an intermediate page (:367-378, :494-497; InMemoryHashAggregationBuilder.isFull :208-215) */
+int32_t tgpu_hash_aggregation_factory_set_max_partial_memory(tgpu_operator_factory *factory, int64_t bytes);
 /* spills so far (DummySpillerFactory.getSpillsCount in the reference's tests) and the host bytes they hold or held */
 int32_t tgpu_operator_spill_stats(tgpu_operator *op, int64_t *spill_count, int64_t *spilled_bytes);
 int32_t tgpu_operator_finish(tgpu_operator *op);

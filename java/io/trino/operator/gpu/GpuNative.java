@@ -62,6 +62,7 @@ public final class GpuNative
     public static native void startMemoryRevoke(long operator);
     public static native void finishMemoryRevoke(long operator);
     public static native void setSpillEnabled(long factory, boolean enabled);
+    public static native void setMaxPartialMemory(long factory, long bytes);
     public static native long getOutput(long operator, boolean[] wouldBlock);
 
     // output pages

@@ -150,6 +150,8 @@ JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_startMemoryRevoke(JN
 { int32_t r = tgpu_operator_start_memory_revoke(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
 JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_finishMemoryRevoke(JNIEnv *env, jclass c, jlong op)
 { int32_t r = tgpu_operator_finish_memory_revoke(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
+JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_setMaxPartialMemory(JNIEnv *env, jclass c, jlong factory, jlong bytes)
+{ int32_t r = tgpu_hash_aggregation_factory_set_max_partial_memory(H(tgpu_operator_factory, factory), bytes); if (r < 0) throw_native(env, r); }
 JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_setSpillEnabled(JNIEnv *env, jclass c, jlong factory, jboolean enabled)
 { int32_t r = tgpu_hash_aggregation_factory_set_spill_enabled(H(tgpu_operator_factory, factory), enabled ? 1 : 0); if (r < 0) throw_native(env, r); }
 

@@ -120,6 +120,7 @@ SYMBOLS = {
     "tgpu_operator_revocable_memory_bytes": (i64, [vp]),
     "tgpu_operator_spill_stats": (i32, [vp, P(i64), P(i64)]),
     "tgpu_hash_aggregation_factory_set_spill_enabled": (i32, [vp, i32]),
+    "tgpu_hash_aggregation_factory_set_max_partial_memory": (i32, [vp, i64]),
     "tgpu_operator_factory_destroy": (None, [vp]),
     "tgpu_operator_needs_input": (i32, [vp]),
     "tgpu_operator_add_input": (i32, [vp, P(Page)]),

@@ -687,6 +687,17 @@ int32_t tgpu_operator_spill_stats(tgpu_operator *op, int64_t *spill_count, int64
     });
 }
 
+int32_t tgpu_hash_aggregation_factory_set_max_partial_memory(tgpu_operator_factory *factory, int64_t bytes)
+{
+    return guard_on(ctx_of(factory), [&] {
+        TG_CHECK_ARG(factory != nullptr && factory->f, "factory is null");
+        TG_CHECK_ARG(bytes >= 0, "maxPartialMemory must not be negative");
+        if (auto *f = dynamic_cast<HashAggregationOperatorFactory *>(factory->f.get())) f->set_max_partial_memory(bytes);
+        else if (auto *g = dynamic_cast<FusedFilterProjectAggregationOperatorFactory *>(factory->f.get())) g->set_max_partial_memory(bytes);
+        else fail(TGPU_ERR_NOT_SUPPORTED, "only hash aggregation factories have a partial-aggregation memory limit");
+    });
+}
+
 int32_t tgpu_hash_aggregation_factory_set_spill_enabled(tgpu_operator_factory *factory, int32_t enabled)
 {
     return guard_on(ctx_of(factory), [&] {

@@ -112,6 +112,7 @@ public:
     std::unique_ptr<Operator> create_operator() override;
     std::unique_ptr<OperatorFactory> duplicate() override;
     void set_spill_enabled(bool on) { cfg_.spill_enabled = on; }
+    void set_max_partial_memory(int64_t bytes) { cfg_.max_partial_memory = bytes; }
 
 private:
     Context *ctx_;
@@ -322,6 +323,7 @@ public:
     std::unique_ptr<Operator> create_operator() override;
     std::unique_ptr<OperatorFactory> duplicate() override;
     void set_spill_enabled(bool on) { cfg_.spill_enabled = on; }
+    void set_max_partial_memory(int64_t bytes) { cfg_.max_partial_memory = bytes; }
 
 private:
     Context *ctx_;

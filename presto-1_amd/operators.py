@@ -194,6 +194,10 @@ class OperatorFactory:
     def noMoreOperators(self):
         _lib.check(_lib.lib().tgpu_operator_factory_no_more_operators(self.handle))
 
+    def setMaxPartialMemory(self, nbytes):
+        """maxPartialMemory of HashAggregationOperatorFactory (M/operator/HashAggregationOperator.java:128-131), for operators created afterwards"""
+        _lib.check(_lib.lib().tgpu_hash_aggregation_factory_set_max_partial_memory(self.handle, int(nbytes)))
+
     def setSpillEnabled(self, on=True):
         """spillEnabled of HashAggregationOperatorFactory (M/operator/HashAggregationOperator.java:133), for operators created afterwards;
         hash aggregation factories only (NOT_SUPPORTED otherwise)"""

@@ -220,6 +220,23 @@ def test_hash_aggregation_golden(oracle):
     assert np.array_equal(asum / acnt, i.astype(np.float64))
 
 
+@pytest.mark.parametrize("name,pages", [("testMultiplePartialFlushes", [(0, 500), (500, 500), (1000, 500), (1500, 500)]), ("testMergeWithMemorySpill", [(0, 150_000), (150_000, 10)])])
+def test_hash_aggregation_sequence_fixtures(oracle, name, pages):
+    # T/operator/TestHashAggregationOperator.java:512-591, :594-634: every key occurs once, the expected rows are (i, i) -- min in the
+    # reference, sum here (fixture "substitution"); the oracle's group-by + long sum over the same sequence pages
+    case = GOLD["hash_aggregation"][name]
+    n = case["rows"]
+    g = oracle.BigintGroupByHash(100_000 if name == "testMultiplePartialFlushes" else 1)
+    sums = np.zeros(n, dtype=np.int64)
+    for start, rows in pages:
+        keys = np.arange(start, start + rows, dtype=np.int64)
+        gids = g.get_group_ids(oracle.Col(BIGINT, keys))
+        c, s = oracle.agg_long_sum(gids, keys, n)
+        sums += s
+    assert g.group_count == n
+    assert np.array_equal(g.values()[0], np.arange(n)) and np.array_equal(sums, np.arange(n))
+
+
 def test_exact_sum_matches_fsum(oracle):
     rng = np.random.default_rng(3)
     v = rng.standard_normal(20000) * 10.0 ** rng.integers(-8, 8, 20000)
