@@ -694,7 +694,7 @@ class DynamicFilterSource:
         for k, ch in enumerate(self.channels):
             for v in self._values(cols[ch]):
                 self.sets[k].setdefault(v, True)
-        if max(len(s) for s in self.sets) > self.max_distinct or sum(self._size(k) for k in range(len(self.channels))) > self.max_size:
+        if max((len(s) for s in self.sets), default=0) > self.max_distinct or sum(self._size(k) for k in range(len(self.channels))) > self.max_size:
             if not self.min_max_channels or self.limit < 0:         # handleTooLargePredicate
                 self.mins = None
             else:

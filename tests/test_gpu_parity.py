@@ -2538,3 +2538,34 @@ def test_merge_with_memory_spill_golden(pkg, oracle):
     assert sorted(rows) == [(i, i) for i in range(case["rows"])]
     op.close()
     ctx.close()
+
+
+def _dfs_cases():
+    import dfs_fixtures
+    return dfs_fixtures.cases(GOLD)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in _dfs_cases()])
+def test_dynamic_filter_source_golden(pkg, ctx, name):
+    """T/operator/TestDynamicFilterSourceOperator.java through the GPU operator: pages pass through unchanged (verifyPassthrough) and every
+    filter channel's domain is the reference's (value sets as sets; the two VARCHAR size-limit cases answer ALL, the documented superset)"""
+    import dfs_fixtures as F
+    _, types, channels, params, ops = next(c for c in _dfs_cases() if c[0] == name)
+    fac = pkg.DynamicFilterSourceOperatorFactory(ctx, 90, types, channels, *params)
+    for pages, expect in ops:
+        op = fac.createOperator()
+        for pg in pages:
+            page = pkg.Page(*[pkg.Block(t, F.column_values(t, desc)) for t, desc in zip(types, pg)])
+            assert op.needsInput()
+            op.addInput(page)
+            out = op.getOutput()
+            norm = lambda rows: [tuple("nan" if isinstance(v, float) and v != v else v for v in r) for r in rows]
+            assert out is not None and norm(out.to_host().rows()) == norm(page.rows())
+            out.release()
+        op.finish()
+        assert op.isFinished()
+        got = [F.normalise(op.domain(k), types[channels[k]]) for k in range(len(channels))]
+        got = [("none",) if g == ("values", []) else g for g in got]     # an empty value set IS Domain.none() (empty build side, only nulls)
+        assert got == [F.expected(e) for e in expect]
+        op.close()
+    fac.close()

@@ -320,3 +320,29 @@ def test_outer_joins_and_join_filter_function_golden(oracle, name):
         row += [None] * len(T) if b < 0 else [list(v)[b] if not isinstance(v, np.ndarray) else v[b].item() for v in bvals]
         rows.append(row)
     assert rows == case["expect_rows"]
+
+
+def _dfs_cases():
+    import dfs_fixtures
+    return dfs_fixtures.cases(GOLD)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in _dfs_cases()])
+def test_dynamic_filter_source_golden(oracle, name):
+    """T/operator/TestDynamicFilterSourceOperator.java: the restatement of DynamicFilterSourceOperator (oracle.DynamicFilterSource) on the
+    reference's own cases -- value sets, the min / max fallback, nulls, NaN, the row limit, several operators of one factory"""
+    import dfs_fixtures as F
+    _, types, channels, params, ops = next(c for c in _dfs_cases() if c[0] == name)
+    for pages, expect in ops:
+        ref = oracle.DynamicFilterSource(types, channels, *params)
+        for pg in pages:
+            cols = []
+            for t, desc in zip(types, pg):
+                vals = F.column_values(t, desc)
+                cols.append(oracle.Col(t, vals) if t == VARCHAR else oracle.Col(t, np.array([0 if v is None else v for v in vals], dtype=F._NP[t]),
+                                                                                   np.array([v is None for v in vals], dtype=np.uint8) if any(v is None for v in vals) else None))
+            ref.add(cols)
+        got = [F.normalise(ref.domain(k), types[channels[k]]) for k in range(len(channels))]
+        want = [F.expected(e) for e in expect]
+        got = [("none",) if g == ("values", []) else g for g in got]     # an empty value set IS Domain.none() (empty build side, only nulls)
+        assert got == want
