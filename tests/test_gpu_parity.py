@@ -2569,3 +2569,57 @@ def test_dynamic_filter_source_golden(pkg, ctx, name):
         assert got == [F.expected(e) for e in expect]
         op.close()
     fac.close()
+
+
+@pytest.mark.parametrize("name", list(GOLD["partitioned_output"]["cases"]))
+def test_partitioned_output_operator_golden(pkg, ctx, oracle, name):
+    """T/operator/TestPartitionedOutputOperator.java:98-181: flat, dictionary and run-length input pages through the LocalPartitionGenerator
+    partitioning into 512 partitions, without and with replication (an all-null channel 0 sends every row to every partition):
+    OutputPositions as the reference asserts them; which rows land where is checked against the oracle's partition function"""
+    g = GOLD["partitioned_output"]
+    case = g["cases"][name]
+    n, parts, page_count = 1000, 512, 10
+    seq = np.arange(n, dtype=np.int64)
+    if case["block"] == "TESTING_BLOCK":
+        blk, vals = pkg.Block(pkg.BIGINT, seq), seq
+    elif case["block"] == "TESTING_DICTIONARY_BLOCK":
+        ids = (np.arange(n) % 200).astype(np.int32)
+        blk, vals = pkg.DictionaryBlock(pkg.Block(pkg.BIGINT, np.arange(200, dtype=np.int64)), ids), ids.astype(np.int64)
+    else:
+        blk, vals = pkg.RunLengthEncodedBlock(pkg.Block(pkg.BIGINT, [g["rle_value"]]), n), np.full(n, g["rle_value"], dtype=np.int64)
+    if case["replicate"]:
+        types = [pkg.BIGINT, pkg.BIGINT]
+        page = pkg.Page(pkg.RunLengthEncodedBlock(pkg.Block(pkg.BIGINT, [None]), n), blk)
+        fac = pkg.PartitionedOutputOperatorFactory(ctx, 95, types, [0], parts, null_channel=0, local=True)
+    else:
+        types = [pkg.BIGINT]
+        page = pkg.Page(blk)
+        fac = pkg.PartitionedOutputOperatorFactory(ctx, 95, types, [0], parts, local=True)
+    op = fac.createOperator()
+    want_pid = oracle.partition_local(oracle.hash_rows([oracle.Col(pkg.BIGINT, vals)]), parts)
+    per_partition = {}
+    for _ in range(page_count):
+        assert op.needsInput()
+        op.addInput(page)
+        while True:
+            e = op.poll()
+            if e is None:
+                break
+            part, out = e
+            h = out.to_host()
+            per_partition.setdefault(part, []).append(np.asarray(h.blocks[-1].values[:h.position_count]))
+            if case["replicate"]:
+                assert h.blocks[0].nulls is not None and h.blocks[0].nulls[:h.position_count].all()
+            out.release()
+    op.finish()
+    info = op.info()
+    assert info["rowsAdded"] == case["output_positions"]
+    if "pages_added" in case:
+        assert info["pagesAdded"] == case["pages_added"]
+    for part, chunks in per_partition.items():
+        got = np.concatenate(chunks)
+        want = np.tile(vals if case["replicate"] else vals[want_pid == part], page_count)
+        assert np.array_equal(got, want), part
+    assert sum(len(np.concatenate(c)) for c in per_partition.values()) == case["output_positions"]
+    op.close()
+    fac.close()

@@ -346,3 +346,24 @@ def test_dynamic_filter_source_golden(oracle, name):
         want = [F.expected(e) for e in expect]
         got = [("none",) if g == ("values", []) else g for g in got]     # an empty value set IS Domain.none() (empty build side, only nulls)
         assert got == want
+
+
+@pytest.mark.parametrize("name", list(GOLD["partitioned_output"]["cases"]))
+def test_partitioned_output_golden(oracle, name):
+    """T/operator/TestPartitionedOutputOperator.java:98-181 on the restatement of PagePartitioner.partitionPage: the OutputPositions the
+    reference asserts (10 pages x 1000 rows; x 512 partitions when the all-null channel replicates every row)"""
+    g = GOLD["partitioned_output"]
+    case = g["cases"][name]
+    n, parts = 1000, 512
+    vals = {"TESTING_BLOCK": np.arange(n, dtype=np.int64), "TESTING_DICTIONARY_BLOCK": (np.arange(n) % 200).astype(np.int64),
+            "TESTING_RLE_BLOCK": np.full(n, g["rle_value"], dtype=np.int64)}[case["block"]]
+    pp = oracle.PagePartitioner(parts, False, 0 if case["replicate"] else -1, True)
+    total = 0
+    for _ in range(10):
+        if case["replicate"]:
+            cols = [oracle.Col(BIGINT, np.zeros(n, dtype=np.int64), np.ones(n, dtype=np.uint8)), oracle.Col(BIGINT, vals)]
+        else:
+            cols = [oracle.Col(BIGINT, vals)]
+        out = pp.partition_page(cols, oracle.hash_rows([cols[0]]))
+        total += sum(len(p) for p in out)
+    assert total == case["output_positions"]
