@@ -431,16 +431,18 @@ int32_t tgpu_partition_page(tgpu_context *ctx, const tgpu_page *page, int32_t ke
 /* ---- DynamicFilterSourceOperator ---- */
 /* M/operator/DynamicFilterSourceOperator.java:74-143 (factory), :145-425 (operator): a pass-through operator on the build side of a join
  * that collects, for every `channels[k]`, what the probe side's scan may be narrowed to: the distinct values while no channel has more
- * than max_distinct_values of them and the collected blocks stay within max_filter_size_in_bytes, else a [min, max] range per BIGINT /
- * INTEGER / DATE channel while at most min_max_collection_limit rows have been seen, else nothing ("all").  Sizes are the reference's
- * block accounting, not TypedSet's JVM retained size; both deviations yield supersets, which an advisory filter allows. */
+ * than max_distinct_values of them and the collected blocks stay within max_filter_size_in_bytes, else a [min, max] range per orderable
+ * channel other than DOUBLE (BIGINT / INTEGER / DATE / BOOLEAN / VARCHAR, :187-190) while at most min_max_collection_limit rows have been
+ * seen, else nothing ("all").  Sizes are the reference's block accounting, not TypedSet's JVM retained size (a superset at worst, which an
+ * advisory filter allows). */
 int32_t tgpu_dynamic_filter_source_factory_create(tgpu_context *ctx, int32_t operator_id, int32_t type_count, const int32_t *types, int32_t channel_count,
                                                   const int32_t *channels, int32_t max_distinct_values, int64_t max_filter_size_in_bytes,
                                                   int32_t min_max_collection_limit, tgpu_operator_factory **out);
 typedef enum tgpu_dynamic_filter_kind { TGPU_DF_ALL = 0, TGPU_DF_VALUES = 1, TGPU_DF_RANGE = 2, TGPU_DF_NONE = 3 } tgpu_dynamic_filter_kind;
 /* after finish(): the Domain of filter channel k that DynamicFilterSourceOperator.finish() hands to its consumer (:383-424):
  * VALUES -> *values = a one-channel page of the distinct non-null, non-NaN values (first-seen order; release it as usual);
- * RANGE -> [*min, *max]; NONE -> the channel only saw nulls; ALL -> no constraint */
+ * RANGE -> [*min, *max] (BOOLEAN as 0 / 1); a VARCHAR channel's range comes as *values = a one-channel page of two rows, min then max;
+ * NONE -> the channel only saw nulls; ALL -> no constraint */
 int32_t tgpu_dynamic_filter_source_result(tgpu_operator *op, int32_t filter_channel, int32_t *kind, tgpu_output_page **values, int64_t *min, int64_t *max);
 
 /* ---- MergePages as an operator: page coalescing in HBM ---- */

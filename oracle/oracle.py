@@ -636,14 +636,15 @@ class MergePages:
 # ---- DynamicFilterSourceOperator --------------------------------------------------------------------------------------------
 class DynamicFilterSource:
     """DynamicFilterSourceOperator.addInput / finish (M/operator/DynamicFilterSourceOperator.java:213-424) position at a time, with the
-    two documented deviations of the product (block-accounting size model instead of JVM retained sizes; min / max for BIGINT /
-    INTEGER / DATE only).  domain(k) -> ("all",) | ("values", [..first-seen order..]) | ("range", lo, hi) | ("none",)"""
+    one documented deviation of the product (block-accounting size model instead of JVM retained sizes); min / max for every orderable
+    type but DOUBLE (:187-190; BOOLEAN as 0 / 1, VARCHAR by unsigned bytes).  domain(k) -> ("all",) | ("values", [..first-seen order..]) |
+    ("range", lo, hi) | ("none",)"""
 
     def __init__(self, types, channels, max_distinct_values, max_filter_size_in_bytes, min_max_collection_limit):
         self.types, self.channels = list(types), list(channels)
         self.max_distinct, self.max_size, self.limit = max_distinct_values, max_filter_size_in_bytes, min_max_collection_limit
         self.sets = [dict() for _ in channels]          # insertion-ordered: value (None = null, "nan" marker for NaN) -> True
-        self.min_max_channels = [k for k, ch in enumerate(channels) if min_max_collection_limit > 0 and self.types[ch] in (BIGINT, INTEGER, DATE)]
+        self.min_max_channels = [k for k, ch in enumerate(channels) if min_max_collection_limit > 0 and self.types[ch] != DOUBLE]
         self.mins = {} if self.min_max_channels else None  # None = not collecting min / max
         self.maxs = {}
 
@@ -675,8 +676,10 @@ class DynamicFilterSource:
         vals = [v for v in values if v is not None]
         if not vals:
             return
-        self.mins[k] = min(vals) if k not in self.mins else min(self.mins[k], min(vals))
-        self.maxs[k] = max(vals) if k not in self.maxs else max(self.maxs[k], max(vals))
+        key = (lambda v: v.encode()) if isinstance(vals[0], str) else (lambda v: int(v))   # Slice.compareTo: unsigned bytes; BOOLEAN false < true
+        lo, hi = min(vals, key=key), max(vals, key=key)
+        self.mins[k] = lo if k not in self.mins else min(self.mins[k], lo, key=key)
+        self.maxs[k] = hi if k not in self.maxs else max(self.maxs[k], hi, key=key)
 
     def add(self, cols):
         n = cols[0].n if cols else 0
@@ -709,7 +712,8 @@ class DynamicFilterSource:
             return ("all",)
         if k not in self.mins:
             return ("none",)
-        return ("range", self.mins[k], self.maxs[k])
+        lo, hi = self.mins[k], self.maxs[k]
+        return ("range", lo, hi) if isinstance(lo, str) else ("range", int(lo), int(hi))
 
 
 # ---- join filter function -------------------------------------------------------------------------

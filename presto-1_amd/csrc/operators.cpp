@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <array>
 #include <deque>
+#include <map>
 #include <set>
 
 #include "kernels.h"
@@ -1364,8 +1365,9 @@ std::unique_ptr<OperatorFactory> OrderByOperatorFactory::duplicate()
 // [min, max] range, NONE for a channel that only saw nulls, ALL otherwise.
 // Deviations, both on the safe side of an advisory filter (any superset of the build values is a valid dynamic filter):
 // the size test uses the reference's BLOCK accounting of the collected values ((width + 1) or (length + 5) bytes per value)
-// instead of TypedSet's JVM retained size; min / max is kept for BIGINT / INTEGER / DATE channels only (the reference also
-// orders BOOLEAN and VARCHAR; DOUBLE is excluded there too, :194-196).
+// instead of TypedSet's JVM retained size.  min / max is kept for every orderable type of the path but DOUBLE, like the reference
+// (:187-190): BIGINT / INTEGER / DATE / BOOLEAN by a reduction kernel, VARCHAR by selecting the first row in ascending and in
+// descending order (topn.h: the type's comparison, bytes as unsigned) among the page's values and the running pair.
 // =====================================================================================================================
 namespace {
 __global__ void __launch_bounds__(256) df_minmax_kernel(ColView col, int64_t n, long long *minmax /* [min, max, any non-null] */)
@@ -1373,7 +1375,8 @@ __global__ void __launch_bounds__(256) df_minmax_kernel(ColView col, int64_t n, 
     long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
         if (col.nulls && col.nulls[r]) continue;
-        const long long v = col.type == TGPU_BIGINT ? ((const long long *)col.values)[r] : (long long)((const int *)col.values)[r];
+        const long long v = col.type == TGPU_BIGINT ? ((const long long *)col.values)[r]
+                            : (col.type == TGPU_BOOLEAN ? (long long)(((const unsigned char *)col.values)[r] != 0) : (long long)((const int *)col.values)[r]);
         lo = v < lo ? v : lo;
         hi = v > hi ? v : hi;
     }
@@ -1417,7 +1420,7 @@ public:
         for (int32_t ch : channels_) {
             const int32_t t = types_[(size_t)ch];
             sets_.push_back(std::make_unique<GroupByHashGpu>(ctx, std::vector<int32_t>{t}, false, 1024));
-            const bool orderable = min_max_limit_ > 0 && (t == TGPU_BIGINT || t == TGPU_INTEGER || t == TGPU_DATE);   // :194-196
+            const bool orderable = min_max_limit_ > 0 && t != TGPU_DOUBLE;   // :187-190 (orderable, DOUBLE / REAL left out because of NaN)
             if (orderable) min_max_channels_.push_back((int)sets_.size() - 1);
         }
         collecting_sets_ = true;
@@ -1476,6 +1479,25 @@ public:
         bool is_mm = false;
         for (int c : min_max_channels_) is_mm = is_mm || c == k;
         if (!is_mm) return;                 // a channel without min / max collection is left out of the tuple domain = ALL
+        if (types_[(size_t)channels_[(size_t)k]] == TGPU_VARCHAR) {
+            auto it = varchar_min_max_.find(k);
+            if (it == varchar_min_max_.end()) {
+                *kind = 3;   // no value was ever seen
+                return;
+            }
+            DevicePage pair;   // rows: min, max (both null when every value was null: ASC / DESC NULLS LAST put a null first only then)
+            pair.n = 2;
+            pair.cols.push_back(it->second);
+            uint8_t null_flags[2] = {0, 0};
+            if (it->second.nulls) ctx_->download(null_flags, it->second.nulls, 2);
+            if (null_flags[0]) {
+                *kind = 3;
+                return;
+            }
+            *kind = 2;
+            *values = wrap(std::move(pair));
+            return;
+        }
         long long mm[3];
         ctx_->download(mm, minmax_->as<long long>() + 3 * k, 24);
         if (!mm[2]) {
@@ -1542,6 +1564,33 @@ private:
     void update_min_max(int k, const DeviceColumn &c)
     {
         if (c.n <= 0) return;
+        if (c.type == TGPU_VARCHAR) {
+            // candidates = the running (min, max) pair + this page's values; the new pair = the first row in ascending and the first in
+            // descending order, nulls last (updateMinMaxValues :300-345 compares with the type's comparison operator)
+            PagesIndexGpu cand(ctx_, std::vector<int32_t>{TGPU_VARCHAR});
+            auto it = varchar_min_max_.find(k);
+            if (it != varchar_min_max_.end()) {
+                DevicePage prev;
+                prev.n = 2;
+                prev.cols.push_back(it->second);
+                cand.add_page(prev);
+            }
+            DevicePage pg;
+            pg.n = c.n;
+            pg.cols.push_back(c);
+            cand.add_page(pg);
+            DevicePage all;
+            all.n = cand.position_count();
+            all.cols.push_back(cand.column(0));
+            int64_t cnt = 0;
+            BufferPtr lo = TopNGpu::sorted_positions(ctx_, all, {0}, {TGPU_SORT_ASC_NULLS_LAST}, 1, cnt);
+            BufferPtr hi = TopNGpu::sorted_positions(ctx_, all, {0}, {TGPU_SORT_DESC_NULLS_LAST}, 1, cnt);
+            BufferPtr both = ctx_->alloc(8);
+            HIP_CHECK(hipMemcpyAsync(both->ptr(), lo->ptr(), 4, hipMemcpyDeviceToDevice, ctx_->stream()));
+            HIP_CHECK(hipMemcpyAsync(both->as<int32_t>() + 1, hi->ptr(), 4, hipMemcpyDeviceToDevice, ctx_->stream()));
+            varchar_min_max_[k] = k::gather_column(ctx_, all.cols[0], both->as<int32_t>(), 2, false);
+            return;
+        }
         df_minmax_kernel<<<(int)std::min<int64_t>(ceil_div(c.n, 256), (int64_t)ctx_->cu_count() * 2), 256, 0, ctx_->stream()>>>(view_of(c), c.n, minmax_->as<long long>() + 3 * k);
         check_launch("df_minmax");
     }
@@ -1567,6 +1616,7 @@ private:
     std::vector<std::unique_ptr<GroupByHashGpu>> sets_;
     std::vector<int> min_max_channels_;
     BufferPtr minmax_;
+    std::map<int, DeviceColumn> varchar_min_max_;   // filter channel -> 2 rows (min, max)
     std::unique_ptr<OutputPage> current_;
 };
 

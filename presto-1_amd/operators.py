@@ -635,6 +635,11 @@ class DynamicFilterSourceOperator(Operator):
             vals = page.to_host().blocks[0].to_list() if page.position_count else []
             page.release()
             return ("values", vals)
+        if kind.value == DF_RANGE and out.value:      # a VARCHAR channel: two rows, min then max
+            page = OutputPage(out)
+            vals = page.to_host().blocks[0].to_list()
+            page.release()
+            return ("range", vals[0], vals[1])
         return {DF_ALL: ("all",), DF_RANGE: ("range", int(lo.value), int(hi.value)), DF_NONE: ("none",)}[kind.value]
 
 

@@ -51,6 +51,8 @@ def normalise(domain, type_id):
 def expected(expect):
     if expect[0] == "values":
         return ("values", sorted(expect[1]))
+    if expect[0] == "range_text":
+        return ("range", expect[1][0] * expect[1][1], expect[2][0] * expect[2][1])
     if expect[0] == "values_seq":
         return ("values", list(range(expect[1], expect[2])))
     return tuple(expect)
