@@ -75,7 +75,7 @@ def test_dynamic_filter_source_state_machine(oracle):
     d = O.DynamicFilterSource(types, [0, 1], 2, 1 << 20, 1000)
     d.add(page)
     d.add([O.Col(O.BIGINT, [-4, 20]), O.Col(O.VARCHAR, ["x", "y"])])
-    assert d.domain(0) == ("range", -4, 20) and d.domain(1) == ("all",)
+    assert d.domain(0) == ("range", -4, 20) and d.domain(1) == ("range", "a", "y")
     # ... but only while the row limit holds (DynamicFilterSourceOperator.java:283-289)
     d = O.DynamicFilterSource(types, [0, 1], 2, 1 << 20, 6)
     d.add(page)
