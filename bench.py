@@ -898,7 +898,7 @@ def sub_join_hash_layout(b, steps, warmup, sf):
     # algorithmic bytes of the probe launch, hash layout: filter column 4 B x input rows + (key 8 B + one 16-byte TgSlot16) x rows
     # passing the filter + 8 B per emitted pair (the Bloom word in front of the table is an optimisation, not priced)
     alg = 4.0 * n + 24.0 * n_pass + 8.0 * want_pairs
-    roof = dominant(prof, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n})
+    roof = dominant(prof, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n}, pmc_prefix="sub_join_hash_layout:")
     return {"workload": "fused filter + probe, sparse random 64-bit build keys (open-address TgSlot16 table + Bloom pre-filter)", "build_rows": nb, "input_rows": n,
             "probe_rows": n_pass, "pairs": want_pairs, "table_slots": res["stats"]["hash_size"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n_pass / step_s,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
@@ -935,7 +935,7 @@ def sub_join_duplicate_keys(b, steps, warmup, sf):
     want_pairs = 2 * int((r < (nb + 1) // 2).sum().item())
     ok = res["pairs"] == want_pairs and res["stats"]["link_count"] > 0
     # unfused probe: key 8 B + one table slot 16 B + head / count out 8 B per probe row
-    roof = dominant(prof, {"join_probe_count": n}, {"join_probe_count": 32.0})
+    roof = dominant(prof, {"join_probe_count": n}, {"join_probe_count": 32.0}, pmc_prefix="sub_join_duplicate_keys:")
     return {"workload": "LookupJoinOperator over a table with every build key twice (position links, newest -> oldest chains)", "build_rows": nb, "probe_rows": n,
             "pairs": want_pairs, "link_count": res["stats"]["link_count"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n / step_s,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
@@ -960,7 +960,7 @@ def sub_group_by_hash(b, steps, warmup, rows, groups):
     step_s, prof = b.timed(step, steps, warmup)
     want = int(torch.unique(keys).numel())
     # gbh_insert per row: key 8 B + one 8-byte table word + the 4-byte group id it answers with
-    roof = dominant(prof, {"gbh_insert": rows}, {"gbh_insert": 20.0})
+    roof = dominant(prof, {"gbh_insert": rows}, {"gbh_insert": 20.0}, pmc_prefix="sub_group_by_hash:")
     return {"workload": f"BenchmarkGroupByHash.bigintGroupByHash shape: addPage of {rows} BIGINT keys uniform in [0, {groups}) + appendValuesTo of every group",
             "rows": rows, "groups": want, "ms_per_step": step_s * 1e3, "rows_per_sec": rows / step_s, "ns_per_row": step_s * 1e9 / rows,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
@@ -1080,7 +1080,7 @@ def cpu_baseline(bench, sample_sf):
 PMC_PROFILES = ["r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"]   # newest first
 
 
-def dominant(profile, rows_by_kernel, bytes_per_row):
+def dominant(profile, rows_by_kernel, bytes_per_row, pmc_prefix=""):
     best = None
     for name, st in profile.items():
         if name not in bytes_per_row or st["count"] == 0:
@@ -1098,7 +1098,7 @@ def dominant(profile, rows_by_kernel, bytes_per_row):
     traffic, traffic_source = None, None
     for name in PMC_PROFILES:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"].get(best)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))["kernels"].get(pmc_prefix + best)   # sub-benchmarks: "sub_<name>:<kernel>"
         except (OSError, ValueError, KeyError):
             continue
         if pmc:

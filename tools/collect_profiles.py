@@ -17,7 +17,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("fj_", "fg_", "fa_", "fp_", "tgpu::", "void tgpu::")   # rocPRIM kernels (scan / radix sort) are shared with torch: left out
 PROFILE_NAME = {"fj_probe_direct": "fused_filter_probe", "fj_emit_direct": "fused_probe_emit", "fg_probe": "fused_filter_group_probe",
-                "fa_accumulate_lowcard": "fused_project_accumulate_lowcard", "fp_count": "filter_count", "fp_emit": "filter_project_emit"}
+                "fa_accumulate_lowcard": "fused_project_accumulate_lowcard", "fp_count": "filter_count", "fp_emit": "filter_project_emit",
+                # sub-benchmarks (bench.py looks them up under these keys: their kernels share profile names with the headline's)
+                "fj_probe_bloom": "sub_join_hash_layout:fused_filter_probe",
+                "void tgpu::(anonymous namespace)::probe_count_kernel<true>": "sub_join_duplicate_keys:join_probe_count"}
+
+
+def profile_key(kernel_name):
+    for prefix in PROFILE_NAME:
+        if kernel_name == prefix or (prefix.startswith("void ") and kernel_name.startswith(prefix)):
+            return prefix
+    return None
 
 
 def find(d, suffix):
@@ -43,8 +53,8 @@ def counter(d, name):
     for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
         if r["Counter_Name"] != name:
             continue
-        k = r["Kernel_Name"]
-        if k in PROFILE_NAME:
+        k = profile_key(r["Kernel_Name"])
+        if k is not None:
             per.setdefault(k, []).append(float(r["Counter_Value"]))
     return per
 
