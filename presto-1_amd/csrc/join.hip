@@ -758,8 +758,9 @@ void LookupSourceGpu::build()
             check_launch("bitmap_build");
         }
         else if (has_keys) {
+            static const int bits_per_key = getenv("TGPU_BLOOM_BITS_PER_KEY") ? std::max(1, atoi(getenv("TGPU_BLOOM_BITS_PER_KEY"))) : 16;   // kernel study
             int64_t words = 1024;
-            while (words * 64 < n_ * 16) words <<= 1;
+            while (words * 64 < n_ * bits_per_key) words <<= 1;
             bloom_words_ = words;
             bloom_ = ctx_->alloc_zero((size_t)words * 8);
             bloom_build_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], bloom_->as<unsigned long long>(), (unsigned long long)words - 1);
