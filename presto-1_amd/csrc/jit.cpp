@@ -2533,7 +2533,7 @@ void FusedAggGpu::generate()
 #define FG_TILE (FG_STRIPES * 256)
 // the table path (hashing + probe / insert protocol) is rare once the first groups are cached in LDS: it is kept out of line
 // so that the hot loop stays small enough for the instruction cache
-// It reads its arguments from the copy of the kernel arguments in global memory (G.self): taking the address of the by-value
+// It reads its arguments from the kernel-argument segment in memory (__builtin_amdgcn_kernarg_segment_ptr): taking the address of the by-value
 // kernel parameter instead would make the compiler spill the whole argument block to scratch and turn every column access
 // of the hot loop into scratch + flat loads.  Returns the group result in the low word, the "pending" flag in bit 32.
 __device__ __attribute__((noinline)) long long fg_table_path(const FgArgs* Gm, long long r, int store_groups) {
@@ -2561,6 +2561,9 @@ __device__ __attribute__((noinline)) long long fg_slow_path(const FgArgs* Gm, co
 // (C) compare against the LDS copies of the first groups' keys; only a row that matches none of them touches the table.
 extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
   const FpArgs& A = G.fp;
+  // the out-of-line paths read the arguments from memory: the kernel-argument segment itself (FgArgs is the only parameter, so it
+  // starts the segment) -- no host-side copy of the block per launch
+  const FgArgs* fg_self = (const FgArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   __shared__ __attribute__((aligned(16))) unsigned char rec[FG_LDS_GROUPS * FG_NKEYS * 32];
   const int lg = G.store_groups < FG_LDS_GROUPS ? G.store_groups : FG_LDS_GROUPS;
   fg_build_records(G.store, lg, rec);
@@ -2619,7 +2622,7 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
       const bool redo = open && result >= 0;   // a longer varchar key must be compared byte-wise: from group 0 below
       result = (redo || !sel[s]) ? -1 : result;
       if (sel[s] && result < 0) {
-        const long long tp = fg_slow_path(G.self, rec, kr[s], t0 + o, redo ? 0 : rg, lg, redo);
+        const long long tp = fg_slow_path(fg_self, rec, kr[s], t0 + o, redo ? 0 : rg, lg, redo);
         result = (int)(unsigned int)(tp & 0xffffffffLL);
         npending += (unsigned long long)(tp >> 32);
       }
@@ -2776,9 +2779,7 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     G.row0 = l.row0;
     G.n = l.n;
     G.store_groups = l.store_groups;
-    BufferPtr self = ctx->alloc(sizeof(FgArgsHost));
-    G.self = self->ptr();
-    ctx->upload(self->ptr(), &G, sizeof(FgArgsHost));
+    G.self = nullptr;   // (the kernel takes its argument block from the kernarg segment)
     {
         ProfileScope ps(ctx, "fused_filter_group_probe");
         // persistent grid: exactly the resident workgroups, each walking tiles with a grid stride (no second wave of blocks)
