@@ -2,6 +2,7 @@ package io.trino.operator.gpu;
 
 import io.trino.operator.LookupJoinOperators.JoinType;
 import io.trino.operator.OperatorFactory;
+import io.airlift.units.DataSize;
 import io.trino.spi.type.Type;
 import io.trino.sql.planner.plan.AggregationNode.Step;
 import io.trino.sql.planner.plan.PlanNodeId;
@@ -56,7 +57,7 @@ public final class GpuOperatorFactories
      * resolved by the caller from the AccumulatorFactories' bound signatures (count / sum / avg over BIGINT and DOUBLE; anything else -> Optional.empty()).
      */
     public Optional<OperatorFactory> hashAggregation(int operatorId, PlanNodeId planNodeId, List<Type> inputTypes, List<Type> groupByTypes, List<Integer> groupByChannels, Step step,
-            Optional<int[]> aggregates, Optional<Integer> hashChannel, int expectedGroups, boolean produceDefaultOutput)
+            Optional<int[]> aggregates, Optional<Integer> hashChannel, int expectedGroups, boolean produceDefaultOutput, Optional<DataSize> maxPartialMemory, boolean spillEnabled)
     {
         if (aggregates.isEmpty()) {
             return Optional.empty();
@@ -76,6 +77,11 @@ public final class GpuOperatorFactories
         }
         long factory = GpuNative.createHashAggregationFactory(context, operatorId, keyTypes, groupByChannels.stream().mapToInt(Integer::intValue).toArray(), hashChannel.orElse(-1),
                 stepCode, aggregates.get(), expectedGroups, produceDefaultOutput);
+        // HashAggregationOperatorFactory(..., maxPartialMemory, spillEnabled, ...) (operator/HashAggregationOperator.java:128-154)
+        maxPartialMemory.ifPresent(limit -> GpuNative.setMaxPartialMemory(factory, limit.toBytes()));
+        if (spillEnabled) {
+            GpuNative.setSpillEnabled(factory, true);
+        }
         return Optional.of(new GpuOperatorFactory(operatorId, planNodeId, "GpuHashAggregationOperator", types, poller, factory));
     }
 
