@@ -1,8 +1,8 @@
 package io.trino.operator.gpu;
 
+import io.airlift.units.DataSize;
 import io.trino.operator.LookupJoinOperators.JoinType;
 import io.trino.operator.OperatorFactory;
-import io.airlift.units.DataSize;
 import io.trino.spi.type.Type;
 import io.trino.sql.planner.plan.AggregationNode.Step;
 import io.trino.sql.planner.plan.PlanNodeId;
