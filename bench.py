@@ -197,6 +197,23 @@ class Bench:
     def setup_q3(self, sf):
         p = self.pkg
         self.q3 = gen_q3(self.dev, sf, self.rank, self.world)
+        self.ensure_exchange()
+        pp = self.entry.bench_page_processors(p)
+        B, D, DT, V, I = p.BIGINT, p.DOUBLE, p.DATE, p.VARCHAR, p.INTEGER
+        self.q3_fac = {
+            "cust_fp": p.FilterAndProjectOperatorFactory(self.ctx, 0, *pp["q3_customer"]),
+            "ord_fp": p.FilterAndProjectOperatorFactory(self.ctx, 1, *pp["q3_orders"]),
+            "li_fp": p.FilterAndProjectOperatorFactory(self.ctx, 2, *pp["q3_lineitem"]),
+        }
+        t = self.q3
+        self.q3_pages = {
+            "customer": p.Page(self.dblock(B, t["c_custkey"]), self.dblock(V, t["c_seg_bytes"], t["c_seg_off"])),
+            "orders": p.Page(self.dblock(B, t["o_orderkey"]), self.dblock(B, t["o_custkey"]), self.dblock(DT, t["o_orderdate"]), self.dblock(I, t["o_shippriority"])),
+            "lineitem": p.Page(self.dblock(B, t["l_orderkey"]), self.dblock(D, t["l_extendedprice"]), self.dblock(D, t["l_discount"]), self.dblock(DT, t["l_shipdate"])),
+        }
+        self.q3_stats = {}
+
+    def ensure_exchange(self):
         if self.dist is not None and getattr(self, "exchange", None) is None:
             # the exchange is the native library's (tgpu_exchange_*: RCCL send / recv groups over xGMI); torch.distributed only hands
             # rank 0's RCCL unique id to the other ranks.  Rehearsals of several ranks on one GPU (TGPU_BENCH_BACKEND=gloo) run the same
@@ -212,20 +229,6 @@ class Bench:
                 self.exchange = ex_mod.Exchange.over_rccl(self.ctx, self.rank, self.world, broadcast)
             else:
                 self.exchange = ex_mod.Exchange.over_transport(self.ctx, self.rank, self.world, ex_mod.GlooTransport(self.dist, ex_mod.TorchDeviceMemory(self.dev)))
-        pp = self.entry.bench_page_processors(p)
-        B, D, DT, V, I = p.BIGINT, p.DOUBLE, p.DATE, p.VARCHAR, p.INTEGER
-        self.q3_fac = {
-            "cust_fp": p.FilterAndProjectOperatorFactory(self.ctx, 0, *pp["q3_customer"]),
-            "ord_fp": p.FilterAndProjectOperatorFactory(self.ctx, 1, *pp["q3_orders"]),
-            "li_fp": p.FilterAndProjectOperatorFactory(self.ctx, 2, *pp["q3_lineitem"]),
-        }
-        t = self.q3
-        self.q3_pages = {
-            "customer": p.Page(self.dblock(B, t["c_custkey"]), self.dblock(V, t["c_seg_bytes"], t["c_seg_off"])),
-            "orders": p.Page(self.dblock(B, t["o_orderkey"]), self.dblock(B, t["o_custkey"]), self.dblock(DT, t["o_orderdate"]), self.dblock(I, t["o_shippriority"])),
-            "lineitem": p.Page(self.dblock(B, t["l_orderkey"]), self.dblock(D, t["l_extendedprice"]), self.dblock(D, t["l_discount"]), self.dblock(DT, t["l_shipdate"])),
-        }
-        self.q3_stats = {}
 
     def step_q3(self):
         p, ctx, f, pages = self.pkg, self.ctx, self.q3_fac, self.q3_pages
@@ -675,6 +678,62 @@ class Bench:
         self.q1_result = [o.to_host().rows() for o in outs]
         aop.close()
 
+    def setup_q1_dist(self):
+        """Q1 on N ranks: every rank aggregates its own row-range shard with the fused PARTIAL operator, the 4-row
+        partial pages are all-gathered in rank order (tgpu_exchange_all_gather) and a FINAL HashAggregationOperator combines them on every
+        rank -- the rank order is fixed, so the DOUBLE results are reproducible"""
+        p = self.pkg
+        self.ensure_exchange()
+        pp = self.entry.bench_page_processors(p)
+        V = p.VARCHAR
+        aggs = self.entry.q1_aggregates(p)
+        self.q1_partial = p.FilterProjectHashAggregationOperatorFactory(self.ctx, 22, *pp["q1"], [V, V], [0, 1], aggs, step=p.PARTIAL, expected_groups=16)
+        final_aggs, ch = [], 2
+        for a in aggs:                      # intermediate layout: keys, then per aggregate its count [and its sum]
+            final_aggs.append((a[0], ch))
+            ch += 1 if a[0] in (p.COUNT_ALL, p.COUNT_COLUMN) else 2
+        self.q1_final = p.HashAggregationOperatorFactory(self.ctx, 23, [V, V], [0, 1], final_aggs, step=p.FINAL, expected_groups=16)
+
+    def step_q1_dist(self):
+        aop = self.q1_partial.createOperator()
+        aop.addInput(self.q1_page_)
+        parts = self.finish(aop)
+        fop = self.q1_final.createOperator()
+        for o in parts:
+            g = self.exchange.all_gather(o.as_device_page())
+            fop.addInput(g)
+            g.release()
+            o.release()
+        outs = self.finish(fop)
+        self.q1_result = [o.to_host().rows() for o in outs]
+        aop.close()
+        fop.close()
+
+    def check_q1_dist(self):
+        """counts exact, sums against the all-reduced torch sums of every rank's shard"""
+        t = self.q1
+        sel = t["shipdate"] <= 10471
+        rows = [r for pg in self.q1_result for r in pg]
+        combos = ((65, 70), (78, 70), (78, 79), (82, 70))
+        local = torch.zeros(len(combos), 5, dtype=torch.float64, device=self.dev)
+        for i, (rf, ls) in enumerate(combos):
+            m = sel & (t["returnflag"] == rf) & (t["linestatus"] == ls)
+            q, e, d, x = t["quantity"][m], t["extendedprice"][m], t["discount"][m], t["tax"][m]
+            local[i] = torch.stack([q.sum(), e.sum(), (e * (1 - d)).sum(), (e * (1 - d) * (1 + x)).sum(), m.sum().to(torch.float64)])
+        tot = local.to(self.coll_dev)
+        self.dist.all_reduce(tot)
+        want = {(chr(rf), chr(ls)): tot[i].tolist() for i, (rf, ls) in enumerate(combos)}
+        ok, worst = len(rows) == 4, 0.0
+        for r in rows:
+            w = want.get((r[0], r[1]))
+            if w is None:
+                ok = False
+                continue
+            ok = ok and r[9] == int(w[4])
+            for g, v in zip(r[2:6], w[:4]):
+                worst = max(worst, abs(g - v) / max(abs(v), 1.0))
+        return {"groups": len(rows), "sum_rel_err_vs_all_reduced_torch": worst, "ok": bool(ok and worst < 1e-9)}
+
     def q1_page(self, a, z):
         """rows [a, z) of the Q1 input as a device page (zero-copy views of the generated columns)"""
         p, t = self.pkg, self.q1
@@ -1115,13 +1174,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sf", type=float, default=100.0, help="TPCH scale factor per GPU")
-    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2,sub,paged (default at N=1: q3,q1,cfg2,sub; q3 only at N>1); paged = Q1 fed as 2^20-row pages and PCIe-inclusive Q1 (kept out of the default run so that a profiler's per-kernel averages of that run are those of the headline launches)")
+    ap.add_argument("--only", default="", help="comma list of q3,q1,cfg2,sub,paged (default at N=1: q3,q1,cfg2,sub; at N>1: q3,q1 as distributed plans); paged = Q1 fed as 2^20-row pages and PCIe-inclusive Q1 (kept out of the default run so that a profiler's per-kernel averages of that run are those of the headline launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-sf", type=float, default=20.0, help="scale factor of the bounded sample the CPU baseline runs (~10-25 s of CPU work)")
     args = ap.parse_args()
     b = Bench(args)
     assert b.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={b.world}"
-    only = set(args.only.split(",")) if args.only else ({"q3", "q1", "cfg2", "sub"} if b.world == 1 else {"q3"})
+    only = set(args.only.split(",")) if args.only else ({"q3", "q1", "cfg2", "sub"} if b.world == 1 else {"q3", "q1"})
     b.ctx.profile_enable(os.environ.get("TGPU_BENCH_NOPROFILE") is None)   # (kernel study: cost of the event timers)
     out = {}
     extra = {}
@@ -1218,7 +1277,21 @@ def main():
     del b.q3, b.q3_pages
     torch.cuda.empty_cache()
 
-    if "q1" in only:
+    if "q1" in only and b.world > 1:
+        # Q1 on N ranks: partial aggregation of every rank's shard -> all-gather of the 4-row partial pages -> final combine (8e step 3)
+        n = int(6_000_379.02 * args.sf)
+        b.setup_q1(n)
+        b.setup_q1_dist()
+        s1, p1 = b.timed(b.step_q1_dist, args.steps, args.warmup)
+        out["q1"] = {"metric": "input_rows_per_sec", "value": n * b.world / s1, "unit": "rows/s", "ms_per_step": s1 * 1e3, "rows_per_rank": n, "scaling": "weak",
+                     "workload": "tpch_q1_filter_project_hash_aggregation (BASELINE configs[2]), one SF%g shard per rank" % args.sf,
+                     "plan": f"x{b.world}: fused PARTIAL aggregation per rank -> all-gather of the partial pages (RCCL, rank order) -> FINAL combine on every rank",
+                     "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
+        out["checks"]["q1"] = b.check_q1_dist()
+        del b.q1, b.q1_page_
+        b.q1_result = None
+        torch.cuda.empty_cache()
+    elif "q1" in only:
         n = int(6_000_379.02 * args.sf)
         b.setup_q1(n)
         s1, p1 = b.timed(b.step_q1, args.steps, args.warmup)
