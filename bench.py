@@ -172,6 +172,19 @@ class Bench:
         self.last_readbacks_per_step = prof.pop("__readbacks", {"count": 0})["count"] / steps
         return dt / steps, prof
 
+    def step_stats(self, fn, steps):
+        """median / min of individually timed steps (a device synchronisation around each: SURVEY.md 8d "median + min"); the contract's
+        ms_per_step stays the mean over the back-to-back steps of timed()"""
+        ts = []
+        for _ in range(max(steps, 1)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        return {"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "steps": len(ts)}
+
     def drive(self, op, page):
         """one page through one operator (Driver.processInternal for a single hop); returns device output pages"""
         outs = []
@@ -1263,6 +1276,11 @@ def main():
     })
     if not distributed and b.q3_result:
         extra["q3_top10"] = b.q3_top10(args.steps, args.warmup)
+    if not distributed:
+        for o in (b.q3_result or []):
+            o.release()
+        b.q3_result = None
+        extra["q3_step_stats"] = b.step_stats(b.step_q3, min(args.steps, 20))
     extra["q3_readbacks_per_step"] = q3_readbacks   # host <- device round trips (stream waits) of one Q3 step
     extra["q3_kernels_ms_per_step"] = {k: v["total_ms"] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}
     extra["q3_kernel_launch_min_max_ms"] = {k: [v["min_ms"], v["max_ms"], v["count"]] for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
