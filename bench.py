@@ -593,6 +593,42 @@ class Bench:
         return {"workload": "TopN(10) ORDER BY revenue DESC, o_orderdate over the Q3 groups", "input_rows": rows, "ms_per_step": step_s * 1e3,
                 "rows_per_sec": rows / step_s, "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in prof.items()}, "ok": got == want}
 
+    def q3_top10_dist(self, steps, warmup):
+        """the tail of Q3 on N ranks ("final top-10 is a gather of N x 10 rows"): TopN(10) over each rank's groups ->
+        all-gather of the N x 10 candidate rows (tgpu_exchange_all_gather) -> TopN(10) again on every rank.  Checked against the top 10 of
+        the all-gathered per-rank torch top-10s."""
+        p, ctx = self.pkg, self.ctx
+        B, D, DT, I = p.BIGINT, p.DOUBLE, p.DATE, p.INTEGER
+        pages = [o.as_device_page() for o in self.q3_result]
+        fac = p.TopNOperatorFactory(ctx, 16, [B, DT, I, D], 10, [3, 1], [p.DESC_NULLS_LAST, p.ASC_NULLS_LAST])
+        result = {}
+
+        def step():
+            op = fac.createOperator()
+            for pg in pages:
+                op.addInput(pg)
+            local = self.finish(op)
+            op.close()
+            fin = fac.createOperator()
+            for o in local:
+                g = self.exchange.all_gather(o.as_device_page())
+                fin.addInput(g)
+                g.release()
+                o.release()
+            outs = self.finish(fin)
+            result["rows"] = [r for o in outs for r in o.to_host().rows()]
+            fin.close()
+
+        step_s, prof = self.timed(step, steps, warmup)
+        rev = torch.from_numpy(np.concatenate([o.to_host().getBlock(3).values for o in self.q3_result]))
+        mine = torch.sort(rev, descending=True).values[:10]
+        mine = torch.cat([mine, torch.full((10 - mine.numel(),), -1.0, dtype=torch.float64)]).to(self.coll_dev)
+        parts = [torch.empty(10, dtype=torch.float64, device=self.coll_dev) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        want = torch.sort(torch.cat(parts), descending=True).values[:10].cpu().tolist()
+        got = [r[3] for r in result["rows"]]
+        return {"workload": f"TopN(10) per rank -> all-gather of {self.world} x 10 rows -> TopN(10)", "ms_per_step": step_s * 1e3, "ok": got == [w for w in want if w >= 0.0][:len(got)] and len(got) == 10}
+
     def check_q3_dist(self):
         """N > 1, replicated-customer plan: every count and the revenue total against a reference computed independently with torch
         (each rank evaluates its own split against the all-gathered customer segment flags; totals are all-reduced)."""
@@ -1207,6 +1243,8 @@ def main():
     q3_readbacks = b.last_readbacks_per_step
     q3_check = (b.check_q3_dist_repartition() if repartition else b.check_q3_dist()) if distributed else b.check_q3()
     st = dict(b.q3_stats)
+    if distributed and b.q3_result:
+        extra["q3_top10"] = b.q3_top10_dist(args.steps, args.warmup)
     if distributed and not repartition and os.environ.get("TGPU_BENCH_PLAN") is None:
         # the alternative plan in the same line: every join input hash-repartitioned over xGMI (the all-to-all BASELINE.json's metric
         # names); `value` stays the plan the optimizer picks (co-partitioned joins), this object says what the exchange-heavy plan costs
@@ -1276,6 +1314,7 @@ def main():
     })
     if not distributed and b.q3_result:
         extra["q3_top10"] = b.q3_top10(args.steps, args.warmup)
+
     if not distributed:
         for o in (b.q3_result or []):
             o.release()
