@@ -150,3 +150,102 @@ def test_exchange_two_ranks_on_one_gpu_over_the_callback_transport(pkg, oracle):
         want_rep = [(row[1], row[2]) for src in range(world) for row in sent[src][: 5 + 3 * src]]
         assert rep == want_rep
         assert lonely == [row for row in sent[1] if owner(row[0]) == rank]
+
+
+def _agg_rows(rank, n):
+    rng = np.random.Generator(np.random.PCG64(500 + rank))
+    keys = [None if k == 7 else "g%d" % k for k in rng.integers(0, 9, n)]
+    vals = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, n)
+    ints = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    return keys, vals, ints
+
+
+def _agg_worker(rank, world, port, n, out_q):
+    try:
+        sys.path.insert(0, ROOT)
+        import torch
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pkg = importlib.import_module("presto-1_amd")
+        ex_mod = importlib.import_module("presto-1_amd.exchange")
+        ctx = pkg.Context(0)
+        ex = ex_mod.Exchange.over_transport(ctx, rank, world, ex_mod.GlooTransport(dist, ex_mod.TorchDeviceMemory(torch.device("cuda", 0))))
+        keys, vals, ints = _agg_rows(rank, n)
+        page = pkg.Page(pkg.Block(pkg.VARCHAR, keys), pkg.Block(pkg.DOUBLE, vals), pkg.Block(pkg.BIGINT, ints))
+        aggs = [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, -1), (pkg.SUM_BIGINT, 2), (pkg.AVG_DOUBLE, 1)]
+        part = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.VARCHAR], [0], aggs, step=pkg.PARTIAL).createOperator()
+        part.addInput(page)
+        part.finish()
+        fin = pkg.HashAggregationOperatorFactory(ctx, 1, [pkg.VARCHAR], [0], [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, 3), (pkg.SUM_BIGINT, 4), (pkg.AVG_DOUBLE, 6)], step=pkg.FINAL).createOperator()
+        while not part.isFinished():
+            o = part.getOutput()
+            if o is not None:
+                g = ex.all_gather(o.as_device_page())     # every rank's partial page, in rank order
+                fin.addInput(g)
+                g.release()
+                o.release()
+        fin.finish()
+        rows = []
+        while not fin.isFinished():
+            o = fin.getOutput()
+            if o is not None:
+                rows += o.to_host().rows()
+        out_q.put((rank, rows, None))
+        ex.close()
+        ctx.close()
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        out_q.put((rank, None, traceback.format_exc()))
+
+
+def test_partial_all_gather_final_aggregation_on_two_ranks(pkg, oracle):
+    """SURVEY.md 8e step 3 (what bench.py --gpus N runs for Q1): PARTIAL aggregation per rank -> all-gather of the partial pages ->
+    FINAL combine on every rank.  Counts and bigint sums exact; a double sum = the exact sum of the ranks' exactly rounded partial sums
+    (restated with the oracle); every rank ends with the same rows, groups in first-seen order of the gathered pages."""
+    import torch.multiprocessing as mp
+    from gpu_common import ulp_diff
+    world, n = 2, 20_000
+    port = _free_port()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_agg_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in results:
+        assert r[2] is None, r[2]
+    assert results[0][1] == results[1][1]
+    rows = results[0][1]
+    per_rank = []
+    for r in range(world):
+        keys, vals, ints = _agg_rows(r, n)
+        d = {}
+        for k, v, i in zip(keys, vals, ints):
+            e = d.setdefault(k, [[], 0, 0])
+            e[0].append(v)
+            e[1] += 1
+            e[2] += int(i)
+        per_rank.append(d)
+    order = []
+    for d in per_rank:          # first-seen order of the gathered partial pages: rank 0's groups in ITS first-seen order, then new ones of rank 1
+        for k in d:
+            if k not in order:
+                order.append(k)
+    assert [r[0] for r in rows] == order
+    for row in rows:
+        k = row[0]
+        addends = []
+        for d in per_rank:
+            if k in d:
+                _, s = oracle.agg_double_sum_exact(np.zeros(len(d[k][0]), dtype=np.int64), np.array(d[k][0]), 1)
+                addends.append(float(s[0]))
+        _, total = oracle.agg_double_sum_exact(np.zeros(len(addends), dtype=np.int64), np.array(addends), 1)
+        cnt = sum(d[k][1] for d in per_rank if k in d)
+        assert row[2] == cnt and row[3] == sum(d[k][2] for d in per_rank if k in d)
+        assert ulp_diff(np.array([row[1]]), np.array([float(total[0])])).max() == 0
+        assert ulp_diff(np.array([row[4]]), np.array([float(total[0]) / cnt])).max() == 0
