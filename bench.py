@@ -1243,31 +1243,6 @@ def main():
     q3_readbacks = b.last_readbacks_per_step
     q3_check = (b.check_q3_dist_repartition() if repartition else b.check_q3_dist()) if distributed else b.check_q3()
     st = dict(b.q3_stats)
-    if distributed and b.q3_result:
-        extra["q3_top10"] = b.q3_top10_dist(args.steps, args.warmup)
-    if distributed and not repartition and os.environ.get("TGPU_BENCH_PLAN") is None:
-        # the alternative plan in the same line: every join input hash-repartitioned over xGMI (the all-to-all BASELINE.json's metric
-        # names); `value` stays the plan the optimizer picks (co-partitioned joins), this object says what the exchange-heavy plan costs
-        for o in (b.q3_result or []):
-            o.release()
-        b.q3_result = None
-        keep = dict(b.q3_stats)
-        s_rp, prof_rp = b.timed(b.step_q3_dist_repartition, args.steps, args.warmup)
-        chk_rp = b.check_q3_dist_repartition()
-        st_rp = dict(b.q3_stats)
-        tt = torch.tensor([st_rp["lineitem_probe_rows"], st_rp.get("exchange_bytes_sent", 0)], device=b.coll_dev, dtype=torch.int64)
-        b.dist.all_reduce(tt)
-        ex_ms = prof_rp.get("exchange_all_to_all_v", {"total_ms": 0.0})["total_ms"] / args.steps
-        extra["repartition_plan"] = {
-            "plan": f"hash-repartitioned joins x{b.world}: K10 partition kernels + grouped RCCL send/recv all-to-all-v of every join input (tgpu_exchange_repartition)",
-            "ms_per_step": s_rp * 1e3, "probe_rows_per_sec": int(tt[0].item()) / s_rp, "exchange_bytes_sent_per_step_all_ranks": int(tt[1].item()),
-            "exchange_bytes_sent_per_step_this_rank": st_rp.get("exchange_bytes_sent", 0), "exchange_ms_per_step_this_rank": ex_ms,
-            "achieved_xgmi_GBps_this_rank": (st_rp.get("exchange_bytes_sent", 0) / (ex_ms * 1e-3) / 1e9) if ex_ms > 0 else None,
-            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(prof_rp.items(), key=lambda kv: -kv[1]["total_ms"])[:10]}, "check": chk_rp}
-        for o in (b.q3_result or []):
-            o.release()
-        b.q3_result = None
-        b.q3_stats = keep
     probe_rows = st["lineitem_probe_rows"]
     total_probe = probe_rows
     if b.dist is not None:
@@ -1312,6 +1287,47 @@ def main():
                    "exchange_bytes_sent_per_step": st.get("exchange_bytes_sent", 0)},
         "roofline": roof, "checks": {"q3": q3_check},
     })
+    if distributed:
+        # Extras of the N-rank line (Q3's top-10 tail, the repartition plan): the headline fields above are complete; should an extra raise,
+        # or a collective in it never return, the line still goes out with what is there (a watchdog prints it and ends the process).
+        import threading
+
+        def bail():
+            if b.rank == 0:
+                print(json.dumps({**out, **extra, "extras_timed_out": True}), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("TGPU_BENCH_EXTRAS_TIMEOUT", "300")), bail)
+        watchdog.daemon = True
+        watchdog.start()
+        b.extras_watchdog = watchdog
+        try:
+            if distributed and b.q3_result:
+                extra["q3_top10"] = b.q3_top10_dist(args.steps, args.warmup)
+            if distributed and not repartition and os.environ.get("TGPU_BENCH_PLAN") is None:
+                # the alternative plan in the same line: every join input hash-repartitioned over xGMI (the all-to-all BASELINE.json's metric
+                # names); `value` stays the plan the optimizer picks (co-partitioned joins), this object says what the exchange-heavy plan costs
+                for o in (b.q3_result or []):
+                    o.release()
+                b.q3_result = None
+                keep = dict(b.q3_stats)
+                s_rp, prof_rp = b.timed(b.step_q3_dist_repartition, args.steps, args.warmup)
+                chk_rp = b.check_q3_dist_repartition()
+                st_rp = dict(b.q3_stats)
+                tt = torch.tensor([st_rp["lineitem_probe_rows"], st_rp.get("exchange_bytes_sent", 0)], device=b.coll_dev, dtype=torch.int64)
+                b.dist.all_reduce(tt)
+                ex_ms = prof_rp.get("exchange_all_to_all_v", {"total_ms": 0.0})["total_ms"] / args.steps
+                extra["repartition_plan"] = {
+                    "plan": f"hash-repartitioned joins x{b.world}: K10 partition kernels + grouped RCCL send/recv all-to-all-v of every join input (tgpu_exchange_repartition)",
+                    "ms_per_step": s_rp * 1e3, "probe_rows_per_sec": int(tt[0].item()) / s_rp, "exchange_bytes_sent_per_step_all_ranks": int(tt[1].item()),
+                    "exchange_bytes_sent_per_step_this_rank": st_rp.get("exchange_bytes_sent", 0), "exchange_ms_per_step_this_rank": ex_ms,
+                    "achieved_xgmi_GBps_this_rank": (st_rp.get("exchange_bytes_sent", 0) / (ex_ms * 1e-3) / 1e9) if ex_ms > 0 else None,
+                    "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(prof_rp.items(), key=lambda kv: -kv[1]["total_ms"])[:10]}, "check": chk_rp}
+                for o in (b.q3_result or []):
+                    o.release()
+                b.q3_result = None
+                b.q3_stats = keep
+        except Exception as e:   # (every rank runs the same code on the same schedule: they fail together)
+            extra["extras_error"] = repr(e)
     if not distributed and b.q3_result:
         extra["q3_top10"] = b.q3_top10(args.steps, args.warmup)
 
@@ -1335,19 +1351,22 @@ def main():
     torch.cuda.empty_cache()
 
     if "q1" in only and b.world > 1:
-        # Q1 on N ranks: partial aggregation of every rank's shard -> all-gather of the 4-row partial pages -> final combine (8e step 3)
-        n = int(6_000_379.02 * args.sf)
-        b.setup_q1(n)
-        b.setup_q1_dist()
-        s1, p1 = b.timed(b.step_q1_dist, args.steps, args.warmup)
-        out["q1"] = {"metric": "input_rows_per_sec", "value": n * b.world / s1, "unit": "rows/s", "ms_per_step": s1 * 1e3, "rows_per_rank": n, "scaling": "weak",
-                     "workload": "tpch_q1_filter_project_hash_aggregation (BASELINE configs[2]), one SF%g shard per rank" % args.sf,
-                     "plan": f"x{b.world}: fused PARTIAL aggregation per rank -> all-gather of the partial pages (RCCL, rank order) -> FINAL combine on every rank",
-                     "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
-        out["checks"]["q1"] = b.check_q1_dist()
-        del b.q1, b.q1_page_
-        b.q1_result = None
-        torch.cuda.empty_cache()
+        try:
+            # Q1 on N ranks: partial aggregation of every rank's shard -> all-gather of the 4-row partial pages -> final combine (8e step 3)
+            n = int(6_000_379.02 * args.sf)
+            b.setup_q1(n)
+            b.setup_q1_dist()
+            s1, p1 = b.timed(b.step_q1_dist, args.steps, args.warmup)
+            out["q1"] = {"metric": "input_rows_per_sec", "value": n * b.world / s1, "unit": "rows/s", "ms_per_step": s1 * 1e3, "rows_per_rank": n, "scaling": "weak",
+                         "workload": "tpch_q1_filter_project_hash_aggregation (BASELINE configs[2]), one SF%g shard per rank" % args.sf,
+                         "plan": f"x{b.world}: fused PARTIAL aggregation per rank -> all-gather of the partial pages (RCCL, rank order) -> FINAL combine on every rank",
+                         "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])[:6]}}
+            out["checks"]["q1"] = b.check_q1_dist()
+            del b.q1, b.q1_page_
+            b.q1_result = None
+            torch.cuda.empty_cache()
+        except Exception as e:   # an extra of the N-rank line: the headline goes out whatever happens here
+            out["q1"] = {"error": repr(e)}
     elif "q1" in only:
         n = int(6_000_379.02 * args.sf)
         b.setup_q1(n)
@@ -1410,6 +1429,8 @@ def main():
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(b, args.cpu_sample_sf)
     out.update(extra)
+    if getattr(b, "extras_watchdog", None) is not None:
+        b.extras_watchdog.cancel()
     if b.rank == 0:
         print(json.dumps(out))
     if b.dist is not None:
