@@ -1380,6 +1380,7 @@ def main():
         out["q1"]["roofline"] = dominant(p1, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
                                          {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
+        out["q1"]["step_stats"] = b.step_stats(b.step_q1, min(args.steps, 20))
         if b.world == 1 and "paged" in only:
             # the engine hands over pages, not tables: the same program fed as 2^20-row pages (573 of them at SF100) directly and through MergePages
             out["q1"]["paged"] = {"direct_2^20": b.q1_paged(args.steps, args.warmup, 1 << 20), "merged_2^20_1GB": b.q1_paged(args.steps, args.warmup, 1 << 20, merge_mb=1024),
