@@ -1053,8 +1053,10 @@ namespace {
 static int fj_stripes()
 {
     const char *e = getenv("TGPU_FJ_STRIPES");
-    const int v = e ? atoi(e) : 4;   // 4: ~110 VGPRs = 4 workgroups per CU; the kernel is VALU-issue bound, not latency bound
-    return v >= 1 && v <= 8 ? v : 4;
+    // 3 rows per lane and tile: measured best on the streaming (lineitem) launch of Q3 with the DIRECT layout -- 1.48-1.55 ms against
+    // 1.57-1.62 at 4, 1.60 at 6, 1.67 at 8 and 1.88 at 2 (ABAB on one box): fewer registers = more resident waves with loads in flight
+    const int v = e ? atoi(e) : 3;
+    return v >= 1 && v <= 8 ? v : 3;
 }
 
 const char *kFjKernels = R"SRC(

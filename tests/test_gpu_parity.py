@@ -681,9 +681,9 @@ def test_join_prefilters_dense_bitmap_and_sparse_bloom(pkg, ctx, oracle, stride)
     assert np.array_equal(got, pkeys[op])
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 255, 1023, 1024, 1025, 4097, 65_537, 13_000_003])
+@pytest.mark.parametrize("n", [1, 63, 64, 255, 767, 768, 769, 1023, 1024, 1025, 4097, 65_537, 13_000_003])
 def test_fused_filter_probe_tile_and_chunk_boundaries(pkg, ctx, oracle, n):
-    """the software-pipelined fused filter+probe at page sizes around its tile (1024 rows) and chunk boundaries; the largest
+    """the software-pipelined fused filter+probe at page sizes around its tile (768 rows by default, 1024 with TGPU_FJ_STRIPES=4) and chunk boundaries; the largest
     size makes a workgroup take chunks of several consecutive tiles.  Expected = numpy filter + the oracle's probe."""
     rng = np.random.default_rng(41 + n % 97)
     bkeys = rng.permutation(400_000)[:120_000].astype(np.int64) * 3 + 7
