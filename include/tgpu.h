@@ -228,7 +228,9 @@ int32_t tgpu_partitioned_hash_builder_factory_create(tgpu_context *ctx, int32_t 
                                                      const int32_t *hash_channels, int32_t precomputed_hash_channel, int32_t expected_positions,
                                                      int32_t partition_count, tgpu_lookup_source_factory **bridge_out, tgpu_operator_factory **out);
 /* PartitionedLookupSource's join-position encoding (PartitionedLookupSource.java:212-226): (joinPosition << shiftSize) | partition with
- * shiftSize = numberOfTrailingZeros(partitionCount) + 1; for shims that must hand such positions to Java code */
+ * shiftSize = numberOfTrailingZeros(partitionCount) + 1; for shims that must hand such positions to Java code.  encode returns
+ * TGPU_ERR_INVALID_ARGUMENT (negative, never a position) unless partition_count is a power of two, 0 <= partition < partition_count and
+ * join_position >= 0 */
 int64_t tgpu_partitioned_join_position_encode(int32_t partition, int32_t join_position, int32_t partition_count);
 int32_t tgpu_partitioned_join_position_decode(int64_t partitioned_join_position, int32_t partition_count, int32_t *partition, int32_t *join_position);
 void tgpu_lookup_source_factory_destroy(tgpu_lookup_source_factory *bridge);

@@ -329,6 +329,8 @@ int32_t tgpu_hash_builder_factory_create(tgpu_context *ctx, int32_t operator_id,
 int64_t tgpu_partitioned_join_position_encode(int32_t partition, int32_t join_position, int32_t partition_count)
 {
     // PartitionedLookupSource.java:101-102,222-226: shiftSize = numberOfTrailingZeros(partitions) + 1
+    if (partition_count <= 0 || (partition_count & (partition_count - 1)) || partition < 0 || partition >= partition_count || join_position < 0)
+        return TGPU_ERR_INVALID_ARGUMENT;   // (negative: never a valid encoded position)
     const int shift = __builtin_ctz((unsigned)partition_count) + 1;
     return ((int64_t)join_position << shift) | (int64_t)partition;
 }
@@ -1190,7 +1192,12 @@ int32_t tgpu_exchange_partitioned_output(tgpu_exchange *ex, tgpu_operator *op, i
         TG_CHECK_ARG(ex && op && op->op && out, "null argument");
         TG_CHECK_ARG(op->ctx == ex->ctx, "the operator and the exchange belong to different contexts");
         const int W = ex->ex->world();
-        // pending (partition, page) pairs in enqueue order; several pages of one partition (several input pages) are shuffled round by round
+        // checked BEFORE anything is polled out of the operator: a refused call leaves its pending pages where they are
+        size_t most = 0;
+        int32_t partitions = 0;
+        partitioned_output_pending(op->op.get(), &most, &partitions);
+        TG_CHECK_ARG(partitions == W, "the operator's partition count differs from the exchange's world size");
+        TG_CHECK_ARG(most <= 1, "tgpu_exchange_partitioned_output moves the pages of ONE input page per call: call it after every add_input");
         std::vector<std::vector<std::unique_ptr<OutputPage>>> by_dest((size_t)W);
         for (;;) {
             int32_t part = -1;
@@ -1199,10 +1206,6 @@ int32_t tgpu_exchange_partitioned_output(tgpu_exchange *ex, tgpu_operator *op, i
             TG_CHECK_ARG(part >= 0 && part < W, "the operator's partition count differs from the exchange's world size");
             by_dest[(size_t)part].push_back(std::move(pg));
         }
-        size_t rounds = 0;
-        for (auto &v : by_dest) rounds = std::max(rounds, v.size());
-        // every rank must run the same number of collective rounds: agree on the maximum through the transport's header exchange
-        TG_CHECK_ARG(rounds <= 1, "tgpu_exchange_partitioned_output moves the pages of ONE input page per call: call it after every add_input");
         std::vector<const DevicePage *> per((size_t)W, nullptr);
         for (int r = 0; r < W; r++)
             if (!by_dest[(size_t)r].empty()) per[(size_t)r] = &by_dest[(size_t)r][0]->page;

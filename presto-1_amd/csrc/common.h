@@ -122,9 +122,13 @@ public:
     void download(void *dst, const void *src, size_t bytes);        // D2H + sync
     // A small read-back the caller keeps enqueueing work behind: begin_read copies `bytes` (<= 256) into a pinned slot and marks the
     // stream; finish_read waits for THAT point only (the kernels enqueued after begin_read keep running) and copies the bytes out.
+    // Slots are owned from begin_read to finish_read (handles of one context may be driven by several threads at once: a ring that
+    // merely advanced would hand a slot to a second reader before the first had looked at it); with every slot taken the read is done
+    // synchronously into the AsyncRead itself.
     struct AsyncRead {
-        int slot = -1;
+        int slot = -1;          // -2: completed synchronously, bytes in `inline_bytes`
         size_t bytes = 0;
+        uint8_t inline_bytes[256];
     };
     AsyncRead begin_read(const void *src, size_t bytes);
     void finish_read(const AsyncRead &r, void *dst);
@@ -179,10 +183,10 @@ private:
     size_t in_use_ = 0, cached_ = 0;
     void *pinned_ = nullptr;
     size_t pinned_bytes_ = 0;
-    static constexpr int kReadSlots = 4;
+    static constexpr int kReadSlots = 16;
     void *read_slots_ = nullptr;          // kReadSlots x 256 B pinned
     void *read_events_[kReadSlots] = {};  // hipEvent_t
-    int next_read_slot_ = 0;
+    bool read_busy_[kReadSlots] = {};     // owned by a begin_read whose finish_read has not run yet (under io_mu_)
     bool profiling_ = false;
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending_;

@@ -310,9 +310,17 @@ Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
         }
     }
     AsyncRead r;
-    r.slot = next_read_slot_;
     r.bytes = bytes;
-    next_read_slot_ = (next_read_slot_ + 1) % kReadSlots;   // (a slot is reused kReadSlots reads later: every caller finishes its read within its call)
+    for (int i = 0; i < kReadSlots && r.slot < 0; i++)
+        if (!read_busy_[i]) r.slot = i;
+    if (r.slot < 0) {
+        // every slot is owned by a reader that has not finished yet (many operators of this context inside a read at once)
+        download(r.inline_bytes, src, bytes);
+        readbacks_--;   // (counted once)
+        r.slot = -2;
+        return r;
+    }
+    read_busy_[r.slot] = true;
     HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * 256, src, bytes, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(read_events_[r.slot]), stream_));
     return r;
@@ -320,7 +328,20 @@ Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
 
 void Context::finish_read(const AsyncRead &r, void *dst)
 {
+    if (r.slot == -2) {
+        memcpy(dst, r.inline_bytes, r.bytes);
+        return;
+    }
     TG_CHECK_STATE(r.slot >= 0 && r.slot < kReadSlots, "no read-back in flight");
+    struct Release {   // the slot goes back whatever happens below
+        Context *c;
+        int slot;
+        ~Release()
+        {
+            std::lock_guard<std::recursive_mutex> io(c->io_mu_);
+            c->read_busy_[slot] = false;
+        }
+    } release{this, r.slot};
     hipEvent_t e = static_cast<hipEvent_t>(read_events_[r.slot]);
     static const bool blocking = getenv("TGPU_BLOCKING_WAIT") != nullptr;
     if (blocking) HIP_CHECK(hipEventSynchronize(e));

@@ -260,11 +260,16 @@ DevicePage Exchange::shuffle(const std::vector<int32_t> &types, const std::vecto
         DeviceColumn col;
         col.type = types[(size_t)c];
         col.n = n_out;
+        // The null-vector transfer slot of a channel exists on EVERY rank, used or not: the sends follow what this rank's outgoing pages
+        // carry, the receives what the incoming headers announce -- the two sides are independent (a rank may send a null vector and
+        // receive none, e.g. when all its rows leave for a peer), and the transfer indices stay the same on all ranks.
         bool any_nulls = false;
         for (int r = 0; r < W; r++) any_nulls = any_nulls || (rows[(size_t)r] > 0 && rmeta[(size_t)r * per + 1 + 2 * c] != 0);
         if (any_nulls) {
             col.nulls_buf = ctx_->alloc_zero((size_t)(n_out > 0 ? n_out : 1));   // sources without a null vector: all false
             col.nulls = col.nulls_buf->as<uint8_t>();
+        }
+        {
             const size_t t = add_transfer();
             for (int r = 0; r < W; r++) {
                 const DevicePage &p = page_of(r);

@@ -30,10 +30,38 @@ using GbhProbeFn = std::function<void(const GbhProbeLaunch &)>;
 // steady state of low-cardinality inputs the wait for the counters then overlaps the consumer instead of idling the device.
 using GbhSpeculateFn = std::function<void(const unsigned long long *counters)>;
 
+// The single-integer-key table (groupby_bigint.hip): key inline in a 16-byte slot, one random line per row, one atomic per new group.
+// Used by GroupByHashGpu for one BIGINT key (as GroupByHash.createGroupByHash picks BigintGroupByHash, M/operator/GroupByHash.java:45-59)
+// and for one INTEGER / DATE key without a precomputed hash channel.
+class BigintGroupTable {
+public:
+    BigintGroupTable(Context *ctx, int32_t type);
+    // room for `need_groups` groups at a fill of at most 0.75 (grows by rebuilding from the published groups)
+    void ensure_table(int64_t need_groups);
+    void rebuild(int64_t min_capacity);
+    int64_t capacity() const { return capacity_; }
+    int64_t groups() const { return groups_; }
+    // group ids of one sub-batch (rows numbered from 0): false = the table overflowed (rebuild + re-run); ctr = 8 zeroed device words
+    bool process(const DeviceColumn &keys, const uint8_t *row_mask, int64_t n, int32_t *out_gids, unsigned long long *ctr, int64_t *new_groups);
+    void lookup(const DeviceColumn &keys, int64_t n, int32_t *out_gids, unsigned long long *ctr);
+    DeviceColumn key_column();   // values_by_group (+ the null flag of the NULL group), group-id order
+    int64_t estimated_size() const;
+
+private:
+    void ensure_store(int64_t need_groups);
+    Context *ctx_;
+    int32_t type_;
+    int width_;
+    int64_t groups_ = 0, capacity_ = 0, store_cap_ = 0;
+    int shift_ = 64;
+    BufferPtr slots_, values_, nulls_;
+};
+
 class GroupByHashGpu {
 public:
     static constexpr int kCounterSets = 64;   // counter sets per initialising launch (fresh_counters)
-    GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool has_input_hash, int32_t expected_size);
+    // allow_integer_table = false: the caller brings its own probe kernels (GbhProbeFn), which speak the generic table's layout
+    GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool has_input_hash, int32_t expected_size, bool allow_integer_table = true);
 
     // group id (int32, device) of each of the n rows; new keys get ids in first-seen order.
     // hashes == nullptr -> raw hashes are computed from the keys (InterpretedHashGenerator).
@@ -81,9 +109,13 @@ private:
     BufferPtr device_keys(const KeyCols &k);
     void advance_java_capacity();
 
+    void get_group_ids_integer(const DeviceColumn &key, int64_t n, int32_t *out_gids, const uint8_t *row_mask);
+
     Context *ctx_;
     std::vector<int32_t> types_;
     bool has_input_hash_;
+    std::unique_ptr<BigintGroupTable> integer_;   // set: single integer key, the table of groupby_bigint.hip does the work
+    bool optimistic_ = false;                     // the next sub-batch is an optimistic one (integer table)
     int64_t groups_ = 0;
     int64_t capacity_ = 0;  // slots of the device table (uint64 words)
     BufferPtr words_;

@@ -217,7 +217,7 @@ int32_t java_max_fill(int32_t hash_size)
 
 }  // namespace
 
-GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool has_input_hash, int32_t expected_size)
+GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool has_input_hash, int32_t expected_size, bool allow_integer_table)
     : ctx_(ctx), types_(std::move(types)), has_input_hash_(has_input_hash)
 {
     TG_CHECK_ARG(!types_.empty() && (int)types_.size() <= kMaxKeyChannels, "group by needs 1..8 key channels");
@@ -234,10 +234,18 @@ GroupByHashGpu::GroupByHashGpu(Context *ctx, std::vector<int32_t> types, bool ha
     const char *first = getenv("TGPU_GBH_FIRST_SUB");
     next_sub_ = std::min<int64_t>(sub_batch_, std::max<int64_t>(first ? atoll(first) : (1ll << 14), (int64_t)expected_size * 16));
     counters_ = ctx_->alloc_zero((size_t)GroupByHashGpu::kCounterSets * 8 * 8);
+    // GroupByHash.createGroupByHash (M/operator/GroupByHash.java:45-59): one BIGINT key -> BigintGroupByHash, whose output hash is
+    // recomputed from the value (BigintGroupByHash.java:150-157) -- a precomputed hash channel is not even read.  INTEGER / DATE keys
+    // take the same table when no hash channel is given (their raw hash is then a function of the value, too).
+    const char *off = getenv("TGPU_GBH_INTEGER_TABLE");
+    if (allow_integer_table && types_.size() == 1 && !(off && off[0] == '0') &&
+        (types_[0] == TGPU_BIGINT || ((types_[0] == TGPU_INTEGER || types_[0] == TGPU_DATE) && !has_input_hash_)))
+        integer_ = std::make_unique<BigintGroupTable>(ctx_, types_[0]);
 }
 
 int64_t GroupByHashGpu::estimated_size() const
 {
+    if (integer_) return integer_->estimated_size();
     int64_t s = capacity_ * 8 + raw_hash_cap_ * 8;
     for (auto &k : store_) s += k.cap * (type_width(k.type) + 1) + (k.type == TGPU_VARCHAR ? k.cap * 4 + k.pool_cap : 0);
     return s;
@@ -468,6 +476,11 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
     TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
     for (size_t i = 0; i < keys.size(); i++) TG_CHECK_ARG(keys[i]->type == types_[i], "group-by key channel type mismatch");
     if (n <= 0) return false;
+    if (integer_) {
+        TG_CHECK_STATE(probe == nullptr && out_gids8 == nullptr, "external probe kernels need the generic group-by table");
+        get_group_ids_integer(*keys[0], n, out_gids, row_mask);
+        return false;
+    }
     constexpr int64_t kCompactGroups = 250;   // ids + 1 must stay below the 255 marker
     bool compact = out_gids8 != nullptr && probe != nullptr && groups_ < kCompactGroups;
     if (out_gids8 != nullptr && !compact) {   // no external probe kernel, or already too many groups for a byte
@@ -522,7 +535,13 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
             unsigned long long host_ctr[8];
             const Context::AsyncRead rd = ctx_->begin_read(ctr, sizeof(host_ctr));
             const bool hooked = speculate != nullptr && start == 0 && len == n;
-            if (hooked) (*speculate)(ctr);   // the page's consumer, gated on these counters: runs while the host waits for them
+            try {
+                if (hooked) (*speculate)(ctr);   // the page's consumer, gated on these counters: runs while the host waits for them
+            }
+            catch (...) {
+                ctx_->finish_read(rd, host_ctr);   // gives the read slot back
+                throw;
+            }
             ctx_->finish_read(rd, host_ctr);
             if (hooked && speculated) *speculated = host_ctr[0] == 0 && host_ctr[2] == 0 && host_ctr[7] == ~0ull;
             raise_expression_error(host_ctr[7]);
@@ -564,10 +583,50 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
     return out_gids8 != nullptr;
 }
 
+// Sub-batches of the integer table.  A regular sub-batch is sized by bound (room for every row to be a new group: it cannot overflow);
+// after a sizeable one without a new group the rest of the page goes in ONE optimistic launch with room for 2^24 new groups (an
+// overflow is flagged by the kernel: rebuilt larger, re-run in pieces); a sub-batch in which at least a quarter of the rows were new
+// groups is evidence of a high-cardinality key, and the rest goes in bounded launches of up to 2^27 rows -- the table is sized once
+// from the row bound instead of growing by doubling (12 rehashes on the way to 40 M groups).
+void GroupByHashGpu::get_group_ids_integer(const DeviceColumn &key, int64_t n, int32_t *out_gids, const uint8_t *row_mask)
+{
+    int64_t sub = next_sub_, start = 0;
+    while (start < n) {
+        const int64_t len = std::min(sub, n - start);
+        const DeviceColumn view = k::region_of(ctx_, key, start, len);
+        integer_->ensure_table(integer_->groups() + (optimistic_ ? std::min<int64_t>(len, sub_batch_) : len));
+        int64_t new_groups = 0;
+        if (!integer_->process(view, row_mask ? row_mask + start : nullptr, len, out_gids + start, fresh_counters(), &new_groups)) {
+            integer_->rebuild(integer_->capacity() * 2);
+            sub = std::max<int64_t>(std::min(sub_batch_, len / 4), 1);
+            optimistic_ = false;
+            continue;
+        }
+        start += len;
+        groups_ = integer_->groups();
+        if (new_groups > 0) advance_java_capacity();
+        last_new_groups_ = new_groups;
+        if (new_groups == 0) {
+            optimistic_ = sub >= std::min<int64_t>(1ll << 17, sub_batch_);
+            sub = optimistic_ ? (1ll << 40) : sub * 64;
+        }
+        else {
+            optimistic_ = false;
+            sub = new_groups * 4 >= len ? std::max<int64_t>(sub_batch_, 1ll << 27) : std::min<int64_t>(sub * 8, sub_batch_);
+            if (getenv("TGPU_GBH_SUBBATCH")) sub = std::min(sub, sub_batch_);   // (tests force small sub-batches)
+        }
+        next_sub_ = sub;
+    }
+}
+
 void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids)
 {
     TG_CHECK_ARG(keys.size() == types_.size(), "wrong number of key channels");
     if (n <= 0) return;
+    if (integer_) {
+        integer_->lookup(*keys[0], n, out_gids, fresh_counters());
+        return;
+    }
     BufferPtr own_hashes;
     if (!hashes) {
         own_hashes = ctx_->alloc((size_t)n * 8);
@@ -585,6 +644,23 @@ void GroupByHashGpu::lookup(const std::vector<const DeviceColumn *> &keys, const
 
 DevicePage GroupByHashGpu::key_page(bool with_hash)
 {
+    if (integer_) {
+        DevicePage p;
+        p.n = groups_;
+        p.cols.push_back(integer_->key_column());
+        if (with_hash) {
+            // BigintGroupByHash.appendValuesTo (:150-157): the hash of the value, NULL_HASH_CODE (0) for the null group = H5 over one channel
+            DeviceColumn c;
+            c.type = TGPU_BIGINT;
+            c.n = groups_;
+            c.values_buf = ctx_->alloc((size_t)(groups_ > 0 ? groups_ : 1) * 8);
+            c.values = c.values_buf->ptr();
+            std::vector<const DeviceColumn *> kc{&p.cols[0]};
+            k::hash_rows(ctx_, key_cols_of(kc), groups_, c.values_buf->as<int64_t>());
+            p.cols.push_back(c);
+        }
+        return p;
+    }
     DevicePage p;
     p.n = groups_;
     ensure_store(groups_ > 0 ? groups_ : 1);

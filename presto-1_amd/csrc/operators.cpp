@@ -521,7 +521,7 @@ protected:
     {
         if (builder_) return;
         if (!cfg_.group_by_types.empty())
-            gbh_ = std::make_unique<GroupByHashGpu>(ctx_, cfg_.group_by_types, cfg_.hash_channel >= 0, cfg_.expected_groups);
+            gbh_ = std::make_unique<GroupByHashGpu>(ctx_, cfg_.group_by_types, cfg_.hash_channel >= 0, cfg_.expected_groups, allow_integer_table());
         accs_ = std::make_unique<GroupedAccumulators>(ctx_, cfg_.aggs, cfg_.step);
         accs_->set_allow_ordered(allow_ordered_accumulation());
         accs_->set_force_ordered(ctx_->double_sum_order() == TGPU_SUM_ORDER_JAVA);
@@ -529,6 +529,8 @@ protected:
     }
     // many groups: rows sorted by group id, one lane per group adds them in row order (agg.h)
     virtual bool allow_ordered_accumulation() const { return true; }
+    // the single-integer-key table (groupby_bigint.hip); an operator that brings its own probe kernels needs the generic layout
+    virtual bool allow_integer_table() const { return true; }
     void reset_builder()
     {
         gbh_.reset();
@@ -1163,10 +1165,13 @@ public:
     {
     }
 
+    bool uses_fused_kernels() const { return fused_->supported() && !fused_->key_inputs().empty() && cfg_.step != TGPU_STEP_FINAL && getenv("TGPU_DISABLE_FUSION") == nullptr; }
+    bool allow_integer_table() const override { return !uses_fused_kernels(); }
+
     void add_input(const tgpu_page *page) override
     {
         begin_input();
-        const bool fused_ok = fused_->supported() && gbh_ && !fused_->key_inputs().empty() && cfg_.step != TGPU_STEP_FINAL && getenv("TGPU_DISABLE_FUSION") == nullptr;
+        const bool fused_ok = gbh_ && uses_fused_kernels();
         // the fused kernels address VARCHAR bytes through the offsets alone: the byte ranges of borrowed device columns stay unread
         DevicePage in = ingest_page(ctx_, page, /*resolve_varchar=*/!fused_ok);
         if (in.n == 0) return;
@@ -1906,6 +1911,15 @@ public:
         pending_.pop_front();
         return true;
     }
+    // the largest number of pending pages any one partition has (a consumer that moves one page per partition and call checks BEFORE it polls)
+    size_t max_pending_per_partition() const
+    {
+        std::vector<size_t> cnt((size_t)partition_count_, 0);
+        size_t most = 0;
+        for (auto &pp : pending_) most = std::max(most, ++cnt[(size_t)pp.first]);
+        return most;
+    }
+    int32_t partition_count() const { return partition_count_; }
     int64_t rows_added_ = 0, pages_added_ = 0;   // PartitionedOutputInfo (:396-399)
 
 private:
@@ -1952,6 +1966,14 @@ bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<O
     auto *p = dynamic_cast<PartitionedOutputOperator *>(op);
     TG_CHECK_ARG(p != nullptr, "not a PartitionedOutputOperator");
     return p->poll(partition, out);
+}
+
+void partitioned_output_pending(Operator *op, size_t *max_per_partition, int32_t *partition_count)
+{
+    auto *p = dynamic_cast<PartitionedOutputOperator *>(op);
+    TG_CHECK_ARG(p != nullptr, "not a PartitionedOutputOperator");
+    *max_per_partition = p->max_pending_per_partition();
+    *partition_count = p->partition_count();
 }
 
 void partitioned_output_info(Operator *op, int64_t *rows_added, int64_t *pages_added)

@@ -418,6 +418,7 @@ private:
 };
 // next pending (partition, page) pair of a PartitionedOutputOperator; false = nothing pending
 bool partitioned_output_poll(Operator *op, int32_t *partition, std::unique_ptr<OutputPage> *out);
+void partitioned_output_pending(Operator *op, size_t *max_per_partition, int32_t *partition_count);
 void partitioned_output_info(Operator *op, int64_t *rows_added, int64_t *pages_added);
 
 }  // namespace tgpu

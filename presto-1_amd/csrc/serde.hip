@@ -22,6 +22,8 @@
 // Compressed / encrypted pages are refused (exchange.compression-enabled defaults to false; spill encryption is a CPU path).
 #include "serde.h"
 
+#include <mutex>
+
 #include <cstring>
 
 #include "kernels.h"
@@ -361,10 +363,18 @@ std::vector<uint8_t> lz4_decode_on_device(Context *ctx, const uint8_t *compresse
     std::vector<uint8_t> out((size_t)uncompressed_len);
     if (uncompressed_len == 0) return out;
     BufferPtr src = upload_section(ctx, compressed, compressed_len), dst = ctx->alloc((size_t)uncompressed_len), status = ctx->alloc_zero(4);
-    static bool configured = false;
-    if (!configured) {
-        HIP_CHECK(hipFuncSetAttribute((const void *)lz4_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLz4Window));
-        configured = true;
+    {
+        // the attribute belongs to the kernel's code object on ONE device: set once per device, under a lock (operators of several
+        // contexts / devices decode concurrently)
+        static std::mutex mu;
+        static std::vector<bool> configured;
+        std::lock_guard<std::mutex> lock(mu);
+        const size_t d = (size_t)ctx->device();
+        if (configured.size() <= d) configured.resize(d + 1, false);
+        if (!configured[d]) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)lz4_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLz4Window));
+            configured[d] = true;
+        }
     }
     {
         ProfileScope ps(ctx, "lz4_decode");

@@ -111,14 +111,23 @@ def _rehearsal_worker(rank, world, port, n, out_q):
         empty = pkg.Page(pkg.Block(pkg.BIGINT, np.zeros(0, dtype=np.int64)), pkg.Block(pkg.BIGINT, np.zeros(0, dtype=np.int64)), pkg.Block(pkg.VARCHAR, []),
                          pkg.Block(pkg.DOUBLE, np.zeros(0)))
         lonely = ex.repartition(page if rank == 1 else empty, [0]).to_host()       # one rank contributes nothing
-        out_q.put((rank, got.rows(), rep.rows(), lonely.rows(), ex.bytes_sent, None))
+        # one way: every row of both ranks belongs to rank 1, and only rank 0's page carries a null vector -- rank 0 sends a null vector
+        # and receives nothing at all (the send side of a channel's null transfer must not depend on what the rank receives)
+        from oracle import oracle
+        cand = np.arange(4000, dtype=np.int64)
+        to1 = cand[oracle.partition_remote(oracle.hash_rows([oracle.Col(oracle.BIGINT, cand)]), world) == 1]
+        k1 = to1[(np.arange(400) * (3 + rank)) % len(to1)]
+        d1 = np.arange(400, dtype=np.float64) + 1000.0 * rank
+        n1 = (np.arange(400) % 7 == 0).astype(np.uint8) if rank == 0 else None
+        one_way = ex.repartition(pkg.Page(pkg.Block(pkg.BIGINT, k1), pkg.Block(pkg.DOUBLE, d1, n1)), [0]).to_host()
+        out_q.put((rank, got.rows(), rep.rows(), lonely.rows(), ex.bytes_sent, None, one_way.rows()))
         ex.close()
         ctx.close()
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:   # surfaced by the parent
         import traceback
-        out_q.put((rank, None, None, None, 0, traceback.format_exc()))
+        out_q.put((rank, None, None, None, 0, traceback.format_exc(), None))
 
 
 def test_exchange_two_ranks_on_one_gpu_over_the_callback_transport(pkg, oracle):
@@ -143,7 +152,14 @@ def test_exchange_two_ranks_on_one_gpu_over_the_callback_transport(pkg, oracle):
     def owner(key):
         return int(oracle.partition_remote(oracle.hash_rows([oracle.Col(oracle.BIGINT, np.array([key], dtype=np.int64))]), world)[0])
 
-    for rank, got, rep, lonely, nbytes, _ in results:
+    cand = np.arange(4000, dtype=np.int64)
+    to1 = cand[oracle.partition_remote(oracle.hash_rows([oracle.Col(oracle.BIGINT, cand)]), world) == 1]
+    one_way_sent = []
+    for r in range(world):
+        k1 = to1[(np.arange(400) * (3 + r)) % len(to1)]
+        one_way_sent += [(int(k), None if (r == 0 and i % 7 == 0) else float(i + 1000.0 * r)) for i, k in enumerate(k1)]
+    for rank, got, rep, lonely, nbytes, _, one_way in results:
+        assert one_way == (one_way_sent if rank == 1 else [])
         want = [row for src in range(world) for row in sent[src] if owner(row[0]) == rank]     # grouped by source rank, source order kept
         assert got == want
         assert nbytes > 0

@@ -149,6 +149,65 @@ def test_group_by_hash_sub_batches(pkg, oracle, monkeypatch):
     c.close()
 
 
+@pytest.mark.parametrize("type_name", ["BIGINT", "INTEGER", "DATE"])
+@pytest.mark.parametrize("layout", ["integer_table", "generic_table"])
+def test_group_by_hash_single_integer_key_table(pkg, oracle, monkeypatch, type_name, layout):
+    """the inline-key table of groupby_bigint.hip (one BIGINT / INTEGER / DATE key, BigintGroupByHash.java) against the oracle and against the
+    generic table: the key that equals the table's fill pattern (-1), the NULL group, keys clustered in runs (wave-level followers), keys
+    that collide into long probe sequences, several pages, lookups of absent keys"""
+    monkeypatch.setenv("TGPU_GBH_INTEGER_TABLE", "1" if layout == "integer_table" else "0")
+    t = getattr(pkg, type_name)
+    c = pkg.Context(0)
+    rng = np.random.default_rng(77)
+    dt = np.int64 if t == pkg.BIGINT else np.int32
+    gbh = pkg.GroupByHash(c, [t], [0], expected_size=16)
+    o = oracle.BigintGroupByHash(16) if t == pkg.BIGINT else oracle.MultiChannelGroupByHash([t], 16)
+    pages = []
+    runs = np.repeat(rng.integers(-3, 40, 3000), rng.integers(1, 9, 3000)).astype(dt)               # clustered runs incl. -1
+    pages.append((runs, rng.random(len(runs)) < 0.02))
+    pages.append((rng.integers(-2, 2, 50_000).astype(dt), rng.random(50_000) < 0.3))                  # four keys + many nulls: hot slots
+    stride = (1 << 40) if t == pkg.BIGINT else (1 << 20)
+    pages.append(((rng.integers(0, 5000, 70_000) * stride).astype(dt), None))                         # multiples of a power of two
+    pages.append((rng.integers(-2**31, 2**31 - 1, 100_000).astype(dt), rng.random(100_000) < 0.001))  # mostly distinct
+    pages.append((np.array([-1, -1, 0, -1], dtype=dt), np.array([False, True, False, False])))
+    for vals, nulls in pages:
+        blk = pkg.Block(t, vals, None if nulls is None else nulls.astype(np.uint8))
+        oc = ocol(oracle, blk)
+        want = o.get_group_ids(oc) if t == pkg.BIGINT else o.get_group_ids([oc], None)
+        got = gbh.getGroupIds(pkg.Page(blk))
+        assert np.array_equal(got, want)
+        assert gbh.getGroupCount() == o.group_count and gbh.getCapacity() == o.capacity
+    out = gbh.appendValues()
+    if t == pkg.BIGINT:
+        v, nl, _ = o.values()
+        want_keys = [None if isnull else int(x) for x, isnull in zip(v, nl)]
+    else:
+        first, _ = o.group_rows()
+        want_keys = None
+    got_keys = out.getBlock(0).to_list()
+    assert len(got_keys) == o.group_count and len(set(got_keys)) == o.group_count
+    if want_keys is not None:
+        assert got_keys == want_keys
+    probe = pkg.Page(pkg.Block(t, np.array([-1, 123456789, 0], dtype=dt)))
+    assert gbh.contains(0, probe) and gbh.contains(2, probe)
+    assert gbh.contains(1, probe) == (123456789 in set(k for k in got_keys if k is not None))
+    gbh.close()
+    c.close()
+
+
+def test_group_by_hash_integer_table_output_hash_is_recomputed_from_the_value(pkg, ctx, oracle):
+    """BigintGroupByHash.appendValuesTo (:150-157) writes AbstractLongType.hash(value) / NULL_HASH_CODE -- not the input hash channel"""
+    vals = np.array([5, 7, 5, -1, 9, 7], dtype=np.int64)
+    nulls = np.array([0, 0, 0, 0, 1, 0], dtype=np.uint8)
+    blk = pkg.Block(pkg.BIGINT, vals, nulls)
+    hashes = oracle.hash_rows([ocol(oracle, blk)])
+    gbh = pkg.GroupByHash(ctx, [pkg.BIGINT], [0], input_hash_channel=1, expected_size=10)
+    assert list(gbh.getGroupIds(pkg.Page(blk, pkg.Block(pkg.BIGINT, hashes)))) == [0, 1, 0, 2, 3, 1]
+    out = gbh.appendValues()
+    assert out.getBlock(0).to_list() == [5, 7, -1, None]
+    assert list(out.getBlock(1).values) == [int(hashes[0]), int(hashes[1]), int(hashes[3]), 0]
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # hash aggregation operator
 # ---------------------------------------------------------------------------------------------------------------------
