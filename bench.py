@@ -1006,7 +1006,7 @@ def sub_join_hash_layout(b, steps, warmup, sf):
     # algorithmic bytes of the probe launch, hash layout: filter column 4 B x input rows + (key 8 B + one 16-byte TgSlot16) x rows
     # passing the filter + 8 B per emitted pair (the Bloom word in front of the table is an optimisation, not priced)
     alg = 4.0 * n + 24.0 * n_pass + 8.0 * want_pairs
-    roof = dominant(prof, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n}, pmc_prefix="sub_join_hash_layout:")
+    roof = dominant(prof, steps, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n}, pmc_prefix="sub_join_hash_layout:")
     return {"workload": "fused filter + probe, sparse random 64-bit build keys (open-address TgSlot16 table + Bloom pre-filter)", "build_rows": nb, "input_rows": n,
             "probe_rows": n_pass, "pairs": want_pairs, "table_slots": res["stats"]["hash_size"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n_pass / step_s,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
@@ -1043,7 +1043,7 @@ def sub_join_duplicate_keys(b, steps, warmup, sf):
     want_pairs = 2 * int((r < (nb + 1) // 2).sum().item())
     ok = res["pairs"] == want_pairs and res["stats"]["link_count"] > 0
     # unfused probe: key 8 B + one table slot 16 B + head / count out 8 B per probe row
-    roof = dominant(prof, {"join_probe_count": n}, {"join_probe_count": 32.0}, pmc_prefix="sub_join_duplicate_keys:")
+    roof = dominant(prof, steps, {"join_probe_count": n}, {"join_probe_count": 32.0}, pmc_prefix="sub_join_duplicate_keys:")
     return {"workload": "LookupJoinOperator over a table with every build key twice (position links, newest -> oldest chains)", "build_rows": nb, "probe_rows": n,
             "pairs": want_pairs, "link_count": res["stats"]["link_count"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n / step_s,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
@@ -1068,7 +1068,7 @@ def sub_group_by_hash(b, steps, warmup, rows, groups):
     step_s, prof = b.timed(step, steps, warmup)
     want = int(torch.unique(keys).numel())
     # gbh_insert per row: key 8 B + one 8-byte table word + the 4-byte group id it answers with
-    roof = dominant(prof, {"gbh_insert": rows}, {"gbh_insert": 20.0}, pmc_prefix="sub_group_by_hash:")
+    roof = dominant(prof, steps, {"gbh_insert": rows}, {"gbh_insert": 20.0}, pmc_prefix="sub_group_by_hash:")
     return {"workload": f"BenchmarkGroupByHash.bigintGroupByHash shape: addPage of {rows} BIGINT keys uniform in [0, {groups}) + appendValuesTo of every group",
             "rows": rows, "groups": want, "ms_per_step": step_s * 1e3, "rows_per_sec": rows / step_s, "ns_per_row": step_s * 1e9 / rows,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
@@ -1188,7 +1188,11 @@ def cpu_baseline(bench, sample_sf):
 PMC_PROFILES = ["r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"]   # newest first
 
 
-def dominant(profile, rows_by_kernel, bytes_per_row, pmc_prefix=""):
+def dominant(profile, steps, rows_per_step, bytes_per_row, pmc_prefix=""):
+    """Roofline of the kernel that takes most of the step's device time among those priced in `bytes_per_row`.
+    achieved = ALGORITHMIC bytes of ONE STEP (bytes_per_row x the rows the kernel processes per step, whatever number of launches they are
+    spread over) / the kernel's TOTAL time per step, HIP-event timed on the context's stream.  (Round 2 divided the whole step's bytes by the
+    AVERAGE launch: right for one launch per step, 3-9x too high for the group-by table's 3 / 9 sub-batch launches.)"""
     best = None
     for name, st in profile.items():
         if name not in bytes_per_row or st["count"] == 0:
@@ -1198,9 +1202,10 @@ def dominant(profile, rows_by_kernel, bytes_per_row, pmc_prefix=""):
     if best is None:
         return None
     st = profile[best]
-    avg_ms = st["total_ms"] / st["count"]
-    alg_bytes = bytes_per_row[best] * rows_by_kernel[best]
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    launches = st["count"] / steps
+    ms_per_step = st["total_ms"] / steps
+    alg_bytes_step = bytes_per_row[best] * rows_per_step[best]
+    achieved = alg_bytes_step / (ms_per_step * 1e-3) / 1e9
     # HBM bytes per launch: NOT measured by this process (PMC counters need their own rocprofv3 --pmc passes); the figure is read from
     # the committed summary of those passes over this very command and labelled as such (`traffic_source`); null when absent
     traffic, traffic_source = None, None
@@ -1213,8 +1218,9 @@ def dominant(profile, rows_by_kernel, bytes_per_row, pmc_prefix=""):
             traffic, traffic_source = pmc["traffic_bytes_per_launch_avg"], f"profiles/{name} (committed rocprofv3 --pmc passes of `python bench.py`, not this run)"
             break
     return {"bound": "hbm", "kernel": best, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_source,
-            "avg_launch_ms": avg_ms, "launches": st["count"], "algorithmic_bytes_per_launch": alg_bytes,
-            "algorithmic_bytes_per_row": bytes_per_row[best], "rows_per_launch": rows_by_kernel[best]}
+            "avg_launch_ms": ms_per_step / launches, "launches": st["count"], "launches_per_step": launches, "kernel_ms_per_step": ms_per_step,
+            "algorithmic_bytes_per_step": alg_bytes_step, "algorithmic_bytes_per_launch": alg_bytes_step / launches,
+            "algorithmic_bytes_per_row": bytes_per_row[best], "rows_per_step": rows_per_step[best], "rows_per_launch": rows_per_step[best] / launches}
 
 
 def main():
@@ -1261,9 +1267,9 @@ def main():
     if repartition:
         # behind the exchange the probe is the unfused kernel: key 8 B + one table slot 12 B + head/count out 8 B per probe row
         rows_avg = (st["orders_probe_rows"] + st["lineitem_probe_rows"]) / 2.0
-        roof = dominant(prof, {"join_probe_count": rows_avg}, {"join_probe_count": 28.0})
+        roof = dominant(prof, args.steps, {"join_probe_count": 2.0 * rows_avg}, {"join_probe_count": 28.0})
     else:
-        roof = dominant(prof, {"fused_filter_probe": rows_avg}, {"fused_filter_probe": alg / rows_avg})
+        roof = dominant(prof, args.steps, {"fused_filter_probe": 2.0 * rows_avg}, {"fused_filter_probe": alg / rows_avg})   # two launches per step (orders, lineitem)
         if roof and roof["kernel"] == "fused_filter_probe" and "fused_filter_probe" in prof:
             # the two launches of a step are different animals: the orders launch probes random keys (bound by
             # divergent L2 lookups), the lineitem launch streams.  Their own figures, from the shortest (orders) and the longest
@@ -1289,20 +1295,42 @@ def main():
     })
     if distributed:
         # Extras of the N-rank line (Q3's top-10 tail, the repartition plan): the headline fields above are complete; should an extra raise,
-        # or a collective in it never return, the line still goes out with what is there (a watchdog prints it and ends the process).
+        # the line still goes out with what is there; a collective in an extra that never returns ends the process with exit code 3 after the
+        # watchdog has printed the line marked `extras_timed_out` (a hang is a failure, not a result).
         import threading
 
-        def bail():
-            if b.rank == 0:
-                print(json.dumps({**out, **extra, "extras_timed_out": True}), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(float(os.environ.get("TGPU_BENCH_EXTRAS_TIMEOUT", "300")), bail)
-        watchdog.daemon = True
-        watchdog.start()
+        class ExtrasWatchdog:
+            """armed around EACH extra: a collective that never returns is a failure -- the line goes out with what is there, marked, and the
+            process exits NON-ZERO (a hang must not look like a clean run)"""
+
+            def __init__(self):
+                self.timer, self.what = None, None
+                self.seconds = float(os.environ.get("TGPU_BENCH_EXTRAS_TIMEOUT", "300"))
+
+            def fire(self):
+                if b.rank == 0:
+                    print(json.dumps({**out, **extra, "extras_timed_out": True, "extras_timed_out_in": self.what}), flush=True)
+                os._exit(3)
+
+            def arm(self, what):
+                self.cancel()
+                self.what = what
+                self.timer = threading.Timer(self.seconds, self.fire)
+                self.timer.daemon = True
+                self.timer.start()
+
+            def cancel(self):
+                if self.timer is not None:
+                    self.timer.cancel()
+                    self.timer = None
+
+        watchdog = ExtrasWatchdog()
         b.extras_watchdog = watchdog
         try:
             if distributed and b.q3_result:
+                watchdog.arm("q3_top10")
                 extra["q3_top10"] = b.q3_top10_dist(args.steps, args.warmup)
+                watchdog.cancel()
             if distributed and not repartition and os.environ.get("TGPU_BENCH_PLAN") is None:
                 # the alternative plan in the same line: every join input hash-repartitioned over xGMI (the all-to-all BASELINE.json's metric
                 # names); `value` stays the plan the optimizer picks (co-partitioned joins), this object says what the exchange-heavy plan costs
@@ -1310,6 +1338,7 @@ def main():
                     o.release()
                 b.q3_result = None
                 keep = dict(b.q3_stats)
+                watchdog.arm("repartition_plan")
                 s_rp, prof_rp = b.timed(b.step_q3_dist_repartition, args.steps, args.warmup)
                 chk_rp = b.check_q3_dist_repartition()
                 st_rp = dict(b.q3_stats)
@@ -1326,8 +1355,10 @@ def main():
                     o.release()
                 b.q3_result = None
                 b.q3_stats = keep
+                watchdog.cancel()
         except Exception as e:   # (every rank runs the same code on the same schedule: they fail together)
             extra["extras_error"] = repr(e)
+        watchdog.cancel()
     if not distributed and b.q3_result:
         extra["q3_top10"] = b.q3_top10(args.steps, args.warmup)
 
@@ -1352,6 +1383,7 @@ def main():
 
     if "q1" in only and b.world > 1:
         try:
+            b.extras_watchdog.arm("q1_distributed")
             # Q1 on N ranks: partial aggregation of every rank's shard -> all-gather of the 4-row partial pages -> final combine (8e step 3)
             n = int(6_000_379.02 * args.sf)
             b.setup_q1(n)
@@ -1367,6 +1399,7 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:   # an extra of the N-rank line: the headline goes out whatever happens here
             out["q1"] = {"error": repr(e)}
+        b.extras_watchdog.cancel()
     elif "q1" in only:
         n = int(6_000_379.02 * args.sf)
         b.setup_q1(n)
@@ -1377,7 +1410,7 @@ def main():
                      "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])}}
         # roofline of Q1's dominant kernel: the fused project+accumulate pass reads the group id (one byte per row in the
         # low-cardinality mode Q1 runs in, int32 otherwise) + four 8-byte inputs per row
-        out["q1"]["roofline"] = dominant(p1, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
+        out["q1"]["roofline"] = dominant(p1, args.steps, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
                                          {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
         out["q1"]["step_stats"] = b.step_stats(b.step_q1, min(args.steps, 20))
@@ -1402,7 +1435,7 @@ def main():
                        "full_column_bytes_per_row": 24.8, "achieved_gbps_full_column_bound": 24.8 * n2 / s2 / 1e9, "frac_of_8TBps_full_column_bound": 24.8 * n2 / s2 / 8e12,
                        "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p2.items(), key=lambda kv: -kv[1]["total_ms"])}}
         # pass 1 streams the 8-byte filter column of every row
-        out["cfg2"]["roofline"] = dominant(p2, {"filter_count": n2}, {"filter_count": 8.0})
+        out["cfg2"]["roofline"] = dominant(p2, args.steps, {"filter_count": n2}, {"filter_count": 8.0})
         out["checks"]["cfg2"] = b.check_cfg2()
         del b.c2, b.c2_page
         b.c2_out = None

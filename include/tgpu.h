@@ -24,7 +24,7 @@
  *   - tgpu_merge_pages_*         <-> M/operator/project/MergePages.java:64-190
  *   - tgpu_dynamic_filter_source_* <-> M/operator/DynamicFilterSourceOperator.java:74-425
  *   - tgpu_serialize_page / tgpu_deserialize_page <-> M/execution/buffer/PagesSerde.java:64-160, PagesSerdeUtil.java:45-71,
- *                                    S/block/*BlockEncoding.java, EncoderUtil.java:33-118
+ *                                    S/block/{LongArray,IntArray,ByteArray,VariableWidth,RunLength,Dictionary}BlockEncoding.java, EncoderUtil.java:33-118
  *   - tgpu_exchange_*            <-> M/operator/PartitionedOutputOperator.java:406-476 -> M/operator/ExchangeOperator.java (the hop between
  *                                    the stages of a FIXED_HASH / FIXED_BROADCAST distribution), over RCCL / xGMI instead of HTTP
  *   - tgpu_operator_add_input_output_page: Operator.addInput with a page that never left the device (no reference counterpart:

@@ -44,11 +44,18 @@ public final class GpuNative
         return new TrinoException(code, e.getMessage(), e);
     }
 
-    // context: one per worker and GPU
+    // ---- context: one per worker and GPU (tgpu_context_*) ----
     public static native long createContext(int device);
     public static native void destroyContext(long context);
+    public static native void synchronizeContext(long context);
+    /** output pages cut at PageBuilder.isFull granularity in front of Java operators (tgpu_context_set_max_output_page); 0 = no limit */
+    public static native void setMaxOutputPage(long context, long maxBytes, long maxRows);
+    /** 0 = EXACT (correctly rounded sums), 1 = JAVA (row order, bit-identical to DoubleSumAggregation); tgpu_context_set_double_sum_order */
+    public static native void setDoubleSumOrder(long context, int order);
+    public static native void profileEnable(long context, boolean enabled);
+    public static native String profileDump(long context);
 
-    // Operator protocol (io.trino.operator.Operator)
+    // ---- Operator protocol (io.trino.operator.Operator) ----
     public static native void addInput(long operator, int positions, int[] types, int[] encodings, int[] arrayOffsets, int[] dictionaryPositions,
             Object[] values, Object[] nulls, Object[] offsets, Object[] ids, Object[] dictionaryValues, Object[] dictionaryNulls, Object[] dictionaryOffsets);
     public static native void addInputDevicePage(long operator, long outputPage);
@@ -63,29 +70,68 @@ public final class GpuNative
     public static native void finishMemoryRevoke(long operator);
     public static native void setSpillEnabled(long factory, boolean enabled);
     public static native void setMaxPartialMemory(long factory, long bytes);
+    public static native void spillStats(long operator, long[] countAndBytes);
     public static native long getOutput(long operator, boolean[] wouldBlock);
 
-    // output pages
+    // ---- output pages ----
     public static native int pagePositionCount(long page);
     public static native int pageChannelCount(long page);
     public static native void blockInfo(long page, int channel, long[] typeBytesNulls);
     public static native void copyBlocks(long page, Object[] values, Object[] nulls, Object[] offsets);
     public static native void releasePage(long page);
     public static native long deserializePage(long context, byte[] bytes, int offset, int length, int[] types);
+    /** PagesSerde.serialize of a device-resident page; out == null returns an upper bound of the size */
+    public static native long serializePage(long context, long page, byte[] out);
 
-    // factories (io.trino.operator.OperatorFactory)
+    // ---- factories (io.trino.operator.OperatorFactory).  An expression program travels as the six arrays of GpuRowExpressions.Program. ----
     public static native long createFilterProjectFactory(long context, int operatorId, int[] inputTypes, int[][] nodes, long[] longValues, double[] doubleValues,
+            byte[] stringPool, int filterRoot, int[] projectionRoots);
+    public static native long createScanFilterProjectFactory(long context, int operatorId, int[] types, int[][] nodes, long[] longValues, double[] doubleValues,
             byte[] stringPool, int filterRoot, int[] projectionRoots);
     public static native long createHashAggregationFactory(long context, int operatorId, int[] groupByTypes, int[] groupByChannels, int hashChannel, int step,
             int[] aggregates, int expectedGroups, boolean produceDefaultOutput);
+    /** FilterAndProject feeding HashAggregation as one fused pipeline (tgpu_filter_project_hash_aggregation_factory_create) */
+    public static native long createFilterProjectHashAggregationFactory(long context, int operatorId, int[] inputTypes, int[][] nodes, long[] longValues, double[] doubleValues,
+            byte[] stringPool, int filterRoot, int[] projectionRoots, int[] groupByTypes, int[] groupByChannels, int hashChannel, int step, int[] aggregates, int expectedGroups);
+    /** returns {factory, bridge}; partitionCount > 1: the PartitionedLookupSourceFactory protocol (one build operator per partition) */
     public static native long[] createHashBuilderFactory(long context, int operatorId, int[] types, int[] outputChannels, int[] hashChannels, int precomputedHashChannel,
-            int expectedPositions);
+            int expectedPositions, int partitionCount);
+    public static native void setJoinFilter(long bridge, int[] probeTypes, int[][] nodes, long[] longValues, double[] doubleValues, byte[] stringPool, int filterRoot,
+            int[] projectionRoots);
+    public static native void lookupSourceStats(long bridge, long[] positionsSlotsLinks);
     public static native long createLookupJoinFactory(long context, int operatorId, long bridge, int[] probeTypes, int[] probeJoinChannels, int probeHashChannel,
             int[] probeOutputChannels, int joinType);
+    /** FilterAndProject feeding LookupJoin as one fused pipeline (tgpu_filter_project_lookup_join_factory_create) */
+    public static native long createFilterProjectLookupJoinFactory(long context, int operatorId, long bridge, int[] inputTypes, int[][] nodes, long[] longValues,
+            double[] doubleValues, byte[] stringPool, int filterRoot, int[] projectionRoots, int[] probeJoinChannels, int probeHashChannel, int[] probeOutputChannels, int joinType);
     public static native long createLookupOuterFactory(long context, int operatorId, long bridge, int[] probeOutputTypes);
     public static native void destroyBridge(long bridge);
+    public static native long createTopNFactory(long context, int operatorId, int[] types, long n, int[] sortChannels, int[] sortOrders);
+    public static native long createOrderByFactory(long context, int operatorId, int[] types, int[] outputChannels, int expectedPositions, int[] sortChannels, int[] sortOrders);
+    public static native long createMergePagesFactory(long context, int operatorId, int[] types, long minPageSizeInBytes, int minRowCount, long maxPageSizeInBytes);
+    public static native long createPartitionedOutputFactory(long context, int operatorId, int[] types, int[] partitionChannels, int hashChannel, int partitionCount,
+            boolean replicatesAnyRow, int nullChannel, int partitionFunction);
+    public static native long partitionedOutputPoll(long operator, int[] partition);
+    public static native void partitionedOutputInfo(long operator, long[] rowsAndPages);
+    public static native long createDynamicFilterSourceFactory(long context, int operatorId, int[] types, int[] channels, int maxDistinctValues, long maxFilterSizeInBytes,
+            int minMaxCollectionLimit);
+    public static native long dynamicFilterSourceResult(long operator, int filterChannel, long[] kindMinMax);
     public static native long createOperator(long factory);
     public static native void noMoreOperators(long factory);
     public static native long duplicateFactory(long factory);
     public static native void destroyFactory(long factory);
+
+    // ---- the scan side (ScanFilterAndProjectOperator over a ConnectorPageSource): upcalls into GpuPageSource ----
+    public static native void scanAddPageSource(long operator, GpuPageSource source, int[] types);
+    public static native void scanNoMoreSplits(long operator);
+    public static native void scanStats(long operator, long[] positionsLoadedSkipped);
+
+    // ---- exchange between the GPUs of one node (tgpu_exchange_*); pages are output-page handles: they never leave HBM ----
+    public static native byte[] exchangeUniqueId();
+    public static native long createExchange(long context, byte[] uniqueId, int rank, int world);
+    public static native void destroyExchange(long exchange);
+    public static native long exchangeRepartition(long exchange, long page, int[] keyChannels, int hashChannel);
+    public static native long exchangePartitionedOutput(long exchange, long partitionedOutputOperator, int[] types);
+    public static native long exchangeAllGather(long exchange, long page);
+    public static native long exchangeBytesSent(long exchange);
 }

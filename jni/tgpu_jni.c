@@ -1,22 +1,23 @@
 /*
- * tgpu_jni.c -- the JNI shim between core/trino-main and libtgpu.so: one JNIEXPORT per C-ABI entry point the Java glue
- * (the classes under java/io/trino/operator/gpu) calls.  Plain C over include/tgpu.h; nothing here computes.
+ * tgpu_jni.c -- the JNI shim between core/trino-main and libtgpu.so: one JNIEXPORT per native method of
+ * io.trino.operator.gpu.GpuNative (java/io/trino/operator/gpu/GpuNative.java).  Plain C over include/tgpu.h; nothing here computes.
  *
- * Compiled only where a JDK is present (the build image has none: `java`, `javac`, `jni.h` are absent, so on this image the file
- * compiles to an empty translation unit -- `gcc -fsyntax-only jni/tgpu_jni.c` is part of build()):
  *     gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude jni/tgpu_jni.c -Lpresto-1_amd -ltgpu -o libtgpu_jni.so
  *
+ * The build image has no JDK.  There the file is compiled -- every line of it -- against tests/jni_stub/jni.h, a self-written
+ * declaration of the JNI types and of the JNIEnv functions this file uses (NOT a JDK header: member order differs from a real JVM's
+ * table, so a library built that way only runs against tests/jni_stub/fake_jvm.c, the arrays-and-exceptions mock the tests drive it
+ * with); __graft_entry__.build() does that with -Wall -Wextra -Werror and links the result against libtgpu.so, so a call of a function
+ * tgpu.h does not declare, or with the wrong argument types, fails the build.
+ *
  * Ownership (tgpu.h): Java arrays are pinned with GetPrimitiveArrayCritical for the duration of one call only -- the library has
- * uploaded what it keeps when it returns -- and released in reverse order with no JNI call in between.  Errors: a negative status
- * becomes io.trino.operator.gpu.GpuNative$NativeError(code, message), which the glue maps to TrinoException(StandardErrorCode).
+ * uploaded what it keeps when it returns -- and released in reverse order with no JNI call in between.  The pinned section covers the
+ * host -> device staging of the page (the library waits for its transfers before it returns, tgpu.h "Lifetime of page"); kernels are
+ * only enqueued, not waited for, so the GC locker is held for the copy, not for the GPU work.  Local references: every function that
+ * creates more than a handful runs inside PushLocalFrame / PopLocalFrame (the JVM guarantees 16 without it).
+ * Errors: a negative status becomes io.trino.operator.gpu.GpuNative$NativeError(code, message), which the glue maps to
+ * TrinoException(StandardErrorCode).
  */
-#if defined(__has_include)
-#if __has_include(<jni.h>)
-#define TGPU_HAVE_JNI 1
-#endif
-#endif
-
-#ifdef TGPU_HAVE_JNI
 #include <jni.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,26 +25,157 @@
 #include "../include/tgpu.h"
 
 #define H(type, handle) ((type *)(intptr_t)(handle))
+#define UNUSED(x) (void)(x)
+#define JFN(ret, name) JNIEXPORT ret JNICALL Java_io_trino_operator_gpu_GpuNative_##name
 
-static void throw_native(JNIEnv *env, int32_t rc)
+static void throw_native_message(JNIEnv *env, int32_t rc, const char *message)
 {
     jclass cls = (*env)->FindClass(env, "io/trino/operator/gpu/GpuNative$NativeError");
     if (!cls) return;
     jmethodID ctor = (*env)->GetMethodID(env, cls, "<init>", "(ILjava/lang/String;)V");
-    jstring msg = (*env)->NewStringUTF(env, tgpu_last_error());
+    if (!ctor) return;
+    jstring msg = (*env)->NewStringUTF(env, message);
     jobject ex = (*env)->NewObject(env, cls, ctor, (jint)rc, msg);
     if (ex) (*env)->Throw(env, (jthrowable)ex);
 }
+static void throw_native(JNIEnv *env, int32_t rc) { throw_native_message(env, rc, tgpu_last_error()); }
+
+/* ---- small helpers: int[] arguments, the page-processor program, handle results ---- */
+typedef struct {
+    jintArray array;
+    jint *p;
+    jsize n;
+} ints;
+static ints ints_get(JNIEnv *env, jintArray a)
+{
+    ints x = {a, NULL, 0};
+    if (a) {
+        x.n = (*env)->GetArrayLength(env, a);
+        x.p = (*env)->GetIntArrayElements(env, a, NULL);
+    }
+    return x;
+}
+static void ints_release(JNIEnv *env, ints *x)
+{
+    if (x->array && x->p) (*env)->ReleaseIntArrayElements(env, x->array, x->p, JNI_ABORT);
+    x->p = NULL;
+}
+
+/* GpuRowExpressions.Program: nodes int[node][9] = {kind, type, op, n_args, arg0, arg1, arg2, is_null, slen}; longValues / doubleValues per
+ * node; stringPool = the VARCHAR constants; filterRoot; projectionRoots */
+typedef struct {
+    tgpu_page_processor_spec spec;
+    tgpu_expr_node *nodes;
+    jbyteArray pool_array;
+    jbyte *pool;
+    ints roots;
+} program;
+static int program_read(JNIEnv *env, program *pr, jobjectArray nodes, jlongArray ivals, jdoubleArray dvals, jbyteArray pool, jint filterRoot, jintArray projectionRoots)
+{
+    memset(pr, 0, sizeof(*pr));
+    const jsize n = (*env)->GetArrayLength(env, nodes);
+    if ((*env)->GetArrayLength(env, ivals) < n || (*env)->GetArrayLength(env, dvals) < n) {
+        throw_native_message(env, TGPU_ERR_INVALID_ARGUMENT, "expression program: value arrays shorter than the node array");
+        return 0;
+    }
+    pr->nodes = (tgpu_expr_node *)calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_expr_node));
+    jlong *iv = (*env)->GetLongArrayElements(env, ivals, NULL);
+    jdouble *dv = (*env)->GetDoubleArrayElements(env, dvals, NULL);
+    for (jsize i = 0; i < n; i++) {
+        jintArray row = (jintArray)(*env)->GetObjectArrayElement(env, nodes, i);
+        jint f[9];
+        (*env)->GetIntArrayRegion(env, row, 0, 9, f);
+        tgpu_expr_node *o = &pr->nodes[i];
+        o->kind = f[0]; o->type = f[1]; o->op = f[2]; o->n_args = f[3];
+        o->args[0] = f[4]; o->args[1] = f[5]; o->args[2] = f[6]; o->is_null = f[7]; o->slen = f[8];
+        o->ival = iv[i]; o->dval = dv[i];
+        (*env)->DeleteLocalRef(env, row);
+    }
+    (*env)->ReleaseDoubleArrayElements(env, dvals, dv, JNI_ABORT);
+    (*env)->ReleaseLongArrayElements(env, ivals, iv, JNI_ABORT);
+    pr->pool_array = pool;
+    pr->pool = (*env)->GetByteArrayElements(env, pool, NULL);
+    pr->roots = ints_get(env, projectionRoots);
+    pr->spec.nodes = pr->nodes;
+    pr->spec.node_count = n;
+    pr->spec.string_pool = (const char *)pr->pool;
+    pr->spec.string_pool_len = (*env)->GetArrayLength(env, pool);
+    pr->spec.filter_root = filterRoot;
+    pr->spec.projection_count = pr->roots.n;
+    pr->spec.projection_roots = (const int32_t *)pr->roots.p;
+    return 1;
+}
+static void program_release(JNIEnv *env, program *pr)
+{
+    ints_release(env, &pr->roots);
+    if (pr->pool) (*env)->ReleaseByteArrayElements(env, pr->pool_array, pr->pool, JNI_ABORT);
+    free(pr->nodes);
+}
+#define PROGRAM_PARAMS jobjectArray nodes, jlongArray ivals, jdoubleArray dvals, jbyteArray pool, jint filterRoot, jintArray projectionRoots
+#define PROGRAM_ARGS nodes, ivals, dvals, pool, filterRoot, projectionRoots
+
+static jlong factory_result(JNIEnv *env, int32_t rc, tgpu_operator_factory *f)
+{
+    if (rc < 0) {
+        throw_native(env, rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)f;
+}
+static jlong page_result(JNIEnv *env, int32_t rc, tgpu_output_page *p)
+{
+    if (rc < 0) {
+        throw_native(env, rc);
+        return 0;
+    }
+    return (jlong)(intptr_t)p;
+}
+static jlongArray two_handles(JNIEnv *env, int32_t rc, void *a, void *b)
+{
+    if (rc < 0) {
+        throw_native(env, rc);
+        return NULL;
+    }
+    jlong v[2] = {(jlong)(intptr_t)a, (jlong)(intptr_t)b};
+    jlongArray out = (*env)->NewLongArray(env, 2);
+    if (out) (*env)->SetLongArrayRegion(env, out, 0, 2, v);
+    return out;
+}
+static void set_longs(JNIEnv *env, jlongArray out, const jlong *v, jsize n)
+{
+    if (out && (*env)->GetArrayLength(env, out) >= n) (*env)->SetLongArrayRegion(env, out, 0, n, v);
+}
 
 /* ---- context ---- */
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createContext(JNIEnv *env, jclass c, jint device)
+JFN(jlong, createContext)(JNIEnv *env, jclass c, jint device)
 {
+    UNUSED(c);
     tgpu_context *ctx = NULL;
     int32_t rc = tgpu_context_create(device, NULL, &ctx);
     if (rc < 0) throw_native(env, rc);
     return (jlong)(intptr_t)ctx;
 }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_destroyContext(JNIEnv *env, jclass c, jlong ctx) { tgpu_context_destroy(H(tgpu_context, ctx)); }
+JFN(void, destroyContext)(JNIEnv *env, jclass c, jlong ctx) { UNUSED(env); UNUSED(c); tgpu_context_destroy(H(tgpu_context, ctx)); }
+JFN(void, synchronizeContext)(JNIEnv *env, jclass c, jlong ctx)
+{ UNUSED(c); int32_t rc = tgpu_context_synchronize(H(tgpu_context, ctx)); if (rc < 0) throw_native(env, rc); }
+JFN(void, setMaxOutputPage)(JNIEnv *env, jclass c, jlong ctx, jlong maxBytes, jlong maxRows)
+{ UNUSED(c); int32_t rc = tgpu_context_set_max_output_page(H(tgpu_context, ctx), maxBytes, maxRows); if (rc < 0) throw_native(env, rc); }
+JFN(void, setDoubleSumOrder)(JNIEnv *env, jclass c, jlong ctx, jint order)
+{ UNUSED(c); int32_t rc = tgpu_context_set_double_sum_order(H(tgpu_context, ctx), order); if (rc < 0) throw_native(env, rc); }
+JFN(void, profileEnable)(JNIEnv *env, jclass c, jlong ctx, jboolean enabled)
+{ UNUSED(c); int32_t rc = tgpu_profile_enable(H(tgpu_context, ctx), enabled ? 1 : 0); if (rc < 0) throw_native(env, rc); }
+/* the per-kernel timings as a JSON string (OperatorInfo of the GPU operators) */
+JFN(jstring, profileDump)(JNIEnv *env, jclass c, jlong ctx)
+{
+    UNUSED(c);
+    const int64_t need = tgpu_profile_dump(H(tgpu_context, ctx), NULL, 0);
+    if (need < 0) { throw_native(env, (int32_t)need); return NULL; }
+    char *buf = (char *)calloc((size_t)need + 1, 1);
+    tgpu_profile_dump(H(tgpu_context, ctx), buf, need + 1);
+    jstring s = (*env)->NewStringUTF(env, buf);
+    free(buf);
+    return s;
+}
 
 /* ---- pages: a flat block = the block's own primitive arrays (LongArrayBlock: long[] values + boolean[] valueIsNull + arrayOffset,
  * S/block/LongArrayBlock.java:38-75; VariableWidthBlock: byte[] of the Slice + int[] offsets, S/block/VariableWidthBlock.java:38-83);
@@ -54,25 +186,29 @@ typedef struct {
 } pinned_block;
 
 static void *pin(JNIEnv *env, jarray a) { return a ? (*env)->GetPrimitiveArrayCritical(env, a, NULL) : NULL; }
-static void unpin(JNIEnv *env, jarray a, void *p) { if (a && p) (*env)->ReleasePrimitiveArrayCritical(env, a, p, JNI_ABORT); }
+static void unpin(JNIEnv *env, jarray a, void *p, jint mode) { if (a && p) (*env)->ReleasePrimitiveArrayCritical(env, a, p, mode); }
 static int width_of(jint t) { return t == TGPU_BIGINT || t == TGPU_DOUBLE ? 8 : (t == TGPU_INTEGER || t == TGPU_DATE ? 4 : 1); }
 
-/* GpuPages.flatten() hands every channel as parallel arrays: per channel i
+/* GpuPages hands every channel as parallel arrays: per channel i
  *   types[i], encodings[i] (TGPU_FLAT / TGPU_DICTIONARY / TGPU_RLE), arrayOffsets[i], dictionaryPositions[i],
  *   values[i] / nulls[i] / offsets[i]          the flat block's arrays (FLAT), or null
  *   ids[i]                                     int[] ids (DICTIONARY)
- *   dvalues[i] / dnulls[i] / doffsets[i]       the dictionary's / the RLE value block's arrays */
-static int32_t with_page(JNIEnv *env, jint positions, jintArray types, jintArray encodings, jintArray arrayOffsets, jintArray dictPositions, jobjectArray values,
-                         jobjectArray nulls, jobjectArray offsets, jobjectArray ids, jobjectArray dvalues, jobjectArray dnulls, jobjectArray doffsets,
-                         int32_t (*call)(void *arg, const tgpu_page *page), void *arg)
+ *   dvalues[i] / dnulls[i] / doffsets[i]       the dictionary's / the RLE value block's arrays (compact: offset 0) */
+#define PAGE_PARAMS jint positions, jintArray types, jintArray encodings, jintArray arrayOffsets, jintArray dictPositions, jobjectArray values, jobjectArray nulls, \
+                    jobjectArray offsets, jobjectArray ids, jobjectArray dvalues, jobjectArray dnulls, jobjectArray doffsets
+#define PAGE_ARGS positions, types, encodings, arrayOffsets, dictPositions, values, nulls, offsets, ids, dvalues, dnulls, doffsets
+
+static int32_t with_page(JNIEnv *env, PAGE_PARAMS, int32_t (*call)(void *arg, const tgpu_page *page), void *arg)
 {
     const jsize n = (*env)->GetArrayLength(env, types);
+    if ((*env)->PushLocalFrame(env, 7 * n + 8) != 0) return TGPU_ERR_INSUFFICIENT_RESOURCES;   /* an OutOfMemoryError is pending */
     tgpu_block *blocks = (tgpu_block *)calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_block));
     tgpu_block *dicts = (tgpu_block *)calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_block));
     pinned_block *pins = (pinned_block *)calloc((size_t)(n > 0 ? n : 1), sizeof(pinned_block));
-    jint *t = (*env)->GetIntArrayElements(env, types, NULL), *enc = (*env)->GetIntArrayElements(env, encodings, NULL);
-    jint *ao = (*env)->GetIntArrayElements(env, arrayOffsets, NULL), *dp = (*env)->GetIntArrayElements(env, dictPositions, NULL);
-    for (jsize i = 0; i < n; i++) {   /* object fetches first: no JNI calls are allowed once the first array is pinned */
+    ints t = ints_get(env, types), enc = ints_get(env, encodings), ao = ints_get(env, arrayOffsets), dp = ints_get(env, dictPositions);
+    int32_t rc = TGPU_OK;
+    if (enc.n < n || ao.n < n || dp.n < n) rc = TGPU_ERR_INVALID_ARGUMENT;
+    for (jsize i = 0; i < n && rc == TGPU_OK; i++) {   /* object fetches first: no JNI calls are allowed once the first array is pinned */
         pins[i].values = (jarray)(*env)->GetObjectArrayElement(env, values, i);
         pins[i].nulls = (jarray)(*env)->GetObjectArrayElement(env, nulls, i);
         pins[i].offsets = (jarray)(*env)->GetObjectArrayElement(env, offsets, i);
@@ -80,258 +216,709 @@ static int32_t with_page(JNIEnv *env, jint positions, jintArray types, jintArray
         pins[i].dvalues = (jarray)(*env)->GetObjectArrayElement(env, dvalues, i);
         pins[i].dnulls = (jarray)(*env)->GetObjectArrayElement(env, dnulls, i);
         pins[i].doffsets = (jarray)(*env)->GetObjectArrayElement(env, doffsets, i);
+        /* bounds, while JNI calls are still allowed: the arrays must hold arrayOffset + positions elements */
+        const jlong need = (jlong)ao.p[i] + positions;
+        if (ao.p[i] < 0 || positions < 0) rc = TGPU_ERR_INVALID_ARGUMENT;
+        if (enc.p[i] == TGPU_FLAT) {
+            if (!pins[i].values && positions > 0) rc = TGPU_ERR_INVALID_ARGUMENT;
+            if (pins[i].values && t.p[i] != TGPU_VARCHAR && (*env)->GetArrayLength(env, pins[i].values) < need) rc = TGPU_ERR_INVALID_ARGUMENT;
+            if (pins[i].nulls && (*env)->GetArrayLength(env, pins[i].nulls) < need) rc = TGPU_ERR_INVALID_ARGUMENT;
+            if (t.p[i] == TGPU_VARCHAR && (!pins[i].offsets || (*env)->GetArrayLength(env, pins[i].offsets) < need + 1)) rc = TGPU_ERR_INVALID_ARGUMENT;
+        }
+        else if (enc.p[i] == TGPU_DICTIONARY) {
+            if (!pins[i].ids || (*env)->GetArrayLength(env, pins[i].ids) < need) rc = TGPU_ERR_INVALID_ARGUMENT;
+        }
+    }
+    if (rc != TGPU_OK) {
+        ints_release(env, &dp); ints_release(env, &ao); ints_release(env, &enc); ints_release(env, &t);
+        free(pins); free(dicts); free(blocks);
+        (*env)->PopLocalFrame(env, NULL);
+        throw_native_message(env, rc, "page arrays do not match the page's position count / array offsets");
+        return 1;   /* positive: the exception is already pending, the caller must not throw again */
     }
     for (jsize i = 0; i < n; i++) {
         pinned_block *p = &pins[i];
         p->pv = pin(env, p->values); p->pn = pin(env, p->nulls); p->po = pin(env, p->offsets); p->pi = pin(env, p->ids);
         p->pdv = pin(env, p->dvalues); p->pdn = pin(env, p->dnulls); p->pdo = pin(env, p->doffsets);
-        const int w = width_of(t[i]);
+        const int w = width_of(t.p[i]);
         tgpu_block *b = &blocks[i];
-        b->type = t[i]; b->encoding = enc[i]; b->memory = TGPU_HOST; b->position_count = positions;
-        if (enc[i] == TGPU_FLAT) {
-            b->values = t[i] == TGPU_VARCHAR ? p->pv : (const char *)p->pv + (size_t)ao[i] * (size_t)w;
-            b->nulls = p->pn ? (const uint8_t *)p->pn + ao[i] : NULL;            /* Java boolean[] = one byte per position */
-            b->offsets = p->po ? (const int32_t *)p->po + ao[i] : NULL;
+        b->type = t.p[i]; b->encoding = enc.p[i]; b->memory = TGPU_HOST; b->position_count = positions;
+        if (enc.p[i] == TGPU_FLAT) {
+            b->values = t.p[i] == TGPU_VARCHAR ? p->pv : (const void *)((const char *)p->pv + (size_t)ao.p[i] * (size_t)w);
+            b->nulls = p->pn ? (const uint8_t *)p->pn + ao.p[i] : NULL;            /* Java boolean[] = one byte per position */
+            b->offsets = p->po ? (const int32_t *)p->po + ao.p[i] : NULL;
         }
         else {
             tgpu_block *d = &dicts[i];
-            d->type = t[i]; d->encoding = TGPU_FLAT; d->memory = TGPU_HOST; d->position_count = dp[i];
+            d->type = t.p[i]; d->encoding = TGPU_FLAT; d->memory = TGPU_HOST; d->position_count = dp.p[i];
             d->values = p->pdv; d->nulls = (const uint8_t *)p->pdn; d->offsets = (const int32_t *)p->pdo;
-            b->ids = p->pi ? (const int32_t *)p->pi + ao[i] : NULL;
+            b->ids = p->pi ? (const int32_t *)p->pi + ao.p[i] : NULL;
             b->dictionary = d;
         }
     }
     tgpu_page page = {positions, n, blocks};
-    const int32_t rc = call(arg, &page);    /* the library copies to HBM before it returns: nothing of the heap arrays is retained */
+    rc = call(arg, &page);    /* the library copies to HBM before it returns: nothing of the heap arrays is retained */
     for (jsize i = n; i-- > 0;) {
         pinned_block *p = &pins[i];
-        unpin(env, p->doffsets, p->pdo); unpin(env, p->dnulls, p->pdn); unpin(env, p->dvalues, p->pdv); unpin(env, p->ids, p->pi);
-        unpin(env, p->offsets, p->po); unpin(env, p->nulls, p->pn); unpin(env, p->values, p->pv);
+        unpin(env, p->doffsets, p->pdo, JNI_ABORT); unpin(env, p->dnulls, p->pdn, JNI_ABORT); unpin(env, p->dvalues, p->pdv, JNI_ABORT);
+        unpin(env, p->ids, p->pi, JNI_ABORT); unpin(env, p->offsets, p->po, JNI_ABORT); unpin(env, p->nulls, p->pn, JNI_ABORT);
+        unpin(env, p->values, p->pv, JNI_ABORT);
     }
-    (*env)->ReleaseIntArrayElements(env, dictPositions, dp, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, arrayOffsets, ao, JNI_ABORT);
-    (*env)->ReleaseIntArrayElements(env, encodings, enc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
+    ints_release(env, &dp); ints_release(env, &ao); ints_release(env, &enc); ints_release(env, &t);
     free(pins); free(dicts); free(blocks);
+    (*env)->PopLocalFrame(env, NULL);
     return rc;
 }
 
 static int32_t call_add_input(void *op, const tgpu_page *page) { return tgpu_operator_add_input((tgpu_operator *)op, page); }
 
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_addInput(JNIEnv *env, jclass c, jlong op, jint positions, jintArray types, jintArray encodings,
-        jintArray arrayOffsets, jintArray dictPositions, jobjectArray values, jobjectArray nulls, jobjectArray offsets, jobjectArray ids, jobjectArray dvalues,
-        jobjectArray dnulls, jobjectArray doffsets)
+JFN(void, addInput)(JNIEnv *env, jclass c, jlong op, PAGE_PARAMS)
 {
-    int32_t rc = with_page(env, positions, types, encodings, arrayOffsets, dictPositions, values, nulls, offsets, ids, dvalues, dnulls, doffsets, call_add_input,
-                           H(tgpu_operator, op));
+    UNUSED(c);
+    int32_t rc = with_page(env, PAGE_ARGS, call_add_input, H(tgpu_operator, op));
     if (rc < 0) throw_native(env, rc);
 }
 
 /* chaining two GPU operators: the page never leaves HBM (tgpu_operator_add_input_output_page) */
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_addInputDevicePage(JNIEnv *env, jclass c, jlong op, jlong page)
+JFN(void, addInputDevicePage)(JNIEnv *env, jclass c, jlong op, jlong page)
 {
+    UNUSED(c);
     int32_t rc = tgpu_operator_add_input_output_page(H(tgpu_operator, op), H(tgpu_output_page, page));
     if (rc < 0) throw_native(env, rc);
 }
 
 /* ---- Operator protocol (M/operator/Operator.java:20-102) ---- */
-#define BOOL_CALL(jname, cfn)                                                                                         \
-    JNIEXPORT jboolean JNICALL Java_io_trino_operator_gpu_GpuNative_##jname(JNIEnv *env, jclass c, jlong op)         \
-    { int32_t r = cfn(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); return r == 1; }
+#define BOOL_CALL(jname, cfn)                                                        \
+    JFN(jboolean, jname)(JNIEnv *env, jclass c, jlong op)                            \
+    { UNUSED(c); int32_t r = cfn(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); return r == 1; }
 BOOL_CALL(needsInput, tgpu_operator_needs_input)
 BOOL_CALL(isFinished, tgpu_operator_is_finished)
 BOOL_CALL(isBlocked, tgpu_operator_is_blocked)
 
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_finish(JNIEnv *env, jclass c, jlong op)
-{ int32_t r = tgpu_operator_finish(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_memoryBytes(JNIEnv *env, jclass c, jlong op) { return tgpu_operator_memory_bytes(H(tgpu_operator, op)); }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_close(JNIEnv *env, jclass c, jlong op) { tgpu_operator_close(H(tgpu_operator, op)); }
-/* Operator.startMemoryRevoke / finishMemoryRevoke, OperatorContext.getReservedRevocableBytes (spill-enabled hash aggregations) */
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_revocableMemoryBytes(JNIEnv *env, jclass c, jlong op) { return tgpu_operator_revocable_memory_bytes(H(tgpu_operator, op)); }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_startMemoryRevoke(JNIEnv *env, jclass c, jlong op)
-{ int32_t r = tgpu_operator_start_memory_revoke(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_finishMemoryRevoke(JNIEnv *env, jclass c, jlong op)
-{ int32_t r = tgpu_operator_finish_memory_revoke(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_setMaxPartialMemory(JNIEnv *env, jclass c, jlong factory, jlong bytes)
-{ int32_t r = tgpu_hash_aggregation_factory_set_max_partial_memory(H(tgpu_operator_factory, factory), bytes); if (r < 0) throw_native(env, r); }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_setSpillEnabled(JNIEnv *env, jclass c, jlong factory, jboolean enabled)
-{ int32_t r = tgpu_hash_aggregation_factory_set_spill_enabled(H(tgpu_operator_factory, factory), enabled ? 1 : 0); if (r < 0) throw_native(env, r); }
+#define VOID_OP_CALL(jname, cfn)                                                     \
+    JFN(void, jname)(JNIEnv *env, jclass c, jlong op)                                \
+    { UNUSED(c); int32_t r = cfn(H(tgpu_operator, op)); if (r < 0) throw_native(env, r); }
+VOID_OP_CALL(finish, tgpu_operator_finish)
+VOID_OP_CALL(startMemoryRevoke, tgpu_operator_start_memory_revoke)     /* Operator.startMemoryRevoke / finishMemoryRevoke (spill-enabled hash aggregations) */
+VOID_OP_CALL(finishMemoryRevoke, tgpu_operator_finish_memory_revoke)
+VOID_OP_CALL(scanNoMoreSplits, tgpu_scan_operator_no_more_splits)
+
+JFN(jlong, memoryBytes)(JNIEnv *env, jclass c, jlong op) { UNUSED(env); UNUSED(c); return tgpu_operator_memory_bytes(H(tgpu_operator, op)); }
+JFN(jlong, revocableMemoryBytes)(JNIEnv *env, jclass c, jlong op) { UNUSED(env); UNUSED(c); return tgpu_operator_revocable_memory_bytes(H(tgpu_operator, op)); }
+JFN(void, close)(JNIEnv *env, jclass c, jlong op) { UNUSED(env); UNUSED(c); tgpu_operator_close(H(tgpu_operator, op)); }
+JFN(void, setMaxPartialMemory)(JNIEnv *env, jclass c, jlong factory, jlong bytes)
+{ UNUSED(c); int32_t r = tgpu_hash_aggregation_factory_set_max_partial_memory(H(tgpu_operator_factory, factory), bytes); if (r < 0) throw_native(env, r); }
+JFN(void, setSpillEnabled)(JNIEnv *env, jclass c, jlong factory, jboolean enabled)
+{ UNUSED(c); int32_t r = tgpu_hash_aggregation_factory_set_spill_enabled(H(tgpu_operator_factory, factory), enabled ? 1 : 0); if (r < 0) throw_native(env, r); }
+/* out[0] = spills so far, out[1] = bytes they hold or held */
+JFN(void, spillStats)(JNIEnv *env, jclass c, jlong op, jlongArray out)
+{
+    UNUSED(c);
+    int64_t count = 0, bytes = 0;
+    int32_t r = tgpu_operator_spill_stats(H(tgpu_operator, op), &count, &bytes);
+    if (r < 0) { throw_native(env, r); return; }
+    jlong v[2] = {count, bytes};
+    set_longs(env, out, v, 2);
+}
 
 /* returns the output-page handle, 0 = no page; wouldBlock[0] = 1 when the operator is blocked as well (TGPU_WOULD_BLOCK) */
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_getOutput(JNIEnv *env, jclass c, jlong op, jbooleanArray wouldBlock)
+JFN(jlong, getOutput)(JNIEnv *env, jclass c, jlong op, jbooleanArray wouldBlock)
 {
+    UNUSED(c);
     tgpu_output_page *p = NULL;
     int32_t r = tgpu_operator_get_output(H(tgpu_operator, op), &p);
     if (r < 0) { throw_native(env, r); return 0; }
     jboolean wb = r == TGPU_WOULD_BLOCK;
-    if (wouldBlock) (*env)->SetBooleanArrayRegion(env, wouldBlock, 0, 1, &wb);
+    if (wouldBlock && (*env)->GetArrayLength(env, wouldBlock) >= 1) (*env)->SetBooleanArrayRegion(env, wouldBlock, 0, 1, &wb);
     return (jlong)(intptr_t)p;
 }
 
 /* ---- output pages -> heap blocks (S/Page.java:33-73) ---- */
-JNIEXPORT jint JNICALL Java_io_trino_operator_gpu_GpuNative_pagePositionCount(JNIEnv *env, jclass c, jlong page) { return tgpu_output_page_position_count(H(tgpu_output_page, page)); }
-JNIEXPORT jint JNICALL Java_io_trino_operator_gpu_GpuNative_pageChannelCount(JNIEnv *env, jclass c, jlong page) { return tgpu_output_page_channel_count(H(tgpu_output_page, page)); }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_releasePage(JNIEnv *env, jclass c, jlong page) { tgpu_output_page_release(H(tgpu_output_page, page)); }
+JFN(jint, pagePositionCount)(JNIEnv *env, jclass c, jlong page) { UNUSED(env); UNUSED(c); return tgpu_output_page_position_count(H(tgpu_output_page, page)); }
+JFN(jint, pageChannelCount)(JNIEnv *env, jclass c, jlong page) { UNUSED(env); UNUSED(c); return tgpu_output_page_channel_count(H(tgpu_output_page, page)); }
+JFN(void, releasePage)(JNIEnv *env, jclass c, jlong page) { UNUSED(env); UNUSED(c); tgpu_output_page_release(H(tgpu_output_page, page)); }
 
 /* info[0] = type, info[1] = value bytes (VARCHAR: byte pool size), info[2] = may have nulls */
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_blockInfo(JNIEnv *env, jclass c, jlong page, jint channel, jlongArray info)
+JFN(void, blockInfo)(JNIEnv *env, jclass c, jlong page, jint channel, jlongArray info)
 {
+    UNUSED(c);
     int32_t type = 0, may = 0;
     int64_t bytes = 0;
     int32_t r = tgpu_output_page_block_info(H(tgpu_output_page, page), channel, &type, &bytes, &may);
     if (r < 0) { throw_native(env, r); return; }
     jlong v[3] = {type, bytes, may};
-    (*env)->SetLongArrayRegion(env, info, 0, 3, v);
+    set_longs(env, info, v, 3);
 }
 
 /* every channel in ONE call (one stream synchronisation per page): values[i] is long[] / int[] / byte[] of the size blockInfo gave,
  * nulls[i] boolean[positionCount] or null, offsets[i] int[positionCount + 1] for VARCHAR */
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_copyBlocks(JNIEnv *env, jclass c, jlong page, jobjectArray values, jobjectArray nulls, jobjectArray offsets)
+JFN(void, copyBlocks)(JNIEnv *env, jclass c, jlong page, jobjectArray values, jobjectArray nulls, jobjectArray offsets)
 {
+    UNUSED(c);
     const jsize n = (*env)->GetArrayLength(env, values);
-    jarray *av = calloc((size_t)(3 * n + 1), sizeof(jarray));
-    void **pv = calloc((size_t)(3 * n + 1), sizeof(void *));
+    if ((*env)->GetArrayLength(env, nulls) < n || (*env)->GetArrayLength(env, offsets) < n || n != tgpu_output_page_channel_count(H(tgpu_output_page, page))) {
+        throw_native_message(env, TGPU_ERR_INVALID_ARGUMENT, "copyBlocks: one values / nulls / offsets entry per channel expected");
+        return;
+    }
+    if ((*env)->PushLocalFrame(env, 3 * n + 4) != 0) return;
+    jarray *av = (jarray *)calloc((size_t)(3 * n + 1), sizeof(jarray));
+    void **pv = (void **)calloc((size_t)(3 * n + 1), sizeof(void *));
+    const jint positions = tgpu_output_page_position_count(H(tgpu_output_page, page));
+    int ok = 1;
     for (jsize i = 0; i < n; i++) {
         av[i] = (jarray)(*env)->GetObjectArrayElement(env, values, i);
         av[n + i] = (jarray)(*env)->GetObjectArrayElement(env, nulls, i);
         av[2 * n + i] = (jarray)(*env)->GetObjectArrayElement(env, offsets, i);
+        /* the destination arrays must be as large as block_info said */
+        int32_t type = 0, may = 0;
+        int64_t bytes = 0;
+        if (tgpu_output_page_block_info(H(tgpu_output_page, page), i, &type, &bytes, &may) < 0 || !av[i]) ok = 0;
+        else {
+            const jlong have = (jlong)(*env)->GetArrayLength(env, av[i]) * (type == TGPU_VARCHAR ? 1 : width_of(type));
+            if (have < bytes) ok = 0;
+            if (av[n + i] && (*env)->GetArrayLength(env, av[n + i]) < positions) ok = 0;
+            if (type == TGPU_VARCHAR && (!av[2 * n + i] || (*env)->GetArrayLength(env, av[2 * n + i]) < positions + 1)) ok = 0;
+        }
     }
-    for (jsize i = 0; i < 3 * n; i++) pv[i] = pin(env, av[i]);
-    int32_t r = tgpu_output_page_copy_blocks(H(tgpu_output_page, page), n, (void *const *)pv, (uint8_t *const *)(pv + n), (int32_t *const *)(pv + 2 * n));
-    for (jsize i = 3 * n; i-- > 0;)
-        if (av[i] && pv[i]) (*env)->ReleasePrimitiveArrayCritical(env, av[i], pv[i], 0);   /* 0: copy back / commit */
+    int32_t r = TGPU_OK;
+    if (ok) {
+        for (jsize i = 0; i < 3 * n; i++) pv[i] = pin(env, av[i]);
+        r = tgpu_output_page_copy_blocks(H(tgpu_output_page, page), n, (void *const *)pv, (uint8_t *const *)(pv + n), (int32_t *const *)(pv + 2 * n));
+        for (jsize i = 3 * n; i-- > 0;) unpin(env, av[i], pv[i], 0);   /* 0: copy back / commit */
+    }
     free(pv); free(av);
-    if (r < 0) throw_native(env, r);
+    (*env)->PopLocalFrame(env, NULL);
+    if (!ok) throw_native_message(env, TGPU_ERR_INVALID_ARGUMENT, "copyBlocks: destination arrays smaller than the page's blocks");
+    else if (r < 0) throw_native(env, r);
 }
 
 /* ---- factories ---- */
-static jlong factory_result(JNIEnv *env, int32_t rc, tgpu_operator_factory *f) { if (rc < 0) { throw_native(env, rc); return 0; } return (jlong)(intptr_t)f; }
-
-/* nodes: int[node][9] = {kind, type, op, n_args, arg0, arg1, arg2, is_null, slen}; ivals / dvals per node; pool = the VARCHAR constants */
-static tgpu_expr_node *read_nodes(JNIEnv *env, jobjectArray nodes, jlongArray ivals, jdoubleArray dvals, jsize *count)
+JFN(jlong, createFilterProjectFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray inputTypes, PROGRAM_PARAMS)
 {
-    const jsize n = (*env)->GetArrayLength(env, nodes);
-    tgpu_expr_node *out = calloc((size_t)(n > 0 ? n : 1), sizeof(tgpu_expr_node));
-    jlong *iv = (*env)->GetLongArrayElements(env, ivals, NULL);
-    jdouble *dv = (*env)->GetDoubleArrayElements(env, dvals, NULL);
-    for (jsize i = 0; i < n; i++) {
-        jintArray row = (jintArray)(*env)->GetObjectArrayElement(env, nodes, i);
-        jint f[9];
-        (*env)->GetIntArrayRegion(env, row, 0, 9, f);
-        out[i].kind = f[0]; out[i].type = f[1]; out[i].op = f[2]; out[i].n_args = f[3];
-        out[i].args[0] = f[4]; out[i].args[1] = f[5]; out[i].args[2] = f[6]; out[i].is_null = f[7]; out[i].slen = f[8];
-        out[i].ival = iv[i]; out[i].dval = dv[i];
-        (*env)->DeleteLocalRef(env, row);
-    }
-    (*env)->ReleaseDoubleArrayElements(env, dvals, dv, JNI_ABORT);
-    (*env)->ReleaseLongArrayElements(env, ivals, iv, JNI_ABORT);
-    *count = n;
-    return out;
+    UNUSED(c);
+    program pr;
+    if (!program_read(env, &pr, PROGRAM_ARGS)) return 0;
+    ints t = ints_get(env, inputTypes);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_filter_project_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, &pr.spec, &f);
+    ints_release(env, &t);
+    program_release(env, &pr);
+    return factory_result(env, rc, f);
 }
 
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createFilterProjectFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray inputTypes,
-        jobjectArray nodes, jlongArray ivals, jdoubleArray dvals, jbyteArray pool, jint filterRoot, jintArray projectionRoots)
+/* ScanFilterAndProjectOperatorFactory (M/operator/ScanFilterAndProjectOperator.java:449-560), page-source flavour */
+JFN(jlong, createScanFilterProjectFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, PROGRAM_PARAMS)
 {
-    jsize n_nodes = 0;
-    tgpu_expr_node *nd = read_nodes(env, nodes, ivals, dvals, &n_nodes);
-    jint *types = (*env)->GetIntArrayElements(env, inputTypes, NULL), *roots = (*env)->GetIntArrayElements(env, projectionRoots, NULL);
-    jbyte *pl = (*env)->GetByteArrayElements(env, pool, NULL);
-    tgpu_page_processor_spec spec = {nd, n_nodes, (const char *)pl, (*env)->GetArrayLength(env, pool), filterRoot, (*env)->GetArrayLength(env, projectionRoots),
-                                     (const int32_t *)roots};
+    UNUSED(c);
+    program pr;
+    if (!program_read(env, &pr, PROGRAM_ARGS)) return 0;
+    ints t = ints_get(env, types);
     tgpu_operator_factory *f = NULL;
-    int32_t rc = tgpu_filter_project_factory_create(H(tgpu_context, ctx), operatorId, (*env)->GetArrayLength(env, inputTypes), (const int32_t *)types, &spec, &f);
-    (*env)->ReleaseByteArrayElements(env, pool, pl, JNI_ABORT);
-    (*env)->ReleaseIntArrayElements(env, projectionRoots, roots, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, inputTypes, types, JNI_ABORT);
-    free(nd);
+    int32_t rc = tgpu_scan_filter_project_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, &pr.spec, &f);
+    ints_release(env, &t);
+    program_release(env, &pr);
     return factory_result(env, rc, f);
 }
 
 /* aggregates: int[agg][3] = {function, input channel, mask channel} flattened */
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createHashAggregationFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray groupByTypes,
-        jintArray groupByChannels, jint hashChannel, jint step, jintArray aggregates, jint expectedGroups, jboolean produceDefaultOutput)
+JFN(jlong, createHashAggregationFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray groupByTypes, jintArray groupByChannels, jint hashChannel, jint step,
+                                         jintArray aggregates, jint expectedGroups, jboolean produceDefaultOutput)
 {
-    jint *gt = (*env)->GetIntArrayElements(env, groupByTypes, NULL), *gc = (*env)->GetIntArrayElements(env, groupByChannels, NULL);
-    jint *ag = (*env)->GetIntArrayElements(env, aggregates, NULL);
-    const jsize n_agg = (*env)->GetArrayLength(env, aggregates) / 3;
+    UNUSED(c);
+    ints gt = ints_get(env, groupByTypes), gc = ints_get(env, groupByChannels), ag = ints_get(env, aggregates);
     tgpu_operator_factory *f = NULL;
-    int32_t rc = tgpu_hash_aggregation_factory_create(H(tgpu_context, ctx), operatorId, (*env)->GetArrayLength(env, groupByTypes), (const int32_t *)gt, (const int32_t *)gc,
-                                                      hashChannel, step, n_agg, (const tgpu_agg_spec *)ag, expectedGroups, produceDefaultOutput, &f);
-    (*env)->ReleaseIntArrayElements(env, aggregates, ag, JNI_ABORT);
-    (*env)->ReleaseIntArrayElements(env, groupByChannels, gc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, groupByTypes, gt, JNI_ABORT);
+    int32_t rc = gt.n != gc.n || ag.n % 3 != 0 ? TGPU_ERR_INVALID_ARGUMENT
+                 : tgpu_hash_aggregation_factory_create(H(tgpu_context, ctx), operatorId, gt.n, (const int32_t *)gt.p, (const int32_t *)gc.p, hashChannel, step, ag.n / 3,
+                                                        (const tgpu_agg_spec *)ag.p, expectedGroups, produceDefaultOutput, &f);
+    ints_release(env, &ag); ints_release(env, &gc); ints_release(env, &gt);
+    if (rc == TGPU_ERR_INVALID_ARGUMENT && !f && (gt.n != gc.n || ag.n % 3 != 0)) { throw_native_message(env, rc, "hash aggregation: malformed group-by / aggregate arrays"); return 0; }
     return factory_result(env, rc, f);
 }
 
-/* returns {factory, bridge} */
-JNIEXPORT jlongArray JNICALL Java_io_trino_operator_gpu_GpuNative_createHashBuilderFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types,
-        jintArray outputChannels, jintArray hashChannels, jint precomputedHashChannel, jint expectedPositions)
+/* the fused FilterAndProject -> HashAggregation pipeline (tgpu_filter_project_hash_aggregation_factory_create): what bench.py's Q1 line times */
+JFN(jlong, createFilterProjectHashAggregationFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray inputTypes, PROGRAM_PARAMS, jintArray groupByTypes,
+                                                      jintArray groupByChannels, jint hashChannel, jint step, jintArray aggregates, jint expectedGroups)
 {
-    jint *t = (*env)->GetIntArrayElements(env, types, NULL), *oc = (*env)->GetIntArrayElements(env, outputChannels, NULL), *hc = (*env)->GetIntArrayElements(env, hashChannels, NULL);
+    UNUSED(c);
+    program pr;
+    if (!program_read(env, &pr, PROGRAM_ARGS)) return 0;
+    ints t = ints_get(env, inputTypes), gt = ints_get(env, groupByTypes), gc = ints_get(env, groupByChannels), ag = ints_get(env, aggregates);
+    tgpu_operator_factory *f = NULL;
+    const int malformed = gt.n != gc.n || ag.n % 3 != 0;
+    int32_t rc = malformed ? TGPU_ERR_INVALID_ARGUMENT
+                           : tgpu_filter_project_hash_aggregation_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, &pr.spec, gt.n, (const int32_t *)gt.p,
+                                                                                 (const int32_t *)gc.p, hashChannel, step, ag.n / 3, (const tgpu_agg_spec *)ag.p, expectedGroups, &f);
+    ints_release(env, &ag); ints_release(env, &gc); ints_release(env, &gt); ints_release(env, &t);
+    program_release(env, &pr);
+    if (malformed) { throw_native_message(env, rc, "hash aggregation: malformed group-by / aggregate arrays"); return 0; }
+    return factory_result(env, rc, f);
+}
+
+/* returns {factory, bridge}; partitionCount <= 1: one HashBuilderOperator, else the PartitionedLookupSourceFactory protocol (P build operators) */
+JFN(jlongArray, createHashBuilderFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, jintArray outputChannels, jintArray hashChannels,
+                                          jint precomputedHashChannel, jint expectedPositions, jint partitionCount)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types), oc = ints_get(env, outputChannels), hc = ints_get(env, hashChannels);
     tgpu_lookup_source_factory *bridge = NULL;
     tgpu_operator_factory *f = NULL;
-    int32_t rc = tgpu_hash_builder_factory_create(H(tgpu_context, ctx), operatorId, (*env)->GetArrayLength(env, types), (const int32_t *)t, (*env)->GetArrayLength(env, outputChannels),
-                                                  (const int32_t *)oc, (*env)->GetArrayLength(env, hashChannels), (const int32_t *)hc, precomputedHashChannel, expectedPositions, &bridge, &f);
-    (*env)->ReleaseIntArrayElements(env, hashChannels, hc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, outputChannels, oc, JNI_ABORT);
-    (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
-    if (rc < 0) { throw_native(env, rc); return NULL; }
-    jlong v[2] = {(jlong)(intptr_t)f, (jlong)(intptr_t)bridge};
-    jlongArray out = (*env)->NewLongArray(env, 2);
-    (*env)->SetLongArrayRegion(env, out, 0, 2, v);
-    return out;
+    int32_t rc = partitionCount <= 1
+                     ? tgpu_hash_builder_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, oc.n, (const int32_t *)oc.p, hc.n, (const int32_t *)hc.p,
+                                                        precomputedHashChannel, expectedPositions, &bridge, &f)
+                     : tgpu_partitioned_hash_builder_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, oc.n, (const int32_t *)oc.p, hc.n,
+                                                                    (const int32_t *)hc.p, precomputedHashChannel, expectedPositions, partitionCount, &bridge, &f);
+    ints_release(env, &hc); ints_release(env, &oc); ints_release(env, &t);
+    return two_handles(env, rc, f, bridge);
 }
 
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createLookupJoinFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray probeTypes,
-        jintArray probeJoinChannels, jint probeHashChannel, jintArray probeOutputChannels, jint joinType)
+/* JoinFilterFunction handed to the build side (JoinHashSupplier.java:54-70): the filter of `program` over (build channels, probe channels) */
+JFN(void, setJoinFilter)(JNIEnv *env, jclass c, jlong bridge, jintArray probeTypes, PROGRAM_PARAMS)
 {
-    jint *t = (*env)->GetIntArrayElements(env, probeTypes, NULL), *jc = (*env)->GetIntArrayElements(env, probeJoinChannels, NULL);
-    jint *oc = (*env)->GetIntArrayElements(env, probeOutputChannels, NULL);
+    UNUSED(c);
+    program pr;
+    if (!program_read(env, &pr, PROGRAM_ARGS)) return;
+    ints t = ints_get(env, probeTypes);
+    int32_t rc = tgpu_lookup_source_factory_set_join_filter(H(tgpu_lookup_source_factory, bridge), t.n, (const int32_t *)t.p, &pr.spec);
+    ints_release(env, &t);
+    program_release(env, &pr);
+    if (rc < 0) throw_native(env, rc);
+}
+
+/* out = {positions, table slots, position links} of the built table */
+JFN(void, lookupSourceStats)(JNIEnv *env, jclass c, jlong bridge, jlongArray out)
+{
+    UNUSED(c);
+    int64_t positions = 0, slots = 0, links = 0;
+    int32_t rc = tgpu_lookup_source_stats(H(tgpu_lookup_source_factory, bridge), &positions, &slots, &links);
+    if (rc < 0) { throw_native(env, rc); return; }
+    jlong v[3] = {positions, slots, links};
+    set_longs(env, out, v, 3);
+}
+
+JFN(jlong, createLookupJoinFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray probeTypes, jintArray probeJoinChannels, jint probeHashChannel,
+                                    jintArray probeOutputChannels, jint joinType)
+{
+    UNUSED(c);
+    ints t = ints_get(env, probeTypes), jc = ints_get(env, probeJoinChannels), oc = ints_get(env, probeOutputChannels);
     tgpu_operator_factory *f = NULL;
-    int32_t rc = tgpu_lookup_join_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), (*env)->GetArrayLength(env, probeTypes), (const int32_t *)t,
-                                                 (*env)->GetArrayLength(env, probeJoinChannels), (const int32_t *)jc, probeHashChannel,
-                                                 (*env)->GetArrayLength(env, probeOutputChannels), (const int32_t *)oc, joinType, &f);
-    (*env)->ReleaseIntArrayElements(env, probeOutputChannels, oc, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, probeJoinChannels, jc, JNI_ABORT);
-    (*env)->ReleaseIntArrayElements(env, probeTypes, t, JNI_ABORT);
+    int32_t rc = tgpu_lookup_join_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), t.n, (const int32_t *)t.p, jc.n, (const int32_t *)jc.p,
+                                                 probeHashChannel, oc.n, (const int32_t *)oc.p, joinType, &f);
+    ints_release(env, &oc); ints_release(env, &jc); ints_release(env, &t);
     return factory_result(env, rc, f);
 }
 
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createLookupOuterFactory(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray probeOutputTypes)
+/* the fused FilterAndProject -> LookupJoin pipeline (tgpu_filter_project_lookup_join_factory_create): what bench.py's headline times */
+JFN(jlong, createFilterProjectLookupJoinFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray inputTypes, PROGRAM_PARAMS,
+                                                 jintArray probeJoinChannels, jint probeHashChannel, jintArray probeOutputChannels, jint joinType)
 {
-    jint *t = (*env)->GetIntArrayElements(env, probeOutputTypes, NULL);
+    UNUSED(c);
+    program pr;
+    if (!program_read(env, &pr, PROGRAM_ARGS)) return 0;
+    ints t = ints_get(env, inputTypes), jc = ints_get(env, probeJoinChannels), oc = ints_get(env, probeOutputChannels);
     tgpu_operator_factory *f = NULL;
-    int32_t rc = tgpu_lookup_outer_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), (*env)->GetArrayLength(env, probeOutputTypes), (const int32_t *)t, &f);
-    (*env)->ReleaseIntArrayElements(env, probeOutputTypes, t, JNI_ABORT);
+    int32_t rc = tgpu_filter_project_lookup_join_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), t.n, (const int32_t *)t.p, &pr.spec, jc.n,
+                                                                (const int32_t *)jc.p, probeHashChannel, oc.n, (const int32_t *)oc.p, joinType, &f);
+    ints_release(env, &oc); ints_release(env, &jc); ints_release(env, &t);
+    program_release(env, &pr);
     return factory_result(env, rc, f);
 }
 
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_destroyBridge(JNIEnv *env, jclass c, jlong bridge) { tgpu_lookup_source_factory_destroy(H(tgpu_lookup_source_factory, bridge)); }
-
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_createOperator(JNIEnv *env, jclass c, jlong factory)
+JFN(jlong, createLookupOuterFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jlong bridge, jintArray probeOutputTypes)
 {
+    UNUSED(c);
+    ints t = ints_get(env, probeOutputTypes);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_lookup_outer_factory_create(H(tgpu_context, ctx), operatorId, H(tgpu_lookup_source_factory, bridge), t.n, (const int32_t *)t.p, &f);
+    ints_release(env, &t);
+    return factory_result(env, rc, f);
+}
+
+JFN(void, destroyBridge)(JNIEnv *env, jclass c, jlong bridge) { UNUSED(env); UNUSED(c); tgpu_lookup_source_factory_destroy(H(tgpu_lookup_source_factory, bridge)); }
+
+/* TopNOperator.createOperatorFactory (M/operator/TopNOperator.java:47-62); sortOrders: tgpu_sort_order = SortOrder's ordinal (S/connector/SortOrder.java:18-21) */
+JFN(jlong, createTopNFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, jlong n, jintArray sortChannels, jintArray sortOrders)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types), sc = ints_get(env, sortChannels), so = ints_get(env, sortOrders);
+    tgpu_operator_factory *f = NULL;
+    const int malformed = sc.n != so.n;
+    int32_t rc = malformed ? TGPU_ERR_INVALID_ARGUMENT
+                           : tgpu_top_n_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, n, sc.n, (const int32_t *)sc.p, (const int32_t *)so.p, &f);
+    ints_release(env, &so); ints_release(env, &sc); ints_release(env, &t);
+    if (malformed) { throw_native_message(env, rc, "sort channels and sort orders differ in length"); return 0; }
+    return factory_result(env, rc, f);
+}
+
+/* OrderByOperator.OrderByOperatorFactory (M/operator/OrderByOperator.java:48-131) */
+JFN(jlong, createOrderByFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, jintArray outputChannels, jint expectedPositions, jintArray sortChannels,
+                                 jintArray sortOrders)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types), oc = ints_get(env, outputChannels), sc = ints_get(env, sortChannels), so = ints_get(env, sortOrders);
+    tgpu_operator_factory *f = NULL;
+    const int malformed = sc.n != so.n;
+    int32_t rc = malformed ? TGPU_ERR_INVALID_ARGUMENT
+                           : tgpu_order_by_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, oc.n, (const int32_t *)oc.p, expectedPositions, sc.n,
+                                                          (const int32_t *)sc.p, (const int32_t *)so.p, &f);
+    ints_release(env, &so); ints_release(env, &sc); ints_release(env, &oc); ints_release(env, &t);
+    if (malformed) { throw_native_message(env, rc, "sort channels and sort orders differ in length"); return 0; }
+    return factory_result(env, rc, f);
+}
+
+/* MergePages as an operator (M/operator/project/MergePages.java:64-190) */
+JFN(jlong, createMergePagesFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, jlong minPageSizeInBytes, jint minRowCount, jlong maxPageSizeInBytes)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_merge_pages_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, minPageSizeInBytes, minRowCount, maxPageSizeInBytes, &f);
+    ints_release(env, &t);
+    return factory_result(env, rc, f);
+}
+
+/* PartitionedOutputOperator (M/operator/PartitionedOutputOperator.java:46-300) */
+JFN(jlong, createPartitionedOutputFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, jintArray partitionChannels, jint hashChannel, jint partitionCount,
+                                           jboolean replicatesAnyRow, jint nullChannel, jint partitionFunction)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types), pc = ints_get(env, partitionChannels);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_partitioned_output_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, pc.n, (const int32_t *)pc.p, hashChannel, partitionCount,
+                                                        replicatesAnyRow ? 1 : 0, nullChannel, partitionFunction, &f);
+    ints_release(env, &pc); ints_release(env, &t);
+    return factory_result(env, rc, f);
+}
+/* the next pending (partition, page) pair (PagePartitioner.flush -> outputBuffer.enqueue): returns the page handle, 0 = nothing pending; partition[0] = its partition */
+JFN(jlong, partitionedOutputPoll)(JNIEnv *env, jclass c, jlong op, jintArray partition)
+{
+    UNUSED(c);
+    int32_t part = -1;
+    tgpu_output_page *p = NULL;
+    int32_t rc = tgpu_partitioned_output_poll(H(tgpu_operator, op), &part, &p);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    jint v = part;
+    if (partition && (*env)->GetArrayLength(env, partition) >= 1) (*env)->SetIntArrayRegion(env, partition, 0, 1, &v);
+    return (jlong)(intptr_t)p;
+}
+/* PartitionedOutputInfo (:396-399): out = {rows added, pages added} */
+JFN(void, partitionedOutputInfo)(JNIEnv *env, jclass c, jlong op, jlongArray out)
+{
+    UNUSED(c);
+    int64_t rows = 0, pages = 0;
+    int32_t rc = tgpu_partitioned_output_info(H(tgpu_operator, op), &rows, &pages);
+    if (rc < 0) { throw_native(env, rc); return; }
+    jlong v[2] = {rows, pages};
+    set_longs(env, out, v, 2);
+}
+
+/* DynamicFilterSourceOperator (M/operator/DynamicFilterSourceOperator.java:74-143) */
+JFN(jlong, createDynamicFilterSourceFactory)(JNIEnv *env, jclass c, jlong ctx, jint operatorId, jintArray types, jintArray channels, jint maxDistinctValues,
+                                             jlong maxFilterSizeInBytes, jint minMaxCollectionLimit)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types), ch = ints_get(env, channels);
+    tgpu_operator_factory *f = NULL;
+    int32_t rc = tgpu_dynamic_filter_source_factory_create(H(tgpu_context, ctx), operatorId, t.n, (const int32_t *)t.p, ch.n, (const int32_t *)ch.p, maxDistinctValues,
+                                                           maxFilterSizeInBytes, minMaxCollectionLimit, &f);
+    ints_release(env, &ch); ints_release(env, &t);
+    return factory_result(env, rc, f);
+}
+/* the Domain of filter channel k after finish(): kindMinMax = {tgpu_dynamic_filter_kind, min, max}; returns the values page handle (VALUES, or a VARCHAR range) or 0 */
+JFN(jlong, dynamicFilterSourceResult)(JNIEnv *env, jclass c, jlong op, jint filterChannel, jlongArray kindMinMax)
+{
+    UNUSED(c);
+    int32_t kind = 0;
+    int64_t lo = 0, hi = 0;
+    tgpu_output_page *values = NULL;
+    int32_t rc = tgpu_dynamic_filter_source_result(H(tgpu_operator, op), filterChannel, &kind, &values, &lo, &hi);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    jlong v[3] = {kind, lo, hi};
+    set_longs(env, kindMinMax, v, 3);
+    return (jlong)(intptr_t)values;
+}
+
+JFN(jlong, createOperator)(JNIEnv *env, jclass c, jlong factory)
+{
+    UNUSED(c);
     tgpu_operator *op = NULL;
     int32_t rc = tgpu_operator_factory_create_operator(H(tgpu_operator_factory, factory), &op);
     if (rc < 0) { throw_native(env, rc); return 0; }
     return (jlong)(intptr_t)op;
 }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_noMoreOperators(JNIEnv *env, jclass c, jlong factory)
-{ int32_t rc = tgpu_operator_factory_no_more_operators(H(tgpu_operator_factory, factory)); if (rc < 0) throw_native(env, rc); }
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_duplicateFactory(JNIEnv *env, jclass c, jlong factory)
+JFN(void, noMoreOperators)(JNIEnv *env, jclass c, jlong factory)
+{ UNUSED(c); int32_t rc = tgpu_operator_factory_no_more_operators(H(tgpu_operator_factory, factory)); if (rc < 0) throw_native(env, rc); }
+JFN(jlong, duplicateFactory)(JNIEnv *env, jclass c, jlong factory)
 {
+    UNUSED(c);
     tgpu_operator_factory *f = NULL;
     return factory_result(env, tgpu_operator_factory_duplicate(H(tgpu_operator_factory, factory), &f), f);
 }
-JNIEXPORT void JNICALL Java_io_trino_operator_gpu_GpuNative_destroyFactory(JNIEnv *env, jclass c, jlong factory) { tgpu_operator_factory_destroy(H(tgpu_operator_factory, factory)); }
+JFN(void, destroyFactory)(JNIEnv *env, jclass c, jlong factory) { UNUSED(env); UNUSED(c); tgpu_operator_factory_destroy(H(tgpu_operator_factory, factory)); }
 
-/* ---- SerializedPage bytes straight into HBM (M/execution/buffer/PagesSerde.java:117-160) ---- */
-JNIEXPORT jlong JNICALL Java_io_trino_operator_gpu_GpuNative_deserializePage(JNIEnv *env, jclass c, jlong ctx, jbyteArray bytes, jint offset, jint length, jintArray types)
+/* ---- the scan side: ConnectorPageSource behind tgpu_page_source callbacks (M/operator/ScanFilterAndProjectOperator.java:232-287,354-397) ----
+ * The Java adapter (io.trino.operator.gpu.GpuPageSource) exposes the split's page source through five methods; the callbacks run on the
+ * driver thread inside tgpu_operator_get_output / _is_blocked / _is_finished and reach the adapter through a global reference.  Every
+ * channel is announced as a TGPU_LAZY block; load_block copies the loaded block's arrays into buffers the source owns until the next
+ * page (the library's rule: "arrays stay valid until the next call on this source"), so no Java array stays pinned across calls. */
+typedef struct {
+    JavaVM *vm;
+    jobject adapter;                       /* global reference to the GpuPageSource */
+    jmethodID next_page, is_finished, is_blocked, load_block, close;
+    int32_t channels;
+    int32_t *types;
+    tgpu_block *lazy;                      /* the page handed out last: one TGPU_LAZY block per channel */
+    tgpu_block *dicts;                     /* dictionary / RLE value blocks of loaded channels */
+    void **owned;                          /* 7 buffers per channel, freed when the next page arrives */
+} jni_source;
+
+static JNIEnv *source_env(jni_source *s)
 {
-    jint *t = (*env)->GetIntArrayElements(env, types, NULL);
-    const jsize nt = (*env)->GetArrayLength(env, types);
-    jbyte *p = (*env)->GetPrimitiveArrayCritical(env, bytes, NULL);
-    tgpu_output_page *out = NULL;
-    int32_t rc = tgpu_deserialize_page(H(tgpu_context, ctx), p + offset, length, nt, (const int32_t *)t, &out);
-    (*env)->ReleasePrimitiveArrayCritical(env, bytes, p, JNI_ABORT);   /* the library has consumed the bytes when it returns */
-    (*env)->ReleaseIntArrayElements(env, types, t, JNI_ABORT);
-    if (rc < 0) { throw_native(env, rc); return 0; }
-    return (jlong)(intptr_t)out;
+    JNIEnv *env = NULL;
+    if ((*s->vm)->GetEnv(s->vm, (void **)&env, JNI_VERSION_1_8) != JNI_OK) return NULL;
+    return env;
 }
-#endif /* TGPU_HAVE_JNI */
+static void source_free_page(jni_source *s)
+{
+    for (int32_t i = 0; i < 7 * s->channels; i++) {
+        free(s->owned[i]);
+        s->owned[i] = NULL;
+    }
+}
+static int32_t source_get_next_page(void *user, tgpu_page *page)
+{
+    jni_source *s = (jni_source *)user;
+    JNIEnv *env = source_env(s);
+    if (!env) return TGPU_ERR_INTERNAL;
+    source_free_page(s);
+    const jint positions = (*env)->CallIntMethod(env, s->adapter, s->next_page);   /* -1 = no page right now */
+    if ((*env)->ExceptionCheck(env)) return TGPU_ERR_INTERNAL;                     /* the Java exception stays pending and surfaces when the native call returns */
+    if (positions < 0) return 0;
+    for (int32_t ch = 0; ch < s->channels; ch++) {
+        memset(&s->lazy[ch], 0, sizeof(tgpu_block));
+        s->lazy[ch].type = s->types[ch];
+        s->lazy[ch].encoding = TGPU_LAZY;
+        s->lazy[ch].memory = TGPU_HOST;
+        s->lazy[ch].position_count = positions;
+    }
+    page->position_count = positions;
+    page->channel_count = s->channels;
+    page->blocks = s->lazy;
+    return 1;
+}
+static int32_t source_bool(jni_source *s, jmethodID m)
+{
+    JNIEnv *env = source_env(s);
+    if (!env) return TGPU_ERR_INTERNAL;
+    const jboolean b = (*env)->CallBooleanMethod(env, s->adapter, m);
+    if ((*env)->ExceptionCheck(env)) return TGPU_ERR_INTERNAL;
+    return b ? 1 : 0;
+}
+static int32_t source_is_finished(void *user) { return source_bool((jni_source *)user, ((jni_source *)user)->is_finished); }
+static int32_t source_is_blocked(void *user) { return source_bool((jni_source *)user, ((jni_source *)user)->is_blocked); }
 
-/* keeps the translation unit non-empty (ISO C) where no JDK is installed */
-typedef int tgpu_jni_translation_unit;
+/* a copy of a Java primitive array (element size `width`), NULL for a null reference */
+static void *copy_array(JNIEnv *env, jarray a, size_t width)
+{
+    if (!a) return NULL;
+    const jsize n = (*env)->GetArrayLength(env, a);
+    void *out = malloc((size_t)(n > 0 ? n : 1) * width);
+    void *p = (*env)->GetPrimitiveArrayCritical(env, a, NULL);
+    if (p) {
+        memcpy(out, p, (size_t)n * width);
+        (*env)->ReleasePrimitiveArrayCritical(env, a, p, JNI_ABORT);
+    }
+    return out;
+}
+/* GpuPageSource.loadBlock(channel) returns Object[8] = {int[3]{encoding, arrayOffset, dictionaryPositions}, values, nulls, offsets, ids, dvalues, dnulls, doffsets} */
+static int32_t source_load_block(void *user, int32_t channel, tgpu_block *block)
+{
+    jni_source *s = (jni_source *)user;
+    JNIEnv *env = source_env(s);
+    if (!env || channel < 0 || channel >= s->channels) return TGPU_ERR_INTERNAL;
+    if ((*env)->PushLocalFrame(env, 16) != 0) return TGPU_ERR_INSUFFICIENT_RESOURCES;
+    jobjectArray parts = (jobjectArray)(*env)->CallObjectMethod(env, s->adapter, s->load_block, (jint)channel);
+    if ((*env)->ExceptionCheck(env) || !parts || (*env)->GetArrayLength(env, parts) < 8) {
+        (*env)->PopLocalFrame(env, NULL);
+        return TGPU_ERR_INTERNAL;
+    }
+    jint meta[3] = {0, 0, 0};
+    (*env)->GetIntArrayRegion(env, (jintArray)(*env)->GetObjectArrayElement(env, parts, 0), 0, 3, meta);
+    const int32_t type = s->types[channel];
+    const size_t w = type == TGPU_VARCHAR ? 1 : (size_t)width_of(type);
+    void **own = &s->owned[7 * channel];
+    own[0] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 1), w);
+    own[1] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 2), 1);
+    own[2] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 3), 4);
+    own[3] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 4), 4);
+    own[4] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 5), w);
+    own[5] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 6), 1);
+    own[6] = copy_array(env, (jarray)(*env)->GetObjectArrayElement(env, parts, 7), 4);
+    (*env)->PopLocalFrame(env, NULL);
+    memset(block, 0, sizeof(*block));
+    block->type = type;
+    block->encoding = meta[0];
+    block->memory = TGPU_HOST;
+    block->position_count = s->lazy[channel].position_count;
+    if (meta[0] == TGPU_FLAT) {
+        block->values = type == TGPU_VARCHAR ? own[0] : (const void *)((const char *)own[0] + (size_t)meta[1] * w);
+        block->nulls = own[1] ? (const uint8_t *)own[1] + meta[1] : NULL;
+        block->offsets = own[2] ? (const int32_t *)own[2] + meta[1] : NULL;
+    }
+    else {
+        tgpu_block *d = &s->dicts[channel];
+        memset(d, 0, sizeof(*d));
+        d->type = type; d->encoding = TGPU_FLAT; d->memory = TGPU_HOST; d->position_count = meta[2];
+        d->values = own[4]; d->nulls = (const uint8_t *)own[5]; d->offsets = (const int32_t *)own[6];
+        block->ids = own[3] ? (const int32_t *)own[3] + meta[1] : NULL;
+        block->dictionary = d;
+    }
+    return TGPU_OK;
+}
+static void source_close(void *user)
+{
+    jni_source *s = (jni_source *)user;
+    JNIEnv *env = source_env(s);
+    if (env) {
+        (*env)->CallVoidMethod(env, s->adapter, s->close);
+        (*env)->DeleteGlobalRef(env, s->adapter);
+    }
+    source_free_page(s);
+    free(s->owned); free(s->dicts); free(s->lazy); free(s->types); free(s);
+}
+
+/* SourceOperator.addSplit: the split's page source (one at a time).  `types` = the channels it produces. */
+JFN(void, scanAddPageSource)(JNIEnv *env, jclass c, jlong op, jobject adapter, jintArray types)
+{
+    UNUSED(c);
+    jclass cls = (*env)->GetObjectClass(env, adapter);
+    jni_source *s = (jni_source *)calloc(1, sizeof(jni_source));
+    s->next_page = (*env)->GetMethodID(env, cls, "nextPage", "()I");
+    s->is_finished = (*env)->GetMethodID(env, cls, "isFinished", "()Z");
+    s->is_blocked = (*env)->GetMethodID(env, cls, "isBlocked", "()Z");
+    s->load_block = (*env)->GetMethodID(env, cls, "loadBlock", "(I)[Ljava/lang/Object;");
+    s->close = (*env)->GetMethodID(env, cls, "close", "()V");
+    if (!s->next_page || !s->is_finished || !s->is_blocked || !s->load_block || !s->close || (*env)->GetJavaVM(env, &s->vm) != JNI_OK) {
+        free(s);
+        return;   /* NoSuchMethodError pending */
+    }
+    ints t = ints_get(env, types);
+    s->channels = t.n;
+    s->types = (int32_t *)calloc((size_t)(t.n > 0 ? t.n : 1), sizeof(int32_t));
+    for (jsize i = 0; i < t.n; i++) s->types[i] = t.p[i];
+    ints_release(env, &t);
+    s->lazy = (tgpu_block *)calloc((size_t)(s->channels > 0 ? s->channels : 1), sizeof(tgpu_block));
+    s->dicts = (tgpu_block *)calloc((size_t)(s->channels > 0 ? s->channels : 1), sizeof(tgpu_block));
+    s->owned = (void **)calloc((size_t)(7 * s->channels + 1), sizeof(void *));
+    s->adapter = (*env)->NewGlobalRef(env, adapter);
+    tgpu_page_source src = {s, source_get_next_page, source_is_finished, source_is_blocked, source_load_block, source_close};
+    int32_t rc = tgpu_scan_operator_add_page_source(H(tgpu_operator, op), &src);
+    if (rc < 0) {
+        (*env)->DeleteGlobalRef(env, s->adapter);
+        free(s->owned); free(s->dicts); free(s->lazy); free(s->types); free(s);
+        throw_native(env, rc);
+    }
+}
+/* OperatorStats of the scan side (:354-397): out = {processed positions, lazy blocks loaded, lazy blocks skipped} */
+JFN(void, scanStats)(JNIEnv *env, jclass c, jlong op, jlongArray out)
+{
+    UNUSED(c);
+    int64_t positions = 0, loaded = 0, skipped = 0;
+    int32_t rc = tgpu_scan_operator_stats(H(tgpu_operator, op), &positions, &loaded, &skipped);
+    if (rc < 0) { throw_native(env, rc); return; }
+    jlong v[3] = {positions, loaded, skipped};
+    set_longs(env, out, v, 3);
+}
+
+/* ---- SerializedPage bytes <-> HBM (M/execution/buffer/PagesSerde.java:64-160) ---- */
+JFN(jlong, deserializePage)(JNIEnv *env, jclass c, jlong ctx, jbyteArray bytes, jint offset, jint length, jintArray types)
+{
+    UNUSED(c);
+    if (offset < 0 || length < 0 || (jlong)offset + length > (*env)->GetArrayLength(env, bytes)) {
+        throw_native_message(env, TGPU_ERR_INVALID_ARGUMENT, "deserializePage: offset / length outside the byte array");
+        return 0;
+    }
+    ints t = ints_get(env, types);
+    jbyte *p = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, bytes, NULL);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_deserialize_page(H(tgpu_context, ctx), p + offset, length, t.n, (const int32_t *)t.p, &out);
+    (*env)->ReleasePrimitiveArrayCritical(env, bytes, p, JNI_ABORT);   /* the library has consumed the bytes when it returns */
+    ints_release(env, &t);
+    return page_result(env, rc, out);
+}
+/* PagesSerde.serialize of a device-resident page into `out` (null: returns an upper bound of the size); returns the bytes written */
+JFN(jlong, serializePage)(JNIEnv *env, jclass c, jlong ctx, jlong page, jbyteArray out)
+{
+    UNUSED(c);
+    tgpu_page view;
+    int32_t rc = tgpu_output_page_as_page(H(tgpu_output_page, page), &view);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    int64_t len = 0;
+    if (!out) rc = tgpu_serialize_page(H(tgpu_context, ctx), &view, NULL, 0, &len);
+    else {
+        const jsize cap = (*env)->GetArrayLength(env, out);
+        jbyte *p = (jbyte *)(*env)->GetPrimitiveArrayCritical(env, out, NULL);
+        rc = tgpu_serialize_page(H(tgpu_context, ctx), &view, p, cap, &len);
+        (*env)->ReleasePrimitiveArrayCritical(env, out, p, 0);
+    }
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return len;
+}
+
+/* ---- exchange between the GPUs of one node (tgpu_exchange_*): pages stay in HBM, so the page arguments are output-page handles ---- */
+JFN(jbyteArray, exchangeUniqueId)(JNIEnv *env, jclass c)
+{
+    UNUSED(c);
+    jbyte id[TGPU_EXCHANGE_ID_BYTES];
+    int32_t rc = tgpu_exchange_unique_id(id);
+    if (rc < 0) { throw_native(env, rc); return NULL; }
+    jbyteArray out = (*env)->NewByteArray(env, TGPU_EXCHANGE_ID_BYTES);
+    if (out) (*env)->SetByteArrayRegion(env, out, 0, TGPU_EXCHANGE_ID_BYTES, id);
+    return out;
+}
+JFN(jlong, createExchange)(JNIEnv *env, jclass c, jlong ctx, jbyteArray uniqueId, jint rank, jint world)
+{
+    UNUSED(c);
+    if ((*env)->GetArrayLength(env, uniqueId) != TGPU_EXCHANGE_ID_BYTES) {
+        throw_native_message(env, TGPU_ERR_INVALID_ARGUMENT, "exchange id must be TGPU_EXCHANGE_ID_BYTES long");
+        return 0;
+    }
+    jbyte id[TGPU_EXCHANGE_ID_BYTES];
+    (*env)->GetByteArrayRegion(env, uniqueId, 0, TGPU_EXCHANGE_ID_BYTES, id);
+    tgpu_exchange *ex = NULL;
+    int32_t rc = tgpu_exchange_create(H(tgpu_context, ctx), id, rank, world, &ex);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    return (jlong)(intptr_t)ex;
+}
+JFN(void, destroyExchange)(JNIEnv *env, jclass c, jlong ex) { UNUSED(env); UNUSED(c); tgpu_exchange_destroy(H(tgpu_exchange, ex)); }
+JFN(jlong, exchangeRepartition)(JNIEnv *env, jclass c, jlong ex, jlong page, jintArray keyChannels, jint hashChannel)
+{
+    UNUSED(c);
+    tgpu_page view;
+    int32_t rc = tgpu_output_page_as_page(H(tgpu_output_page, page), &view);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    ints k = ints_get(env, keyChannels);
+    tgpu_output_page *out = NULL;
+    rc = tgpu_exchange_repartition(H(tgpu_exchange, ex), &view, k.n, (const int32_t *)k.p, hashChannel, &out);
+    ints_release(env, &k);
+    return page_result(env, rc, out);
+}
+JFN(jlong, exchangePartitionedOutput)(JNIEnv *env, jclass c, jlong ex, jlong partitionedOutputOperator, jintArray types)
+{
+    UNUSED(c);
+    ints t = ints_get(env, types);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_exchange_partitioned_output(H(tgpu_exchange, ex), H(tgpu_operator, partitionedOutputOperator), t.n, (const int32_t *)t.p, &out);
+    ints_release(env, &t);
+    return page_result(env, rc, out);
+}
+JFN(jlong, exchangeAllGather)(JNIEnv *env, jclass c, jlong ex, jlong page)
+{
+    UNUSED(c);
+    tgpu_page view;
+    int32_t rc = tgpu_output_page_as_page(H(tgpu_output_page, page), &view);
+    if (rc < 0) { throw_native(env, rc); return 0; }
+    tgpu_output_page *out = NULL;
+    rc = tgpu_exchange_all_gather(H(tgpu_exchange, ex), &view, &out);
+    return page_result(env, rc, out);
+}
+JFN(jlong, exchangeBytesSent)(JNIEnv *env, jclass c, jlong ex) { UNUSED(env); UNUSED(c); return tgpu_exchange_bytes_sent(H(tgpu_exchange, ex)); }

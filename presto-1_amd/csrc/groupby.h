@@ -116,6 +116,7 @@ private:
     bool has_input_hash_;
     std::unique_ptr<BigintGroupTable> integer_;   // set: single integer key, the table of groupby_bigint.hip does the work
     bool optimistic_ = false;                     // the next sub-batch is an optimistic one (integer table)
+    bool high_cardinality_ = false;               // the last sub-batch was mostly new groups: size the table from the page's row bound
     int64_t groups_ = 0;
     int64_t capacity_ = 0;  // slots of the device table (uint64 words)
     BufferPtr words_;

@@ -585,16 +585,20 @@ bool GroupByHashGpu::get_group_ids(const std::vector<const DeviceColumn *> &keys
 
 // Sub-batches of the integer table.  A regular sub-batch is sized by bound (room for every row to be a new group: it cannot overflow);
 // after a sizeable one without a new group the rest of the page goes in ONE optimistic launch with room for 2^24 new groups (an
-// overflow is flagged by the kernel: rebuilt larger, re-run in pieces); a sub-batch in which at least a quarter of the rows were new
-// groups is evidence of a high-cardinality key, and the rest goes in bounded launches of up to 2^27 rows -- the table is sized once
-// from the row bound instead of growing by doubling (12 rehashes on the way to 40 M groups).
+// overflow is flagged by the kernel: rebuilt larger, re-run in pieces).  A sub-batch in which at least a quarter of the rows were new
+// groups is evidence of a high-cardinality key: the table is then sized ONCE from the row bound of the rest of the page instead of
+// growing by doubling (12 rehashes on the way to 40 M groups), and the rest goes in sub-batches of 2^24 rows -- rows that
+// meet a group published by an earlier sub-batch are answered by the insert pass alone, only repeats of a key INSIDE its first
+// sub-batch need the resolve pass (one page in one piece: 63 M of 100 M rows; in six pieces: 9 M).
 void GroupByHashGpu::get_group_ids_integer(const DeviceColumn &key, int64_t n, int32_t *out_gids, const uint8_t *row_mask)
 {
     int64_t sub = next_sub_, start = 0;
     while (start < n) {
         const int64_t len = std::min(sub, n - start);
         const DeviceColumn view = k::region_of(ctx_, key, start, len);
-        integer_->ensure_table(integer_->groups() + (optimistic_ ? std::min<int64_t>(len, sub_batch_) : len));
+        int64_t room = optimistic_ ? std::min<int64_t>(len, sub_batch_) : len;
+        if (high_cardinality_) room = std::max(room, std::min<int64_t>(n - start, 1ll << 27));
+        integer_->ensure_table(integer_->groups() + room);
         int64_t new_groups = 0;
         if (!integer_->process(view, row_mask ? row_mask + start : nullptr, len, out_gids + start, fresh_counters(), &new_groups)) {
             integer_->rebuild(integer_->capacity() * 2);
@@ -609,11 +613,12 @@ void GroupByHashGpu::get_group_ids_integer(const DeviceColumn &key, int64_t n, i
         if (new_groups == 0) {
             optimistic_ = sub >= std::min<int64_t>(1ll << 17, sub_batch_);
             sub = optimistic_ ? (1ll << 40) : sub * 64;
+            high_cardinality_ = false;
         }
         else {
             optimistic_ = false;
-            sub = new_groups * 4 >= len ? std::max<int64_t>(sub_batch_, 1ll << 27) : std::min<int64_t>(sub * 8, sub_batch_);
-            if (getenv("TGPU_GBH_SUBBATCH")) sub = std::min(sub, sub_batch_);   // (tests force small sub-batches)
+            high_cardinality_ = new_groups * 4 >= len;
+            sub = high_cardinality_ ? sub_batch_ : std::min<int64_t>(sub * 8, sub_batch_);
         }
         next_sub_ = sub;
     }

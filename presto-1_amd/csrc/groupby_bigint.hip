@@ -14,8 +14,10 @@
 //             the fill pattern re-reads it coherently (the claimer's store is on its way; the key that EQUALS the fill pattern
 //             and the NULL key have slots of their own behind the table, so "fill pattern" always means "not written yet").
 //             Rows that claimed or lowered a slot are *candidates* for being their key's first row (one bit per row, by ballot).
-//   mark    (gbi_mark)   : candidates re-read minrow: equal to the row = the key's first occurrence.  One bit per row + a count
-//             per 1024-row tile; an exclusive scan of the tile counts gives the first-seen rank = BigintGroupByHash's
+//             A row that lowers a slot tells the row it displaced (the value its atomicMin returned) that it is not the first: a bit
+//             in `not_first`.  Lowering is rare -- it takes a row overtaken by a later row of its key.
+//   mark    (gbi_mark)   : first occurrence = candidate & ~not_first, a streaming pass over two bit vectors (no table access); a
+//             count per 1024-row tile; an exclusive scan of the tile counts gives the first-seen rank = BigintGroupByHash's
 //             `nextGroupId++` order (BigintGroupByHash.java:246-253).
 //   publish (gbi_publish): first rows store gid = groups + rank into their slot and the key into values_by_group[gid].
 //   resolve (gbi_resolve): the other pending rows read their slot's gid.
@@ -56,7 +58,7 @@ template <typename T> __device__ __forceinline__ T coherent_load(const T *p) { r
 // `first` is the 16-byte snapshot of the row's home slot loaded by the caller (plain load).
 template <bool INSERT>
 __device__ __forceinline__ unsigned int probe_row(Slot *slots, unsigned int mask, unsigned int cap, long long key, bool is_null, unsigned int s, long long ks,
-                                                  unsigned long long w, unsigned int r, bool &cand, unsigned long long *counters)
+                                                  unsigned long long w, unsigned int r, bool &cand, unsigned long long *counters, unsigned long long *not_first)
 {
     cand = false;
     const bool special = is_null || key == kFillKey;   // slots of their own: cap (NULL group), cap + 1 (the key that equals the fill pattern)
@@ -86,8 +88,12 @@ __device__ __forceinline__ unsigned int probe_row(Slot *slots, unsigned int mask
             if (gid != kNone) return gid;
             if (!INSERT) return kMasked;   // (lookups run between sub-batches: nothing is pending then)
             if (r < (unsigned int)w) {
-                __hip_atomic_fetch_min(&slots[s].minrow, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                cand = true;
+                // lowering is rare (a row overtaken by a later one of its key): the row it displaces is told that it is not the first
+                const unsigned int displaced = __hip_atomic_fetch_min(&slots[s].minrow, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (displaced > r) {
+                    cand = true;
+                    atomicOr(&not_first[displaced >> 6], 1ull << (displaced & 63));
+                }
             }
             return kPending | s;
         }
@@ -104,7 +110,7 @@ __device__ __forceinline__ unsigned int probe_row(Slot *slots, unsigned int mask
 template <typename KT, bool INSERT>
 __global__ void __launch_bounds__(kBlock) gbi_insert_kernel(const KT *__restrict__ values, const uint8_t *__restrict__ nulls, const uint8_t *__restrict__ row_mask, int64_t n,
                                                              Slot *slots, unsigned int cap, int shift, unsigned int *__restrict__ out,
-                                                             unsigned long long *__restrict__ cand_bits, unsigned long long *counters)
+                                                             unsigned long long *__restrict__ cand_bits, unsigned long long *not_first, unsigned long long *counters)
 {
     const unsigned int mask = cap - 1;
     const int lane = threadIdx.x & 63;
@@ -127,23 +133,54 @@ __global__ void __launch_bounds__(kBlock) gbi_insert_kernel(const KT *__restrict
             s[u] = isnull[u] ? cap : (key[u] == kFillKey ? cap + 1 : slot_of(key[u], shift));
             snap[u] = *(const ulonglong2 *)&slots[active[u] ? s[u] : 0];
         }
+        // runs of equal keys in adjacent rows (inputs clustered by key) go to the table once per wave: the followers copy the
+        // first row's answer (same group, or the same pending slot whose first row is the leader's or an earlier one)
+        bool lead[kRowsPerLane], claimed[kRowsPerLane];
+        unsigned long long old[kRowsPerLane];
+#pragma unroll
+        for (int u = 0; u < kRowsPerLane; u++) {
+            const int kind = (active[u] ? 1 : 0) | (isnull[u] ? 2 : 0);
+            const long long key_prev = __shfl_up(key[u], 1, 64);
+            const int kind_prev = __shfl_up(kind, 1, 64);
+            lead[u] = active[u] && !(lane > 0 && kind_prev == kind && key_prev == key[u]);
+        }
+        // the claiming CAS of every row that found its home slot empty, all of a lane's rows in flight together
+#pragma unroll
+        for (int u = 0; u < kRowsPerLane; u++) {
+            claimed[u] = INSERT && lead[u] && snap[u].y == kEmptyWord;
+            old[u] = 0;
+            if (claimed[u]) old[u] = atomicCAS((unsigned long long *)&slots[s[u]].minrow, kEmptyWord, word_of((unsigned int)(base + u * kBlock + threadIdx.x), kNone));
+        }
+        // the winners' keys, ALL of them before any lane may wait for one: a lane that lost a slot spins below until the slot's key is
+        // visible, and the winner may be another row of the same wave (a later u) -- which only gets there once the spinner has moved on
+#pragma unroll
+        for (int u = 0; u < kRowsPerLane; u++)
+            if (claimed[u] && old[u] == kEmptyWord && !(isnull[u] || key[u] == kFillKey))
+                __hip_atomic_store(&slots[s[u]].key, key[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int u = 0; u < kRowsPerLane; u++) {
             const int64_t r = base + u * kBlock + threadIdx.x;
-            // runs of equal keys in adjacent rows (inputs clustered by key) go to the table once per wave: the followers copy the
-            // first row's answer (same group, or the same pending slot whose first row is the leader's or an earlier one)
-            const long long key_prev = __shfl_up(key[u], 1, 64);
-            const int same_kind_prev = __shfl_up((active[u] ? 1 : 0) | (isnull[u] ? 2 : 0), 1, 64);
-            const bool follower = active[u] && lane > 0 && same_kind_prev == ((active[u] ? 1 : 0) | (isnull[u] ? 2 : 0)) && key_prev == key[u];
-            const unsigned long long leaders = __ballot(active[u] && !follower);
+            const bool special = isnull[u] || key[u] == kFillKey;
             bool cand = false;
             unsigned int result = kMasked;
-            if (active[u] && !follower)
-                result = probe_row<INSERT>(slots, mask, cap, key[u], isnull[u], s[u], (long long)snap[u].x, snap[u].y, (unsigned int)r, cand, counters);
+            if (claimed[u] && old[u] == kEmptyWord) {
+                cand = true;
+                result = kPending | s[u];
+            }
+            else if (lead[u]) {
+                long long ks = (long long)snap[u].x;
+                unsigned long long w = snap[u].y;
+                if (claimed[u]) {   // lost the slot to another row: carry on with what is there now
+                    w = old[u];
+                    ks = special ? key[u] : coherent_load(&slots[s[u]].key);
+                }
+                result = probe_row<INSERT>(slots, mask, cap, key[u], isnull[u], s[u], ks, w, (unsigned int)r, cand, counters, not_first);
+            }
+            const unsigned long long leaders = __ballot(lead[u]);
             const unsigned long long at_or_below = leaders & ((2ULL << lane) - 1ULL);
             const int src = at_or_below ? 63 - __clzll((long long)at_or_below) : lane;
             const unsigned int lead_result = __shfl(result, src, 64);
-            if (follower) result = lead_result;
+            if (active[u] && !lead[u]) result = lead_result;
             if (r < n) out[r] = result;
             if (INSERT) {
                 const unsigned long long cb = __ballot(cand);
@@ -167,40 +204,22 @@ __global__ void __launch_bounds__(kBlock) gbi_insert_kernel(const KT *__restrict
     }
 }
 
-// first-occurrence rows of the sub-batch: candidates whose slot still holds their row.  One workgroup per 1024-row tile.
-__global__ void __launch_bounds__(kBlock) gbi_mark_kernel(const unsigned int *__restrict__ out, int64_t n, const Slot *__restrict__ slots,
-                                                           const unsigned long long *__restrict__ cand_bits, unsigned long long *__restrict__ first_bits,
-                                                           int32_t *__restrict__ tile_counts, const unsigned long long *__restrict__ counters)
+// first-occurrence rows of the sub-batch = candidates that nobody displaced: one thread per 64-row word, 16 words per 1024-row tile
+__global__ void __launch_bounds__(kBlock) gbi_mark_kernel(int64_t words, const unsigned long long *__restrict__ cand_bits, const unsigned long long *__restrict__ not_first,
+                                                           unsigned long long *__restrict__ first_bits, int32_t *__restrict__ tile_counts,
+                                                           const unsigned long long *__restrict__ counters)
 {
     if (counters[0] == 0) return;   // nothing pending: the host will not look at the counts
-    const int lane = threadIdx.x & 63;
-    const int64_t base = (int64_t)blockIdx.x * kTile;
-    unsigned int mine = 0;
-#pragma unroll
-    for (int u = 0; u < kRowsPerLane; u++) {
-        const int64_t r = base + u * kBlock + threadIdx.x;
-        const int64_t word = (base + u * kBlock + (threadIdx.x & ~63)) >> 6;
-        bool first = false;
-        if (base + u * kBlock + (threadIdx.x & ~63) < n) {
-            const unsigned long long cb = cand_bits[word];
-            if ((cb >> lane) & 1ull) {
-                const unsigned int s = out[r] & ~kPending;
-                first = slots[s].minrow == (unsigned int)r;
-            }
-            const unsigned long long fb = __ballot(first);
-            if (lane == 0) first_bits[word] = fb;
-            mine += lane == 0 ? (unsigned int)__popcll(fb) : 0u;
-        }
+    const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long fb = 0;
+    if (w < words) {
+        fb = cand_bits[w] & ~not_first[w];
+        first_bits[w] = fb;
     }
-    __shared__ unsigned int s_cnt[kBlock / 64];
-    if (lane == 0) s_cnt[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int t = 0;
+    unsigned int c = (unsigned int)__popcll(fb);
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) t += s_cnt[w];
-        tile_counts[blockIdx.x] = (int32_t)t;
-    }
+    for (int d = 8; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 15) == 0 && w < words) tile_counts[w >> 4] = (int32_t)c;
 }
 
 // exclusive scan of the tile counts by ONE workgroup (a tile is 1024 rows: 600 M rows are 586 K counts): every thread sums a contiguous
@@ -364,24 +383,26 @@ bool BigintGroupTable::process(const DeviceColumn &keys, const uint8_t *row_mask
     ensure_store(groups_ > 0 ? groups_ : 1);
     unsigned int *out = reinterpret_cast<unsigned int *>(out_gids);
     const int64_t tiles = ceil_div(n, kTile), words = ceil_div(n, 64);
-    BufferPtr cand = ctx_->alloc((size_t)words * 8), first = ctx_->alloc((size_t)words * 8), counts = ctx_->alloc((size_t)tiles * 4), prefix = ctx_->alloc((size_t)tiles * 4);
+    BufferPtr cand = ctx_->alloc((size_t)words * 8), displaced = ctx_->alloc_zero((size_t)words * 8), first = ctx_->alloc((size_t)words * 8),
+              counts = ctx_->alloc((size_t)tiles * 4), prefix = ctx_->alloc((size_t)tiles * 4);
     Slot *slots = slots_->as<Slot>();
     {
         ProfileScope ps(ctx_, "gbh_insert");
         const int g = grid_for(ctx_, n, kTile);
         if (width_ == 8)
             gbi_insert_kernel<int64_t, true><<<g, kBlock, 0, ctx_->stream()>>>((const int64_t *)keys.values, keys.nulls, row_mask, n, slots, (unsigned int)capacity_, shift_, out,
-                                                                              cand->as<unsigned long long>(), ctr);
+                                                                              cand->as<unsigned long long>(), displaced->as<unsigned long long>(), ctr);
         else
             gbi_insert_kernel<int32_t, true><<<g, kBlock, 0, ctx_->stream()>>>((const int32_t *)keys.values, keys.nulls, row_mask, n, slots, (unsigned int)capacity_, shift_, out,
-                                                                              cand->as<unsigned long long>(), ctr);
+                                                                              cand->as<unsigned long long>(), displaced->as<unsigned long long>(), ctr);
         check_launch("gbh_insert");
     }
     {
         // gated on the pending count on the device: with nothing pending (the steady state) both launches return at once, and the
         // ONE read-back below brings the pending count, the number of new groups and the overflow flag
         ProfileScope ps(ctx_, "gbh_assign");
-        gbi_mark_kernel<<<(unsigned)tiles, kBlock, 0, ctx_->stream()>>>(out, n, slots, cand->as<unsigned long long>(), first->as<unsigned long long>(), counts->as<int32_t>(), ctr);
+        gbi_mark_kernel<<<(unsigned)ceil_div(words, kBlock), kBlock, 0, ctx_->stream()>>>(words, cand->as<unsigned long long>(), displaced->as<unsigned long long>(),
+                                                                                        first->as<unsigned long long>(), counts->as<int32_t>(), ctr);
         check_launch("gbh_mark");
         gbi_scan_kernel<<<1, kScanThreads, 0, ctx_->stream()>>>(counts->as<int32_t>(), prefix->as<int32_t>(), tiles, ctr);
         check_launch("gbh_scan");
@@ -416,10 +437,10 @@ void BigintGroupTable::lookup(const DeviceColumn &keys, int64_t n, int32_t *out_
     const int g = grid_for(ctx_, n, kTile);
     if (width_ == 8)
         gbi_insert_kernel<int64_t, false><<<g, kBlock, 0, ctx_->stream()>>>((const int64_t *)keys.values, keys.nulls, nullptr, n, slots_->as<Slot>(), (unsigned int)capacity_, shift_,
-                                                                           reinterpret_cast<unsigned int *>(out_gids), nullptr, ctr);
+                                                                           reinterpret_cast<unsigned int *>(out_gids), nullptr, nullptr, ctr);
     else
         gbi_insert_kernel<int32_t, false><<<g, kBlock, 0, ctx_->stream()>>>((const int32_t *)keys.values, keys.nulls, nullptr, n, slots_->as<Slot>(), (unsigned int)capacity_, shift_,
-                                                                           reinterpret_cast<unsigned int *>(out_gids), nullptr, ctr);
+                                                                           reinterpret_cast<unsigned int *>(out_gids), nullptr, nullptr, ctr);
     check_launch("gbh_lookup");
 }
 

@@ -95,14 +95,4 @@ def test_every_handle_entry_point_binds_the_device():
     assert checked >= 40
 
 
-def test_jni_shim_and_java_glue_agree():
-    """jni/tgpu_jni.c exports exactly the native methods java/io/trino/operator/gpu/GpuNative.java declares, and every tgpu_* function the
-    shim calls is declared in include/tgpu.h (neither side is compiled here: no JDK in the image)"""
-    c = open(os.path.join(ROOT, "jni", "tgpu_jni.c")).read()
-    java = open(os.path.join(ROOT, "java", "io", "trino", "operator", "gpu", "GpuNative.java")).read()
-    exported = set(re.findall(r"Java_io_trino_operator_gpu_GpuNative_(\w+)\(", c)) | set(re.findall(r"BOOL_CALL\((\w+),", c))
-    exported.discard("jname")   # the macro's own parameter
-    declared = set(re.findall(r"public static native [\w\[\]]+ (\w+)\(", java))
-    assert exported == declared, (exported ^ declared)
-    called = set(re.findall(r"\b(tgpu_[a-z0-9_]+)\(", c))
-    assert called <= set(header_symbols()), called - set(header_symbols())
+# (the JNI shim and the Java glue: tests/test_jni_shim_cpu.py, tests/test_java_glue_cpu.py)
