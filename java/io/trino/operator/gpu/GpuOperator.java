@@ -6,7 +6,9 @@ import io.trino.memory.context.LocalMemoryContext;
 import io.trino.operator.Operator;
 import io.trino.operator.OperatorContext;
 import io.trino.spi.Page;
+import io.trino.spi.type.Type;
 
+import java.util.List;
 import java.util.concurrent.ScheduledExecutorService;
 import java.util.concurrent.TimeUnit;
 
@@ -21,12 +23,12 @@ public class GpuOperator
     private final LocalMemoryContext memory;
     private final LocalMemoryContext revocableMemory;
     private final ScheduledExecutorService poller;
-    private long handle;                                   // tgpu_operator*
+    protected long handle;                                 // tgpu_operator*
     private final boolean[] wouldBlock = new boolean[1];
 
-    private final int[] inputTypes;                        // tgpu_type of every input channel
+    private final List<Type> inputTypes;                   // the type of every input channel (LongArrayBlock holds BIGINT or DOUBLE: the channel type decides)
 
-    public GpuOperator(OperatorContext operatorContext, long handle, int[] inputTypes, ScheduledExecutorService poller)
+    public GpuOperator(OperatorContext operatorContext, long handle, List<Type> inputTypes, ScheduledExecutorService poller)
     {
         this.inputTypes = inputTypes;
         this.operatorContext = operatorContext;
@@ -77,9 +79,12 @@ public class GpuOperator
     public void addInput(Page page)
     {
         try {
-            if (page instanceof GpuPages.DeviceResidentPage) {
-                // the producer was a GPU operator: the page never left HBM (tgpu_operator_add_input_output_page)
-                GpuNative.addInputDevicePage(handle, ((GpuPages.DeviceResidentPage) page).handle());
+            GpuPages.DevicePageHandle device = GpuPages.deviceHandle(page);
+            if (device != null) {
+                // the producer was a GPU operator and nothing touched the page in between: it never left HBM (tgpu_operator_add_input_output_page
+                // shares the buffers, so the producer's handle can go at once)
+                GpuNative.addInputDevicePage(handle, device.handle);
+                device.release();
             }
             else {
                 GpuPages.addInput(handle, page.getLoadedPage(), inputTypes);
@@ -92,7 +97,7 @@ public class GpuOperator
     }
 
     // OperatorContext.java:263-275; SpillableHashAggregationBuilder.updateMemory :117-128 (user vs revocable)
-    private void updateMemory()
+    protected void updateMemory()
     {
         memory.setBytes(GpuNative.memoryBytes(handle));
         revocableMemory.setBytes(GpuNative.revocableMemoryBytes(handle));
@@ -159,12 +164,18 @@ public class GpuOperator
         }
     }
 
-    private interface BooleanCall
+    /** the operator's native handle, for the pieces that are not part of the Operator interface (PartitionedOutput's pending pages, DynamicFilterSource's result) */
+    public long nativeHandle()
+    {
+        return handle;
+    }
+
+    protected interface BooleanCall
     {
         boolean get();
     }
 
-    private static boolean call(BooleanCall c)
+    protected static boolean call(BooleanCall c)
     {
         try {
             return c.get();

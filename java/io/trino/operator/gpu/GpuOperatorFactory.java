@@ -4,8 +4,10 @@ import io.trino.operator.DriverContext;
 import io.trino.operator.Operator;
 import io.trino.operator.OperatorContext;
 import io.trino.operator.OperatorFactory;
+import io.trino.spi.type.Type;
 import io.trino.sql.planner.plan.PlanNodeId;
 
+import java.util.List;
 import java.util.concurrent.ScheduledExecutorService;
 
 /**
@@ -15,15 +17,15 @@ import java.util.concurrent.ScheduledExecutorService;
 public class GpuOperatorFactory
         implements OperatorFactory
 {
-    private final int operatorId;
-    private final PlanNodeId planNodeId;
-    private final String operatorType;
-    private final int[] inputTypes;
-    private final ScheduledExecutorService poller;
-    private long factory;                                  // tgpu_operator_factory*
-    private boolean closed;
+    protected final int operatorId;
+    protected final PlanNodeId planNodeId;
+    protected final String operatorType;
+    protected final List<Type> inputTypes;
+    protected final ScheduledExecutorService poller;
+    protected long factory;                                // tgpu_operator_factory*
+    protected boolean closed;
 
-    GpuOperatorFactory(int operatorId, PlanNodeId planNodeId, String operatorType, int[] inputTypes, ScheduledExecutorService poller, long factory)
+    GpuOperatorFactory(int operatorId, PlanNodeId planNodeId, String operatorType, List<Type> inputTypes, ScheduledExecutorService poller, long factory)
     {
         this.operatorId = operatorId;
         this.planNodeId = planNodeId;
