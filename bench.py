@@ -1004,7 +1004,7 @@ def sub_join_hash_layout(b, steps, warmup, sf):
         o.release()
     ok = res["pairs"] == want_pairs and abs(got_sum - want_sum) <= 1e-9 * max(abs(want_sum), 1.0) and res["stats"]["link_count"] == 0
     # algorithmic bytes of the probe launch, hash layout: filter column 4 B x input rows + (key 8 B + one 16-byte TgSlot16) x rows
-    # passing the filter + 8 B per emitted pair (the Bloom word in front of the table is an optimisation, not priced)
+    # passing the filter + 8 B per emitted pair
     alg = 4.0 * n + 24.0 * n_pass + 8.0 * want_pairs
     roof = dominant(prof, steps, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n}, pmc_prefix="sub_join_hash_layout:")
     return {"workload": "fused filter + probe, sparse random 64-bit build keys (open-address TgSlot16 table + Bloom pre-filter)", "build_rows": nb, "input_rows": n,

@@ -6,7 +6,8 @@
 struct TgSlot16 {
     long long key;
     int head;   // build position of the newest row with this key (PagesHash.key[]), -1 = empty
-    int pad;
+    int count;  // tables with repeated build keys (position links): rows that carry this key = the length of the chain behind `head`, so that
+                // counting a probe row's matches needs no walk over the links (one random line per probe row instead of 1 + chain length)
 };
 
 // Blocked Bloom filter in front of the table: one 64-bit word per key, 4 bits set.  Sized to stay cache resident
@@ -49,8 +50,8 @@ __device__ inline unsigned long long tg_slot_of(long long key, unsigned long lon
     return ((unsigned long long)key * 0x9E3779B97F4A7C15ULL) >> (64 - __popcll(mask));
 }
 
-// head build position of `key`, or -1 (PagesHash.getAddressIndex, M/operator/PagesHash.java:157-169, specialised)
-__device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long mask, const TgPrefilter &pf, long long key)
+// head build position of `key`, or -1 (PagesHash.getAddressIndex, M/operator/PagesHash.java:157-169, specialised); *count = the slot's chain length
+__device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long mask, const TgPrefilter &pf, long long key, int *count = nullptr)
 {
     if (pf.bitmap) {
         if (key < pf.key_min || key > pf.key_max) return -1;
@@ -70,7 +71,10 @@ __device__ inline int tg_find_head_int(const TgSlot16 *slots, unsigned long long
     for (unsigned long long iter = 0; iter <= mask; iter++) {
         const TgSlot16 s = slots[pos];
         if (s.head < 0) return -1;
-        if (s.key == key) return s.head;
+        if (s.key == key) {
+            if (count) *count = s.count;
+            return s.head;
+        }
         pos = (pos + 1) & mask;
     }
     return -1;

@@ -1150,7 +1150,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   for (int s = 0; s < FJ_STRIPES; s++) {
     tg_zero_row(rw[s]);
     pkey[s] = 0; psidx[s] = 0; pbits[s] = 0; pbw[s] = 0; pfl[s] = 0;
-    skey[s] = 0; ssidx[s] = 0; sfl[s] = 0; ssl[s].key = 0; ssl[s].head = -1; ssl[s].pad = 0;
+    skey[s] = 0; ssidx[s] = 0; sfl[s] = 0; ssl[s].key = 0; ssl[s].head = -1; ssl[s].count = 0;
   }
   for (long long it = 0; it < my_tiles + 3; it++) {
     const long long jD = it - 3, jC = it - 2, jB = it - 1, jA = it;

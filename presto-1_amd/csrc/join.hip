@@ -202,48 +202,111 @@ __global__ void __launch_bounds__(kBlock) build_insert_kernel(KeyCols keys, cons
     }
 }
 
-// int-key fast path: insert + key publication + key range in one pass.  The row that claims an empty slot (CAS on head) also
-// stores the key into it; rows that meet an occupied slot compare against the KEY COLUMN at the slot's current head (the
-// slot's key field may not be visible yet inside this kernel), and a row with the same key raises the head to the newest
-// position (PagesHash.java:104-119 keeps the last inserted position as the head of the key's chain).
+// int-key fast path: insert + key publication + key range in one pass, four rows per lane: all row loads, then all slot loads (one
+// 16-byte load brings key and head), then the claiming CAS of every row that found its slot empty -- independent requests in flight
+// together (tools/exp_random_access.hip: the memory system answers 55 G random loads and 27 G atomics per second, whatever the table size;
+// one row per lane with its load -> CAS -> store chain left most of that unused).  The row that claims an empty slot stores the key into
+// it; a row that meets an occupied slot compares against the slot's key when it is published, and against the KEY COLUMN at the slot's
+// current head while the slot still shows the unwritten pattern (the claimer's store may be on its way -- or the key may really be
+// that value: the column decides either way).  A row with the slot's key raises the head to the newest position (PagesHash.java:104-119
+// keeps the last inserted position as the head of the key's chain).
 // counters[0] = rows that joined an existing key, counters[1] = error; minmax[0] / [1] = smallest / largest indexed key
+constexpr long long kUnwrittenKey = (long long)0x8000000000000001ull;
+constexpr int kBuildRows = 4;
+
+__device__ __forceinline__ int build_insert_row(const ColView &key, long long k, int r, Slot16 *slots, uint64_t mask, uint64_t pos, long long ks, int head, bool &dup,
+                                                unsigned long long *counters)
+{
+    for (uint64_t iter = 0; iter <= mask; iter++) {
+        if (head == -1) {
+            const int old = atomicCAS(&slots[pos].head, -1, r);
+            if (old == -1) {
+                __hip_atomic_store(&slots[pos].key, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return (int)pos;
+            }
+            head = old;
+            ks = __hip_atomic_load(&slots[pos].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool same = ks == kUnwrittenKey ? int_key_at(key, head) == k : ks == k;
+        if (same) {
+            (void)__hip_atomic_fetch_max(&slots[pos].head, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dup = true;
+            return (int)pos;
+        }
+        pos = (pos + 1) & mask;
+        const ulonglong2 v = *(const ulonglong2 *)&slots[pos];
+        ks = (long long)v.x;
+        head = (int)(unsigned int)v.y;
+    }
+    atomicExch(&counters[1], 1ull);
+    return -1;
+}
+
 __global__ void __launch_bounds__(kBlock) build_insert_int_kernel(ColView key, int64_t n, Slot16 *slots, uint64_t mask, int32_t *__restrict__ row_slot,
                                                                    unsigned long long *counters, long long *minmax)
 {
     long long lo = 0x7fffffffffffffffLL, hi = -0x7fffffffffffffffLL - 1;
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        bool dup = false;
-        int32_t slot = -1;
-        if (!(key.nulls && key.nulls[r])) {  // PagesHash.java:94-96: rows with a null key are not indexed
-            const long long k = int_key_at(key, r);
-            lo = k < lo ? k : lo;
-            hi = k > hi ? k : hi;
-            uint64_t pos = tg_slot_of(k, mask);
-            for (uint64_t iter = 0; iter <= mask; iter++) {
-                int *hp = &slots[pos].head;
-                int cur = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (cur == -1) {
-                    const int old = atomicCAS(hp, -1, (int)r);
-                    if (old == -1) {
-                        slots[pos].key = k;
-                        slot = (int32_t)pos;
-                        break;
-                    }
-                    cur = old;
-                }
-                if (int_key_at(key, cur) == k) {
-                    atomicMax(hp, (int)r);
-                    slot = (int32_t)pos;
-                    dup = true;
-                    break;
-                }
-                pos = (pos + 1) & mask;
-                if (iter == mask) atomicExch(&counters[1], 1ull);
+    unsigned int my_dups = 0;
+    for (int64_t base = (int64_t)blockIdx.x * (kBlock * kBuildRows); base < n; base += (int64_t)gridDim.x * (kBlock * kBuildRows)) {
+        long long k[kBuildRows];
+        bool live[kBuildRows], claimed[kBuildRows];
+        uint64_t pos[kBuildRows];
+        ulonglong2 snap[kBuildRows];
+        int old[kBuildRows];
+#pragma unroll
+        for (int u = 0; u < kBuildRows; u++) {
+            const int64_t r = base + u * kBlock + threadIdx.x;
+            live[u] = r < n && !(key.nulls && key.nulls[r]);   // PagesHash.java:94-96: rows with a null key are not indexed
+            k[u] = live[u] ? int_key_at(key, r) : 0;
+            if (live[u]) {
+                lo = k[u] < lo ? k[u] : lo;
+                hi = k[u] > hi ? k[u] : hi;
             }
         }
-        row_slot[r] = slot;
-        const unsigned long long b = __ballot(dup);
-        if (dup && (threadIdx.x & 63) == (__ffsll((long long)b) - 1)) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+#pragma unroll
+        for (int u = 0; u < kBuildRows; u++) {
+            pos[u] = tg_slot_of(k[u], mask);
+            snap[u] = *(const ulonglong2 *)&slots[live[u] ? pos[u] : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kBuildRows; u++) {
+            claimed[u] = live[u] && (int)(unsigned int)snap[u].y == -1;
+            old[u] = 0;
+            if (claimed[u]) old[u] = atomicCAS(&slots[pos[u]].head, -1, (int)(base + u * kBlock + threadIdx.x));
+        }
+#pragma unroll
+        for (int u = 0; u < kBuildRows; u++)
+            if (claimed[u] && old[u] == -1) __hip_atomic_store(&slots[pos[u]].key, k[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < kBuildRows; u++) {
+            const int64_t r = base + u * kBlock + threadIdx.x;
+            int32_t slot = -1;
+            bool dup = false;
+            if (claimed[u] && old[u] == -1) slot = (int32_t)pos[u];
+            else if (live[u]) {
+                long long ks = (long long)snap[u].x;
+                int head = (int)(unsigned int)snap[u].y;
+                if (claimed[u]) {   // lost the slot to another row
+                    head = old[u];
+                    ks = __hip_atomic_load(&slots[pos[u]].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                slot = build_insert_row(key, k[u], (int)r, slots, mask, pos[u], ks, head, dup, counters);
+            }
+            if (r < n) row_slot[r] = slot;
+            my_dups += dup ? 1u : 0u;
+        }
+    }
+    // one atomic per workgroup
+    __shared__ unsigned int s_dups[kBlock / 64];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) my_dups += __shfl_down(my_dups, d, 64);
+    if ((threadIdx.x & 63) == 0) s_dups[threadIdx.x >> 6] = my_dups;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) total += s_dups[w];
+        if (total) atomicAdd(&counters[0], total);
     }
     block_minmax(lo, hi, minmax);
 }
@@ -256,7 +319,9 @@ __global__ void __launch_bounds__(kBlock) sort_keys_kernel(const int32_t *__rest
     }
 }
 
-__global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long *__restrict__ sorted, int64_t n, int32_t *__restrict__ links)
+// sorted = (slot << 32 | position), ascending: a slot's rows sit next to each other, oldest first.  links[p] = the next older row of p's key; the
+// newest row of a run (the slot's head) also counts the run and publishes the count in the slot (int-key table: TgSlot16.count)
+__global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long *__restrict__ sorted, int64_t n, int32_t *__restrict__ links, Slot16 *slots)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         unsigned long long k = sorted[i];
@@ -267,6 +332,11 @@ __global__ void __launch_bounds__(kBlock) links_kernel(const unsigned long long 
             if ((p >> 32) == (k >> 32)) link = (int32_t)(uint32_t)p;
         }
         links[(uint32_t)k] = link;
+        if (slots && (i + 1 == n || (sorted[i + 1] >> 32) != (k >> 32))) {
+            int64_t first = i;
+            while (first > 0 && (sorted[first - 1] >> 32) == (k >> 32)) first--;
+            slots[k >> 32].count = (int)(i - first + 1);
+        }
     }
 }
 
@@ -360,14 +430,14 @@ __global__ void __launch_bounds__(kBlock) build_direct_kernel(ColView key, int64
     }
 }
 
-// int-key fast path: empty table = {key 0, head -1}
+// int-key fast path: empty table = {key = the unwritten pattern, head -1, count 1}
 __global__ void __launch_bounds__(kBlock) init_slots_kernel(Slot16 *__restrict__ slots, int64_t capacity)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * kBlock) {
         Slot16 s;
-        s.key = 0;
+        s.key = kUnwrittenKey;
         s.head = -1;
-        s.pad = 0;
+        s.count = 1;
         slots[i] = s;
     }
 }
@@ -440,13 +510,19 @@ __global__ void __launch_bounds__(kBlock) probe_count_kernel(ProbeTable t, KeyCo
                                                               int probe_outer, int32_t *__restrict__ heads_out, int32_t *__restrict__ counts)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
-        int head = -1;
-        if (!row_has_null(probe, r)) head = find_head<FAST>(t, build, probe, r, FAST ? 0 : hashes[r]);  // JoinProbe.java:87-97
+        int head = -1, chain = 0;
+        if (!row_has_null(probe, r)) {  // JoinProbe.java:87-97
+            if (FAST) head = tg_find_head_int(t.slots, t.mask, t.pf, int_key_at(probe.c[0], r), &chain);   // the slot knows its chain's length
+            else head = find_head<FAST>(t, build, probe, r, hashes[r]);
+        }
         int32_t c = 0;
         if (head >= 0) {
             c = 1;
-            if (t.links)
-                for (int p = t.links[head]; p >= 0; p = t.links[p]) c++;
+            if (t.links) {
+                if (FAST && !t.pf.rank_base) c = chain;
+                else
+                    for (int p = t.links[head]; p >= 0; p = t.links[p]) c++;
+            }
         }
         else if (probe_outer) c = 1;
         heads_out[r] = head;
@@ -455,16 +531,20 @@ __global__ void __launch_bounds__(kBlock) probe_count_kernel(ProbeTable t, KeyCo
 }
 
 __global__ void __launch_bounds__(kBlock) probe_write_kernel(const int32_t *__restrict__ links, const int32_t *__restrict__ heads, const int32_t *__restrict__ offsets,
-                                                              int64_t n, int probe_outer, int32_t *__restrict__ out_probe, int32_t *__restrict__ out_build)
+                                                              const int32_t *__restrict__ counts, int64_t n, int probe_outer, int32_t *__restrict__ out_probe,
+                                                              int32_t *__restrict__ out_build)
 {
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
         int head = heads[r];
         int64_t o = offsets[r];
         if (head >= 0) {
-            for (int p = head; p >= 0; p = links ? links[p] : -1) {
+            // the row's match count is known: the last link (the -1 that ends the chain) is never fetched
+            int p = head;
+            for (int32_t left = counts[r]; left > 0; left--) {
                 out_probe[o] = (int32_t)r;
                 out_build[o] = p;
                 o++;
+                if (left > 1) p = links[p];
             }
         }
         else if (probe_outer) {
@@ -738,7 +818,7 @@ void LookupSourceGpu::build()
         HIP_CHECK(rocprim::radix_sort_keys(nullptr, temp_bytes, keys_in->as<unsigned long long>(), keys_out->as<unsigned long long>(), (size_t)n_, 0, 64, ctx_->stream()));
         BufferPtr temp = ctx_->alloc(temp_bytes ? temp_bytes : 1);
         HIP_CHECK(rocprim::radix_sort_keys(temp->ptr(), temp_bytes, keys_in->as<unsigned long long>(), keys_out->as<unsigned long long>(), (size_t)n_, 0, 64, ctx_->stream()));
-        links_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys_out->as<unsigned long long>(), n_, links_->as<int32_t>());
+        links_kernel<<<g, kBlock, 0, ctx_->stream()>>>(keys_out->as<unsigned long long>(), n_, links_->as<int32_t>(), int_key_fast_ ? slots16_->as<Slot16>() : nullptr);
         check_launch("links");
     }
     if (int_key_fast_) {
@@ -761,10 +841,17 @@ void LookupSourceGpu::build()
             static const int bits_per_key = getenv("TGPU_BLOOM_BITS_PER_KEY") ? std::max(1, atoi(getenv("TGPU_BLOOM_BITS_PER_KEY"))) : 16;   // kernel study
             int64_t words = 1024;
             while (words * 64 < n_ * bits_per_key) words <<= 1;
-            bloom_words_ = words;
-            bloom_ = ctx_->alloc_zero((size_t)words * 8);
-            bloom_build_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], bloom_->as<unsigned long long>(), (unsigned long long)words - 1);
-            check_launch("bloom_build");
+            // (Kernel study, round 3: a probe of the filter and a probe of the table are one random request each, so the filter cannot lower
+            // the request count -- yet without it the 324 M-row probe of 14.6 M sparse keys takes 13.5 ms instead of 6.95, the 100 M-row
+            // duplicate-key probe 2.60 instead of 2.42: a probe that MISSES walks 2.5 slots on average at a fill of 0.5 before it meets an
+            // empty one, each step a dependent load, and the filter spares 7 of 8 rows that walk.  TGPU_BLOOM_MAX_BYTES bounds the filter.)
+            static const int64_t max_bloom_bytes = getenv("TGPU_BLOOM_MAX_BYTES") ? atoll(getenv("TGPU_BLOOM_MAX_BYTES")) : (1ll << 40);
+            if (words * 8 <= max_bloom_bytes) {
+                bloom_words_ = words;
+                bloom_ = ctx_->alloc_zero((size_t)words * 8);
+                bloom_build_kernel<<<g, kBlock, 0, ctx_->stream()>>>(row_slot->as<int32_t>(), n_, keys.c[0], bloom_->as<unsigned long long>(), (unsigned long long)words - 1);
+                check_launch("bloom_build");
+            }
         }
     }
 }
@@ -916,7 +1003,7 @@ void LookupSourceGpu::probe(const std::vector<const DeviceColumn *> &probe_keys,
     out_build_idx = ctx_->alloc((size_t)(out_count > 0 ? out_count : 1) * 4);
     if (out_count > 0) {
         ProfileScope ps(ctx_, "join_probe_write");
-        probe_write_kernel<<<g, kBlock, 0, ctx_->stream()>>>(t.links, heads->as<int32_t>(), offsets->as<int32_t>(), n, probe_outer ? 1 : 0,
+        probe_write_kernel<<<g, kBlock, 0, ctx_->stream()>>>(t.links, heads->as<int32_t>(), offsets->as<int32_t>(), counts->as<int32_t>(), n, probe_outer ? 1 : 0,
                                                             out_probe_idx->as<int32_t>(), out_build_idx->as<int32_t>());
         check_launch("probe_write");
     }
