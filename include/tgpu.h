@@ -124,6 +124,14 @@ int32_t tgpu_set_resource_dir(const char *dir);
  * zero-copy regions of at most max_rows rows and about max_bytes bytes (Java block accounting); 0 = no limit (the default). */
 int32_t tgpu_context_set_max_output_page(tgpu_context *ctx, int64_t max_bytes, int64_t max_rows);
 
+/* A promise about borrowed TGPU_DEVICE input (hosts that keep their own HBM buffers; library-owned pages and host pages need none): the
+ * blocks of a page stay valid and UNCHANGED until the operator's next call (add_input / finish / get_output after finish) has returned,
+ * instead of "until overwritten in stream order".  It lets the fused aggregation run one launch per page without waiting for the page's
+ * counters: a page that turns out to carry a new group is re-run from its blocks one call later (DESIGN.md "Page granularity").  Java
+ * pages are immutable and referenced by the operator for as long as it needs them (Operator.addInput transfers a reference,
+ * SURVEY.md 8b "Ownership"): this is the device-memory counterpart of that rule.  Default off. */
+int32_t tgpu_context_set_device_input_stable(tgpu_context *ctx, int32_t stable);
+
 typedef enum tgpu_double_sum_order { TGPU_SUM_ORDER_EXACT = 0, TGPU_SUM_ORDER_JAVA = 1 } tgpu_double_sum_order;
 int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order);
 

@@ -58,9 +58,12 @@ public:
     struct FoldScratch {
         unsigned long long *partials;
         int32_t stride;
+        unsigned long long *pending;   // the one-pass launches' totals of a page not yet known to be clean (TgFoldScratch)
     };
     FoldScratch fold_scratch(int64_t blocks, int64_t group_capacity);
     void flush_fold();
+    // the pending totals of the LAST one-pass launch (`blocks` workgroup rows): added to the partials (the page was clean) or dropped
+    void resolve_pending(int64_t blocks, bool commit);
     // Spill support (SpillableHashAggregationBuilder.java:283-299): the accumulator state of groups [0, groups) in host memory -- the
     // EXACT state itself (counts, limb accumulators, NaN / inf flags, 128-bit bigint sums; ORDERED mode: the running double sums), not a
     // rounded intermediate value, so that merging runs loses nothing.
@@ -104,7 +107,7 @@ private:
     std::vector<State> states_;
     int32_t step_;
     BufferPtr error_;  // device uint32
-    BufferPtr fold_partials_;
+    BufferPtr fold_partials_, fold_pending_;
     int64_t fold_rows_ = 0, fold_stride_ = 0;
     bool fold_dirty_ = false;
 };

@@ -388,10 +388,32 @@ GroupedAccumulators::FoldScratch GroupedAccumulators::fold_scratch(int64_t block
         fold_rows_ = std::max<int64_t>(blocks, fold_rows_);
         fold_stride_ = stride;
         fold_partials_ = ctx_->alloc_zero((size_t)fold_rows_ * (size_t)stride * 24);
+        fold_pending_ = ctx_->alloc_zero((size_t)fold_rows_ * (size_t)stride * 24);
     }
     ensure(group_capacity);   // the flush addresses the states of every group a row has room for
     fold_dirty_ = true;
-    return {fold_partials_->as<unsigned long long>(), (int32_t)stride};
+    return {fold_partials_->as<unsigned long long>(), (int32_t)stride, fold_pending_->as<unsigned long long>()};
+}
+
+__global__ void __launch_bounds__(kBlock) agg_resolve_pending_kernel(TgFoldScratch fs, int n_aggs, LowCardStates states, int commit)
+{
+    if (commit) tg_commit_pending(fs, n_aggs, states.st, true);
+    else {
+        unsigned long long *pend = fs.pending + (size_t)blockIdx.x * fs.stride * 3;
+        for (int i = threadIdx.x; i < fs.stride * 3; i += kBlock) pend[i] = 0;
+    }
+}
+
+void GroupedAccumulators::resolve_pending(int64_t blocks, bool commit)
+{
+    if (!fold_pending_ || blocks <= 0) return;
+    TG_CHECK_STATE(blocks <= fold_rows_, "pending rows beyond the fold scratch");
+    LowCardStates states{};
+    for (size_t k = 0; k < states_.size(); k++) states.st[k].function = device_state((int)k).function;
+    agg_resolve_pending_kernel<<<(int)blocks, kBlock, 0, ctx_->stream()>>>(
+        TgFoldScratch{fold_partials_->as<unsigned long long>(), (int)fold_stride_, fold_pending_->as<unsigned long long>()}, (int)states_.size(), states, commit ? 1 : 0);
+    check_launch("agg_resolve_pending");
+    fold_dirty_ = true;
 }
 
 void GroupedAccumulators::flush_fold()
@@ -409,7 +431,7 @@ void GroupedAccumulators::flush_fold()
         states.st[k].dsum = nullptr;
     }
     ProfileScope ps(ctx_, "agg_fold_flush");
-    agg_fold_flush_kernel<<<(int)ceil_div(fold_stride_, kBlock / 64), kBlock, 0, ctx_->stream()>>>(TgFoldScratch{fold_partials_->as<unsigned long long>(), (int)fold_stride_},
+    agg_fold_flush_kernel<<<(int)ceil_div(fold_stride_, kBlock / 64), kBlock, 0, ctx_->stream()>>>(TgFoldScratch{fold_partials_->as<unsigned long long>(), (int)fold_stride_, nullptr},
                                                                                                 (int)fold_rows_, (int)states_.size(), states);
     check_launch("agg_fold_flush");
 }
@@ -750,7 +772,7 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
             states.st[k].dsum = nullptr;
         }
         const FoldScratch fs = fold_scratch(blocks, (160 * 1024) / plan.per_group_bytes);   // (states reserved above: nothing moves)
-        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, states, plan, gids, n, TgFoldScratch{fs.partials, fs.stride});
+        agg_lowcard_kernel<<<(int)blocks, kBlock, (size_t)lds_bytes, ctx_->stream()>>>(args, states, plan, gids, n, TgFoldScratch{fs.partials, fs.stride, nullptr});
         check_launch("agg_accumulate_lowcard");
         return;
     }

@@ -176,6 +176,14 @@ int32_t tgpu_context_set_double_sum_order(tgpu_context *ctx, int32_t order)
     });
 }
 
+int32_t tgpu_context_set_device_input_stable(tgpu_context *ctx, int32_t stable)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx != nullptr, "context is null");
+        ctx->ctx->set_device_input_stable(stable != 0);
+    });
+}
+
 int32_t tgpu_pinned_alloc(tgpu_context *ctx, int64_t bytes, void **out)
 {
     return guard_on(ctx_of(ctx), [&] {

@@ -157,6 +157,9 @@ public:
     int64_t max_output_page_bytes() const { return max_out_bytes_; }
     int64_t max_output_page_rows() const { return max_out_rows_; }
     void set_max_output_page(int64_t bytes, int64_t rows) { max_out_bytes_ = bytes; max_out_rows_ = rows; }
+    // tgpu_context_set_device_input_stable: borrowed TGPU_DEVICE input stays valid and unchanged until the operator's NEXT call returns
+    bool device_input_stable() const { return device_input_stable_; }
+    void set_device_input_stable(bool on) { device_input_stable_ = on; }
     int double_sum_order() const { return double_sum_order_; }
     void set_double_sum_order(int order) { double_sum_order_ = order; }
 
@@ -178,6 +181,7 @@ private:
     bool own_stream_ = false;
     int cu_count_ = 256;
     int double_sum_order_ = 0;
+    bool device_input_stable_ = false;
     int64_t max_out_bytes_ = 0, max_out_rows_ = 0;
     std::multimap<size_t, void *> free_;
     size_t in_use_ = 0, cached_ = 0;

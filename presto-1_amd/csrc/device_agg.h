@@ -138,6 +138,10 @@ __device__ inline void tg_flag_special(unsigned int *special, double v)
 struct TgFoldScratch {
     unsigned long long *partials;   // [workgroups][stride][3]
     int stride;                     // items per row = group capacity x n_aggs
+    // One-pass launches (filter + group lookup + accumulate in ONE kernel, no read-back in front of the next page): a page's block totals
+    // are PENDING here, same shape as `partials`, until the page is known to be clean (no row met a group the kernel did not know); the
+    // next one-pass launch of the operator -- or the host, for the last page -- adds them to `partials`, or drops them.
+    unsigned long long *pending;
 };
 
 // a += b for a (hi, lo) double-double pair, or for the (low, high) words of a 128-bit integer
@@ -170,12 +174,12 @@ __device__ inline void tg_fold_wave(bool bigint, unsigned long long &c, unsigned
 // rotated start keeps the wave's reads on distinct banks, then three shuffle rounds fold the 8 sums -- 32 items per pass with every
 // lane busy (one wave per item with six full-width shuffle rounds was issue bound: ~2600 cycles per item, 10 us for TPCH Q1's 32
 // items).  The item's total is added to the block's slot: plain read-modify-write, no atomics, no cross-workgroup traffic.
-__device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, const TgAggState *st, TgFoldScratch fs)
+template <bool OVERWRITE>
+__device__ inline void tg_lc_fold_to(unsigned char *lds, const TgLowCardPlan &p, const TgAggState *st, unsigned long long *mine)
 {
     __syncthreads();
     const int t = threadIdx.x, chunk = t & 7;
     const int items = p.n_groups * p.n_aggs;
-    unsigned long long *mine = fs.partials + (size_t)blockIdx.x * fs.stride * 3;
     for (int base = 0; base < items; base += TG_AGG_BLOCK / 8) {
         int it = base + (t >> 3);
         const bool live = it < items;
@@ -204,7 +208,15 @@ __device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, co
 #ifdef FA_DEBUG_SKIP
         if (FA_DEBUG_SKIP & 8) continue;
 #endif
-        if (chunk == 0 && live && c != 0) {
+        if (OVERWRITE) {
+            if (chunk == 0 && live) {   // the slot takes this launch's totals whatever it held (a zero count marks "nothing")
+                unsigned long long *slot = mine + (size_t)it * 3;
+                slot[0] = c;
+                slot[1] = w >= 0 ? a0 : 0ULL;
+                slot[2] = w >= 0 ? a1 : 0ULL;
+            }
+        }
+        else if (chunk == 0 && live && c != 0) {
             unsigned long long *slot = mine + (size_t)it * 3;
             slot[0] += c;
             if (w >= 0) {
@@ -214,6 +226,31 @@ __device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, co
                 slot[2] = s1;
             }
         }
+    }
+}
+
+__device__ inline void tg_lc_fold(unsigned char *lds, const TgLowCardPlan &p, const TgAggState *st, TgFoldScratch fs)
+{
+    tg_lc_fold_to<false>(lds, p, st, fs.partials + (size_t)blockIdx.x * fs.stride * 3);
+}
+
+// a workgroup row of pending totals joins the same row of the folded partials (the page they belong to turned out clean); the pending
+// row is cleared when `clear` is set (host-side commit of the last page; a one-pass launch overwrites its row anyway)
+__device__ inline void tg_commit_pending(TgFoldScratch fs, int n_aggs, const TgAggState *st, bool clear)
+{
+    unsigned long long *mainr = fs.partials + (size_t)blockIdx.x * fs.stride * 3, *pend = fs.pending + (size_t)blockIdx.x * fs.stride * 3;
+    for (int it = threadIdx.x; it < fs.stride; it += TG_AGG_BLOCK) {
+        unsigned long long *src = pend + (size_t)it * 3, *dst = mainr + (size_t)it * 3;
+        const unsigned long long c = src[0];
+        if (c != 0) {
+            const bool bigint = st[it % n_aggs].function == TG_AGG_SUM_BIGINT;
+            dst[0] += c;
+            unsigned long long s0 = dst[1], s1 = dst[2];
+            tg_fold_pair(bigint, s0, s1, src[1], src[2]);
+            dst[1] = s0;
+            dst[2] = s1;
+        }
+        if (clear) src[0] = src[1] = src[2] = 0;
     }
 }
 

@@ -80,6 +80,10 @@ public:
     void lookup(const std::vector<const DeviceColumn *> &keys, const int64_t *hashes, int64_t n, int32_t *out_gids);
 
     int64_t group_count() const { return groups_; }
+    // for callers that run lookups of their own against the groups' keys (the one-pass fused aggregation): the key store by group id, and a
+    // zeroed counter set ([7] = ~0) from the ring
+    KeyCols key_store_view() { ensure_store(groups_ > 0 ? groups_ : 1); return store_view(); }
+    unsigned long long *counter_set() { return fresh_counters(); }
     int32_t java_capacity() const { return java_capacity_; }
     int32_t java_rehash_count() const { return java_rehashes_; }
     int64_t estimated_size() const;

@@ -1974,6 +1974,99 @@ extern "C" __global__ void __launch_bounds__(256) fa_accumulate_ordered(FaArgs F
 }
 )SRC";
 
+static const char *kFqKernel = R"SRC(
+// ---- ONE pass per page (DESIGN.md "Page granularity"): filter + group lookup + the aggregates' input projections + accumulate, no group ids
+// in memory, no read-back in front of the next page.  For the steady state of few groups: a row is matched against the register
+// signatures / LDS records of the groups the table holds (at most FG_LDS_GROUPS); a row that matches none only COUNTS (counters[0]) -- the
+// page is then "dirty": its totals stay pending and are dropped, the host re-runs it through the insert protocol.  A clean page's totals are
+// made final by the NEXT one-pass launch (stream order), or by the host for the last one.
+struct FqArgs {
+  FaArgs fa;
+  TgKeyCols store;
+  int store_groups;
+  int pad;
+  unsigned long long* counters;        // this page: [0] rows of unknown groups, [7] expression error word (~0 = none)
+  const unsigned long long* prev;      // the previous one-pass page's counters (its totals are in fold.pending), or null
+};
+#define FQ_STRIPES 4
+#define FQ_TILE (FQ_STRIPES * 256)
+extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
+  const FaArgs& F = Q.fa;
+  const FpArgs& A = F.fp;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[FQ_LDS_BYTES];   // the lane-private states of the groups a one-pass launch may meet
+  __shared__ __attribute__((aligned(16))) unsigned char rec[FG_LDS_GROUPS * FG_NKEYS * 32];
+  // (1) the previous page's totals of this workgroup row: final if that page was clean, else dropped (overwritten below either way)
+  if (Q.prev && (Q.prev[0] | Q.prev[2] | ~Q.prev[7]) == 0ULL) tg_commit_pending(F.fold, F.plan.n_aggs, F.st, false);
+  tg_lc_zero(lds, F.plan);
+  const int lg = Q.store_groups < FG_LDS_GROUPS ? Q.store_groups : FG_LDS_GROUPS;
+  fg_build_records(Q.store, lg, rec);   // ends with a workgroup barrier (also between the commit above and the fold below)
+  TgRecReg rr[FG_REG_GROUPS];
+#pragma unroll
+  for (int g = 0; g < FG_REG_GROUPS; g++) {
+    fg_load_recreg(rec, g < lg ? g : 0, rr[g]);
+    if (g >= lg) rr[g].s[0] = ~(FG_SIG_T)0;
+  }
+  const int rg = lg < FG_REG_GROUPS ? lg : FG_REG_GROUPS;
+  const long long tiles = (A.n + FQ_TILE - 1) / FQ_TILE;
+  unsigned long long unknown = 0;
+  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const long long tb = tile * FQ_TILE;
+    const long long left = A.n - tb;
+    const unsigned int lim = (unsigned int)(left < FQ_TILE ? left : FQ_TILE) - 1u;
+    bool sel[FQ_STRIPES];
+    TgKeyRow kr[FQ_STRIPES];
+    TgRow row[FQ_STRIPES];
+    {
+      TgFRow fr[FQ_STRIPES];
+#pragma unroll
+      for (int s = 0; s < FQ_STRIPES; s++) {   // phase A: loads only, unconditional (rows past the end re-read the tile's last row)
+        const unsigned int o = threadIdx.x + s * 256;
+        const unsigned int oc = o < lim ? o : lim;
+        fg_zero_key(kr[s]);
+        tg_load_frow(A, tb, oc, fr[s]);
+        fg_load_key_a(A, tb, oc, kr[s]);
+        tg_load_row(A, tb + oc, row[s]);
+      }
+#pragma unroll
+      for (int s = 0; s < FQ_STRIPES; s++) {
+        const unsigned int o = threadIdx.x + s * 256;
+        sel[s] = o <= lim && tg_filter_f(A, tb + o, fr[s]);
+        fg_key_lengths(kr[s]);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < FQ_STRIPES; s++) fg_load_key_b(A, kr[s], sel[s]);   // phase B: first varchar bytes
+#pragma unroll
+    for (int s = 0; s < FQ_STRIPES; s++) {
+      const unsigned int o = threadIdx.x + s * 256;
+      FG_SIG_T sig[FG_SIG_WORDS];
+      bool open;
+      fg_row_sig(kr[s], sig, open);
+      int result = -1;
+#pragma unroll
+      for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < FG_SIG_WORDS; j++) same = same && sig[j] == rr[g].s[j];
+        result = same ? g : result;
+      }
+      const bool redo = open && result >= 0;
+      result = (redo || !sel[s]) ? -1 : result;
+      if (sel[s] && result < 0) {   // not decided by the signatures: the byte-wise LDS records; a row no record matches is left to the host
+        for (int g = redo ? 0 : rg; g < lg; g++)
+          if (fg_eq_record(A, kr[s], rec, g) > 0) { result = g; break; }
+        unknown += result < 0 ? 1ULL : 0ULL;
+      }
+      if (sel[s] && result >= 0) tg_accumulate_row_lc(F, A, tb + o, row[s], result, lds);
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) unknown += __shfl_down(unknown, d, 64);
+  if ((threadIdx.x & 63) == 0 && unknown) atomicAdd(&Q.counters[0], unknown);
+  tg_lc_fold_to<true>(lds, F.plan, F.st, F.fold.pending + (size_t)blockIdx.x * F.fold.stride * 3);
+}
+)SRC";
+
 // host mirror of the generated FaArgs
 struct FaArgsHost {
     FpArgs fp;
@@ -2006,8 +2099,18 @@ struct FaArgsHost {
     struct {
         unsigned long long *partials;
         int32_t stride;
+        unsigned long long *pending;
     } fold;
     const unsigned long long *gate;
+};
+// host mirror of the generated FqArgs (fq_onepass)
+struct FqArgsHost {
+    FaArgsHost fa;
+    KeyCols store;
+    int32_t store_groups;
+    int32_t pad;
+    unsigned long long *counters;
+    const unsigned long long *prev;
 };
 
 }  // namespace
@@ -2665,6 +2768,7 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     const std::string tag = "@FA_STRIPES@";
     tail.replace(tail.find(tag), tag.size(), std::to_string(fa_stripes()));
     src << tail;
+    if (!key_inputs_.empty()) src << "#define FQ_LDS_BYTES " << std::max(2048, onepass_groups() * per_group_bytes_) << "\n" << kFqKernel;
     source_ = src.str();
 }
 
@@ -2788,6 +2892,63 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
         const int64_t blocks = std::min<int64_t>(ceil_div(l.n, 256), (int64_t)ctx->cu_count() * module->blocks_per_cu("fg_probe"));
         launch_args(module->fn("fg_probe"), (int)blocks, G, ctx->stream());
     }
+}
+
+// One pass per page (fq_onepass): see the kernel.  `blocks` is fixed per operator (one workgroup row of pending totals per workgroup).
+void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulators &accs, const KeyCols &store, int64_t groups, unsigned long long *counters,
+                          const unsigned long long *prev, int64_t blocks)
+{
+    TG_CHECK_STATE(supported_ && !key_inputs_.empty() && groups > 0 && groups <= max_groups_ && !accumulate_can_raise_, "one-pass aggregation not available for this configuration");
+    JitModule *module = module_for(in, false);
+    accs.reserve(max_groups_);
+    FqArgsHost Q{};
+    FaArgsHost &F = Q.fa;
+    fill_fp_cols(F.fp, in);
+    F.fp.error = counters + 7;
+    BufferPtr dummy;
+    for (int ch : key_inputs_)
+        if (input_types_[(size_t)ch] == TGPU_VARCHAR && F.fp.col_values[ch] == nullptr) {
+            if (!dummy) {
+                dummy = ctx->alloc(16);
+                HIP_CHECK(hipMemsetAsync(dummy->ptr(), 0, 16, ctx->stream()));
+            }
+            F.fp.col_values[ch] = dummy->ptr();
+        }
+    for (size_t k = 0; k < aggs_.size(); k++) {
+        GroupedAccumulators::DeviceState d = accs.device_state((int)k);
+        F.st[k].function = d.function;
+        F.st[k].counts = d.counts;
+        F.st[k].limbs = d.limbs;
+        F.st[k].special = d.special;
+        F.st[k].i128 = d.i128;
+        F.st[k].dsum = d.dsum;
+    }
+    F.plan.n_aggs = (int32_t)aggs_.size();
+    F.plan.n_wide = n_wide_;
+    F.plan.n_cnt = n_cnt_ + 1;
+    F.plan.rows_slot = rows_slot_;
+    for (size_t k = 0; k < aggs_.size(); k++) {
+        F.plan.wide_slot[k] = wide_slot_[k];
+        F.plan.cnt_slot[k] = cnt_slot_[k];
+        const int cs = cnt_slot_[k];
+        bool from_rows = !cnt_masked_[(size_t)cs];
+        for (int ch : cnt_inputs_[(size_t)cs]) from_rows = from_rows && ch >= 0 && in.cols[(size_t)ch].nulls == nullptr;
+        F.plan.count_from_rows[k] = from_rows ? 1 : 0;
+    }
+    F.plan.per_group_bytes = per_group_bytes_;
+    F.lowcard = 1;
+    F.plan.n_groups = (int32_t)groups;
+    F.tiles = ceil_div(in.n, 4 * 256);
+    const GroupedAccumulators::FoldScratch fs = accs.fold_scratch(blocks, max_groups_);
+    F.fold.partials = fs.partials;
+    F.fold.stride = fs.stride;
+    F.fold.pending = fs.pending;
+    Q.store = store;
+    Q.store_groups = (int32_t)groups;
+    Q.counters = counters;
+    Q.prev = prev;
+    ProfileScope ps(ctx, "fused_filter_group_accumulate_onepass");
+    launch_args(module->fn("fq_onepass"), (int)blocks, Q, ctx->stream());
 }
 
 // gids8 -> gids, for the (rare) page whose ids arrived compact but whose groups do not fit the lane-private LDS path

@@ -3,6 +3,8 @@
 // fused, row-selective kernel pair and cached on disk by source hash.
 #pragma once
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace tgpu {
@@ -201,6 +203,19 @@ public:
     // gate (optional): device counters of the group-by probe launch in front (GbhSpeculateFn): the kernels do nothing unless they are clean
     void accumulate(Context *ctx, const DevicePage &in, const int32_t *gids, const uint8_t *gids8, int64_t groups, GroupedAccumulators &accs,
                     const unsigned long long *gate = nullptr);
+    // ONE launch per page for the steady state of few groups (fq_onepass, jit.cpp): filter + lookup among the `groups` (<= 16) groups whose keys
+    // `store` holds + accumulate into lane-private LDS states; the page's totals stay pending (GroupedAccumulators::FoldScratch) until its
+    // counters say no row met an unknown group.  prev = the counters of the previous one-pass page of the operator (its pending totals are
+    // made final or dropped by this launch), or null.
+    void onepass(Context *ctx, const DevicePage &in, GroupedAccumulators &accs, const KeyCols &store, int64_t groups, unsigned long long *counters,
+                 const unsigned long long *prev, int64_t blocks);
+    // groups a one-pass launch has LDS for: its key records (16 groups x keys x 32 B) sit next to the lane-private states
+    int onepass_groups() const
+    {
+        const int room = 160 * 1024 - 64 - 16 * (int)key_inputs_.size() * 32;
+        return per_group_bytes_ > 0 ? std::min(16, room / per_group_bytes_) : 0;
+    }
+    bool can_onepass(int64_t groups) const { return can_speculate(groups) && !key_inputs_.empty() && groups <= onepass_groups(); }
     // the accumulate launch can be enqueued speculatively behind a probe launch (no error read-back of its own, lane-private LDS states)
     bool can_speculate(int64_t groups) const { return supported_ && !accumulate_can_raise_ && groups > 0 && groups <= max_groups_; }
 

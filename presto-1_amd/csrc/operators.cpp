@@ -1170,17 +1170,48 @@ public:
 
     void add_input(const tgpu_page *page) override
     {
+        confirm_pending(kOnepassDepth - 1);   // (errors and dirty pages of earlier one-pass launches surface here at the latest)
         begin_input();
         const bool fused_ok = gbh_ && uses_fused_kernels();
         // the fused kernels address VARCHAR bytes through the offsets alone: the byte ranges of borrowed device columns stay unread
         DevicePage in = ingest_page(ctx_, page, /*resolve_varchar=*/!fused_ok);
         if (in.n == 0) return;
         if (!fused_ok) {
+            drain_onepass();
             // unfused composition: FilterAndProject, then the aggregation
             DevicePage mid;
             if (processor_->process(ctx_, in, mid)) process_page(mid);
             return;
         }
+        if (onepass_ready(in)) {
+            launch_onepass(std::move(in));
+            return;
+        }
+        drain_onepass();
+        process_fused(in);
+    }
+
+    // a finishing / revoking / closing operator has no page in flight
+    void finish() override
+    {
+        drain_onepass();
+        HashAggregationOperator::finish();
+    }
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        if (finishing_) drain_onepass();   // (the driver asks after every addInput: a page in flight stays in flight)
+        return HashAggregationOperator::get_output();
+    }
+    void start_memory_revoke() override
+    {
+        drain_onepass();
+        HashAggregationOperator::start_memory_revoke();
+    }
+
+private:
+    // the two-launch path: group probe (insert protocol when a page brings new groups) + accumulate, one read-back per page
+    void process_fused(const DevicePage &in)
+    {
         // the filter is fused in front of the group-by table (rows it rejects get group id -1), the key code is generated
         // for the key schema, and the raw hash is computed in the kernel (a $hashvalue channel equals it by construction)
         std::vector<const DeviceColumn *> keys;
@@ -1198,9 +1229,82 @@ public:
         bool speculated = false;
         const bool compact = gbh_->get_group_ids(keys, nullptr, in.n, gids->as<int32_t>(), nullptr, /*inline_hash=*/true, &probe, gids8->as<uint8_t>(),
                                                  may_speculate ? &speculate : nullptr, &speculated);
+        clean_streak_ = speculated ? clean_streak_ + 1 : 0;   // a speculated page met no new group: the group set is settling
         if (speculated) return;
         fused_->accumulate(ctx_, in, compact ? nullptr : gids->as<int32_t>(), compact ? gids8->as<uint8_t>() : nullptr, gbh_->group_count(), *accs_);
     }
+
+    // ---- one launch per page, no read-back in front of the next one (FusedAggGpu::onepass) ------------------------------------------------
+    // Entered once the group set has settled (kOnepassAfter consecutive pages without a new group, at most 16 groups).  The host reads a
+    // page's counters one call LATER (while its successor runs): clean = nothing to do, the successor's launch made the page's totals
+    // final; dirty (a row met a group the launch did not know) = the totals were dropped on the device and the page is re-run here through
+    // the insert protocol -- possible because the page is still there: library-owned pages (another operator's output, an ingested host
+    // page) are kept by reference, borrowed device blocks only qualify under tgpu_context_set_device_input_stable.  Sums are exact
+    // (order-independent), so re-running a page after its successors does not change a bit; new groups still get their ids in page order
+    // because a successor that met one of them is dirty itself and is re-run after it.  An expression error of page i is raised by the call
+    // that confirms it (the next add_input, finish or get_output).
+    static constexpr int kOnepassDepth = 2, kOnepassAfter = 2;
+    struct PendingPage {
+        DevicePage page;
+        unsigned long long *counters;
+        Context::AsyncRead read;
+    };
+    bool retained(const DevicePage &in) const
+    {
+        if (ctx_->device_input_stable()) return true;
+        for (const DeviceColumn &c : in.cols) {
+            if (c.n > 0 && !c.values_buf) return false;
+            if (c.nulls && !c.nulls_buf) return false;
+            if (c.offsets && !c.offsets_buf) return false;
+        }
+        return true;
+    }
+    bool onepass_ready(const DevicePage &in) const
+    {
+        const bool disabled = getenv("TGPU_DISABLE_ONEPASS") != nullptr || getenv("TGPU_DISABLE_SPECULATION") != nullptr;
+        return !disabled && clean_streak_ >= kOnepassAfter && fused_->can_onepass(gbh_->group_count()) && !accs_->force_ordered() && !accs_->ordered() && retained(in);
+    }
+    void launch_onepass(DevicePage in)
+    {
+        PendingPage p;
+        p.counters = gbh_->counter_set();
+        const unsigned long long *prev = last_onepass_counters_;
+        onepass_blocks_ = ctx_->cu_count();   // one workgroup per CU (the lane-private states fill the LDS), one row of pending totals each
+        fused_->onepass(ctx_, in, *accs_, gbh_->key_store_view(), gbh_->group_count(), p.counters, prev, onepass_blocks_);
+        p.read = ctx_->begin_read(p.counters, 64);
+        p.page = std::move(in);
+        last_onepass_counters_ = p.counters;
+        pending_.push_back(std::move(p));
+        confirm_pending(kOnepassDepth);
+    }
+    // confirms launched pages, oldest first, until at most `keep` are in flight
+    void confirm_pending(size_t keep)
+    {
+        while (pending_.size() > keep) {
+            PendingPage p = std::move(pending_.front());
+            pending_.pop_front();
+            unsigned long long ctr[8];
+            ctx_->finish_read(p.read, ctr);
+            const bool last = pending_.empty();
+            const bool dirty = ctr[0] != 0 || ctr[2] != 0 || ctr[7] != ~0ull;
+            if (last) {
+                // nobody launched behind it: its pending totals are still on the device, and the host decides
+                accs_->resolve_pending(onepass_blocks_, !dirty);
+                last_onepass_counters_ = nullptr;
+            }
+            raise_expression_error(ctr[7]);
+            if (dirty) {
+                clean_streak_ = 0;
+                process_fused(p.page);   // (the pages launched behind it ran against the same group set: each is judged by its own counters)
+            }
+        }
+    }
+    void drain_onepass() { confirm_pending(0); }
+
+    std::deque<PendingPage> pending_;
+    const unsigned long long *last_onepass_counters_ = nullptr;
+    int64_t onepass_blocks_ = 0;
+    int clean_streak_ = 0;
 
 private:
     std::shared_ptr<PageProcessorGpu> processor_;

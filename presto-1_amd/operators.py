@@ -67,6 +67,10 @@ class Context:
         """SUM_ORDER_EXACT (default) or SUM_ORDER_JAVA for the aggregation operators created from now on (tgpu.h)"""
         _lib.check(_lib.lib().tgpu_context_set_double_sum_order(self.handle, order))
 
+    def set_device_input_stable(self, stable=True):
+        """the promise of tgpu_context_set_device_input_stable: borrowed device blocks stay valid and unchanged until the operator's next call returns"""
+        _lib.check(_lib.lib().tgpu_context_set_device_input_stable(self.handle, int(bool(stable))))
+
     def profile_enable(self, on=True):
         _lib.check(_lib.lib().tgpu_profile_enable(self.handle, int(on)))
 

@@ -961,6 +961,109 @@ def test_group_by_hash_optimistic_sub_batch_overflow_retry(pkg, oracle, monkeypa
     c.close()
 
 
+def _onepass_pages(pkg, rng, npages, rows, late_groups, error_page=None):
+    """pages of a Q1-like program: 2 varchar(1) keys (3 x 2 values), some pages add a new key value late in the stream"""
+    pages = []
+    for i in range(npages):
+        k1 = rng.integers(0, 3, rows)
+        k2 = rng.integers(0, 2, rows)
+        a = [("A", "N", "R")[x] for x in k1]
+        b = [("F", "O")[x] for x in k2]
+        if i in late_groups:               # a few rows of a group nobody has seen, in the middle of the page
+            for r in (rows // 2, rows // 2 + 7):
+                a[r] = late_groups[i]
+        qty = rng.integers(1, 51, rows).astype(np.float64)
+        price = qty * rng.integers(90000, 210000, rows) / 100.0
+        disc = rng.integers(0, 11, rows) / 100.0
+        ship = rng.integers(8036, 10562, rows).astype(np.int32)
+        div = np.ones(rows, dtype=np.int64)
+        if error_page == i:
+            div[rows // 3] = 0
+        pages.append(pkg.Page(pkg.Block(pkg.VARCHAR, a), pkg.Block(pkg.VARCHAR, b), pkg.Block(pkg.DOUBLE, qty), pkg.Block(pkg.DOUBLE, price),
+                              pkg.Block(pkg.DOUBLE, disc, (rng.random(rows) < 0.02).astype(np.uint8)), pkg.Block(pkg.DATE, ship), pkg.Block(pkg.BIGINT, div)))
+    return pages
+
+
+def _onepass_program(pkg, with_division=False):
+    f, c = pkg.field, pkg.constant
+    V, D, DT, B = pkg.VARCHAR, pkg.DOUBLE, pkg.DATE, pkg.BIGINT
+    T = [V, V, D, D, D, DT, B]
+    filt = f(5, DT) <= 10471
+    if with_division:                      # a filter that can raise: 10 / div > 0
+        filt = pkg.and_(filt, (c(10, B) / f(6, B)) > 0)
+    projs = [f(0, V), f(1, V), f(2, D), f(3, D), f(3, D) * (c(1.0, D) - f(4, D))]
+    aggs = [(pkg.SUM_DOUBLE, 2), (pkg.SUM_DOUBLE, 3), (pkg.SUM_DOUBLE, 4), (pkg.AVG_DOUBLE, 4), (pkg.COUNT_ALL, -1), (pkg.COUNT_COLUMN, 4)]
+    return T, filt, projs, aggs
+
+
+@pytest.mark.parametrize("late", [{}, {6: "X"}, {5: "X", 6: "Y", 9: "Z"}, {4: "X", 5: "X"}])
+def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, monkeypatch, late):
+    """once the group set has settled the fused aggregation runs ONE launch per page and reads a page's counters a call later
+    (FusedAggGpu::onepass): same rows, bit for bit, as the probe + accumulate path -- also when pages in the middle of the stream bring new
+    groups (their totals are dropped on the device, the pages re-run through the insert protocol, ids in first-seen order)"""
+    rng = np.random.default_rng(41)
+    pages = _onepass_pages(pkg, rng, 12, 9000, late)
+    T, filt, projs, aggs = _onepass_program(pkg)
+    results = {}
+    for mode in ("onepass", "two_launch"):
+        if mode == "two_launch":
+            monkeypatch.setenv("TGPU_DISABLE_ONEPASS", "1")
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.VARCHAR, pkg.VARCHAR], [0, 1], aggs)
+        out = pkg.to_pages(fac.createOperator(), pages)
+        results[mode] = [r for p in out for r in p.rows()]
+        prof = ctx.profile()
+        launches = prof.get("fused_filter_group_accumulate_onepass", {"count": 0})["count"]
+        if mode == "onepass":
+            assert launches >= 12 - 3 - 2 * len(late)      # host pages are library-owned copies: the one-pass path needs no promise for them
+        else:
+            assert launches == 0
+        ctx.close()
+    a, b = results["onepass"], results["two_launch"]
+    assert [r[:2] for r in a] == [r[:2] for r in b] and len(a) >= 6 + len(set(late.values()))
+    for ra, rb in zip(a, b):
+        assert ra[6] == rb[6] and ra[7] == rb[7]
+        assert ulp_diff([np.nan if x is None else x for x in ra[2:6]], [np.nan if x is None else x for x in rb[2:6]]).max() == 0
+
+
+def test_fused_aggregation_one_launch_per_page_raises_expression_errors_a_call_later(pkg):
+    """a filter that divides by zero on a page of the one-pass stream: the page's error word comes back with its counters, one call later"""
+    rng = np.random.default_rng(43)
+    pages = _onepass_pages(pkg, rng, 10, 5000, {}, error_page=7)
+    T, filt, projs, aggs = _onepass_program(pkg, with_division=True)
+    ctx = pkg.Context(0)
+    fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.VARCHAR, pkg.VARCHAR], [0, 1], aggs)
+    with pytest.raises(pkg.TgpuError) as e:
+        pkg.to_pages(fac.createOperator(), pages)
+    assert e.value.code == -7
+    ctx.close()
+
+
+def test_fused_aggregation_one_launch_per_page_needs_the_promise_for_borrowed_device_blocks(pkg):
+    """borrowed device blocks are only kept across calls under tgpu_context_set_device_input_stable; results are the same either way"""
+    rng = np.random.default_rng(47)
+    host = _onepass_pages(pkg, rng, 10, 6000, {7: "X"})
+    T, filt, projs, aggs = _onepass_program(pkg)
+    f = pkg.field
+    rows = {}
+    for promise in (False, True):
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        ctx.set_device_input_stable(promise)
+        # device-resident pages whose memory the test owns (the output pages of an identity operator, handed on as BORROWED device blocks)
+        ident = pkg.FilterAndProjectOperatorFactory(ctx, 9, T, None, [f(i, t) for i, t in enumerate(T)])
+        owners = [pkg.to_pages(ident.createOperator(), [p], to_host=False)[0] for p in host]
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.VARCHAR, pkg.VARCHAR], [0, 1], aggs)
+        out = pkg.to_pages(fac.createOperator(), [o.as_device_page() for o in owners])
+        rows[promise] = [r for p in out for r in p.rows()]
+        assert (ctx.profile().get("fused_filter_group_accumulate_onepass", {"count": 0})["count"] > 0) == promise
+        for o in owners:
+            o.release()
+        ctx.close()
+    assert rows[True] == rows[False]
+
+
 # (the exchange tests live in tests/test_gpu_exchange.py)
 
 

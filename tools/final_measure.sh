@@ -1,20 +1,18 @@
 #!/bin/bash
-# the round's final measurement set on the GPU box: default bench line, paged sub-lines, rocprofv3 kernel statistics and the two PMC
+# the round's final measurement set on the GPU box: default bench line (paged and PCIe-inclusive sub-lines included), rocprofv3 kernel statistics and the two PMC
 # passes (separate runs, kernel trace only) of the default command; tools/collect_profiles.py turns the output into profiles/
 set -o pipefail
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd $R
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
+timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err || exit 1
 echo bench done
-timeout -k 10 400 python bench.py --only q3,q1,paged --no-cpu-baseline > $O/bench_paged.json 2> $O/bench_paged.err || exit 1
-echo paged done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --only q3,q1,cfg2,sub > $O/stats.log 2>&1 || exit 1
 echo stats done
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --only q3,q1,cfg2,sub > $O/pmc_fetch.log 2>&1 || exit 1
 echo fetch done
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --only q3,q1,cfg2,sub > $O/pmc_write.log 2>&1 || exit 1
 echo write done
 ls $O
