@@ -430,6 +430,7 @@ class Bench:
         ojoin = oj.createOperator()
         st["orders_build_rows"] = 0
         for j in self.drive(ojoin, pages["orders"]):
+            self.captured("orders_join", j)
             st["orders_build_rows"] = j.position_count
             obuild.addInput(j.as_device_page())
             j.release()
@@ -447,6 +448,7 @@ class Bench:
             aop = agg.createOperator()
             st["lineitem_join_rows"] = 0
             for j in self.drive(ljoin, pages["lineitem"]):
+                self.captured("lineitem_join", j)
                 st["lineitem_join_rows"] = j.position_count
                 aop.addInput(j.as_device_page())
                 j.release()
@@ -536,9 +538,15 @@ class Bench:
         # orders: filter -> exchange(custkey) -> probe customers -> exchange(orderkey) -> build
         opage = repartition(filtered(f["ord_fp"], pages["orders"]), [1], [B, B, DT, I])
         st["orders_probe_rows"] = opage.position_count
-        oj = p.LookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, [B, B, DT, I], [1], probe_output_channels=[0, 2, 3])
+        # behind the exchange the filter has already run: the probe is still the FUSED operator (identity projections, no filter), i.e. the
+        # pipelined fj_probe_* / fj_emit_* kernels and the DIRECT table layout, not the three-pass LookupJoinOperator
+        fld = p.field
+        oj = p.FilterProjectLookupJoinOperatorFactory(ctx, 11, cb.lookup_source_factory, [B, B, DT, I], None, [fld(0, B), fld(1, B), fld(2, DT), fld(3, I)], [1],
+                                                      probe_output_channels=[0, 2, 3])
         ojoin = oj.createOperator()
         joined = self.drive(ojoin, opage) if opage.position_count else []
+        for j in joined:
+            self.captured("orders_join", j)
         opage.release()
         ob = p.HashBuilderOperatorFactory(ctx, 12, [B, DT, I], [1, 2], [0])
         obuild = ob.createOperator()
@@ -552,12 +560,13 @@ class Bench:
         # lineitem: filter/project -> exchange(orderkey) -> probe orders -> aggregate (groups are co-located: no second exchange)
         lpage = repartition(filtered(f["li_fp"], pages["lineitem"]), [0], [B, D])
         st["lineitem_probe_rows"] = lpage.position_count
-        lj = p.LookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, [B, D], [0], probe_output_channels=[0, 1])
+        lj = p.FilterProjectLookupJoinOperatorFactory(ctx, 13, ob.lookup_source_factory, [B, D], None, [fld(0, B), fld(1, D)], [0], probe_output_channels=[0, 1])
         agg = p.HashAggregationOperatorFactory(ctx, 14, [B, DT, I], [0, 2, 3], [(p.SUM_DOUBLE, 1)], expected_groups=1 << 20)
         ljoin = lj.createOperator()
         aop = agg.createOperator()
         st["lineitem_join_rows"] = 0
         for j in (self.drive(ljoin, lpage) if lpage.position_count else []):
+            self.captured("lineitem_join", j)
             st["lineitem_join_rows"] = j.position_count
             aop.addInput(j.as_device_page())
             j.release()
@@ -1270,7 +1279,8 @@ def main():
     if repartition:
         # behind the exchange the probe is the unfused kernel: key 8 B + one table slot 12 B + head/count out 8 B per probe row
         rows_avg = (st["orders_probe_rows"] + st["lineitem_probe_rows"]) / 2.0
-        roof = dominant(prof, args.steps, {"join_probe_count": 2.0 * rows_avg}, {"join_probe_count": 28.0})
+        # behind the exchange the probes are the fused kernels without a filter: key 8 B + bitmap word 8 B per probe row + 12 B per pair (DIRECT layout)
+        roof = dominant(prof, args.steps, {"fused_filter_probe": 2.0 * rows_avg, "join_probe_count": 2.0 * rows_avg}, {"fused_filter_probe": 16.0 + 12.0 * (st["orders_build_rows"] + st["lineitem_join_rows"]) / max(2.0 * rows_avg, 1.0), "join_probe_count": 28.0})
     else:
         roof = dominant(prof, args.steps, {"fused_filter_probe": 2.0 * rows_avg}, {"fused_filter_probe": alg / rows_avg})   # two launches per step (orders, lineitem)
         if roof and roof["kernel"] == "fused_filter_probe" and "fused_filter_probe" in prof:

@@ -50,6 +50,8 @@ public:
     void set_allow_ordered(bool on) { allow_ordered_ = on; }
     // TGPU_SUM_ORDER_JAVA: ORDERED whatever the number of groups (every group's rows are added in row order)
     void set_force_ordered(bool on) { force_ordered_ = on; }
+    // merge(): every spilled run carries row-order sums -> combine them like the reference (sequential double adds in run order)
+    void set_combine_ordered(bool on) { combine_ordered_ = on; }
     bool force_ordered() const { return force_ordered_ && allow_ordered_; }
     bool ordered() const { return mode_ == Mode::ORDERED; }
     DeviceState device_state(int k) const;
@@ -108,6 +110,7 @@ private:
     int32_t step_;
     BufferPtr error_;  // device uint32
     BufferPtr fold_partials_, fold_pending_;
+    bool combine_ordered_ = false;
     int64_t fold_rows_ = 0, fold_stride_ = 0;
     bool fold_dirty_ = false;
 };

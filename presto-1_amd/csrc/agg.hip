@@ -485,6 +485,7 @@ struct MergeArgs {
         const unsigned int *r_special;
         const unsigned long long *r_i128;
         const double *r_dsum;
+        double *dsum;   // ORDERED target: the run's sum joins it with ONE double add -- DoubleSumAggregation.combine, run after run
     } a[kMaxAggs];
 };
 
@@ -503,7 +504,8 @@ __global__ void __launch_bounds__(kBlock) agg_merge_states_kernel(MergeArgs args
             if (l != 0) continue;
             a.counts[g] += a.r_counts[i];
             if (a.r_special) a.special[g] |= a.r_special[i];
-            if (a.r_dsum && a.limbs) {
+            if (a.r_dsum && a.dsum) a.dsum[g] = a.dsum[g] + a.r_dsum[i];   // state.setDouble(state.getDouble() + otherState.getDouble()) (DoubleSumAggregation.java:48-52)
+            else if (a.r_dsum && a.limbs) {
                 const double v = a.r_dsum[i];
                 if (!(fabs(v) <= 1.7976931348623157e308)) tg_flag_special(&a.special[g], v);
                 else tg_kulisch_add(&a.limbs[g * kLimbs], &a.special[g], v);   // (atomic adds: lane l == 0 of this group races with the limb lanes above)
@@ -522,8 +524,14 @@ void GroupedAccumulators::merge(const int32_t *gids, const HostStates &run, int6
 {
     if (states_.empty() || run.groups <= 0) return;
     TG_CHECK_STATE(run.aggs.size() == states_.size(), "spilled run has a different number of aggregates");
-    TG_CHECK_STATE(mode_ != Mode::ORDERED, "runs are merged into exact accumulators");
-    mode_ = Mode::EXACT;
+    // Runs whose double sums are running (row-order) sums -- ORDERED runs -- are combined the reference's way when `combine_ordered` says
+    // every run is one: the target keeps plain doubles and each run's sum joins it with one double add, run after run in spill order
+    // (SpillableHashAggregationBuilder.mergeFromDisk :229-240 feeds the runs' intermediate states to addIntermediate = combine).  Else the
+    // target is EXACT: limbs add limb-wise (exact, bit-identical to the unspilled result), a stray ORDERED run's sum is one exact addend.
+    bool run_ordered = false;
+    for (size_t k = 0; k < states_.size(); k++) run_ordered = run_ordered || !run.aggs[k].dsum.empty();
+    if (mode_ == Mode::UNDECIDED) mode_ = (combine_ordered_ && run_ordered) ? Mode::ORDERED : Mode::EXACT;
+    TG_CHECK_STATE(mode_ == Mode::EXACT || run_ordered, "an exact run cannot join row-order sums");
     ensure(live_groups > 0 ? live_groups : 1);
     // an aggregate of a run carries either limbs (EXACT run) or running double sums (ORDERED run), never both: the plain limb adds and
     // the atomic adds of a double never meet on one group's limbs
@@ -546,6 +554,7 @@ void GroupedAccumulators::merge(const int32_t *gids, const HostStates &run, int6
         a.limbs = st.limbs ? st.limbs->as<long long>() : nullptr;
         a.special = st.special ? st.special->as<unsigned int>() : nullptr;
         a.i128 = st.i128 ? st.i128->as<unsigned long long>() : nullptr;
+        a.dsum = st.dsum ? st.dsum->as<double>() : nullptr;
         a.r_counts = (const long long *)up(r.counts.data(), r.counts.size() * 8);
         a.r_limbs = (const long long *)up(r.limbs.data(), r.limbs.size() * 8);
         a.r_special = (const unsigned int *)up(r.special.data(), r.special.size() * 4);

@@ -1988,13 +1988,31 @@ struct FqArgs {
   unsigned long long* counters;        // this page: [0] rows of unknown groups, [7] expression error word (~0 = none)
   const unsigned long long* prev;      // the previous one-pass page's counters (its totals are in fold.pending), or null
 };
-#define FQ_STRIPES 4
+#define FQ_STRIPES 8
 #define FQ_TILE (FQ_STRIPES * 256)
+// the raw loads of one row: filter inputs, key cells (phase A: null flags, fixed-width values, varchar offsets) and the aggregates' inputs
+struct TgQRow { TgFRow f; TgKeyRow k; TgRow r; };
+__device__ inline void fq_load_a(const FpArgs& A, long long row, TgQRow& R) {
+  // unconditional (a row past the end re-reads the page's last row): scalar tile base 0 + the row as the lane offset
+  fg_zero_key(R.k);
+  tg_load_frow(A, 0, (unsigned int)row, R.f);
+  fg_load_key_a(A, 0, (unsigned int)row, R.k);
+  tg_load_row(A, row, R.r);
+}
 extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
   const FaArgs& F = Q.fa;
   const FpArgs& A = F.fp;
   __shared__ __attribute__((aligned(16))) unsigned char lds[FQ_LDS_BYTES];   // the lane-private states of the groups a one-pass launch may meet
   __shared__ __attribute__((aligned(16))) unsigned char rec[FG_LDS_GROUPS * FG_NKEYS * 32];
+  const long long tiles = (A.n + FQ_TILE - 1) / FQ_TILE;
+  const long long last = A.n - 1;
+  // the first tile's loads go out before anything else: they land under the set-up below
+  TgQRow cur[FQ_STRIPES], nxt[FQ_STRIPES];
+#pragma unroll
+  for (int s = 0; s < FQ_STRIPES; s++) {
+    const long long row = (long long)blockIdx.x * FQ_TILE + threadIdx.x + s * 256;
+    fq_load_a(A, row < last ? row : last, cur[s]);
+  }
   // (1) the previous page's totals of this workgroup row: final if that page was clean, else dropped (overwritten below either way)
   if (Q.prev && (Q.prev[0] | Q.prev[2] | ~Q.prev[7]) == 0ULL) tg_commit_pending(F.fold, F.plan.n_aggs, F.st, false);
   tg_lc_zero(lds, F.plan);
@@ -2007,41 +2025,35 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
     if (g >= lg) rr[g].s[0] = ~(FG_SIG_T)0;
   }
   const int rg = lg < FG_REG_GROUPS ? lg : FG_REG_GROUPS;
-  const long long tiles = (A.n + FQ_TILE - 1) / FQ_TILE;
   unsigned long long unknown = 0;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prologue's loads do not flow into the loop header (see fa_accumulate_body)
   for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const long long tb = tile * FQ_TILE;
     const long long left = A.n - tb;
     const unsigned int lim = (unsigned int)(left < FQ_TILE ? left : FQ_TILE) - 1u;
     bool sel[FQ_STRIPES];
-    TgKeyRow kr[FQ_STRIPES];
-    TgRow row[FQ_STRIPES];
-    {
-      TgFRow fr[FQ_STRIPES];
+    // this tile's first varchar bytes (their offsets have landed), then the NEXT tile's row loads: both in flight under the accumulation
 #pragma unroll
-      for (int s = 0; s < FQ_STRIPES; s++) {   // phase A: loads only, unconditional (rows past the end re-read the tile's last row)
-        const unsigned int o = threadIdx.x + s * 256;
-        const unsigned int oc = o < lim ? o : lim;
-        fg_zero_key(kr[s]);
-        tg_load_frow(A, tb, oc, fr[s]);
-        fg_load_key_a(A, tb, oc, kr[s]);
-        tg_load_row(A, tb + oc, row[s]);
-      }
-#pragma unroll
-      for (int s = 0; s < FQ_STRIPES; s++) {
-        const unsigned int o = threadIdx.x + s * 256;
-        sel[s] = o <= lim && tg_filter_f(A, tb + o, fr[s]);
-        fg_key_lengths(kr[s]);
-      }
+    for (int s = 0; s < FQ_STRIPES; s++) {
+      const unsigned int o = threadIdx.x + s * 256;
+      sel[s] = o <= lim && tg_filter_f(A, tb + o, cur[s].f);
+      fg_key_lengths(cur[s].k);
     }
 #pragma unroll
-    for (int s = 0; s < FQ_STRIPES; s++) fg_load_key_b(A, kr[s], sel[s]);   // phase B: first varchar bytes
+    for (int s = 0; s < FQ_STRIPES; s++) fg_load_key_b(A, cur[s].k, sel[s]);
+    const long long ntile = tile + gridDim.x;
+#pragma unroll
+    for (int s = 0; s < FQ_STRIPES; s++) {
+      const long long row = ntile * FQ_TILE + threadIdx.x + s * 256;
+      fq_load_a(A, row < last ? row : last, nxt[s]);
+    }
+    asm volatile("" ::: "memory");
 #pragma unroll
     for (int s = 0; s < FQ_STRIPES; s++) {
       const unsigned int o = threadIdx.x + s * 256;
       FG_SIG_T sig[FG_SIG_WORDS];
       bool open;
-      fg_row_sig(kr[s], sig, open);
+      fg_row_sig(cur[s].k, sig, open);
       int result = -1;
 #pragma unroll
       for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {
@@ -2054,11 +2066,13 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
       result = (redo || !sel[s]) ? -1 : result;
       if (sel[s] && result < 0) {   // not decided by the signatures: the byte-wise LDS records; a row no record matches is left to the host
         for (int g = redo ? 0 : rg; g < lg; g++)
-          if (fg_eq_record(A, kr[s], rec, g) > 0) { result = g; break; }
+          if (fg_eq_record(A, cur[s].k, rec, g) > 0) { result = g; break; }
         unknown += result < 0 ? 1ULL : 0ULL;
       }
-      if (sel[s] && result >= 0) tg_accumulate_row_lc(F, A, tb + o, row[s], result, lds);
+      if (sel[s] && result >= 0) tg_accumulate_row_lc(F, A, tb + o, cur[s].r, result, lds);
     }
+#pragma unroll
+    for (int s = 0; s < FQ_STRIPES; s++) cur[s] = nxt[s];
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) unknown += __shfl_down(unknown, d, 64);
@@ -2938,7 +2952,7 @@ void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulator
     F.plan.per_group_bytes = per_group_bytes_;
     F.lowcard = 1;
     F.plan.n_groups = (int32_t)groups;
-    F.tiles = ceil_div(in.n, 4 * 256);
+    F.tiles = ceil_div(in.n, 8 * 256);
     const GroupedAccumulators::FoldScratch fs = accs.fold_scratch(blocks, max_groups_);
     F.fold.partials = fs.partials;
     F.fold.stride = fs.stride;

@@ -498,6 +498,17 @@ protected:
         if (builder_) spill_run();
         ensure_builder();
         accs_->set_allow_ordered(false);
+        // all runs in many-group (row-order) mode: combined like the reference, one double add per run in spill order; few-group runs keep
+        // their exact limb state and merge exactly (bit-identical with and without spills)
+        bool all_ordered = !runs_.empty();
+        for (const SpilledRun &run : runs_) {
+            bool ordered = false;
+            for (const auto &a : run.states.aggs) ordered = ordered || !a.dsum.empty();
+            bool has_double = false;
+            for (const auto &sp : cfg_.aggs) has_double = has_double || sp.function == TGPU_AGG_SUM_DOUBLE || sp.function == TGPU_AGG_AVG_DOUBLE || sp.function == TGPU_AGG_AVG_BIGINT;
+            all_ordered = all_ordered && (ordered || !has_double);
+        }
+        accs_->set_combine_ordered(all_ordered);
         for (const SpilledRun &run : runs_) {
             BufferPtr gid_buf;
             const int32_t *gids = nullptr;

@@ -2536,7 +2536,8 @@ def test_hash_aggregation_golden_with_spill(pkg, oracle, hash_enabled, spill_ena
 @pytest.mark.parametrize("groups", [5, 40_000])
 def test_hash_aggregation_spill_merges_exact_states(pkg, oracle, groups):
     """spilled runs carry the exact accumulator state: after any number of revokes double sums are still the correctly rounded exact sums
-    (few groups; many groups: each run's row-order sums, added exactly), bigint sums and counts exact, varchar + bigint keys with nulls"""
+    (few groups); many groups: each run holds row-order sums, combined sequentially in run order like the reference's merge; bigint sums and
+    counts exact, varchar + bigint keys with nulls"""
     rng = np.random.default_rng(101)
     n = 60_000
     pages, K1, K2, V, D = [], [], [], [], []
@@ -2568,8 +2569,9 @@ def test_hash_aggregation_spill_merges_exact_states(pkg, oracle, groups):
     if groups == 5:
         assert ulp_diff(sa[:, 0], sb[:, 0]).max() == 0 and ulp_diff(sa[:, 1], sb[:, 1]).max() == 0       # exact either way
     else:
-        # many groups: every run (= one page here) holds row-order (Java-order) sums; the merge adds the runs' sums exactly and rounds
-        # once.  Restated with the oracle: per-page Java-order sums per group, then the exact sum of those addends -- bit-identical.
+        # many groups: every run (= one page here) holds row-order (Java-order) sums, and the runs are merged the reference's way --
+        # SpillableHashAggregationBuilder.mergeFromDisk (:229-240) feeds their intermediate states to addIntermediate = combine
+        # (DoubleSumAggregation.java:48-52: state = state + other), run after run: total = ((run0 + run1) + run2) + run3 in doubles.
         og = oracle.MultiChannelGroupByHash([pkg.VARCHAR, pkg.BIGINT], 1000)
         per_page, key_of = [], {}
         for pg in pages:
@@ -2579,12 +2581,13 @@ def test_hash_aggregation_spill_merges_exact_states(pkg, oracle, groups):
             for g, row in zip(first[0].tolist(), first[1].tolist()):
                 key_of.setdefault(g, (pg.getBlock(0).get(row), pg.getBlock(1).get(row)))
         ng = og.group_count
-        addends, owners = [], []
+        want, seen = np.zeros(ng), np.zeros(ng, dtype=bool)
         for gids, blk in per_page:
-            cnt, js = oracle.agg_double_sum(gids, blk.values, ng, nulls=blk.nulls)
-            addends.append(np.where(cnt > 0, js, 0.0))
-            owners.append(np.arange(ng, dtype=np.int64))
-        _, want = oracle.agg_double_sum_exact(np.concatenate(owners), np.concatenate(addends), ng)
+            cnt, js = oracle.agg_double_sum(gids, blk.values, ng, nulls=blk.nulls)      # the run's Java-order sums
+            in_run = np.zeros(ng, dtype=bool)
+            in_run[np.unique(gids)] = True                                             # a group the run holds combines even with count 0 (sum 0.0)
+            want = np.where(in_run, want + np.where(cnt > 0, js, 0.0), want)
+            seen |= cnt > 0
         got = np.array([np.nan if b[key_of[i]][2] is None else b[key_of[i]][2] for i in range(ng)])
         has = ~np.isnan(got)
         assert has.sum() > 20_000 and ulp_diff(got[has], want[has]).max() == 0
