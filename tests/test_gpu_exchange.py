@@ -284,11 +284,11 @@ def _q3_worker(rank, world, port, sf, out_q):
             step()
             cap, b.capture = b.capture, None
             rows = [r for o in b.q3_result for r in o.to_host().rows()]
+            check = b.check_q3_dist() if plan == "co_partitioned" else b.check_q3_dist_repartition()
             for o in b.q3_result:
                 o.release()
             b.q3_result = None
             joins = {name: [r for pg in pages for r in pg.rows()] for name, pages in cap.items()}
-            check = b.check_q3_dist() if plan == "co_partitioned" else b.check_q3_dist_repartition()
             result[plan] = {"rows": rows, "joins": joins, "stats": dict(b.q3_stats), "check_ok": check["ok"]}
         out_q.put((rank, tables, result, None))
         b.exchange.close()
@@ -301,14 +301,14 @@ def _q3_worker(rank, world, port, sf, out_q):
 
 
 def test_q3_join_chain_on_two_ranks_equals_the_single_instance_oracle(pkg, oracle):
-    """bench.py's two distributed Q3 plans (what `bench.py --gpus N` times) on two processes over the callback transport, SF 0.05 per rank:
+    """bench.py's two distributed Q3 plans (what `bench.py --gpus N` times) on two processes over the callback transport, SF 0.2 per rank:
     the co-partitioned plan (replicated customer build via all-gather, fused probes, single-step aggregation per rank) and the repartition
     plan (every join input through tgpu_exchange_repartition, fused probes behind the exchange).  The union of the ranks' join outputs and of
     their final (orderkey, orderdate, shippriority) -> sum(revenue) rows equals the single-instance oracle over the union of the ranks'
     inputs: rows as multisets per join, groups as a map, sums bit for bit (a group's rows all sit on one rank, in their input order)."""
     import torch.multiprocessing as mp
     from gpu_common import ulp_diff
-    world, sf = 2, 0.05
+    world, sf = 2, 0.2
     port = _free_port()
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
@@ -348,7 +348,7 @@ def test_q3_join_chain_on_two_ranks_equals_the_single_instance_oracle(pkg, oracl
     first_rows, _ = gbh.group_rows()
     _, sums = oracle.agg_double_sum(gids, rev[lp], gbh.group_count)
     want_groups = {(int(h["l_orderkey"][lm][lp][fr]), int(odate[lb][fr]), int(oprio[lb][fr])): float(s) for fr, s in zip(first_rows, sums)}
-    assert len(want_groups) > 10_000
+    assert len(want_groups) > 3_000
     for plan in ("co_partitioned", "repartition"):
         per_rank = [results[r][2][plan] for r in range(world)]
         assert all(x["check_ok"] for x in per_rank), plan
