@@ -502,6 +502,26 @@ int32_t tgpu_serialize_page(tgpu_context *ctx, const tgpu_page *page, void *out,
  * inflated on the device first; ENCRYPTED: TGPU_ERR_NOT_SUPPORTED.  (tgpu_serialize_page always writes uncompressed pages, which every reader accepts.) */
 int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len, int32_t type_count, const int32_t *types, tgpu_output_page **out);
 
+/* ---- scan-side decode, first slice: ORC stripe streams -> device-resident blocks ---- */
+/* What an ORC page source does per column and stripe / row group (lib/trino-orc/src/main/java/io/trino/orc/reader/LongColumnReader.java:100-230,
+ * BooleanColumnReader.java, SliceDictionaryColumnReader.java:120-330 over stream/LongInputStreamV2.java:59-312, LongBitPacker.java:82-108,
+ * ByteInputStream.java:43-75, BooleanInputStream.java:36-58), on the device: the streams are handed over DECOMPRESSED in host memory (the
+ * chunk framing and its codecs stay with the file reader), `present` = the PRESENT stream or NULL (no nulls); *out = a one-channel page.
+ * `encoding` = the column's ColumnEncoding kind; RLEv1 encodings (DIRECT / DICTIONARY, files written before Hive 0.12): TGPU_ERR_NOT_SUPPORTED. */
+typedef enum tgpu_orc_encoding { TGPU_ORC_DIRECT = 0, TGPU_ORC_DICTIONARY = 1, TGPU_ORC_DIRECT_V2 = 2, TGPU_ORC_DICTIONARY_V2 = 3 } tgpu_orc_encoding;
+/* SHORT / INT / LONG / DATE columns: DATA = signed RLEv2; type = TGPU_BIGINT, TGPU_INTEGER or TGPU_DATE (32-bit types check the range like
+ * LongInputStreamV2.next(int[]) :356-364) */
+int32_t tgpu_orc_decode_long_column(tgpu_context *ctx, int32_t type, int32_t encoding, int32_t position_count, const void *present, int64_t present_len,
+                                    const void *data, int64_t data_len, tgpu_output_page **out);
+/* BOOLEAN columns: DATA = a boolean stream */
+int32_t tgpu_orc_decode_boolean_column(tgpu_context *ctx, int32_t position_count, const void *present, int64_t present_len, const void *data, int64_t data_len,
+                                       tgpu_output_page **out);
+/* STRING / VARCHAR / CHAR columns in DICTIONARY_V2 encoding: DATA = unsigned RLEv2 ids, LENGTH = unsigned RLEv2 lengths of the dictionary_size
+ * entries, DICTIONARY_DATA = their bytes; the result is a flat VARCHAR block */
+int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len,
+                                                 const void *data, int64_t data_len, int32_t dictionary_size, const void *length_stream, int64_t length_len,
+                                                 const void *dictionary_data, int64_t dictionary_data_len, tgpu_output_page **out);
+
 /* ---- exchange between the GPUs of one node ---- */
 /* What replaces PartitionedOutputOperator -> OutputBuffer -> HTTP -> ExchangeOperator (M/operator/PartitionedOutputOperator.java:406-476,
  * M/operator/ExchangeOperator.java) when the consumers of a FIXED_HASH_DISTRIBUTION / FIXED_BROADCAST_DISTRIBUTION stage

@@ -8,6 +8,7 @@
 #include "kernels.h"
 #include "operators.h"
 #include "serde.h"
+#include "orc.h"
 
 namespace tgpu {
 const std::string &last_error();
@@ -1227,6 +1228,44 @@ int32_t tgpu_exchange_all_gather(tgpu_exchange *ex, const tgpu_page *page, tgpu_
         TG_CHECK_ARG(ex && page && out, "null argument");
         DevicePage in = ingest_page(ex->ctx, page);
         *out = release_output(make_output(ex->ctx, ex->ex->all_gather(in)));
+    });
+}
+
+static tgpu_output_page *one_column_page(Context *c, DeviceColumn col)
+{
+    DevicePage p;
+    p.n = col.n;
+    p.cols.push_back(std::move(col));
+    return release_output(make_output(c, std::move(p)));
+}
+
+int32_t tgpu_orc_decode_long_column(tgpu_context *ctx, int32_t type, int32_t encoding, int32_t position_count, const void *present, int64_t present_len, const void *data,
+                                    int64_t data_len, tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && (data || data_len == 0) && present_len >= 0 && data_len >= 0, "bad argument");
+        *out = one_column_page(ctx->ctx.get(), orc::decode_long_column(ctx->ctx.get(), type, encoding, position_count, (const uint8_t *)present, present_len, (const uint8_t *)data, data_len));
+    });
+}
+
+int32_t tgpu_orc_decode_boolean_column(tgpu_context *ctx, int32_t position_count, const void *present, int64_t present_len, const void *data, int64_t data_len,
+                                       tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && (data || data_len == 0) && present_len >= 0 && data_len >= 0, "bad argument");
+        *out = one_column_page(ctx->ctx.get(), orc::decode_boolean_column(ctx->ctx.get(), position_count, (const uint8_t *)present, present_len, (const uint8_t *)data, data_len));
+    });
+}
+
+int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len, const void *data,
+                                                 int64_t data_len, int32_t dictionary_size, const void *length_stream, int64_t length_len, const void *dictionary_data,
+                                                 int64_t dictionary_data_len, tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && present_len >= 0 && data_len >= 0 && length_len >= 0 && dictionary_data_len >= 0, "bad argument");
+        *out = one_column_page(ctx->ctx.get(), orc::decode_dictionary_string_column(ctx->ctx.get(), encoding, position_count, (const uint8_t *)present, present_len,
+                                                                                  (const uint8_t *)data, data_len, dictionary_size, (const uint8_t *)length_stream, length_len,
+                                                                                  (const uint8_t *)dictionary_data, dictionary_data_len));
     });
 }
 

@@ -1,0 +1,141 @@
+"""ORC stream decode on the device (csrc/orc.hip behind tgpu_orc_decode_*) against the oracle (oracle/orc_oracle.c, pinned on the writer's
+statistics of the reference's ORC test resources in tests/test_orc_oracle_cpu.py): the streams of those files, every RLEv2 run kind at its edge
+sizes, PRESENT streams, 32-bit range errors, boolean and dictionary-string columns.  Bit-exact."""
+import base64
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def gorc():
+    return importlib.import_module("presto-1_amd.orc")
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc as m
+    return m
+
+
+def test_the_reference_files_streams_decode_like_the_oracle_and_the_writers_statistics(pkg, ctx, gorc, orc):
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "orc_streams.json")))
+    seen = 0
+    for f in fx["files"]:
+        for st in f["stripes"]:
+            for s in st["streams"]:
+                ctype = f["column_types"][s["column"]]
+                if s["kind"] != "DATA" or ctype not in ("INT", "LONG"):
+                    continue
+                data = base64.b64decode(s["bytes"])
+                want = orc.rle_v2(data, True)
+                t = pkg.INTEGER if ctype == "INT" else pkg.BIGINT
+                got = gorc.decode_long_column(ctx, t, st["rows"], data).to_host().getBlock(0)
+                assert got.nulls is None or not got.nulls.any()
+                assert np.array_equal(got.values.astype(np.int64), want[:st["rows"]])
+                stats = (st["statistics"] or [None] * 99)[s["column"]]
+                if stats and stats.get("int") and stats["number_of_values"]:
+                    assert int(got.values.min()) == stats["int"]["min"] and int(got.values.max()) == stats["int"]["max"]
+                    if stats["int"]["sum"] is not None:
+                        assert sum(int(v) for v in got.values) == stats["int"]["sum"]
+                seen += 1
+    assert seen >= 11
+
+
+def test_every_rle_v2_run_kind_and_width(pkg, ctx, gorc, orc):
+    rng = np.random.default_rng(7)
+    streams = []
+    for width in list(range(1, 25)) + [26, 28, 30, 32, 40, 48, 56, 64]:
+        for n in (1, 2, 63, 64, 65, 511, 512):
+            hi = (1 << (width - 1)) - 1 if width < 64 else (1 << 62)
+            vals = rng.integers(-hi - 1 if width > 1 else 0, hi + 1 if width > 1 else 1, n)
+            streams.append(orc.rle_v2_direct([orc.zigzag(int(v)) for v in vals], False, width=width))
+    streams += [orc.rle_v2_short_repeat(v, c, True) for v in (0, -1, 2**40, -2**62) for c in (3, 10)]
+    streams += [orc.rle_v2_delta(10, [0] * 5, True), orc.rle_v2_delta(-3, [2] * 511, True), orc.rle_v2_delta(2**40, [-7] * 300, True)]
+    for n in (2, 3, 64, 65, 500, 511):
+        inc = [int(rng.integers(0, 5))] + rng.integers(0, 2**20, n - 1).tolist()
+        streams.append(orc.rle_v2_delta(int(rng.integers(-1000, 1000)), inc, True))
+        dec = [-int(rng.integers(1, 5))] + rng.integers(0, 2**9, n - 1).tolist()
+        streams.append(orc.rle_v2_delta(2**50, dec, True))
+    for n, gaps in ((40, [3, 9]), (512, [255, 255, 1]), (300, [17, 200, 60]), (512, [0] + [16] * 30)):
+        base, fb, pw = int(rng.integers(-5000, 5000)), int(rng.choice([3, 8, 13])), int(rng.choice([4, 12, 24]))
+        patches = [(g, int(rng.integers(1, 1 << pw)) if not (g == 255 and i < len(gaps) - 1 and False) else 0) for i, g in enumerate(gaps)]
+        low = rng.integers(0, 1 << fb, n).astype(np.int64)
+        vals = base + low
+        at = 0
+        for g, p_ in patches:
+            at += g
+            if at < n:
+                vals[at] += p_ << fb
+        streams.append(orc.rle_v2_patched_base(vals, base, fb, pw, [(g, p_) for g, p_ in patches if sum(x for x, _ in patches[:patches.index((g, p_)) + 1]) < n] or patches[:1]))
+    # a patch list with a (255, 0) continuation entry: the gap to the next patch is 255 + 45
+    vals = 100 + rng.integers(0, 256, 512).astype(np.int64)
+    vals[300] += 0x7 << 8
+    streams.append(orc.rle_v2_patched_base(vals, 100, 8, 4, [(255, 0), (45, 7)]))
+    whole = b"".join(streams)
+    want = orc.rle_v2(whole, True)
+    got = gorc.decode_long_column(ctx, pkg.BIGINT, len(want), whole).to_host().getBlock(0).values
+    assert np.array_equal(got, want)
+    for s in streams[::7]:      # and stream by stream
+        w = orc.rle_v2(s, True)
+        assert np.array_equal(gorc.decode_long_column(ctx, pkg.BIGINT, len(w), s).to_host().getBlock(0).values, w)
+
+
+def test_present_stream_expands_values_to_their_rows(pkg, ctx, gorc, orc):
+    rng = np.random.default_rng(11)
+    for n, null_frac in ((1, 1.0), (9, 0.5), (10_000, 0.3), (70_001, 0.01), (513, 0.0)):
+        present = (rng.random(n) >= null_frac).astype(np.uint8)
+        vals = rng.integers(-2**31, 2**31 - 1, int(present.sum()))
+        data = b"".join(orc.rle_v2_direct(vals[i:i + 512], True) for i in range(0, len(vals), 512))
+        for t, dt in ((pkg.BIGINT, np.int64), (pkg.DATE, np.int32)):
+            blk = gorc.decode_long_column(ctx, t, n, data, present=orc.boolean_encode(present.tolist())).to_host().getBlock(0)
+            nulls = blk.nulls if blk.nulls is not None else np.zeros(n, dtype=np.uint8)
+            assert np.array_equal(nulls.astype(bool), present == 0)
+            assert np.array_equal(blk.values[present == 1], vals.astype(dt))
+    with pytest.raises(pkg.TgpuError) as e:        # LongInputStreamV2.next(int[]): "Decoded value out of range for a 32bit number"
+        gorc.decode_long_column(ctx, pkg.INTEGER, 3, orc.rle_v2_direct([1, 2**31, 3], True))
+    assert "32bit" in str(e.value)
+    with pytest.raises(pkg.TgpuError) as e:        # RLEv1 is not decoded
+        gorc.decode_long_column(ctx, pkg.BIGINT, 3, b"\x00\x01\x02", encoding=gorc.DIRECT)
+    assert e.value.code == -8
+    with pytest.raises(pkg.TgpuError):             # a truncated run
+        gorc.decode_long_column(ctx, pkg.BIGINT, 512, orc.rle_v2_direct(list(range(512)), True)[:-5])
+
+
+def test_boolean_and_dictionary_string_columns(pkg, ctx, gorc, orc):
+    rng = np.random.default_rng(13)
+    n = 30_000
+    bits = (rng.random(n) < 0.4).astype(np.uint8)
+    got = gorc.decode_boolean_column(ctx, n, orc.boolean_encode(bits.tolist())).to_host().getBlock(0)
+    assert np.array_equal(got.values, bits)
+    present = (rng.random(n) < 0.9).astype(np.uint8)
+    vb = (rng.random(int(present.sum())) < 0.5).astype(np.uint8)
+    got = gorc.decode_boolean_column(ctx, n, orc.boolean_encode(vb.tolist()), present=orc.boolean_encode(present.tolist())).to_host().getBlock(0)
+    assert np.array_equal(got.nulls.astype(bool), present == 0) and np.array_equal(got.values[present == 1], vb)
+    # SliceDictionaryColumnReader: ids (unsigned RLEv2) into a dictionary given as LENGTH stream + DICTIONARY_DATA
+    words = ["", "a", "BUILDING", "MACHINERY", "x" * 40, "AUTOMOBILE", "héllo"]
+    ids = rng.integers(0, len(words), int(present.sum()))
+    id_stream = b"".join(orc.rle_v2_direct(ids[i:i + 512], False) for i in range(0, len(ids), 512))
+    enc = [w.encode("utf-8") for w in words]
+    length_stream = orc.rle_v2_direct([len(b) for b in enc], False)
+    got = gorc.decode_dictionary_string_column(ctx, n, id_stream, len(words), length_stream, b"".join(enc), present=orc.boolean_encode(present.tolist())).to_host().getBlock(0)
+    want = []
+    it = iter(ids.tolist())
+    for p_ in present:
+        want.append(words[next(it)] if p_ else None)
+    assert got.to_list() == want
+    with pytest.raises(pkg.TgpuError):             # an id outside the dictionary
+        gorc.decode_dictionary_string_column(ctx, 3, orc.rle_v2_direct([0, 9, 1], False), 2, orc.rle_v2_direct([1, 1], False), b"ab")
