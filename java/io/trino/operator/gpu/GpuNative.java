@@ -126,6 +126,14 @@ public final class GpuNative
     public static native void scanNoMoreSplits(long operator);
     public static native void scanStats(long operator, long[] positionsLoadedSkipped);
 
+    // ---- scan-side decode (tgpu_orc_decode_*): the decompressed streams of one ORC column of one stripe / row group -> a device-resident page ----
+    /** LongColumnReader: PRESENT (or null) + DATA; type = GpuPages.T_BIGINT / T_INTEGER / T_DATE, encoding = the ColumnEncoding kind's ordinal */
+    public static native long orcDecodeLongColumn(long context, int type, int encoding, int positionCount, byte[] present, byte[] data);
+    public static native long orcDecodeBooleanColumn(long context, int positionCount, byte[] present, byte[] data);
+    /** SliceDictionaryColumnReader: DATA ids + the dictionary as LENGTH stream and DICTIONARY_DATA bytes */
+    public static native long orcDecodeDictionaryStringColumn(long context, int encoding, int positionCount, byte[] present, byte[] data, int dictionarySize, byte[] lengthStream,
+            byte[] dictionaryData);
+
     // ---- exchange between the GPUs of one node (tgpu_exchange_*); pages are output-page handles: they never leave HBM ----
     public static native byte[] exchangeUniqueId();
     public static native long createExchange(long context, byte[] uniqueId, int rank, int world);

@@ -864,6 +864,54 @@ JFN(jlong, serializePage)(JNIEnv *env, jclass c, jlong ctx, jlong page, jbyteArr
     return len;
 }
 
+/* ---- scan-side decode (tgpu_orc_decode_*): the decompressed streams of one ORC column of one stripe -> a device-resident page handle ---- */
+typedef struct {
+    jbyteArray array;
+    jbyte *p;
+    jsize n;
+} bytes_arg;
+static bytes_arg bytes_get(JNIEnv *env, jbyteArray a)
+{
+    bytes_arg x = {a, NULL, 0};
+    if (a) {
+        x.n = (*env)->GetArrayLength(env, a);
+        x.p = (*env)->GetByteArrayElements(env, a, NULL);
+    }
+    return x;
+}
+static void bytes_release(JNIEnv *env, bytes_arg *x)
+{
+    if (x->array && x->p) (*env)->ReleaseByteArrayElements(env, x->array, x->p, JNI_ABORT);
+}
+JFN(jlong, orcDecodeLongColumn)(JNIEnv *env, jclass c, jlong ctx, jint type, jint encoding, jint positionCount, jbyteArray present, jbyteArray data)
+{
+    UNUSED(c);
+    bytes_arg p = bytes_get(env, present), d = bytes_get(env, data);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_orc_decode_long_column(H(tgpu_context, ctx), type, encoding, positionCount, p.p, p.n, d.p, d.n, &out);
+    bytes_release(env, &d); bytes_release(env, &p);
+    return page_result(env, rc, out);
+}
+JFN(jlong, orcDecodeBooleanColumn)(JNIEnv *env, jclass c, jlong ctx, jint positionCount, jbyteArray present, jbyteArray data)
+{
+    UNUSED(c);
+    bytes_arg p = bytes_get(env, present), d = bytes_get(env, data);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_orc_decode_boolean_column(H(tgpu_context, ctx), positionCount, p.p, p.n, d.p, d.n, &out);
+    bytes_release(env, &d); bytes_release(env, &p);
+    return page_result(env, rc, out);
+}
+JFN(jlong, orcDecodeDictionaryStringColumn)(JNIEnv *env, jclass c, jlong ctx, jint encoding, jint positionCount, jbyteArray present, jbyteArray data, jint dictionarySize,
+                                            jbyteArray lengthStream, jbyteArray dictionaryData)
+{
+    UNUSED(c);
+    bytes_arg p = bytes_get(env, present), d = bytes_get(env, data), l = bytes_get(env, lengthStream), x = bytes_get(env, dictionaryData);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_orc_decode_dictionary_string_column(H(tgpu_context, ctx), encoding, positionCount, p.p, p.n, d.p, d.n, dictionarySize, l.p, l.n, x.p, x.n, &out);
+    bytes_release(env, &x); bytes_release(env, &l); bytes_release(env, &d); bytes_release(env, &p);
+    return page_result(env, rc, out);
+}
+
 /* ---- exchange between the GPUs of one node (tgpu_exchange_*): pages stay in HBM, so the page arguments are output-page handles ---- */
 JFN(jbyteArray, exchangeUniqueId)(JNIEnv *env, jclass c)
 {

@@ -291,3 +291,19 @@ def test_serialized_page_round_trip_through_the_shim(pkg, jvm, jctx, oracle):
     assert bytes(jvm.read(out, np.int8)[:written].tobytes()) == bytes(wire)
     jvm.call("releasePage", None, I64(page))
     clean(jvm)
+
+
+def test_orc_column_decode_through_the_shim(pkg, jvm, jctx):
+    """GpuNative.orcDecodeLongColumn: PRESENT + DATA streams of an ORC column (decompressed bytes) -> a device page, read back through copyBlocks"""
+    from oracle import orc
+    rng = np.random.default_rng(3)
+    n = 5000
+    present = (rng.random(n) < 0.8).astype(np.uint8)
+    vals = rng.integers(-10**9, 10**9, int(present.sum()))
+    data = b"".join(orc.rle_v2_direct(vals[i:i + 512], True) for i in range(0, len(vals), 512))
+    page = jvm.checked("orcDecodeLongColumn", I64, jctx, I32(pkg.BIGINT), I32(2), I32(n), jvm.array(np.frombuffer(orc.boolean_encode(present.tolist()), dtype=np.int8)),
+                       jvm.array(np.frombuffer(data, dtype=np.int8)))
+    got, nulls = heap_blocks(jvm, page)[0]
+    assert np.array_equal(nulls, present == 0) and np.array_equal(got[present == 1], vals)
+    jvm.call("releasePage", None, I64(page))
+    clean(jvm)
