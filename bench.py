@@ -739,6 +739,50 @@ class Bench:
         self.q1_result = [o.to_host().rows() for o in outs]
         aop.close()
 
+    def q1_double_sum_modes(self, steps, warmup, sf_java=1.0):
+        """What `north_star` asks of DOUBLE aggregates (<= 1 ULP against the Java operators) and what the timed mode delivers, measured:
+          * the line's Q1 number is timed in the EXACT order (correctly rounded exact sums: 0 ULP against the exact sum, and as far from the
+            Java left-to-right sum as that sum's own rounding error);
+          * TGPU_SUM_ORDER_JAVA adds every group's rows in row order -- bit-identical to DoubleSumAggregation.java:34-38 -- at the price of a
+            sequential chain per group: timed here on an SF`sf_java` shard (a size that finishes in seconds);
+          * the ULP distance between the two modes' sums (= EXACT vs the Java order) at page-sized inputs of 8 K and 64 K rows."""
+        p = self.pkg
+        keep = (getattr(self, "q1", None), getattr(self, "q1_page_", None), getattr(self, "q1_agg", None))
+        out = {"timed_mode": "EXACT (correctly rounded exact sums; order independent)", "strict_mode": "TGPU_SUM_ORDER_JAVA (row order, bit-identical to the Java operators)"}
+
+        def sums(order, n):
+            self.ctx.set_double_sum_order(order)
+            try:
+                self.setup_q1(n)
+                self.step_q1()
+            finally:
+                self.ctx.set_double_sum_order(p.SUM_ORDER_EXACT)
+            return {(r[0], r[1]): np.array(r[2:6], dtype=np.float64) for pg in self.q1_result for r in pg}
+
+        def ulps(a, b):
+            ia, ib = a.view(np.int64).copy(), b.view(np.int64).copy()
+            ia = np.where(ia < 0, np.int64(-2**63) - ia, ia)
+            ib = np.where(ib < 0, np.int64(-2**63) - ib, ib)
+            return int(np.abs(ia - ib).max())
+
+        dist = {}
+        for n in (8192, 65536):
+            ex, ja = sums(p.SUM_ORDER_EXACT, n), sums(p.SUM_ORDER_JAVA, n)
+            dist[str(n)] = max(ulps(ex[k], ja[k]) for k in ex)
+        out["ulp_distance_exact_vs_java_order"] = dist
+        n = int(6_000_379.02 * sf_java)
+        self.ctx.set_double_sum_order(p.SUM_ORDER_JAVA)
+        try:
+            self.setup_q1(n)
+            s, prof = self.timed(self.step_q1, max(2, steps // 4), 1)
+        finally:
+            self.ctx.set_double_sum_order(p.SUM_ORDER_EXACT)
+        out["java_order_timing"] = {"rows": n, "ms_per_step": s * 1e3, "rows_per_sec": n / s,
+                                    "kernels_ms_per_step": {k: v["total_ms"] / max(2, steps // 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:4]}}
+        self.q1, self.q1_page_, self.q1_agg = keep
+        self.q1_result = None
+        return out
+
     def setup_q1_dist(self):
         """Q1 on N ranks: every rank aggregates its own row-range shard with the fused PARTIAL operator, the 4-row
         partial pages are all-gathered in rank order (tgpu_exchange_all_gather) and a FINAL HashAggregationOperator combines them on every
@@ -1427,6 +1471,9 @@ def main():
                                          {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
         out["q1"]["step_stats"] = b.step_stats(b.step_q1, min(args.steps, 20))
+        out["q1"]["double_sum_order"] = "EXACT"
+        if b.world == 1:
+            out["q1"]["double_sum_modes"] = b.q1_double_sum_modes(args.steps, args.warmup)
         if b.world == 1 and "paged" in only:
             # the engine hands over pages, not tables: the same program fed as 2^20-row pages (573 of them at SF100) directly and through MergePages
             out["q1"]["paged"] = {"direct_2^20": b.q1_paged(args.steps, args.warmup, 1 << 20), "merged_2^20_1GB": b.q1_paged(args.steps, args.warmup, 1 << 20, merge_mb=1024),

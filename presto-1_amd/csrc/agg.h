@@ -54,6 +54,14 @@ public:
     void set_combine_ordered(bool on) { combine_ordered_ = on; }
     bool force_ordered() const { return force_ordered_ && allow_ordered_; }
     bool ordered() const { return mode_ == Mode::ORDERED; }
+    // The DOUBLE mode (EXACT limbs vs ORDERED row-order sums) is a function of the operator's ROW STREAM, not of how it is cut into pages: it
+    // is decided once, from the number of groups among the stream's first kModePrefixRows rows (the callers hold accumulation back until
+    // they have seen that many rows, HashAggregationOperator::process_page).  lowcard_max_groups <= 0: the AOT kernels' own capacity.
+    static constexpr int64_t kModePrefixRows = 65536;
+    bool decided() const { return mode_ != Mode::UNDECIDED; }
+    void decide(int64_t groups_in_prefix, int64_t lowcard_max_groups = 0);
+    // number of groups among the first m rows of a page whose ids are first-seen ranks: max id + 1 (compact ids: byte = id + 1)
+    static int64_t groups_among(Context *ctx, const int32_t *gids, const uint8_t *gids8, int64_t m);
     DeviceState device_state(int k) const;
     // folded partials of the low-cardinality launches (device_agg.h TgFoldScratch): one row per workgroup, `group_capacity` x
     // aggregates items per row; the launches add to them, flush_fold() adds them exactly into the states (evaluate does it)

@@ -661,6 +661,37 @@ void GroupedAccumulators::decide_mode(int64_t groups, int64_t lowcard_max_groups
     mode_ = (allow_ordered_ && many && getenv("TGPU_DISABLE_ORDERED") == nullptr) ? Mode::ORDERED : Mode::EXACT;
 }
 
+void GroupedAccumulators::decide(int64_t groups_in_prefix, int64_t lowcard_max_groups)
+{
+    if (lowcard_max_groups <= 0) lowcard_max_groups = (160 * 1024) / std::max<int64_t>(lowcard_bytes_per_group(specs()), 1);
+    decide_mode(groups_in_prefix > 0 ? groups_in_prefix : 1, lowcard_max_groups);
+}
+
+static __global__ void __launch_bounds__(kBlock) max_gid_kernel(const int32_t *__restrict__ gids, const uint8_t *__restrict__ gids8, int64_t m, int *out)
+{
+    int best = -1;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+        const int g = gids8 ? (int)gids8[i] - 1 : gids[i];
+        best = g > best ? g : best;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_down(best, d, 64);
+        best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0 && best >= 0) atomicMax(out, best);
+}
+
+int64_t GroupedAccumulators::groups_among(Context *ctx, const int32_t *gids, const uint8_t *gids8, int64_t m)
+{
+    if (m <= 0 || (!gids && !gids8)) return 0;
+    BufferPtr out = ctx->alloc(4);
+    HIP_CHECK(hipMemsetAsync(out->ptr(), 0xff, 4, ctx->stream()));   // -1
+    max_gid_kernel<<<(int)std::min<int64_t>(ceil_div(m, kBlock), 64), kBlock, 0, ctx->stream()>>>(gids, gids8, m, out->as<int>());
+    check_launch("max_gid");
+    return (int64_t)ctx->read_scalar(out->as<int>()) + 1;
+}
+
 bool GroupedAccumulators::begin_ordered(const int32_t *gids, int64_t n, int64_t groups, int64_t lowcard_max_groups, BufferPtr &keys, BufferPtr &rows)
 {
     if (n <= 0) return false;

@@ -215,6 +215,7 @@ public:
         const int room = 160 * 1024 - 64 - 16 * (int)key_inputs_.size() * 32;
         return per_group_bytes_ > 0 ? std::min(16, room / per_group_bytes_) : 0;
     }
+    int lowcard_groups() const { return max_groups_; }   // groups whose lane-private states fit the LDS: the EXACT / ORDERED threshold of this operator
     bool can_onepass(int64_t groups) const { return can_speculate(groups) && !key_inputs_.empty() && groups <= onepass_groups(); }
     // the accumulate launch can be enqueued speculatively behind a probe launch (no error read-back of its own, lane-private LDS states)
     bool can_speculate(int64_t groups) const { return supported_ && !accumulate_can_raise_ && groups > 0 && groups <= max_groups_; }

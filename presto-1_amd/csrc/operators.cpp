@@ -412,10 +412,61 @@ protected:
             gid_buf = ctx_->alloc((size_t)in.n * 4);
             gbh_->get_group_ids(keys, hashes, in.n, gid_buf->as<int32_t>());
             gids = gid_buf->as<int32_t>();
+            if (hold_back(in, gid_buf, nullptr, /*lowcard_max_groups=*/0)) return;
         }
+        accumulate_page(gids, in);
+    }
+
+    void accumulate_page(const int32_t *gids, const DevicePage &in)
+    {
         const int64_t groups = gbh_ ? gbh_->group_count() : 1;
         if (cfg_.step == TGPU_STEP_FINAL) accs_->add_intermediate(gids, in.n, in, groups);
         else accs_->add_input(gids, in.n, in, groups);
+    }
+
+    // ---- the DOUBLE mode is decided from the first kModePrefixRows rows of the stream, however they are cut into pages (agg.h) ----------------
+    // Pages that arrive before that many rows have been seen are kept (an owned copy + their group ids: they are small) and accumulated, in
+    // order, once the mode is known; the page that crosses the mark tells how many groups its first rows hold.  Returns true when the page
+    // has been kept back.  The group-by table itself always runs at once: group ids do not depend on the mode.
+    struct HeldPage {
+        DevicePage page;
+        BufferPtr gids, gids8;
+    };
+    bool hold_back(const DevicePage &in, const BufferPtr &gids, const BufferPtr &gids8, int64_t lowcard_max_groups)
+    {
+        if (accs_->decided()) return false;
+        const int64_t prefix = getenv("TGPU_MODE_PREFIX_ROWS") ? atoll(getenv("TGPU_MODE_PREFIX_ROWS")) : GroupedAccumulators::kModePrefixRows;   // (tests shorten it)
+        if (rows_seen_ + in.n < prefix) {
+            HeldPage h;
+            h.page = in;
+            resolve_varchar_ends(ctx_, h.page);   // (the fused path leaves the byte ranges of borrowed VARCHAR blocks unread)
+            own_borrowed_columns(ctx_, h.page);
+            h.gids = gids;
+            h.gids8 = gids8;
+            held_.push_back(std::move(h));
+            rows_seen_ += in.n;
+            groups_in_prefix_ = gbh_->group_count();
+            return true;
+        }
+        const int64_t m = prefix - rows_seen_;
+        const int64_t here = GroupedAccumulators::groups_among(ctx_, gids8 ? nullptr : gids->as<int32_t>(), gids8 ? gids8->as<uint8_t>() : nullptr, std::max<int64_t>(m, 1));
+        accs_->decide(std::max(groups_in_prefix_, here), lowcard_max_groups);
+        rows_seen_ += in.n;
+        release_held();
+        return false;
+    }
+    // the stream ended (or its state is needed) before the prefix was full: every row seen so far is the prefix
+    void decide_now(int64_t lowcard_max_groups = 0)
+    {
+        if (!accs_ || accs_->decided() || held_.empty()) return;
+        accs_->decide(gbh_ ? gbh_->group_count() : 1, lowcard_max_groups);
+        release_held();
+    }
+    virtual void release_held()
+    {
+        std::vector<HeldPage> held = std::move(held_);
+        held_.clear();
+        for (HeldPage &h : held) accumulate_page(h.gids ? h.gids->as<int32_t>() : nullptr, h.page);
     }
 
 public:
@@ -423,6 +474,7 @@ public:
     std::unique_ptr<OutputPage> get_output() override
     {
         if (finished_) return nullptr;
+        if (finishing_ || builder_full()) decide_now(held_lowcard_max_groups());
         if (finishing_) {
             if (!input_processed_ && cfg_.produce_default_output && cfg_.group_by_types.empty()) {
                 // global aggregation without input: one row of default values (count 0, sum NULL) :481-485
@@ -475,6 +527,7 @@ protected:
     };
     void spill_run()
     {
+        decide_now(held_lowcard_max_groups());
         const int64_t groups = gbh_ ? gbh_->group_count() : (input_processed_ ? 1 : 0);
         if (groups > 0) {
             SpilledRun run;
@@ -547,7 +600,11 @@ protected:
         gbh_.reset();
         accs_.reset();
         builder_ = false;
+        held_.clear();
+        rows_seen_ = 0;
+        groups_in_prefix_ = 0;
     }
+    virtual int64_t held_lowcard_max_groups() const { return 0; }
     // InMemoryHashAggregationBuilder.isFull :208-215: only partial aggregations have a memory limit
     bool builder_full()
     {
@@ -586,6 +643,8 @@ protected:
     HashAggregationConfig cfg_;
     std::unique_ptr<GroupByHashGpu> gbh_;
     std::unique_ptr<GroupedAccumulators> accs_;
+    std::vector<HeldPage> held_;
+    int64_t rows_seen_ = 0, groups_in_prefix_ = 0;
     bool builder_ = false, finishing_ = false, finished_ = false, input_processed_ = false;
     std::vector<SpilledRun> runs_;
     bool producing_output_ = false, hash_sorted_output_ = false;
@@ -1233,7 +1292,8 @@ private:
         // steady state (every group of the page exists already, few groups): the accumulate launch goes out behind the probe launch,
         // gated on the probe's counters, and runs while the host waits for them (groupby.h GbhSpeculateFn)
         const int64_t groups_before = gbh_->group_count();
-        const bool may_speculate = fused_->can_speculate(groups_before) && !accs_->force_ordered() && getenv("TGPU_DISABLE_SPECULATION") == nullptr;
+        // (while the DOUBLE mode is still open -- the stream's first rows, agg.h kModePrefixRows -- nothing is accumulated behind the probe)
+        const bool may_speculate = fused_->can_speculate(groups_before) && !accs_->force_ordered() && accs_->decided() && getenv("TGPU_DISABLE_SPECULATION") == nullptr;
         GbhSpeculateFn speculate = [&](const unsigned long long *counters) {
             fused_->accumulate(ctx_, in, nullptr, gids8->as<uint8_t>(), groups_before, *accs_, counters);
         };
@@ -1242,7 +1302,20 @@ private:
                                                  may_speculate ? &speculate : nullptr, &speculated);
         clean_streak_ = speculated ? clean_streak_ + 1 : 0;   // a speculated page met no new group: the group set is settling
         if (speculated) return;
+        if (hold_back(in, compact ? BufferPtr() : gids, compact ? gids8 : BufferPtr(), fused_->lowcard_groups())) return;
         fused_->accumulate(ctx_, in, compact ? nullptr : gids->as<int32_t>(), compact ? gids8->as<uint8_t>() : nullptr, gbh_->group_count(), *accs_);
+    }
+    int64_t held_lowcard_max_groups() const override { return uses_fused_kernels() ? fused_->lowcard_groups() : 0; }
+    void release_held() override
+    {
+        if (!uses_fused_kernels()) {
+            HashAggregationOperator::release_held();
+            return;
+        }
+        std::vector<HeldPage> held = std::move(held_);
+        held_.clear();
+        for (HeldPage &h : held)
+            fused_->accumulate(ctx_, h.page, h.gids ? h.gids->as<int32_t>() : nullptr, h.gids8 ? h.gids8->as<uint8_t>() : nullptr, gbh_->group_count(), *accs_);
     }
 
     // ---- one launch per page, no read-back in front of the next one (FusedAggGpu::onepass) ------------------------------------------------
@@ -1273,7 +1346,8 @@ private:
     bool onepass_ready(const DevicePage &in) const
     {
         const bool disabled = getenv("TGPU_DISABLE_ONEPASS") != nullptr || getenv("TGPU_DISABLE_SPECULATION") != nullptr;
-        return !disabled && clean_streak_ >= kOnepassAfter && fused_->can_onepass(gbh_->group_count()) && !accs_->force_ordered() && !accs_->ordered() && retained(in);
+        return !disabled && clean_streak_ >= kOnepassAfter && fused_->can_onepass(gbh_->group_count()) && !accs_->force_ordered() && accs_->decided() && !accs_->ordered() &&
+               retained(in);
     }
     void launch_onepass(DevicePage in)
     {

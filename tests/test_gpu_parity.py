@@ -961,6 +961,51 @@ def test_group_by_hash_optimistic_sub_batch_overflow_retry(pkg, oracle, monkeypa
     c.close()
 
 
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("shape", ["few_then_many", "many_from_the_start", "few"])
+def test_double_sums_do_not_depend_on_how_the_rows_are_cut_into_pages(pkg, shape, fused):
+    """the accumulators' DOUBLE mode (exact limbs vs row-order sums) is decided from the stream's first 65 536 rows, not from its first page:
+    one input cut into pages three different ways gives the same bits -- a stream that starts with a handful of groups and
+    grows to thousands, one with thousands from the start, one that stays small; fused and unfused operators"""
+    rng = np.random.default_rng({"few_then_many": 3, "many_from_the_start": 5, "few": 7}[shape])
+    n = 200_000
+    if shape == "few_then_many":
+        keys = np.concatenate([rng.integers(0, 3, 70_000), rng.integers(0, 5000, n - 70_000)])
+    elif shape == "many_from_the_start":
+        keys = rng.integers(0, 5000, n)
+    else:
+        keys = rng.integers(0, 4, n)
+    keys = keys.astype(np.int64)
+    vals = rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, n)
+    nulls = (rng.random(n) < 0.02).astype(np.uint8)
+    B, D = pkg.BIGINT, pkg.DOUBLE
+    f = pkg.field
+    cuts = {"one_page": [n], "small_first_page": [10, 1000, 50_000, 64_000, n], "ragged": [7_777, 65_536, 65_537, 131_072, n], "tiny_pages": list(range(4_000, n, 4_000)) + [n]}
+    results = {}
+    for name, ends in cuts.items():
+        ctx = pkg.Context(0)
+        pages, a = [], 0
+        for z in ends:
+            pages.append(pkg.Page(pkg.Block(B, keys[a:z]), pkg.Block(D, vals[a:z], nulls[a:z])))
+            a = z
+        aggs = [(pkg.SUM_DOUBLE, 1), (pkg.AVG_DOUBLE, 1), (pkg.COUNT_COLUMN, 1)]
+        if fused:
+            fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, [B, D], None, [f(0, B), f(1, D)], [B], [0], aggs)
+        else:
+            fac = pkg.HashAggregationOperatorFactory(ctx, 0, [B], [0], aggs, expected_groups=100)
+        out = pkg.to_pages(fac.createOperator(), pages)
+        results[name] = [r for p in out for r in p.rows()]
+        ctx.close()
+    base = results["one_page"]
+    assert len(base) == len(np.unique(keys))
+    for name, rows in results.items():
+        assert [r[0] for r in rows] == [r[0] for r in base], name
+        a_ = np.array([[np.nan if x is None else x for x in r[1:3]] for r in rows])
+        b_ = np.array([[np.nan if x is None else x for x in r[1:3]] for r in base])
+        assert ulp_diff(a_.ravel(), b_.ravel()).max() == 0, name
+        assert [r[3] for r in rows] == [r[3] for r in base], name
+
+
 def _onepass_pages(pkg, rng, npages, rows, late_groups, error_page=None):
     """pages of a Q1-like program: 2 varchar(1) keys (3 x 2 values), some pages add a new key value late in the stream"""
     pages = []
@@ -1001,6 +1046,7 @@ def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, m
     """once the group set has settled the fused aggregation runs ONE launch per page and reads a page's counters a call later
     (FusedAggGpu::onepass): same rows, bit for bit, as the probe + accumulate path -- also when pages in the middle of the stream bring new
     groups (their totals are dropped on the device, the pages re-run through the insert protocol, ids in first-seen order)"""
+    monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "5000")   # (the DOUBLE mode is decided within the first page: the stream settles early)
     rng = np.random.default_rng(41)
     pages = _onepass_pages(pkg, rng, 12, 9000, late)
     T, filt, projs, aggs = _onepass_program(pkg)
@@ -1040,8 +1086,9 @@ def test_fused_aggregation_one_launch_per_page_raises_expression_errors_a_call_l
     ctx.close()
 
 
-def test_fused_aggregation_one_launch_per_page_needs_the_promise_for_borrowed_device_blocks(pkg):
+def test_fused_aggregation_one_launch_per_page_needs_the_promise_for_borrowed_device_blocks(pkg, monkeypatch):
     """borrowed device blocks are only kept across calls under tgpu_context_set_device_input_stable; results are the same either way"""
+    monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "5000")
     rng = np.random.default_rng(47)
     host = _onepass_pages(pkg, rng, 10, 6000, {7: "X"})
     T, filt, projs, aggs = _onepass_program(pkg)
