@@ -393,9 +393,57 @@ protected:
         ensure_builder();
     }
 
+    // ---- small input pages are coalesced in HBM before they meet the group-by table ----------------------------------------------------------
+    // A join's output pages are a fraction of its probe pages (TPCH Q3: 5 K rows out of a 2^20-row probe page), and every page costs the
+    // group-by its insert / rank / publish protocol: launches and a read-back, whatever its size.  What the reference solves with MergePages
+    // in front of its operators (M/operator/project/MergePages.java) happens inside the operator here: pages below kCoalesceBelowRows rows
+    // are appended to a device column store (ONE launch per page, no read-back: fixed-width channels only) and processed as one page once
+    // kCoalesceFlushRows rows are there -- or when the operator's state is needed (finish, output, revoke).  Rows keep their order, so
+    // group ids and row-order sums are those of the unmerged stream.  Not for PARTIAL steps (their memory limit is checked per page).
+    static constexpr int64_t kCoalesceBelowRows = 1 << 16, kCoalesceFlushRows = 1 << 20;
+    bool coalesce(const DevicePage &in)
+    {
+        if (!gbh_ || cfg_.step == TGPU_STEP_PARTIAL || getenv("TGPU_DISABLE_COALESCE")) return false;
+        const bool small = in.n < kCoalesceBelowRows;
+        if (!small) {
+            flush_coalesced();   // (order: what was buffered came first)
+            return false;
+        }
+        for (const DeviceColumn &c : in.cols)
+            if (c.type == TGPU_VARCHAR) {
+                flush_coalesced();
+                return false;
+            }
+        if (!pending_pages_) {
+            std::vector<int32_t> types;
+            for (const DeviceColumn &c : in.cols) types.push_back(c.type);
+            pending_pages_ = std::make_unique<PagesIndexGpu>(ctx_, types);
+        }
+        TG_CHECK_ARG(pending_pages_->types().size() == in.cols.size(), "page channel count changed between pages");
+        static const std::vector<std::array<int32_t, 2>> no_ends(64, {0, 0});
+        pending_pages_->add_page(in, &no_ends);
+        if (pending_pages_->position_count() >= kCoalesceFlushRows) flush_coalesced();
+        return true;
+    }
+    void flush_coalesced()
+    {
+        if (!pending_pages_ || pending_pages_->position_count() == 0) return;
+        std::unique_ptr<PagesIndexGpu> store = std::move(pending_pages_);
+        DevicePage merged;
+        merged.n = store->position_count();
+        for (int ch = 0; ch < (int)store->types().size(); ch++) merged.cols.push_back(store->column(ch));
+        process_page_now(merged);
+    }
+
     void process_page(const DevicePage &in)
     {
         if (in.n == 0) return;
+        if (coalesce(in)) return;
+        process_page_now(in);
+    }
+
+    void process_page_now(const DevicePage &in)
+    {
         const int32_t *gids = nullptr;
         BufferPtr gid_buf;
         if (gbh_) {
@@ -474,6 +522,7 @@ public:
     std::unique_ptr<OutputPage> get_output() override
     {
         if (finished_) return nullptr;
+        if (finishing_) flush_coalesced();
         if (finishing_ || builder_full()) decide_now(held_lowcard_max_groups());
         if (finishing_) {
             if (!input_processed_ && cfg_.produce_default_output && cfg_.group_by_types.empty()) {
@@ -517,7 +566,10 @@ public:
     }
 
 protected:
-    int64_t builder_bytes() const { return (gbh_ ? gbh_->estimated_size() : 0) + (accs_ ? accs_->estimated_size() : 0); }
+    int64_t builder_bytes() const
+    {
+        return (gbh_ ? gbh_->estimated_size() : 0) + (accs_ ? accs_->estimated_size() : 0) + (pending_pages_ ? pending_pages_->estimated_size() : 0);
+    }
     bool spillable() const { return cfg_.spill_enabled && (cfg_.step == TGPU_STEP_SINGLE || cfg_.step == TGPU_STEP_FINAL); }   // HashAggregationOperator.java:390
     bool revocable() const { return spillable() && !producing_output_; }
     struct SpilledRun {
@@ -527,6 +579,7 @@ protected:
     };
     void spill_run()
     {
+        flush_coalesced();
         decide_now(held_lowcard_max_groups());
         const int64_t groups = gbh_ ? gbh_->group_count() : (input_processed_ ? 1 : 0);
         if (groups > 0) {
@@ -644,6 +697,7 @@ protected:
     std::unique_ptr<GroupByHashGpu> gbh_;
     std::unique_ptr<GroupedAccumulators> accs_;
     std::vector<HeldPage> held_;
+    std::unique_ptr<PagesIndexGpu> pending_pages_;
     int64_t rows_seen_ = 0, groups_in_prefix_ = 0;
     bool builder_ = false, finishing_ = false, finished_ = false, input_processed_ = false;
     std::vector<SpilledRun> runs_;
