@@ -155,11 +155,31 @@ class Bench:
             self.dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(self, fn, steps, warmup):
+    def timed(self, fn, steps, warmup, profile_apart=False):
         """(seconds per step, per-kernel profile); the profile's pseudo entry "__readbacks" (host <- device round trips of the timed
-        region) is moved to self.last_readbacks_per_step"""
+        region) is moved to self.last_readbacks_per_step.  profile_apart (page-at-a-time runs: thousands of launches per step, and the
+        library's per-kernel profile costs two event records per launch): the K steps are timed with the profile switched off, the
+        per-kernel breakdown comes from one more, untimed, step"""
         for _ in range(warmup):
             fn()
+        if profile_apart:
+            self.ctx.profile_enable(False)
+            self.barrier_sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            self.barrier_sync()
+            dt = time.perf_counter() - t0
+            self.ctx.profile_enable(True)
+            self.ctx.profile_reset()
+            fn()
+            self.barrier_sync()
+            prof = self.ctx.profile()
+            self.last_readbacks_per_step = prof.pop("__readbacks", {"count": 0})["count"]
+            for v in prof.values():   # callers divide by `steps`
+                v["total_ms"] *= steps
+                v["count"] *= steps
+            return dt / steps, prof
         self.ctx.profile_reset()
         self.barrier_sync()
         t0 = time.perf_counter()
@@ -189,13 +209,18 @@ class Bench:
         return {"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "steps": len(ts)}
 
     def drive(self, op, page):
-        """one page through one operator (Driver.processInternal for a single hop); returns device output pages"""
+        """the operator's only page through it (Driver.processInternal for a single hop: addInput, finish, getOutput until isFinished -- an
+        operator may hold its output back until then, the fused join does for small pages); returns device output pages"""
         outs = []
         assert op.needsInput()
         op.addInput(page)
-        o = op.getOutput()
-        if o is not None:
-            outs.append(o)
+        op.finish()
+        while not op.isFinished():
+            o = op.getOutput()
+            if o is not None:
+                outs.append(o)
+            elif op.isBlocked():
+                break
         return outs
 
     def finish(self, op):
@@ -318,13 +343,20 @@ class Bench:
 
         def pump(op, name, sink):
             rows = 0
-            for cp, keep in marshalled[name]:
-                p._lib.check(L.tgpu_operator_add_input(op.handle, C.byref(cp)))
+
+            def move():
+                nonlocal rows
                 o = op.getOutput()
                 if o is not None:
                     rows += o.position_count
                     sink.addInput(o)
                     o.release()
+            for cp, keep in marshalled[name]:
+                p._lib.check(L.tgpu_operator_add_input(op.handle, C.byref(cp)))
+                move()
+            op.finish()
+            while not op.isFinished():
+                move()
             return rows
 
         def step():
@@ -373,7 +405,7 @@ class Bench:
             for op in (ljoin, cfp, cbuild, obuild, aop):
                 op.close()
 
-        step_s, prof = self.timed(step, steps, warmup)
+        step_s, prof = self.timed(step, steps, warmup, profile_apart=True)
         keep = self.q3_stats
         self.q3_stats = dict(st)
         chk = self.check_q3()
@@ -381,7 +413,7 @@ class Bench:
         self.q3_stats = keep
         n_pages = len(cust) + len(orders) + len(lineitem)
         return {"page_rows": page_rows, "pages": {"customer": len(cust), "orders": len(orders), "lineitem": len(lineitem)}, "merge_pages_before_aggregation_mb": merge_mb,
-                "ms_per_step": step_s * 1e3,
+                "ms_per_step": step_s * 1e3, "per_kernel_profile": "one more, untimed, step (the timed steps run with the library's profile off)",
                 "probe_rows_per_sec": probe_rows / step_s, "readbacks_per_page": self.last_readbacks_per_step / n_pages,
                 "kernel_launches_per_page": sum(v["count"] for v in prof.values()) / steps / n_pages,
                 "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}, "ok": chk["ok"]}
@@ -886,7 +918,7 @@ class Bench:
             res["rows"] = [o.to_host().rows() for o in outs]
             aop.close()
 
-        step_s, prof = self.timed(step, steps, warmup)
+        step_s, prof = self.timed(step, steps, warmup, profile_apart=True)
         self.q1_result = res["rows"]
         ok = self.check_q1()["ok"]
         return {"page_rows": page_rows, "pages": len(pages), "through_merge_pages_mb": merge_mb, "ms_per_step": step_s * 1e3, "rows_per_sec": n / step_s,

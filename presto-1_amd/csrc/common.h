@@ -120,18 +120,36 @@ public:
     void *pinned_alloc(size_t bytes);    // hipHostMalloc for the embedding host (tgpu_pinned_alloc): e.g. the exchange client's receive buffers
     void pinned_free(void *p);
     void download(void *dst, const void *src, size_t bytes);        // D2H + sync
-    // A small read-back the caller keeps enqueueing work behind: begin_read copies `bytes` (<= 256) into a pinned slot and marks the
+    // A small read-back the caller keeps enqueueing work behind: begin_read copies `bytes` (<= kReadSlotBytes) into a pinned slot and marks the
     // stream; finish_read waits for THAT point only (the kernels enqueued after begin_read keep running) and copies the bytes out.
     // Slots are owned from begin_read to finish_read (handles of one context may be driven by several threads at once: a ring that
     // merely advanced would hand a slot to a second reader before the first had looked at it); with every slot taken the read is done
     // synchronously into the AsyncRead itself.
     struct AsyncRead {
-        int slot = -1;          // -2: completed synchronously, bytes in `inline_bytes`
+        int slot = -1;          // -2: completed synchronously, bytes in `sync_bytes`
         size_t bytes = 0;
-        uint8_t inline_bytes[256];
+        std::vector<uint8_t> sync_bytes;
     };
+    static constexpr size_t kReadSlotBytes = 16384;
     AsyncRead begin_read(const void *src, size_t bytes);
     void finish_read(const AsyncRead &r, void *dst);
+    // The same without the copy engine: a result the KERNEL writes into host memory itself.  begin_signal hands out one of the read slots
+    // (fine-grained pinned memory, first kSignalWords words zeroed, `device` = the pointer the kernel stores through); the kernel's last
+    // workgroup writes its result words and then, with a system-scope release, a non-zero word [kSignalWords - 1]; finish_signal polls that
+    // word.  No copy, no event, no stream wait: what a page-at-a-time operator pays per page.  slot == -1: every slot taken, use begin_read.
+    static constexpr int kSignalWords = 8;
+    struct Signal {
+        int slot = -1;
+        volatile unsigned long long *host = nullptr;
+        unsigned long long *device = nullptr;
+    };
+    Signal begin_signal();
+    void finish_signal(const Signal &s, unsigned long long out[kSignalWords]);
+    // persistent device words (kZeroedScratchBytes; word [0] rests at ~0 = the expression-error word's "no error", all others at 0) for
+    // kernels that count into them and put them back before they end: a launch that needs fresh counters does not need a launch that
+    // resets them.  Stream-ordered: one user at a time per context.
+    static constexpr size_t kZeroedScratchBytes = 16384;
+    void *zeroed_scratch();
     // many small D2H copies with ONE synchronisation: staged through pinned memory, then scattered to the destinations
     struct Transfer { void *dst; const void *src; size_t bytes; };
     void download_batch(const std::vector<Transfer> &transfers);
@@ -188,9 +206,12 @@ private:
     void *pinned_ = nullptr;
     size_t pinned_bytes_ = 0;
     static constexpr int kReadSlots = 16;
-    void *read_slots_ = nullptr;          // kReadSlots x 256 B pinned
+    void *read_slots_ = nullptr;          // kReadSlots x kReadSlotBytes pinned
     void *read_events_[kReadSlots] = {};  // hipEvent_t
     bool read_busy_[kReadSlots] = {};     // owned by a begin_read whose finish_read has not run yet (under io_mu_)
+    void *read_slots_device_ = nullptr;   // the slots as the device addresses them
+    void *zeroed_scratch_ = nullptr;
+    void ensure_read_slots();
     bool profiling_ = false;
     struct Pending { std::string name; hipEvent_t a, b; };
     std::vector<Pending> pending_;

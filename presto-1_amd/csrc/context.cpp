@@ -55,6 +55,7 @@ Context::~Context()
     if (copy_stream_) hipStreamDestroy(copy_stream_);
     if (pinned_) hipHostFree(pinned_);
     if (wait_event_) hipEventDestroy(wait_event_);
+    if (zeroed_scratch_) hipFree(zeroed_scratch_);
     if (read_slots_) {
         hipHostFree(read_slots_);
         for (void *e : read_events_)
@@ -296,32 +297,94 @@ void Context::download(void *dst, const void *src, size_t bytes)
     HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
-Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
+void Context::ensure_read_slots()
 {
-    TG_CHECK_STATE(bytes > 0 && bytes <= 256, "asynchronous read-backs are at most 256 bytes");
+    if (read_slots_) return;
+    // fine-grained (coherent) and mapped: kernels store results straight into the slots (begin_signal), the host polls them
+    HIP_CHECK(hipHostMalloc(&read_slots_, (size_t)kReadSlots * kReadSlotBytes, hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_CHECK(hipHostGetDevicePointer(&read_slots_device_, read_slots_, 0));
+    for (int i = 0; i < kReadSlots; i++) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        read_events_[i] = e;
+    }
+}
+
+Context::Signal Context::begin_signal()
+{
     std::lock_guard<std::recursive_mutex> io(io_mu_);
+    ensure_read_slots();
+    Signal s;
+    for (int i = 0; i < kReadSlots && s.slot < 0; i++)
+        if (!read_busy_[i]) s.slot = i;
+    if (s.slot < 0) return s;
     readbacks_++;
-    if (!read_slots_) {
-        HIP_CHECK(hipHostMalloc(&read_slots_, (size_t)kReadSlots * 256, hipHostMallocDefault));
-        for (int i = 0; i < kReadSlots; i++) {
-            hipEvent_t e;
-            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            read_events_[i] = e;
+    read_busy_[s.slot] = true;
+    s.host = reinterpret_cast<volatile unsigned long long *>(static_cast<uint8_t *>(read_slots_) + (size_t)s.slot * kReadSlotBytes);
+    s.device = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(read_slots_device_) + (size_t)s.slot * kReadSlotBytes);
+    for (int i = 0; i < kSignalWords; i++) s.host[i] = 0;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    return s;
+}
+
+void Context::finish_signal(const Signal &s, unsigned long long out[kSignalWords])
+{
+    TG_CHECK_STATE(s.slot >= 0 && s.slot < kReadSlots && s.host, "no signal in flight");
+    struct Release {
+        Context *c;
+        int slot;
+        ~Release()
+        {
+            std::lock_guard<std::recursive_mutex> io(c->io_mu_);
+            c->read_busy_[slot] = false;
+        }
+    } release{this, s.slot};
+    // the flag word arrives while the stream keeps running; a stream that has drained without it means the kernel never ran to its end
+    for (uint64_t spins = 1;; spins++) {
+        if (__atomic_load_n(const_cast<unsigned long long *>(&s.host[kSignalWords - 1]), __ATOMIC_ACQUIRE) != 0) break;
+        if ((spins & 0xfffff) == 0) {
+            const hipError_t q = hipStreamQuery(stream_);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(const_cast<unsigned long long *>(&s.host[kSignalWords - 1]), __ATOMIC_ACQUIRE) != 0) break;
+                fail(TGPU_ERR_DEVICE, "a kernel finished without delivering its result words");
+            }
+            if (q != hipErrorNotReady) HIP_CHECK(q);
         }
     }
+    for (int i = 0; i < kSignalWords; i++) out[i] = s.host[i];
+}
+
+void *Context::zeroed_scratch()
+{
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
+    if (!zeroed_scratch_) {
+        HIP_CHECK(hipMalloc(&zeroed_scratch_, kZeroedScratchBytes));
+        HIP_CHECK(hipMemsetAsync(zeroed_scratch_, 0, kZeroedScratchBytes, stream_));
+        HIP_CHECK(hipMemsetAsync(zeroed_scratch_, 0xff, 8, stream_));   // word [0] rests at ~0: "no error" of the expression-error word
+    }
+    return zeroed_scratch_;
+}
+
+Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
+{
+    TG_CHECK_STATE(bytes > 0 && bytes <= kReadSlotBytes, "asynchronous read-backs are at most 16 KB");
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
+    readbacks_++;
+    ensure_read_slots();
     AsyncRead r;
     r.bytes = bytes;
     for (int i = 0; i < kReadSlots && r.slot < 0; i++)
         if (!read_busy_[i]) r.slot = i;
     if (r.slot < 0) {
         // every slot is owned by a reader that has not finished yet (many operators of this context inside a read at once)
-        download(r.inline_bytes, src, bytes);
+        r.sync_bytes.resize(bytes);
+        download(r.sync_bytes.data(), src, bytes);
         readbacks_--;   // (counted once)
         r.slot = -2;
         return r;
     }
     read_busy_[r.slot] = true;
-    HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * 256, src, bytes, hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * kReadSlotBytes, src, bytes, hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipEventRecord(static_cast<hipEvent_t>(read_events_[r.slot]), stream_));
     return r;
 }
@@ -329,7 +392,7 @@ Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
 void Context::finish_read(const AsyncRead &r, void *dst)
 {
     if (r.slot == -2) {
-        memcpy(dst, r.inline_bytes, r.bytes);
+        memcpy(dst, r.sync_bytes.data(), r.bytes);
         return;
     }
     TG_CHECK_STATE(r.slot >= 0 && r.slot < kReadSlots, "no read-back in flight");
@@ -351,7 +414,7 @@ void Context::finish_read(const AsyncRead &r, void *dst)
             if (q == hipSuccess) break;
             if (q != hipErrorNotReady) HIP_CHECK(q);
         }
-    memcpy(dst, static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * 256, r.bytes);
+    memcpy(dst, static_cast<uint8_t *>(read_slots_) + (size_t)r.slot * kReadSlotBytes, r.bytes);
 }
 
 void Context::download_batch(const std::vector<Transfer> &transfers)

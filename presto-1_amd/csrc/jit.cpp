@@ -1082,6 +1082,8 @@ struct FjArgs {
   int pad2;
   void* carry[4];           // FJ_CARRY: block-private regions of the probe-side output VALUES (pass 1 evaluates them from its row
   unsigned char* carry_nulls; // registers for every emitted pair; pass 2 moves them instead of re-reading the input columns sparsely)
+  unsigned long long* host_out; // epilogue (small pages): host-visible result words, written by the LAST workgroup of pass 1 (null: none)
+  unsigned int* done;           //                         workgroups that have finished (rests at 0)
 };
 #define FJ_STRIPES @FJ_STRIPES@
 #define FJ_TILE (FJ_STRIPES * 256)
@@ -1224,7 +1226,10 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       }
       local += tile_total;
       // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
-      if (threadIdx.x == 0) { J.tile_cnt[tile >> csh] = (int)(local - chunk_local0); J.tile_src[tile >> csh] = (int)chunk_local0; }
+      if (threadIdx.x == 0) {   // (agent-scope store: the epilogue's reader may sit on another XCD)
+        __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        J.tile_src[tile >> csh] = (int)chunk_local0;
+      }
     }
 #endif
     // stage C: tile jC -- pre-filter verdicts; the survivors' first table slot is loaded below (lanes without a survivor read
@@ -1385,7 +1390,10 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       }
       local += tile_total;
       // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
-      if (threadIdx.x == 0) { J.tile_cnt[tile >> csh] = (int)(local - chunk_local0); J.tile_src[tile >> csh] = (int)chunk_local0; }
+      if (threadIdx.x == 0) {   // (agent-scope store: the epilogue's reader may sit on another XCD)
+        __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        J.tile_src[tile >> csh] = (int)chunk_local0;
+      }
     }
 #endif
   }
@@ -1398,9 +1406,65 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   __shared__ unsigned long long S[4];
   if (lane == 0) S[w] = selected_wave;
   __syncthreads();
+  // Epilogue of a small page (J.host_out): the workgroup that finishes LAST scans the chunk counts into the chunks' output offsets (what
+  // a scan launch would do) and stores {error word, pairs, selected rows} straight into host memory, then a flag the host polls (what a
+  // device-to-host copy and an event would do); it also puts the counters it read back to their rest values, so the next launch needs
+  // no launch that zeroes them.  Three launches and a copy per page become one launch.
+  // Who is last: the workgroup's one atomic on its count slot also carries an arrival (bits 48+); the workgroup that completes a slot
+  // bumps `done`, the one that completes `done` is last -- 64 atomics on one word instead of one per workgroup (13 ns each, serialised).
+  // No fences: chunk counts are published with agent-scope stores (write-through) that the barrier's wait has seen acknowledged before the
+  // arrival atomic is issued, and the last workgroup reads them with agent-scope loads.
+  __shared__ int S_last;
   if (threadIdx.x == 0) {
     const unsigned long long block_total = S[0] + S[1] + S[2] + S[3];
-    if (block_total) atomicAdd(&J.counters[(blockIdx.x % FJ_COUNT_SLOTS) * 16], block_total);
+    S_last = 0;
+    if (!J.host_out) {
+      if (block_total) atomicAdd(&J.counters[(blockIdx.x % FJ_COUNT_SLOTS) * 16], block_total);
+    } else {
+      const unsigned int slot = blockIdx.x % FJ_COUNT_SLOTS;
+      const unsigned int in_slot = (gridDim.x - slot + FJ_COUNT_SLOTS - 1) / FJ_COUNT_SLOTS;          // workgroups that count into this slot
+      const unsigned int live_slots = gridDim.x < FJ_COUNT_SLOTS ? gridDim.x : FJ_COUNT_SLOTS;
+      const unsigned long long before = atomicAdd(&J.counters[slot * 16], block_total + (1ULL << 48));
+      if ((unsigned int)(before >> 48) + 1u == in_slot) S_last = (atomicAdd(J.done, 1u) + 1u == live_slots) ? 1 : 0;
+    }
+  }
+  if (J.host_out) {
+    __shared__ int S_part[4];
+    __syncthreads();
+    if (S_last) {
+      const long long chunks = (J.tiles + (1LL << J.chunk_shift) - 1) >> J.chunk_shift;
+      const long long per = (chunks + 255) >> 8;
+      const long long a = (long long)threadIdx.x * per < chunks ? (long long)threadIdx.x * per : chunks;
+      const long long z = a + per < chunks ? a + per : chunks;
+      int mine = 0;
+      for (long long i = a; i < z; i++) mine += __hip_atomic_load(&J.tile_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+      if (lane == 63) S_part[w] = incl;
+      __syncthreads();
+      int run = incl - mine;
+      for (int k = 0; k < w; k++) run += S_part[k];
+      const int total = S_part[0] + S_part[1] + S_part[2] + S_part[3];
+      int* dst = (int*)J.tile_dst;
+      for (long long i = a; i < z; i++) { dst[i] = run; run += __hip_atomic_load(&J.tile_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      if (w == 0) {
+        unsigned long long sel = __hip_atomic_load(&J.counters[lane * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1ULL << 48) - 1);
+        __hip_atomic_store(&J.counters[lane * 16], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sel += __shfl_down(sel, d, 64);
+        if (lane == 0) {
+          const unsigned long long err = __hip_atomic_load(A.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(A.error, ~0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(J.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          J.host_out[0] = err;
+          J.host_out[1] = (unsigned long long)total;
+          J.host_out[2] = sel;
+          __threadfence_system();
+          __hip_atomic_store(&J.host_out[7], 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
   }
 }
 
@@ -1690,9 +1754,31 @@ JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls, bool carry)
     return modules_[variant].get();
 }
 
+// What a probe page has in flight between its two passes: pass 1 (filter + probe + in-tile compaction) and the scan of the chunk counts are
+// launched by begin(), which also starts the read-back of the totals; finish() waits for THAT read only, sizes the output and launches pass 2.
+// An operator that keeps the input page alive can put the next page's begin() between the two (operators.cpp), so that nobody waits for
+// a read-back on the common path.
+struct FusedProbeGpu::Pending {
+    FjArgs J{};
+    JitModule *module = nullptr;
+    int pf_kind = 0;
+    int64_t chunks = 0;
+    bool outer = false, need_build_positions = false, carry = false;
+    BufferPtr tile_cnt, tile_src, tile_dst, misc, pair_probe, pair_build;
+    std::vector<BufferPtr> carry_regions;
+    Context::AsyncRead read;
+    Context::Signal signal;   // epilogue path: the kernel delivers the totals itself
+};
+
 void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions,
                             std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count, int64_t &selected_rows,
                             const std::vector<DeviceColumn> *build_cols, std::vector<DeviceColumn> *build_out)
+{
+    std::shared_ptr<Pending> p = begin(ctx, in, source, outer, need_build_positions);
+    finish(ctx, p, in, probe_out, build_idx, count, selected_rows, build_cols, build_out);
+}
+
+std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions)
 {
     TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
@@ -1711,11 +1797,13 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     if (const char *f = getenv("TGPU_FJ_CARRY")) carry = atoi(f) != 0 && carry_supported_ && (tv.rank_base || tv.bitmap) && !output_channels_.empty() && !outer;
     JitModule *module = module_for(tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls, carry);
     const int64_t n = in.n;
-    count = 0;
-    selected_rows = 0;
-    probe_out.clear();
-    if (n == 0) return;
-    FjArgs J{};
+    if (n == 0) return nullptr;
+    std::shared_ptr<Pending> pend = std::make_shared<Pending>();
+    pend->module = module;
+    pend->outer = outer;
+    pend->need_build_positions = need_build_positions;
+    pend->carry = carry;
+    FjArgs &J = pend->J;
     for (size_t i = 0; i < in.cols.size() && i < (size_t)kFpMaxCols; i++) {
         J.fp.col_values[i] = in.cols[i].values;
         J.fp.col_nulls[i] = in.cols[i].nulls;
@@ -1738,7 +1826,6 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     // persistent workgroups: exactly as many as are resident at once (a second round of workgroups would only add a tail)
     const int pf_kind = tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0));
     static const char *probe_names[4] = {"fj_probe_plain", "fj_probe_bitmap", "fj_probe_bloom", "fj_probe_direct"};
-    static const char *emit_names[4] = {"fj_emit_plain", "fj_emit_bitmap", "fj_emit_bloom", "fj_emit_direct"};
     const int64_t resident = (int64_t)ctx->cu_count() * module->blocks_per_cu(probe_names[pf_kind]);
     // chunks of consecutive tiles per workgroup (fj_probe): up to 64 tiles, but at least ~4 chunks per resident workgroup
     int chunk_shift = 0;
@@ -1746,15 +1833,32 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     while (chunk_shift < max_chunk_shift && (J.tiles >> (chunk_shift + 1)) >= 4 * resident) chunk_shift++;
     J.chunk_shift = chunk_shift;
     const int64_t chunks = (J.tiles + (1ll << chunk_shift) - 1) >> chunk_shift;
+    pend->chunks = chunks;
+    pend->pf_kind = pf_kind;
     const int64_t grid1 = std::min<int64_t>(chunks, resident);
     J.grid1 = grid1;
     BufferPtr tile_cnt = ctx->alloc((size_t)chunks * 4), tile_src = ctx->alloc((size_t)chunks * 4), tile_dst = ctx->alloc((size_t)chunks * 4);
     // [0] expression error word, [2] total pairs, [16 + 16 i] rows selected by the filter as counted by workgroups i mod 64 (FJ_COUNT_SLOTS)
-    constexpr int kCountSlots = 64, kMiscWords = 16 + kCountSlots * 16;
-    BufferPtr misc = ctx->alloc((size_t)kMiscWords * 8);
-    init_words_kernel<<<1, 256, 0, ctx->stream()>>>(misc->as<unsigned long long>(), 1, kMiscWords - 1);   // one launch: [0] = ~0 (no error), the rest 0
-    J.fp.error = misc->as<unsigned long long>();
-    J.counters = misc->as<unsigned long long>() + 16;
+    constexpr int kMiscWords = kFjMiscWords;
+    // small pages: the probe kernel's last workgroup does the scan and hands the totals to the host itself (fj_probe's epilogue): its
+    // counters live in the context's persistent scratch words ([0] error word, [1] finished workgroups, [16 + 16 i] selected rows), which
+    // every launch leaves at rest
+    static_assert((size_t)kFjMiscWords * 8 <= Context::kZeroedScratchBytes, "the probe's counters fit the context's scratch words");
+    if (chunks <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr) pend->signal = ctx->begin_signal();
+    const bool epilogue = pend->signal.slot >= 0;
+    BufferPtr misc;
+    if (epilogue) {
+        unsigned long long *z = static_cast<unsigned long long *>(ctx->zeroed_scratch());
+        J.fp.error = z;
+        J.done = reinterpret_cast<unsigned int *>(z + 1);
+        J.counters = z + 16;
+        J.host_out = pend->signal.device;
+    } else {
+        misc = ctx->alloc((size_t)kMiscWords * 8);
+        init_words_kernel<<<1, 256, 0, ctx->stream()>>>(misc->as<unsigned long long>(), 1, kMiscWords - 1);   // one launch: [0] = ~0 (no error), the rest 0
+        J.fp.error = misc->as<unsigned long long>();
+        J.counters = misc->as<unsigned long long>() + 16;
+    }
     J.tile_cnt = tile_cnt->as<int32_t>();
     J.tile_src = tile_src->as<int32_t>();
     J.tile_dst = tile_dst->as<int32_t>();
@@ -1763,7 +1867,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     BufferPtr pair_probe = ctx->alloc((size_t)cap * 4), pair_build = ctx->alloc((size_t)cap * 4);
     J.pair_probe = pair_probe->as<int32_t>();
     J.pair_build = pair_build->as<int32_t>();
-    std::vector<BufferPtr> carry_regions;
+    std::vector<BufferPtr> &carry_regions = pend->carry_regions;
     if (carry) {
         bool nullable = false;
         for (size_t i = 0; i < output_channels_.size(); i++) {
@@ -1781,16 +1885,58 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
         ProfileScope ps(ctx, "fused_filter_probe");
         launch_args(module->fn(probe_names[pf_kind]), (int)grid1, J, ctx->stream());
     }
-    {
-        ProfileScope ps(ctx, "fused_probe_scan");
-        k::exclusive_scan_i32(ctx, J.tile_cnt, tile_dst->as<int32_t>(), chunks, (int64_t *)(misc->as<unsigned long long>() + 2));
+    pend->tile_cnt = tile_cnt; pend->tile_src = tile_src; pend->tile_dst = tile_dst; pend->misc = misc; pend->pair_probe = pair_probe; pend->pair_build = pair_build;
+    if (!epilogue) {
+        {
+            ProfileScope ps(ctx, "fused_probe_scan");
+            k::exclusive_scan_i32(ctx, J.tile_cnt, tile_dst->as<int32_t>(), chunks, (int64_t *)(misc->as<unsigned long long>() + 2));
+        }
+        pend->read = ctx->begin_read(misc->ptr(), (size_t)kFjMiscWords * 8);
     }
-    std::vector<unsigned long long> h((size_t)kMiscWords);
-    ctx->download(h.data(), misc->ptr(), (size_t)kMiscWords * 8);
-    raise_expression_error(h[0]);
+    return pend;
+}
+
+void FusedProbeGpu::cancel(Context *ctx, const std::shared_ptr<Pending> &pend)
+{
+    if (!pend) return;
+    if (pend->signal.slot >= 0) {
+        unsigned long long words[Context::kSignalWords];
+        ctx->finish_signal(pend->signal, words);   // waits: the kernel still owns the slot until it has written it
+        pend->signal.slot = -1;
+        return;
+    }
+    std::vector<unsigned long long> h((size_t)kFjMiscWords);
+    ctx->finish_read(pend->read, h.data());   // gives the read-back slot back; the page's buffers go with `pend`
+}
+
+void FusedProbeGpu::finish(Context *ctx, const std::shared_ptr<Pending> &pend, const DevicePage &in, std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count,
+                           int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols, std::vector<DeviceColumn> *build_out)
+{
+    count = 0;
     selected_rows = 0;
-    for (int i = 0; i < kCountSlots; i++) selected_rows += (int64_t)h[(size_t)(16 + i * 16)];
-    count = (int64_t)h[2];
+    probe_out.clear();
+    if (!pend) return;
+    FjArgs &J = pend->J;
+    JitModule *module = pend->module;
+    const int pf_kind = pend->pf_kind;
+    const int64_t chunks = pend->chunks;
+    const bool outer = pend->outer, need_build_positions = pend->need_build_positions;
+    static const char *emit_names[4] = {"fj_emit_plain", "fj_emit_bitmap", "fj_emit_bloom", "fj_emit_direct"};
+    if (pend->signal.slot >= 0) {
+        unsigned long long words[Context::kSignalWords];
+        Context::Signal sig = pend->signal;
+        pend->signal.slot = -1;
+        ctx->finish_signal(sig, words);
+        raise_expression_error(words[0]);
+        count = (int64_t)words[1];
+        selected_rows = (int64_t)words[2];
+    } else {
+        std::vector<unsigned long long> h((size_t)kFjMiscWords);
+        ctx->finish_read(pend->read, h.data());
+        raise_expression_error(h[0]);
+        for (int i = 0; i < kFjCountSlots; i++) selected_rows += (int64_t)h[(size_t)(16 + i * 16)];
+        count = (int64_t)h[2];
+    }
     if (count == 0) return;
     if (count > 0x7fffffffLL) fail(TGPU_ERR_INSUFFICIENT_RESOURCES, "join output of one probe page cannot exceed 2 billion rows");
     build_idx = ctx->alloc((size_t)count * 4);

@@ -98,6 +98,7 @@ private:
 // private regions, then a scan over the per-tile counts); the probe-side output projections are then evaluated for the
 // matching rows only.  Results are identical to running the two
 // reference operators back to back (M/operator/FilterAndProjectOperator.java + LookupJoinOperator.java).
+constexpr int kFjCountSlots = 64, kFjMiscWords = 16 + kFjCountSlots * 16;   // misc words of a probe launch: [0] error, [2] pairs, [16 + 16 i] selected rows
 struct FjArgs {  // must match the generated struct
     FpArgs fp;
     const void *slots;
@@ -132,8 +133,11 @@ struct FjArgs {  // must match the generated struct
     int32_t pad2;
     void *carry[4];         // carry variant: block-private regions of the probe-side output values, one per output channel
     uint8_t *carry_nulls;   //                and of their null bits (nullptr: no output can be null)
+    unsigned long long *host_out;   // small pages: pass 1's last workgroup scans the chunk counts and writes {error, pairs, selected} here
+    unsigned int *done;             //              (host-visible signal slot); `done` counts finished workgroups
 };
 constexpr int kFjMaxBuildCols = 4;
+constexpr int64_t kFjEpilogueMaxChunks = 8192;   // pages of up to 8192 chunks (6.3 M rows at 768-row tiles) end pass 1 with the epilogue
 
 class LookupSourceGpu;
 
@@ -155,6 +159,13 @@ public:
     void process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, std::vector<DeviceColumn> &probe_out,
                  BufferPtr &build_idx, int64_t &count, int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols = nullptr,
                  std::vector<DeviceColumn> *build_out = nullptr);
+    // the same in two halves: begin() launches pass 1 and the read-back of its totals, finish() waits for that read and launches pass 2.  `in`
+    // and the lookup source must stay alive and unchanged in between (null from begin() = empty page)
+    struct Pending;
+    std::shared_ptr<Pending> begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions);
+    void finish(Context *ctx, const std::shared_ptr<Pending> &pending, const DevicePage &in, std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count,
+                int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols = nullptr, std::vector<DeviceColumn> *build_out = nullptr);
+    void cancel(Context *ctx, const std::shared_ptr<Pending> &pending);   // a begun page nobody will finish (operator closed early)
     const std::string &source() const { return source_; }
 
 private:

@@ -14,6 +14,20 @@
 
 namespace tgpu {
 
+// May an operator keep `in` by reference after add_input returned?  Library-owned pages (another operator's output, an ingested host
+// page) hold their buffers; borrowed device blocks are the caller's unless it promised to leave them alone
+// (tgpu_context_set_device_input_stable).
+static bool page_is_retained(Context *ctx, const DevicePage &in)
+{
+    if (ctx->device_input_stable()) return true;
+    for (const DeviceColumn &c : in.cols) {
+        if (c.n > 0 && !c.values_buf) return false;
+        if (c.nulls && !c.nulls_buf) return false;
+        if (c.offsets && !c.offsets_buf) return false;
+    }
+    return true;
+}
+
 // =====================================================================================================================
 // FilterAndProjectOperator: WorkProcessorOperatorAdapter protocol (M/operator/WorkProcessorOperatorAdapter.java:138-216)
 // around PageProcessor (M/operator/FilterAndProjectOperator.java:56-64).  One output page per input page that selects
@@ -1158,12 +1172,21 @@ public:
     ~FusedFilterProjectJoinOperator() override { close(); }
 
     bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
-    bool needs_input() override { return !finishing_ && !pending_ && !is_blocked(); }
+    bool needs_input() override { return !finishing_ && ready_.empty() && (int)inflight_.size() < kDepth && !is_blocked(); }
+
+    // Pages of up to kAsyncBelowRows rows are probed asynchronously: add_input launches pass 1 and the read-back of its output row count,
+    // get_output hands the page's output over once a SECOND page is in flight (or the operator is finishing) -- by then the read-back has
+    // completed behind the second page's pass 1, so nobody waits for the device on the common path.  The Operator contract allows exactly
+    // this (getOutput() may return null whenever it likes; Driver.processInternal polls).  It needs the input page to stay alive between the
+    // two calls: library-owned pages (another operator's output, an ingested host page) are kept by reference, borrowed device blocks only
+    // qualify under tgpu_context_set_device_input_stable.  An expression error of page i is raised by the get_output that completes it.
+    static constexpr int kDepth = 2;
+    static constexpr int64_t kAsyncBelowRows = 1ll << 22;
 
     void add_input(const tgpu_page *page) override
     {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
-        TG_CHECK_STATE(!pending_, "Operator still has pending output");
+        TG_CHECK_STATE(ready_.empty() && (int)inflight_.size() < kDepth, "Operator still has pending output");
         std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
         DevicePage in = ingest_page(ctx_, page);
@@ -1175,65 +1198,107 @@ public:
         const bool fused_ok = !filter && fused_->supported() && cfg_.probe_join_channels.size() == 1 && source->int_table(tv) && tv.links == nullptr &&
                               tv.key_type == fused_->projection_types()[(size_t)cfg_.probe_join_channels[0]] && getenv("TGPU_DISABLE_FUSION") == nullptr;
         if (fused_ok) {
-            std::vector<DeviceColumn> probe_out;
-            BufferPtr build_idx;
-            int64_t count = 0, selected = 0;
-            const bool need_positions = track || !source->output_channels().empty();
+            InFlight f;
+            f.source = source;
+            f.outer = outer;
+            f.track = track;
+            f.need_positions = track || !source->output_channels().empty();
             // fixed-width build output channels are gathered by the probe's emit pass itself (no launch of their own)
             const int nb = (int)source->output_channels().size();
-            std::vector<DeviceColumn> build_cols, build_out;
-            bool gather_fused = nb > 0 && nb <= kFjMaxBuildCols;
-            for (int i = 0; i < nb && gather_fused; i++) {
-                build_cols.push_back(source->build_column(i));
-                gather_fused = build_cols.back().type != TGPU_VARCHAR && build_cols.back().values != nullptr;
+            f.gather_fused = nb > 0 && nb <= kFjMaxBuildCols;
+            for (int i = 0; i < nb && f.gather_fused; i++) {
+                f.build_cols.push_back(source->build_column(i));
+                f.gather_fused = f.build_cols.back().type != TGPU_VARCHAR && f.build_cols.back().values != nullptr;
             }
-            fused_->process(ctx_, in, *source, outer, need_positions, probe_out, build_idx, count, selected, gather_fused ? &build_cols : nullptr,
-                            gather_fused ? &build_out : nullptr);
-            probe_rows_ += selected;
-            if (count == 0) return;
-            if (track) source->mark_visited(build_idx->as<int32_t>(), count);
-            DevicePage out;
-            out.n = count;
-            out.cols = std::move(probe_out);
-            if (gather_fused) for (DeviceColumn &c : build_out) out.cols.push_back(std::move(c));
-            else {
-                ProfileScope ps(ctx_, "join_gather");
-                for (int i = 0; i < nb; i++) out.cols.push_back(source->gather_build(i, build_idx->as<int32_t>(), count, outer));
-            }
-            pending_ = wrap(std::move(out));
+            const bool async = in.n <= kAsyncBelowRows && page_is_retained(ctx_, in) && getenv("TGPU_DISABLE_ASYNC_JOIN") == nullptr;
+            f.pending = fused_->begin(ctx_, in, *source, outer, f.need_positions);
+            f.in = std::move(in);
+            inflight_.push_back(std::move(f));
+            if (!async) complete_all();
             return;
         }
+        complete_all();
         // unfused composition: FilterAndProject, then the probe
         DevicePage mid, out;
         if (!processor_->process(ctx_, in, mid)) return;
         probe_rows_ += mid.n;
-        if (probe_page(ctx_, *source, mid, cfg_, out, filter.get())) pending_ = wrap(std::move(out));
+        if (probe_page(ctx_, *source, mid, cfg_, out, filter.get())) ready_.push_back(wrap(std::move(out)));
     }
 
-    std::unique_ptr<OutputPage> get_output() override { return std::move(pending_); }
+    std::unique_ptr<OutputPage> get_output() override
+    {
+        while (ready_.empty() && !inflight_.empty() && ((int)inflight_.size() >= kDepth || finishing_)) complete_oldest();
+        if (ready_.empty()) return nullptr;
+        std::unique_ptr<OutputPage> out = std::move(ready_.front());
+        ready_.pop_front();
+        return out;
+    }
     void finish() override { finishing_ = true; }
     bool is_finished() override
     {
-        bool done = finishing_ && !pending_;
+        bool done = finishing_ && ready_.empty() && inflight_.empty();
         if (done) close();
         return done;
     }
-    int64_t memory_bytes() override { return pending_ ? pending_->page.size_in_bytes() : 0; }
+    int64_t memory_bytes() override
+    {
+        int64_t b = 0;
+        for (const auto &o : ready_) b += o->page.size_in_bytes();
+        for (const InFlight &f : inflight_) b += f.in.size_in_bytes();
+        return b;
+    }
     int64_t probe_rows() const { return probe_rows_; }
     void close() override
     {
         if (!closed_) {
             closed_ = true;
+            for (InFlight &f : inflight_) fused_->cancel(ctx_, f.pending);
+            inflight_.clear();
             bridge_->probe_closed();
         }
     }
 
 private:
+    struct InFlight {
+        DevicePage in;
+        std::shared_ptr<FusedProbeGpu::Pending> pending;
+        std::shared_ptr<LookupSourceGpu> source;
+        std::vector<DeviceColumn> build_cols;
+        bool outer = false, track = false, need_positions = false, gather_fused = false;
+    };
+    void complete_all()
+    {
+        while (!inflight_.empty()) complete_oldest();
+    }
+    void complete_oldest()
+    {
+        InFlight f = std::move(inflight_.front());
+        inflight_.pop_front();
+        std::vector<DeviceColumn> probe_out, build_out;
+        BufferPtr build_idx;
+        int64_t count = 0, selected = 0;
+        fused_->finish(ctx_, f.pending, f.in, probe_out, build_idx, count, selected, f.gather_fused ? &f.build_cols : nullptr, f.gather_fused ? &build_out : nullptr);
+        probe_rows_ += selected;
+        if (count == 0) return;
+        if (f.track) f.source->mark_visited(build_idx->as<int32_t>(), count);
+        DevicePage out;
+        out.n = count;
+        out.cols = std::move(probe_out);
+        if (f.gather_fused) for (DeviceColumn &c : build_out) out.cols.push_back(std::move(c));
+        else {
+            ProfileScope ps(ctx_, "join_gather");
+            const int nb = (int)f.source->output_channels().size();
+            for (int i = 0; i < nb; i++) out.cols.push_back(f.source->gather_build(i, build_idx->as<int32_t>(), count, f.outer));
+        }
+        ready_.push_back(wrap(std::move(out)));
+    }
+
     LookupJoinConfig cfg_;
     std::shared_ptr<LookupSourceFactory> bridge_;
     std::shared_ptr<PageProcessorGpu> processor_;
     std::shared_ptr<FusedProbeGpu> fused_;
-    std::unique_ptr<OutputPage> pending_;
+    std::deque<InFlight> inflight_;
+    std::deque<std::unique_ptr<OutputPage>> ready_;
     int64_t probe_rows_ = 0;
     bool finishing_ = false, closed_ = false;
 };
@@ -1387,16 +1452,7 @@ private:
         unsigned long long *counters;
         Context::AsyncRead read;
     };
-    bool retained(const DevicePage &in) const
-    {
-        if (ctx_->device_input_stable()) return true;
-        for (const DeviceColumn &c : in.cols) {
-            if (c.n > 0 && !c.values_buf) return false;
-            if (c.nulls && !c.nulls_buf) return false;
-            if (c.offsets && !c.offsets_buf) return false;
-        }
-        return true;
-    }
+    bool retained(const DevicePage &in) const { return page_is_retained(ctx_, in); }
     bool onepass_ready(const DevicePage &in) const
     {
         const bool disabled = getenv("TGPU_DISABLE_ONEPASS") != nullptr || getenv("TGPU_DISABLE_SPECULATION") != nullptr;
