@@ -145,6 +145,7 @@ public:
     };
     Signal begin_signal();
     void finish_signal(const Signal &s, unsigned long long out[kSignalWords]);
+    void abandon_signal(const Signal &s);   // the kernel that would have written the slot was never launched
     // persistent device words (kZeroedScratchBytes; word [0] rests at ~0 = the expression-error word's "no error", all others at 0) for
     // kernels that count into them and put them back before they end: a launch that needs fresh counters does not need a launch that
     // resets them.  Stream-ordered: one user at a time per context.

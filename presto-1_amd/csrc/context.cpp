@@ -354,6 +354,13 @@ void Context::finish_signal(const Signal &s, unsigned long long out[kSignalWords
     for (int i = 0; i < kSignalWords; i++) out[i] = s.host[i];
 }
 
+void Context::abandon_signal(const Signal &s)
+{
+    if (s.slot < 0) return;
+    std::lock_guard<std::recursive_mutex> io(io_mu_);
+    read_busy_[s.slot] = false;
+}
+
 void *Context::zeroed_scratch()
 {
     std::lock_guard<std::recursive_mutex> io(io_mu_);

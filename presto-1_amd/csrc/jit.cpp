@@ -1226,8 +1226,9 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       }
       local += tile_total;
       // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
-      if (threadIdx.x == 0) {   // (agent-scope store: the epilogue's reader may sit on another XCD)
-        __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) {   // (epilogue: agent-scope store, its reader may sit on another XCD)
+        if (J.host_out) __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else J.tile_cnt[tile >> csh] = (int)(local - chunk_local0);
         J.tile_src[tile >> csh] = (int)chunk_local0;
       }
     }
@@ -1390,8 +1391,9 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       }
       local += tile_total;
       // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
-      if (threadIdx.x == 0) {   // (agent-scope store: the epilogue's reader may sit on another XCD)
-        __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x == 0) {   // (epilogue: agent-scope store, its reader may sit on another XCD)
+        if (J.host_out) __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else J.tile_cnt[tile >> csh] = (int)(local - chunk_local0);
         J.tile_src[tile >> csh] = (int)chunk_local0;
       }
     }
@@ -1432,22 +1434,32 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     __shared__ int S_part[4];
     __syncthreads();
     if (S_last) {
+      // (acquire at agent scope = invalidate this XCD's view: the plain, batched loads below then see the other XCDs' write-through stores)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       const long long chunks = (J.tiles + (1LL << J.chunk_shift) - 1) >> J.chunk_shift;
-      const long long per = (chunks + 255) >> 8;
-      const long long a = (long long)threadIdx.x * per < chunks ? (long long)threadIdx.x * per : chunks;
-      const long long z = a + per < chunks ? a + per : chunks;
-      int mine = 0;
-      for (long long i = a; i < z; i++) mine += __hip_atomic_load(&J.tile_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int incl = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
-      if (lane == 63) S_part[w] = incl;
-      __syncthreads();
-      int run = incl - mine;
-      for (int k = 0; k < w; k++) run += S_part[k];
-      const int total = S_part[0] + S_part[1] + S_part[2] + S_part[3];
       int* dst = (int*)J.tile_dst;
-      for (long long i = a; i < z; i++) { dst[i] = run; run += __hip_atomic_load(&J.tile_cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      int carry = 0;
+      for (long long base = 0; base < chunks; base += 2048) {   // 8 consecutive counts per lane: 2 KB per wave and pass, coalesced
+        const long long i0 = base + (long long)threadIdx.x * 8;
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = i0 + k < chunks ? J.tile_cnt[i0 + k] : 0;
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) mine += v[k];
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) S_part[w] = incl;
+        __syncthreads();
+        int run = carry + incl - mine;
+        for (int k = 0; k < w; k++) run += S_part[k];
+        carry += S_part[0] + S_part[1] + S_part[2] + S_part[3];
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (i0 + k < chunks) { dst[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+      }
+      const int total = carry;
       if (w == 0) {
         unsigned long long sel = __hip_atomic_load(&J.counters[lane * 16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ((1ULL << 48) - 1);
         __hip_atomic_store(&J.counters[lane * 16], 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1844,7 +1856,20 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // counters live in the context's persistent scratch words ([0] error word, [1] finished workgroups, [16 + 16 i] selected rows), which
     // every launch leaves at rest
     static_assert((size_t)kFjMiscWords * 8 <= Context::kZeroedScratchBytes, "the probe's counters fit the context's scratch words");
-    if (chunks <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr) pend->signal = ctx->begin_signal();
+    // (measured on the SF100 tables, 12 207 chunks of 64 tiles: lineitem launch 1.50 -> 1.82 ms with the epilogue -- it is for pages)
+    if (chunk_shift == 0 && chunks <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr) pend->signal = ctx->begin_signal();
+    struct SignalGuard {   // an allocation that fails between here and the launch must not leave the slot waiting for a kernel that never runs
+        Context *ctx;
+        Context::Signal *signal;
+        bool armed = true;
+        ~SignalGuard()
+        {
+            if (armed && signal->slot >= 0) {
+                ctx->abandon_signal(*signal);
+                signal->slot = -1;
+            }
+        }
+    } signal_guard{ctx, &pend->signal};
     const bool epilogue = pend->signal.slot >= 0;
     BufferPtr misc;
     if (epilogue) {
@@ -1885,6 +1910,7 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
         ProfileScope ps(ctx, "fused_filter_probe");
         launch_args(module->fn(probe_names[pf_kind]), (int)grid1, J, ctx->stream());
     }
+    signal_guard.armed = false;
     pend->tile_cnt = tile_cnt; pend->tile_src = tile_src; pend->tile_dst = tile_dst; pend->misc = misc; pend->pair_probe = pair_probe; pend->pair_build = pair_build;
     if (!epilogue) {
         {
@@ -2133,6 +2159,8 @@ struct FqArgs {
   int pad;
   unsigned long long* counters;        // this page: [0] rows of unknown groups, [7] expression error word (~0 = none)
   const unsigned long long* prev;      // the previous one-pass page's counters (its totals are in fold.pending), or null
+  unsigned long long* host_out;        // host-visible words for the counters ({[0], [2], [7]}, then a flag in word 7), written by the
+  unsigned int* done;                  // workgroup that finishes last (`done` = finished workgroups, rests at 0); null: the host copies
 };
 #define FQ_STRIPES 8
 #define FQ_TILE (FQ_STRIPES * 256)
@@ -2224,6 +2252,19 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
   for (int d = 32; d >= 1; d >>= 1) unknown += __shfl_down(unknown, d, 64);
   if ((threadIdx.x & 63) == 0 && unknown) atomicAdd(&Q.counters[0], unknown);
   tg_lc_fold_to<true>(lds, F.plan, F.st, F.fold.pending + (size_t)blockIdx.x * F.fold.stride * 3);
+  // the page's verdict goes to the host without a copy in the stream (a copy between two pages' launches keeps the second one waiting):
+  // the workgroup that arrives last stores the counters into host memory and raises the flag the host polls
+  if (Q.host_out) {
+    __syncthreads();   // (every wave's counter atomics have been acknowledged)
+    if (threadIdx.x == 0 && atomicAdd(Q.done, 1u) + 1u == gridDim.x) {
+      __hip_atomic_store(Q.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Q.host_out[0] = __hip_atomic_load(&Q.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Q.host_out[1] = __hip_atomic_load(&Q.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      Q.host_out[2] = __hip_atomic_load(&Q.counters[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence_system();
+      __hip_atomic_store(&Q.host_out[7], 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 )SRC";
 
@@ -2271,6 +2312,8 @@ struct FqArgsHost {
     int32_t pad;
     unsigned long long *counters;
     const unsigned long long *prev;
+    unsigned long long *host_out;
+    unsigned int *done;
 };
 
 }  // namespace
@@ -3056,7 +3099,7 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
 
 // One pass per page (fq_onepass): see the kernel.  `blocks` is fixed per operator (one workgroup row of pending totals per workgroup).
 void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulators &accs, const KeyCols &store, int64_t groups, unsigned long long *counters,
-                          const unsigned long long *prev, int64_t blocks)
+                          const unsigned long long *prev, int64_t blocks, unsigned long long *host_out)
 {
     TG_CHECK_STATE(supported_ && !key_inputs_.empty() && groups > 0 && groups <= max_groups_ && !accumulate_can_raise_, "one-pass aggregation not available for this configuration");
     JitModule *module = module_for(in, false);
@@ -3107,6 +3150,8 @@ void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulator
     Q.store_groups = (int32_t)groups;
     Q.counters = counters;
     Q.prev = prev;
+    Q.host_out = host_out;
+    Q.done = host_out ? reinterpret_cast<unsigned int *>(static_cast<unsigned long long *>(ctx->zeroed_scratch()) + 1) : nullptr;
     ProfileScope ps(ctx, "fused_filter_group_accumulate_onepass");
     launch_args(module->fn("fq_onepass"), (int)blocks, Q, ctx->stream());
 }

@@ -137,7 +137,7 @@ struct FjArgs {  // must match the generated struct
     unsigned int *done;             //              (host-visible signal slot); `done` counts finished workgroups
 };
 constexpr int kFjMaxBuildCols = 4;
-constexpr int64_t kFjEpilogueMaxChunks = 8192;   // pages of up to 8192 chunks (6.3 M rows at 768-row tiles) end pass 1 with the epilogue
+constexpr int64_t kFjEpilogueMaxChunks = 8192;   // probe launches of up to 8192 one-tile chunks (6.3 M rows at 768-row tiles) end pass 1 with the epilogue
 
 class LookupSourceGpu;
 
@@ -219,7 +219,7 @@ public:
     // counters say no row met an unknown group.  prev = the counters of the previous one-pass page of the operator (its pending totals are
     // made final or dropped by this launch), or null.
     void onepass(Context *ctx, const DevicePage &in, GroupedAccumulators &accs, const KeyCols &store, int64_t groups, unsigned long long *counters,
-                 const unsigned long long *prev, int64_t blocks);
+                 const unsigned long long *prev, int64_t blocks, unsigned long long *host_out = nullptr);   // host_out: Context::Signal::device
     // groups a one-pass launch has LDS for: its key records (16 groups x keys x 32 B) sit next to the lane-private states
     int onepass_groups() const
     {

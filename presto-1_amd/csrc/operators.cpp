@@ -1451,6 +1451,7 @@ private:
         DevicePage page;
         unsigned long long *counters;
         Context::AsyncRead read;
+        Context::Signal signal;
     };
     bool retained(const DevicePage &in) const { return page_is_retained(ctx_, in); }
     bool onepass_ready(const DevicePage &in) const
@@ -1465,8 +1466,15 @@ private:
         p.counters = gbh_->counter_set();
         const unsigned long long *prev = last_onepass_counters_;
         onepass_blocks_ = ctx_->cu_count();   // one workgroup per CU (the lane-private states fill the LDS), one row of pending totals each
-        fused_->onepass(ctx_, in, *accs_, gbh_->key_store_view(), gbh_->group_count(), p.counters, prev, onepass_blocks_);
-        p.read = ctx_->begin_read(p.counters, 64);
+        // the kernel hands its counters to the host itself (a signal slot); with every slot taken they are copied behind it
+        p.signal = ctx_->begin_signal();
+        try {
+            fused_->onepass(ctx_, in, *accs_, gbh_->key_store_view(), gbh_->group_count(), p.counters, prev, onepass_blocks_, p.signal.device);
+        } catch (...) {
+            ctx_->abandon_signal(p.signal);
+            throw;
+        }
+        if (p.signal.slot < 0) p.read = ctx_->begin_read(p.counters, 64);
         p.page = std::move(in);
         last_onepass_counters_ = p.counters;
         pending_.push_back(std::move(p));
@@ -1478,8 +1486,14 @@ private:
         while (pending_.size() > keep) {
             PendingPage p = std::move(pending_.front());
             pending_.pop_front();
-            unsigned long long ctr[8];
-            ctx_->finish_read(p.read, ctr);
+            unsigned long long ctr[8] = {};
+            if (p.signal.slot >= 0) {
+                unsigned long long w[Context::kSignalWords];
+                ctx_->finish_signal(p.signal, w);
+                ctr[0] = w[0];
+                ctr[2] = w[1];
+                ctr[7] = w[2];
+            } else ctx_->finish_read(p.read, ctr);
             const bool last = pending_.empty();
             const bool dirty = ctr[0] != 0 || ctr[2] != 0 || ctr[7] != ~0ull;
             if (last) {
