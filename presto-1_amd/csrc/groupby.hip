@@ -350,19 +350,22 @@ KeyCols GroupByHashGpu::store_view() const
 }
 
 // the eight counter words of a sub-batch, the last one being an error word whose "none" is ~0: a ring of kCounterSets sets is
-// initialised by ONE launch and handed out set by set (a launch per sub-batch was a tenth of a 2^20-row page's device time)
-static __global__ void init_counters_kernel(unsigned long long *ctr)
+// initialised half by half by ONE launch per half and handed out set by set (a launch per sub-batch was a tenth of a 2^20-row page's
+// device time).  Half by half because the set handed out LAST may still be read by the next launch (a one-pass aggregation launch gates
+// the commit of its predecessor's totals on the predecessor's counters): the launch that re-initialises a half never touches the other.
+static __global__ void init_counters_kernel(unsigned long long *ctr, int words)
 {
-    for (int i = threadIdx.x; i < GroupByHashGpu::kCounterSets * 8; i += blockDim.x) ctr[i] = (i & 7) == 7 ? ~0ull : 0ull;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) ctr[i] = (i & 7) == 7 ? ~0ull : 0ull;
 }
 
 unsigned long long *GroupByHashGpu::fresh_counters()
 {
-    if (next_counter_set_ % kCounterSets == 0) {
-        // every earlier user of the ring is in front of this launch on the stream
-        init_counters_kernel<<<1, 256, 0, ctx_->stream()>>>(counters_->as<unsigned long long>());
+    constexpr int half = kCounterSets / 2;
+    if (next_counter_set_ % half == 0) {
+        if (next_counter_set_ == kCounterSets) next_counter_set_ = 0;
+        // every earlier user of this half is in front of this launch on the stream
+        init_counters_kernel<<<1, 256, 0, ctx_->stream()>>>(counters_->as<unsigned long long>() + 8 * next_counter_set_, half * 8);
         check_launch("init_counters");
-        next_counter_set_ = 0;
     }
     return counters_->as<unsigned long long>() + 8 * (next_counter_set_++);
 }

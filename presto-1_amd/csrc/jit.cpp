@@ -2161,6 +2161,9 @@ struct FqArgs {
   const unsigned long long* prev;      // the previous one-pass page's counters (its totals are in fold.pending), or null
   unsigned long long* host_out;        // host-visible words for the counters ({[0], [2], [7]}, then a flag in word 7), written by the
   unsigned int* done;                  // workgroup that finishes last (`done` = finished workgroups, rests at 0); null: the host copies
+  const FpArgs* pages;                 // fq_onepass_multi: the launch's pages in order (device memory; error words all = fa.fp.error)
+  int n_pages;
+  int pad3;
 };
 #define FQ_STRIPES 8
 #define FQ_TILE (FQ_STRIPES * 256)
@@ -2173,19 +2176,30 @@ __device__ inline void fq_load_a(const FpArgs& A, long long row, TgQRow& R) {
   fg_load_key_a(A, 0, (unsigned int)row, R.k);
   tg_load_row(A, row, R.r);
 }
-extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
+// MULTI: the launch covers a LIST of pages (Q.pages: one FpArgs per page, in device memory), taken as one sequence of tiles in page order --
+// a blocking operator that is handed small pages need not launch per page (the fixed cost of a launch, ~18 us, is 1.3 M rows' worth of
+// streaming).  The page of a tile is workgroup-uniform: its column pointers are scalar loads.
+template <bool MULTI> __device__ __forceinline__ void fq_body(const FqArgs& Q) {
   const FaArgs& F = Q.fa;
-  const FpArgs& A = F.fp;
+#define FQ_PAGE(i) (MULTI ? Q.pages[i] : F.fp)
+#define FQ_TILES(n) (((n) + FQ_TILE - 1) / FQ_TILE)
   __shared__ __attribute__((aligned(16))) unsigned char lds[FQ_LDS_BYTES];   // the lane-private states of the groups a one-pass launch may meet
   __shared__ __attribute__((aligned(16))) unsigned char rec[FG_LDS_GROUPS * FG_NKEYS * 32];
-  const long long tiles = (A.n + FQ_TILE - 1) / FQ_TILE;
-  const long long last = A.n - 1;
+  const int np = MULTI ? Q.n_pages : 1;
+  // this workgroup's tiles: global tile numbers blockIdx.x, + gridDim.x, ...; (pc, base) = the page of tile g and that page's first tile
+  long long g = blockIdx.x, base = 0;
+  int pc = 0;
+  while (pc < np) { const long long t = FQ_TILES(FQ_PAGE(pc).n); if (g < base + t) break; base += t; pc++; }
   // the first tile's loads go out before anything else: they land under the set-up below
   TgQRow cur[FQ_STRIPES], nxt[FQ_STRIPES];
+  {
+    const FpArgs A = FQ_PAGE(pc < np ? pc : 0);
+    const long long last = A.n - 1;
 #pragma unroll
-  for (int s = 0; s < FQ_STRIPES; s++) {
-    const long long row = (long long)blockIdx.x * FQ_TILE + threadIdx.x + s * 256;
-    fq_load_a(A, row < last ? row : last, cur[s]);
+    for (int s = 0; s < FQ_STRIPES; s++) {
+      const long long row = (g - base) * FQ_TILE + threadIdx.x + s * 256;
+      fq_load_a(A, (pc < np && row < last) ? row : last, cur[s]);
+    }
   }
   // (1) the previous page's totals of this workgroup row: final if that page was clean, else dropped (overwritten below either way)
   if (Q.prev && (Q.prev[0] | Q.prev[2] | ~Q.prev[7]) == 0ULL) tg_commit_pending(F.fold, F.plan.n_aggs, F.st, false);
@@ -2194,15 +2208,16 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
   fg_build_records(Q.store, lg, rec);   // ends with a workgroup barrier (also between the commit above and the fold below)
   TgRecReg rr[FG_REG_GROUPS];
 #pragma unroll
-  for (int g = 0; g < FG_REG_GROUPS; g++) {
-    fg_load_recreg(rec, g < lg ? g : 0, rr[g]);
-    if (g >= lg) rr[g].s[0] = ~(FG_SIG_T)0;
+  for (int g2 = 0; g2 < FG_REG_GROUPS; g2++) {
+    fg_load_recreg(rec, g2 < lg ? g2 : 0, rr[g2]);
+    if (g2 >= lg) rr[g2].s[0] = ~(FG_SIG_T)0;
   }
   const int rg = lg < FG_REG_GROUPS ? lg : FG_REG_GROUPS;
   unsigned long long unknown = 0;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the prologue's loads do not flow into the loop header (see fa_accumulate_body)
-  for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const long long tb = tile * FQ_TILE;
+  while (pc < np) {
+    const FpArgs A = FQ_PAGE(pc);
+    const long long tb = (g - base) * FQ_TILE;
     const long long left = A.n - tb;
     const unsigned int lim = (unsigned int)(left < FQ_TILE ? left : FQ_TILE) - 1u;
     bool sel[FQ_STRIPES];
@@ -2215,11 +2230,19 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
     }
 #pragma unroll
     for (int s = 0; s < FQ_STRIPES; s++) fg_load_key_b(A, cur[s].k, sel[s]);
-    const long long ntile = tile + gridDim.x;
+    const long long gn = g + gridDim.x;
+    long long bn = base;
+    int pn = pc;
+    while (pn < np) { const long long t = FQ_TILES(FQ_PAGE(pn).n); if (gn < bn + t) break; bn += t; pn++; }
+    {
+      // (past the last tile: the loads re-read this page's last row)
+      const FpArgs N = FQ_PAGE(pn < np ? pn : pc);
+      const long long nlast = N.n - 1;
 #pragma unroll
-    for (int s = 0; s < FQ_STRIPES; s++) {
-      const long long row = ntile * FQ_TILE + threadIdx.x + s * 256;
-      fq_load_a(A, row < last ? row : last, nxt[s]);
+      for (int s = 0; s < FQ_STRIPES; s++) {
+        const long long row = (gn - bn) * FQ_TILE + threadIdx.x + s * 256;
+        fq_load_a(N, (pn < np && row < nlast) ? row : nlast, nxt[s]);
+      }
     }
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -2230,23 +2253,24 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
       fg_row_sig(cur[s].k, sig, open);
       int result = -1;
 #pragma unroll
-      for (int g = FG_REG_GROUPS - 1; g >= 0; g--) {
+      for (int g2 = FG_REG_GROUPS - 1; g2 >= 0; g2--) {
         bool same = true;
 #pragma unroll
-        for (int j = 0; j < FG_SIG_WORDS; j++) same = same && sig[j] == rr[g].s[j];
-        result = same ? g : result;
+        for (int j = 0; j < FG_SIG_WORDS; j++) same = same && sig[j] == rr[g2].s[j];
+        result = same ? g2 : result;
       }
       const bool redo = open && result >= 0;
       result = (redo || !sel[s]) ? -1 : result;
       if (sel[s] && result < 0) {   // not decided by the signatures: the byte-wise LDS records; a row no record matches is left to the host
-        for (int g = redo ? 0 : rg; g < lg; g++)
-          if (fg_eq_record(A, cur[s].k, rec, g) > 0) { result = g; break; }
+        for (int g2 = redo ? 0 : rg; g2 < lg; g2++)
+          if (fg_eq_record(A, cur[s].k, rec, g2) > 0) { result = g2; break; }
         unknown += result < 0 ? 1ULL : 0ULL;
       }
       if (sel[s] && result >= 0) tg_accumulate_row_lc(F, A, tb + o, cur[s].r, result, lds);
     }
 #pragma unroll
     for (int s = 0; s < FQ_STRIPES; s++) cur[s] = nxt[s];
+    g = gn; base = bn; pc = pn;
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) unknown += __shfl_down(unknown, d, 64);
@@ -2265,7 +2289,11 @@ extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) {
       __hip_atomic_store(&Q.host_out[7], 1ULL, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+#undef FQ_PAGE
+#undef FQ_TILES
 }
+extern "C" __global__ void __launch_bounds__(256) fq_onepass(FqArgs Q) { fq_body<false>(Q); }
+extern "C" __global__ void __launch_bounds__(256) fq_onepass_multi(FqArgs Q) { fq_body<true>(Q); }
 )SRC";
 
 // host mirror of the generated FaArgs
@@ -2314,6 +2342,9 @@ struct FqArgsHost {
     const unsigned long long *prev;
     unsigned long long *host_out;
     unsigned int *done;
+    const FpArgs *pages;
+    int32_t n_pages;
+    int32_t pad3;
 };
 
 }  // namespace
@@ -2995,9 +3026,14 @@ void FusedAggGpu::ensure_loaded()
 
 JitModule *FusedAggGpu::module_for(const DevicePage &in, bool gid8)
 {
-    std::lock_guard<std::mutex> lk(mu_);
     bool nulls = false;
     for (const DeviceColumn &c : in.cols) nulls = nulls || c.nulls != nullptr;
+    return module_variant(nulls, gid8);
+}
+
+JitModule *FusedAggGpu::module_variant(bool nulls, bool gid8)
+{
+    std::lock_guard<std::mutex> lk(mu_);
     if (gid8) {
         std::shared_ptr<JitModule> &m = nulls ? module_g8_ : module_nn_g8_;
         if (!m) m = load_module(gid8_source(nulls ? source_ : no_nulls_source(source_)));
@@ -3097,26 +3133,35 @@ void FusedAggGpu::probe_groups(Context *ctx, const DevicePage &in, const GbhProb
     }
 }
 
-// One pass per page (fq_onepass): see the kernel.  `blocks` is fixed per operator (one workgroup row of pending totals per workgroup).
-void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulators &accs, const KeyCols &store, int64_t groups, unsigned long long *counters,
-                          const unsigned long long *prev, int64_t blocks, unsigned long long *host_out)
+// One pass per launch (fq_onepass / fq_onepass_multi): see the kernel.  `blocks` is fixed per operator (one workgroup row of pending totals per
+// workgroup).  Several pages: their column pointers travel as an array of FpArgs behind one small upload (kept alive by `keep`).
+void FusedAggGpu::onepass(Context *ctx, const std::vector<const DevicePage *> &pages, GroupedAccumulators &accs, const KeyCols &store, int64_t groups,
+                          unsigned long long *counters, const unsigned long long *prev, int64_t blocks, unsigned long long *host_out, BufferPtr *keep)
 {
     TG_CHECK_STATE(supported_ && !key_inputs_.empty() && groups > 0 && groups <= max_groups_ && !accumulate_can_raise_, "one-pass aggregation not available for this configuration");
-    JitModule *module = module_for(in, false);
+    TG_CHECK_ARG(!pages.empty(), "one-pass launch without a page");
+    const DevicePage &in = *pages[0];
+    bool any_nulls = false;
+    for (const DevicePage *pg : pages)
+        for (const DeviceColumn &c : pg->cols) any_nulls = any_nulls || c.nulls != nullptr;
+    JitModule *module = module_variant(any_nulls, false);   // (the variant without null handling only when no page of the launch carries a null vector)
     accs.reserve(max_groups_);
     FqArgsHost Q{};
     FaArgsHost &F = Q.fa;
-    fill_fp_cols(F.fp, in);
-    F.fp.error = counters + 7;
     BufferPtr dummy;
-    for (int ch : key_inputs_)
-        if (input_types_[(size_t)ch] == TGPU_VARCHAR && F.fp.col_values[ch] == nullptr) {
-            if (!dummy) {
-                dummy = ctx->alloc(16);
-                HIP_CHECK(hipMemsetAsync(dummy->ptr(), 0, 16, ctx->stream()));
+    auto fill = [&](FpArgs &fp, const DevicePage &pg) {
+        fill_fp_cols(fp, pg);
+        fp.error = counters + 7;
+        for (int ch : key_inputs_)
+            if (input_types_[(size_t)ch] == TGPU_VARCHAR && fp.col_values[ch] == nullptr) {
+                if (!dummy) {
+                    dummy = ctx->alloc(16);
+                    HIP_CHECK(hipMemsetAsync(dummy->ptr(), 0, 16, ctx->stream()));
+                }
+                fp.col_values[ch] = dummy->ptr();
             }
-            F.fp.col_values[ch] = dummy->ptr();
-        }
+    };
+    fill(F.fp, in);
     for (size_t k = 0; k < aggs_.size(); k++) {
         GroupedAccumulators::DeviceState d = accs.device_state((int)k);
         F.st[k].function = d.function;
@@ -3135,7 +3180,8 @@ void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulator
         F.plan.cnt_slot[k] = cnt_slot_[k];
         const int cs = cnt_slot_[k];
         bool from_rows = !cnt_masked_[(size_t)cs];
-        for (int ch : cnt_inputs_[(size_t)cs]) from_rows = from_rows && ch >= 0 && in.cols[(size_t)ch].nulls == nullptr;
+        for (const DevicePage *pg : pages)
+            for (int ch : cnt_inputs_[(size_t)cs]) from_rows = from_rows && ch >= 0 && pg->cols[(size_t)ch].nulls == nullptr;
         F.plan.count_from_rows[k] = from_rows ? 1 : 0;
     }
     F.plan.per_group_bytes = per_group_bytes_;
@@ -3152,8 +3198,31 @@ void FusedAggGpu::onepass(Context *ctx, const DevicePage &in, GroupedAccumulator
     Q.prev = prev;
     Q.host_out = host_out;
     Q.done = host_out ? reinterpret_cast<unsigned int *>(static_cast<unsigned long long *>(ctx->zeroed_scratch()) + 1) : nullptr;
+    const bool multi = pages.size() > 1;
+    if (multi) {
+        std::vector<FpArgs> desc(pages.size());
+        for (size_t i = 0; i < pages.size(); i++) {
+            TG_CHECK_ARG(pages[i]->n > 0, "empty page in a multi-page launch");
+            desc[i] = FpArgs{};
+            fill(desc[i], *pages[i]);
+        }
+        BufferPtr d = ctx->alloc(desc.size() * sizeof(FpArgs));
+        ctx->upload(d->ptr(), desc.data(), desc.size() * sizeof(FpArgs));
+        Q.pages = d->as<FpArgs>();
+        Q.n_pages = (int32_t)pages.size();
+        if (keep) *keep = d;
+    }
+    if (getenv("TGPU_DEBUG_LAUNCH")) {   // kernel studies: what a launch was given (stderr)
+        fprintf(stderr, "[tgpu] fq_onepass%s pages=%zu groups=%lld blocks=%lld prev=%p counters=%p host_out=%p desc=%p\n", multi ? "_multi" : "", pages.size(), (long long)groups,
+                (long long)blocks, (const void *)prev, (void *)counters, (void *)host_out, (const void *)Q.pages);
+        for (size_t i = 0; i < pages.size(); i++) {
+            fprintf(stderr, "[tgpu]   page %zu n=%lld", i, (long long)pages[i]->n);
+            for (const DeviceColumn &c : pages[i]->cols) fprintf(stderr, " (%p %p %p)", c.values, (const void *)c.nulls, (const void *)c.offsets);
+            fprintf(stderr, "\n");
+        }
+    }
     ProfileScope ps(ctx, "fused_filter_group_accumulate_onepass");
-    launch_args(module->fn("fq_onepass"), (int)blocks, Q, ctx->stream());
+    launch_args(module->fn(multi ? "fq_onepass_multi" : "fq_onepass"), (int)blocks, Q, ctx->stream());
 }
 
 // gids8 -> gids, for the (rare) page whose ids arrived compact but whose groups do not fit the lane-private LDS path

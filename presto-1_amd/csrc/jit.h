@@ -218,8 +218,11 @@ public:
     // `store` holds + accumulate into lane-private LDS states; the page's totals stay pending (GroupedAccumulators::FoldScratch) until its
     // counters say no row met an unknown group.  prev = the counters of the previous one-pass page of the operator (its pending totals are
     // made final or dropped by this launch), or null.
-    void onepass(Context *ctx, const DevicePage &in, GroupedAccumulators &accs, const KeyCols &store, int64_t groups, unsigned long long *counters,
-                 const unsigned long long *prev, int64_t blocks, unsigned long long *host_out = nullptr);   // host_out: Context::Signal::device
+    // `pages`: one page, or several that are taken as one sequence of rows (a blocking operator batching small pages: one launch for all).
+    // host_out: Context::Signal::device (the kernel delivers its counters itself), or null.  keep: receives the buffer of page descriptors
+    // a multi-page launch reads (alive until the launch has run).
+    void onepass(Context *ctx, const std::vector<const DevicePage *> &pages, GroupedAccumulators &accs, const KeyCols &store, int64_t groups,
+                 unsigned long long *counters, const unsigned long long *prev, int64_t blocks, unsigned long long *host_out = nullptr, BufferPtr *keep = nullptr);
     // groups a one-pass launch has LDS for: its key records (16 groups x keys x 32 B) sit next to the lane-private states
     int onepass_groups() const
     {
@@ -235,6 +238,7 @@ private:
     void generate();
     void ensure_loaded();
     struct JitModule *module_for(const DevicePage &in, bool gid8 = false);   // the no-nulls specialisation when no column of the page has a null vector
+    struct JitModule *module_variant(bool nulls, bool gid8);
     std::mutex mu_;
     void raise_if_error(Context *ctx, BufferPtr &err);
     std::vector<int32_t> input_types_;

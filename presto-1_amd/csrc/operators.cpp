@@ -1183,13 +1183,16 @@ public:
     static constexpr int kDepth = 2;
     static constexpr int64_t kAsyncBelowRows = 1ll << 22;
 
-    void add_input(const tgpu_page *page) override
+    void add_input(const tgpu_page *page) override { add_page(page, nullptr); }
+    void add_input_owned(const DevicePage &page) override { add_page(nullptr, &page); }   // (keeps the page's buffers: it may stay in flight)
+
+    void add_page(const tgpu_page *page, const DevicePage *owned)
     {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
         TG_CHECK_STATE(ready_.empty() && (int)inflight_.size() < kDepth, "Operator still has pending output");
         std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
-        DevicePage in = ingest_page(ctx_, page);
+        DevicePage in = owned ? DevicePage(*owned) : ingest_page(ctx_, page);
         if (in.n == 0) return;
         const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
         const bool track = cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
@@ -1357,13 +1360,19 @@ public:
     bool uses_fused_kernels() const { return fused_->supported() && !fused_->key_inputs().empty() && cfg_.step != TGPU_STEP_FINAL && getenv("TGPU_DISABLE_FUSION") == nullptr; }
     bool allow_integer_table() const override { return !uses_fused_kernels(); }
 
-    void add_input(const tgpu_page *page) override
+    void add_input(const tgpu_page *page) override { add_page(page, nullptr); }
+    // a page of this library keeps its buffers through the DevicePage's owners: it may wait for a common launch or be re-run after the call
+    // (the default, a borrowed view of the page, would only be safe under the caller's device_input_stable promise -- which is about the
+    // CALLER's memory, not about an output page it releases right after handing it on)
+    void add_input_owned(const DevicePage &page) override { add_page(nullptr, &page); }
+
+    void add_page(const tgpu_page *page, const DevicePage *owned)
     {
         confirm_pending(kOnepassDepth - 1);   // (errors and dirty pages of earlier one-pass launches surface here at the latest)
         begin_input();
         const bool fused_ok = gbh_ && uses_fused_kernels();
         // the fused kernels address VARCHAR bytes through the offsets alone: the byte ranges of borrowed device columns stay unread
-        DevicePage in = ingest_page(ctx_, page, /*resolve_varchar=*/!fused_ok);
+        DevicePage in = owned ? DevicePage(*owned) : ingest_page(ctx_, page, /*resolve_varchar=*/!fused_ok);
         if (in.n == 0) return;
         if (!fused_ok) {
             drain_onepass();
@@ -1373,7 +1382,10 @@ public:
             return;
         }
         if (onepass_ready(in)) {
-            launch_onepass(std::move(in));
+            // the operator is blocking (nothing leaves it before finish): small pages are collected, by reference, into one launch
+            batch_rows_ += in.n;
+            batch_.push_back(std::move(in));
+            if (batch_rows_ >= onepass_batch_rows() || (int)batch_.size() >= kOnepassBatchPages) launch_onepass();
             return;
         }
         drain_onepass();
@@ -1446,9 +1458,20 @@ private:
     // (order-independent), so re-running a page after its successors does not change a bit; new groups still get their ids in page order
     // because a successor that met one of them is dirty itself and is re-run after it.  An expression error of page i is raised by the call
     // that confirms it (the next add_input, finish or get_output).
-    static constexpr int kOnepassDepth = 2, kOnepassAfter = 2;
+    // Pages below kOnepassBatchRows rows wait (by reference) until that many rows or kOnepassBatchPages pages have come together and go out as
+    // ONE launch over the list of pages (fq_onepass_multi): a launch costs ~18 us whatever it covers, 1.3 M rows' worth of streaming.  A dirty
+    // launch re-runs its pages one by one in page order, an expression error in a launch of several pages likewise (the re-run raises the
+    // error of the first failing page, like the reference).
+    static constexpr int kOnepassDepth = 2, kOnepassAfter = 2, kOnepassBatchPages = 64;
+    static constexpr int64_t kOnepassBatchRows = 1ll << 23;
+    static int64_t onepass_batch_rows()
+    {
+        const char *e = getenv("TGPU_ONEPASS_BATCH_ROWS");
+        return e ? std::max<int64_t>(1, atoll(e)) : kOnepassBatchRows;
+    }
     struct PendingPage {
-        DevicePage page;
+        std::vector<DevicePage> pages;
+        BufferPtr descriptors;
         unsigned long long *counters;
         Context::AsyncRead read;
         Context::Signal signal;
@@ -1460,27 +1483,36 @@ private:
         return !disabled && clean_streak_ >= kOnepassAfter && fused_->can_onepass(gbh_->group_count()) && !accs_->force_ordered() && accs_->decided() && !accs_->ordered() &&
                retained(in);
     }
-    void launch_onepass(DevicePage in)
+    void launch_onepass()
     {
+        if (batch_.empty()) return;
         PendingPage p;
+        p.pages = std::move(batch_);
+        batch_.clear();
+        batch_rows_ = 0;
         p.counters = gbh_->counter_set();
         const unsigned long long *prev = last_onepass_counters_;
         onepass_blocks_ = ctx_->cu_count();   // one workgroup per CU (the lane-private states fill the LDS), one row of pending totals each
+        std::vector<const DevicePage *> list;
+        for (const DevicePage &pg : p.pages) list.push_back(&pg);
         // the kernel hands its counters to the host itself (a signal slot); with every slot taken they are copied behind it
         p.signal = ctx_->begin_signal();
         try {
-            fused_->onepass(ctx_, in, *accs_, gbh_->key_store_view(), gbh_->group_count(), p.counters, prev, onepass_blocks_, p.signal.device);
+            fused_->onepass(ctx_, list, *accs_, gbh_->key_store_view(), gbh_->group_count(), p.counters, prev, onepass_blocks_, p.signal.device, &p.descriptors);
         } catch (...) {
             ctx_->abandon_signal(p.signal);
-            throw;
+            // (nothing was launched: the pages go the two-launch way, after whatever is in flight)
+            std::vector<DevicePage> pages = std::move(p.pages);
+            confirm_pending(0);
+            for (const DevicePage &pg : pages) process_fused(pg);
+            return;
         }
         if (p.signal.slot < 0) p.read = ctx_->begin_read(p.counters, 64);
-        p.page = std::move(in);
         last_onepass_counters_ = p.counters;
         pending_.push_back(std::move(p));
         confirm_pending(kOnepassDepth);
     }
-    // confirms launched pages, oldest first, until at most `keep` are in flight
+    // confirms launches, oldest first, until at most `keep` are in flight
     void confirm_pending(size_t keep)
     {
         while (pending_.size() > keep) {
@@ -1501,15 +1533,24 @@ private:
                 accs_->resolve_pending(onepass_blocks_, !dirty);
                 last_onepass_counters_ = nullptr;
             }
-            raise_expression_error(ctr[7]);
+            if (p.pages.size() == 1) raise_expression_error(ctr[7]);
             if (dirty) {
                 clean_streak_ = 0;
-                process_fused(p.page);   // (the pages launched behind it ran against the same group set: each is judged by its own counters)
+                // (the launches behind it ran against the same group set: each is judged by its own counters)
+                for (const DevicePage &pg : p.pages) process_fused(pg);
             }
         }
     }
-    void drain_onepass() { confirm_pending(0); }
+    // nothing collected, nothing in flight
+    void flush_onepass()
+    {
+        launch_onepass();
+        confirm_pending(0);
+    }
+    void drain_onepass() { flush_onepass(); }
 
+    std::vector<DevicePage> batch_;   // pages waiting for their common launch
+    int64_t batch_rows_ = 0;
     std::deque<PendingPage> pending_;
     const unsigned long long *last_onepass_counters_ = nullptr;
     int64_t onepass_blocks_ = 0;

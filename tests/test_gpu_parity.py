@@ -1132,12 +1132,17 @@ def _onepass_program(pkg, with_division=False):
     return T, filt, projs, aggs
 
 
+@pytest.mark.parametrize("batch_rows", ["1", "20000", None])
 @pytest.mark.parametrize("late", [{}, {6: "X"}, {5: "X", 6: "Y", 9: "Z"}, {4: "X", 5: "X"}])
-def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, monkeypatch, late):
-    """once the group set has settled the fused aggregation runs ONE launch per page and reads a page's counters a call later
-    (FusedAggGpu::onepass): same rows, bit for bit, as the probe + accumulate path -- also when pages in the middle of the stream bring new
-    groups (their totals are dropped on the device, the pages re-run through the insert protocol, ids in first-seen order)"""
+def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, monkeypatch, late, batch_rows):
+    """once the group set has settled the fused aggregation runs ONE launch per page -- or per batch of small pages: by default pages wait until
+    2^23 rows have come together (here: all of them, launched by finish()); TGPU_ONEPASS_BATCH_ROWS=20000 makes launches of three pages, =1 one
+    per page -- and reads a launch's counters a call later (FusedAggGpu::onepass): same rows, bit for bit, as the probe + accumulate path -- also
+    when pages in the middle of the stream bring new groups (their totals are dropped on the device, the pages re-run through the insert
+    protocol, ids in first-seen order)"""
     monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "5000")   # (the DOUBLE mode is decided within the first page: the stream settles early)
+    if batch_rows:
+        monkeypatch.setenv("TGPU_ONEPASS_BATCH_ROWS", batch_rows)
     rng = np.random.default_rng(41)
     pages = _onepass_pages(pkg, rng, 12, 9000, late)
     T, filt, projs, aggs = _onepass_program(pkg)
@@ -1152,8 +1157,10 @@ def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, m
         results[mode] = [r for p in out for r in p.rows()]
         prof = ctx.profile()
         launches = prof.get("fused_filter_group_accumulate_onepass", {"count": 0})["count"]
-        if mode == "onepass":
+        if mode == "onepass" and batch_rows == "1":
             assert launches >= 12 - 3 - 2 * len(late)      # host pages are library-owned copies: the one-pass path needs no promise for them
+        elif mode == "onepass":
+            assert 1 <= launches <= (4 if batch_rows else 2)
         else:
             assert launches == 0
         ctx.close()
@@ -1164,8 +1171,48 @@ def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, m
         assert ulp_diff([np.nan if x is None else x for x in ra[2:6]], [np.nan if x is None else x for x in rb[2:6]]).max() == 0
 
 
-def test_fused_aggregation_one_launch_per_page_raises_expression_errors_a_call_later(pkg):
-    """a filter that divides by zero on a page of the one-pass stream: the page's error word comes back with its counters, one call later"""
+def test_fused_aggregation_launch_over_ragged_pages_with_and_without_null_vectors(pkg, monkeypatch):
+    """one launch over a list of pages (fq_onepass_multi): page sizes around the 2048-row tile (1, 2047, 2048, 2049 rows ...), pages whose
+    columns carry null vectors next to pages that carry none, launches of 1 to 64 pages -- bit for bit the two-launch path"""
+    monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "3000")
+    rng = np.random.default_rng(53)
+    T, filt, projs, aggs = _onepass_program(pkg)
+    sizes = [4000, 4000, 4000, 4000, 1, 2047, 2048, 2049, 5, 4096, 10_000, 3, 6143, 6145, 70_000, 2, 2048] + [17] * 70 + [30_000]
+    pages = []
+    for i, n in enumerate(sizes):
+        pg = _onepass_pages(pkg, rng, 1, n, {})[0]
+        if i % 3 == 1:      # no null vector anywhere in this page
+            blocks = [pkg.Block(b.type, b.values, None, b.offsets) for b in pg.blocks]
+            pg = pkg.Page(*blocks)
+        pages.append(pg)
+    results = {}
+    for mode in ("multi", "two_launch"):
+        if mode == "two_launch":
+            monkeypatch.setenv("TGPU_DISABLE_ONEPASS", "1")
+        else:
+            monkeypatch.setenv("TGPU_ONEPASS_BATCH_ROWS", "9000")
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.VARCHAR, pkg.VARCHAR], [0, 1], aggs)
+        out = pkg.to_pages(fac.createOperator(), pages)
+        results[mode] = [r for p in out for r in p.rows()]
+        launches = ctx.profile().get("fused_filter_group_accumulate_onepass", {"count": 0})["count"]
+        assert launches == (6 if mode == "multi" else 0)   # 5 + 3 + 3 + 1 + 64 + 9 pages (9000 rows or 64 pages make a launch)
+        ctx.close()
+    a, b = results["multi"], results["two_launch"]
+    assert [r[:2] for r in a] == [r[:2] for r in b] and len(a) == 6
+    for ra, rb in zip(a, b):
+        assert ra[6] == rb[6] and ra[7] == rb[7]
+        assert ulp_diff([np.nan if x is None else x for x in ra[2:6]], [np.nan if x is None else x for x in rb[2:6]]).max() == 0
+
+
+@pytest.mark.parametrize("batch_rows", ["1", "12000", None])
+def test_fused_aggregation_one_launch_per_page_raises_expression_errors_a_call_later(pkg, monkeypatch, batch_rows):
+    """a filter that divides by zero on a page of the one-pass stream: the page's error word comes back with its counters, one call later; a
+    launch over several pages is re-run page by page and the first failing page raises"""
+    if batch_rows:
+        monkeypatch.setenv("TGPU_ONEPASS_BATCH_ROWS", batch_rows)
+    monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "5000")
     rng = np.random.default_rng(43)
     pages = _onepass_pages(pkg, rng, 10, 5000, {}, error_page=7)
     T, filt, projs, aggs = _onepass_program(pkg, with_division=True)
@@ -1200,6 +1247,42 @@ def test_fused_aggregation_one_launch_per_page_needs_the_promise_for_borrowed_de
             o.release()
         ctx.close()
     assert rows[True] == rows[False]
+
+
+def test_fused_aggregation_keeps_the_buffers_of_library_pages_that_wait_for_their_launch(pkg, monkeypatch):
+    """pages of this library (another operator's output) handed on with addInput(OutputPage) and released right away -- the way a driver
+    moves pages: the aggregation collects them for a common launch and re-runs them when the launch meets a new group, so it must hold their
+    buffers itself (the context's device_input_stable promise is set here and must not be what keeps them: the pool reuses a released
+    page's memory for the next page)"""
+    monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "3000")
+    rng = np.random.default_rng(59)
+    T, filt, projs, aggs = _onepass_program(pkg)
+    host = _onepass_pages(pkg, rng, 30, 6000, {17: "X", 24: "Y"})
+    f = pkg.field
+    rows = {}
+    for mode in ("owned", "host"):
+        ctx = pkg.Context(0)
+        ctx.set_device_input_stable(True)
+        ident = pkg.FilterAndProjectOperatorFactory(ctx, 9, T, None, [f(i, t) for i, t in enumerate(T)]).createOperator()
+        op = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [pkg.VARCHAR, pkg.VARCHAR], [0, 1], aggs).createOperator()
+        for pg in host:
+            if mode == "host":
+                op.addInput(pg)
+                continue
+            ident.addInput(pg)
+            o = ident.getOutput()
+            op.addInput(o)
+            o.release()          # its memory goes back to the pool: the next identity output reuses it
+        op.finish()
+        out = []
+        while not op.isFinished():
+            o = op.getOutput()
+            if o is not None:
+                out += o.to_host().rows()
+                o.release()
+        rows[mode] = out
+        op.close(); ident.close(); ctx.close()
+    assert rows["owned"] == rows["host"] and 6 + 2 <= len(rows["host"]) <= 6 + 2 * 2
 
 
 # (the exchange tests live in tests/test_gpu_exchange.py)
