@@ -1088,6 +1088,9 @@ struct FjArgs {
 #define FJ_STRIPES @FJ_STRIPES@
 #define FJ_TILE (FJ_STRIPES * 256)
 #define FJ_COUNT_SLOTS 64
+#ifndef FJ_EPILOGUE
+#define FJ_EPILOGUE 0   // the variant for pages (few, one-tile chunks): pass 1 ends with the scan and hands its totals to the host itself
+#endif
 
 // rows-capacity offset of block b's private pair region: CHUNKS of 2^chunk_shift consecutive tiles are dealt round-robin, block b
 // owns ceil((chunks - b) / grid) of them
@@ -1226,9 +1229,12 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       }
       local += tile_total;
       // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
-      if (threadIdx.x == 0) {   // (epilogue: agent-scope store, its reader may sit on another XCD)
-        if (J.host_out) __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else J.tile_cnt[tile >> csh] = (int)(local - chunk_local0);
+      if (threadIdx.x == 0) {
+#if FJ_EPILOGUE   // (agent-scope store: the epilogue's reader may sit on another XCD)
+        __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        J.tile_cnt[tile >> csh] = (int)(local - chunk_local0);
+#endif
         J.tile_src[tile >> csh] = (int)chunk_local0;
       }
     }
@@ -1391,9 +1397,12 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
       }
       local += tile_total;
       // per-chunk bookkeeping, rewritten after every tile of the chunk (the last one stands)
-      if (threadIdx.x == 0) {   // (epilogue: agent-scope store, its reader may sit on another XCD)
-        if (J.host_out) __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else J.tile_cnt[tile >> csh] = (int)(local - chunk_local0);
+      if (threadIdx.x == 0) {
+#if FJ_EPILOGUE   // (agent-scope store: the epilogue's reader may sit on another XCD)
+        __hip_atomic_store(&J.tile_cnt[tile >> csh], (int)(local - chunk_local0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        J.tile_cnt[tile >> csh] = (int)(local - chunk_local0);
+#endif
         J.tile_src[tile >> csh] = (int)chunk_local0;
       }
     }
@@ -1408,6 +1417,13 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   __shared__ unsigned long long S[4];
   if (lane == 0) S[w] = selected_wave;
   __syncthreads();
+#if !FJ_EPILOGUE
+  if (threadIdx.x == 0) {
+    const unsigned long long block_total = S[0] + S[1] + S[2] + S[3];
+    if (block_total) atomicAdd(&J.counters[(blockIdx.x % FJ_COUNT_SLOTS) * 16], block_total);
+  }
+}
+#else
   // Epilogue of a small page (J.host_out): the workgroup that finishes LAST scans the chunk counts into the chunks' output offsets (what
   // a scan launch would do) and stores {error word, pairs, selected rows} straight into host memory, then a flag the host polls (what a
   // device-to-host copy and an event would do); it also puts the counters it read back to their rest values, so the next launch needs
@@ -1479,6 +1495,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     }
   }
 }
+#endif
 
 // pass 2: one workgroup per chunk: moves the chunk's pairs to their final position and evaluates the probe-side output
 // projections for the matching rows only
@@ -1746,22 +1763,25 @@ static std::string prefilter_source(const std::string &src, int variant)
     // statistics then keep the DIRECT-layout launches (TPCH keys) apart from the open-address ones
     static const char *layout[4] = {"plain", "bitmap", "bloom", "direct"};
     const std::string l = layout[variant % 4];
-    return "#define FJ_PF " + std::to_string(variant % 4) + "\n#define FJ_NO_NULLS " + std::to_string((variant / 4) % 2) + "\n#define FJ_CARRY " + std::to_string(variant / 8) +
-           "\n#define fj_probe fj_probe_" + l +
+    return "#define FJ_PF " + std::to_string(variant % 4) + "\n#define FJ_NO_NULLS " + std::to_string((variant / 4) % 2) + "\n#define FJ_CARRY " + std::to_string((variant / 8) % 2) +
+           "\n#define FJ_EPILOGUE " + std::to_string(variant / 16) + "\n#define fj_probe fj_probe_" + l +
            "\n#define fj_emit fj_emit_" + l + "\n" + src;
 }
 
 void FusedProbeGpu::precompile()
 {
     if (!supported_) return;
-    for (int variant = 0; variant < 8; variant++) (void)code_object_for(prefilter_source(source_, variant));
+    for (int variant = 0; variant < 8; variant++) {
+        (void)code_object_for(prefilter_source(source_, variant));
+        (void)code_object_for(prefilter_source(source_, 16 + variant));   // the page variants (FJ_EPILOGUE)
+    }
     // (the opt-in carry variants, 8 + ..., are compiled on first use)
 }
 
-JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls, bool carry)
+JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls, bool carry, bool epilogue)
 {
     std::lock_guard<std::mutex> lk(mu_);
-    const int variant = kind + (no_nulls ? 4 : 0) + (carry ? 8 : 0);
+    const int variant = kind + (no_nulls ? 4 : 0) + (carry ? 8 : 0) + (epilogue ? 16 : 0);
     if (!modules_[variant]) modules_[variant] = load_module(prefilter_source(source_, variant));
     return modules_[variant].get();
 }
@@ -1807,9 +1827,13 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // variant is opt-in (TGPU_FJ_CARRY=1; exact key bitmaps, inner joins) and stays tested; the default keeps the two-pass gather.
     bool carry = false;
     if (const char *f = getenv("TGPU_FJ_CARRY")) carry = atoi(f) != 0 && carry_supported_ && (tv.rank_base || tv.bitmap) && !output_channels_.empty() && !outer;
-    JitModule *module = module_for(tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls, carry);
     const int64_t n = in.n;
     if (n == 0) return nullptr;
+    // pages of up to kFjEpilogueMaxChunks tiles (always one-tile chunks, see below) run the kernel variant whose pass 1 ends with the scan and
+    // the hand-over of the totals; whole tables keep the variant without it (measured on the SF100 tables: the epilogue's write-through
+    // count stores and its extra state cost the lineitem launch 1.50 -> 1.82 ms)
+    const bool page_variant = ceil_div(n, (int64_t)fj_stripes() * 256) <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr;
+    JitModule *module = module_for(tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls, carry, page_variant);
     std::shared_ptr<Pending> pend = std::make_shared<Pending>();
     pend->module = module;
     pend->outer = outer;
@@ -1856,8 +1880,7 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // counters live in the context's persistent scratch words ([0] error word, [1] finished workgroups, [16 + 16 i] selected rows), which
     // every launch leaves at rest
     static_assert((size_t)kFjMiscWords * 8 <= Context::kZeroedScratchBytes, "the probe's counters fit the context's scratch words");
-    // (measured on the SF100 tables, 12 207 chunks of 64 tiles: lineitem launch 1.50 -> 1.82 ms with the epilogue -- it is for pages)
-    if (chunk_shift == 0 && chunks <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr) pend->signal = ctx->begin_signal();
+    if (page_variant && chunk_shift == 0) pend->signal = ctx->begin_signal();   // (no slot free: host_out stays null, the scan launch and the copy do it)
     struct SignalGuard {   // an allocation that fails between here and the launch must not leave the slot waiting for a kernel that never runs
         Context *ctx;
         Context::Signal *signal;

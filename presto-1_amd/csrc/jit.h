@@ -137,7 +137,7 @@ struct FjArgs {  // must match the generated struct
     unsigned int *done;             //              (host-visible signal slot); `done` counts finished workgroups
 };
 constexpr int kFjMaxBuildCols = 4;
-constexpr int64_t kFjEpilogueMaxChunks = 8192;   // probe launches of up to 8192 one-tile chunks (6.3 M rows at 768-row tiles) end pass 1 with the epilogue
+constexpr int64_t kFjEpilogueMaxChunks = 2048;   // probe launches of up to 2048 tiles (1.5 M rows at 768-row tiles; always one-tile chunks) end pass 1 with the epilogue
 
 class LookupSourceGpu;
 
@@ -170,7 +170,7 @@ public:
 
 private:
     void generate();
-    struct JitModule *module_for(int prefilter_kind, bool no_nulls, bool carry);
+    struct JitModule *module_for(int prefilter_kind, bool no_nulls, bool carry, bool epilogue);
     std::mutex mu_;
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
@@ -180,7 +180,7 @@ private:
     int32_t join_channel_;
     bool supported_ = false;
     std::string source_;
-    std::shared_ptr<JitModule> modules_[16];   // layout (4) x no-null-vectors (2) x carry (2)
+    std::shared_ptr<JitModule> modules_[32];   // layout (4) x no-null-vectors (2) x carry (2) x page variant with the epilogue (2)
     bool carry_supported_ = false;
 };
 
