@@ -1156,7 +1156,8 @@ def sub_group_by_hash(b, steps, warmup, rows, groups):
     step_s, prof = b.timed(step, steps, warmup)
     want = int(torch.unique(keys).numel())
     # gbh_insert per row: key 8 B + one 8-byte table word + the 4-byte group id it answers with
-    roof = dominant(prof, steps, {"gbh_insert": rows}, {"gbh_insert": 20.0}, pmc_prefix="sub_group_by_hash:")
+    shape = f"{rows // 1_000_000}M_{groups // 1_000_000}M"
+    roof = dominant(prof, steps, {"gbh_insert": rows}, {"gbh_insert": 20.0}, pmc_prefix=f"sub_group_by_hash_{shape}:")
     return {"workload": f"BenchmarkGroupByHash.bigintGroupByHash shape: addPage of {rows} BIGINT keys uniform in [0, {groups}) + appendValuesTo of every group",
             "rows": rows, "groups": want, "ms_per_step": step_s * 1e3, "rows_per_sec": rows / step_s, "ns_per_row": step_s * 1e9 / rows,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
@@ -1273,7 +1274,7 @@ def cpu_baseline(bench, sample_sf):
                       f"(one operator instance per row-range shard, partial -> final aggregation) {dtt:.1f} s; reference Java operators not runnable: no JVM"}
 
 
-PMC_PROFILES = ["r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"]   # newest first
+PMC_PROFILES = ["r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_v5_pmc_traffic.json"]   # newest first
 
 
 def dominant(profile, steps, rows_per_step, bytes_per_row, pmc_prefix=""):
