@@ -52,6 +52,9 @@ public final class GpuNative
     public static native void setMaxOutputPage(long context, long maxBytes, long maxRows);
     /** 0 = EXACT (correctly rounded sums), 1 = JAVA (row order, bit-identical to DoubleSumAggregation); tgpu_context_set_double_sum_order */
     public static native void setDoubleSumOrder(long context, int order);
+    /** the embedding's promise that device blocks it passes with addInput stay untouched until the operator has finished: lets the fused
+     * operators keep such pages by reference after the call (tgpu_context_set_device_input_stable); pages of this library never need it */
+    public static native void setDeviceInputStable(long context, boolean stable);
     public static native void profileEnable(long context, boolean enabled);
     public static native String profileDump(long context);
 

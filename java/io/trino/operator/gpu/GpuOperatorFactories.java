@@ -53,6 +53,16 @@ public final class GpuOperatorFactories
         GpuNative.setDoubleSumOrder(context, javaOrder ? 1 : 0);
     }
 
+    /**
+     * The promise that device blocks this embedding passes to addInput stay untouched until the operator that took them has finished
+     * (a device-resident connector whose stripes live as long as the split): lets the fused aggregation / join keep such pages by reference.
+     * Pages of the library itself (DevicePageHandle) never need it.
+     */
+    public void setDeviceInputStable(boolean stable)
+    {
+        GpuNative.setDeviceInputStable(context, stable);
+    }
+
     private static int[] ints(List<Integer> values)
     {
         return values.stream().mapToInt(Integer::intValue).toArray();

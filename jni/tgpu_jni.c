@@ -162,6 +162,8 @@ JFN(void, setMaxOutputPage)(JNIEnv *env, jclass c, jlong ctx, jlong maxBytes, jl
 { UNUSED(c); int32_t rc = tgpu_context_set_max_output_page(H(tgpu_context, ctx), maxBytes, maxRows); if (rc < 0) throw_native(env, rc); }
 JFN(void, setDoubleSumOrder)(JNIEnv *env, jclass c, jlong ctx, jint order)
 { UNUSED(c); int32_t rc = tgpu_context_set_double_sum_order(H(tgpu_context, ctx), order); if (rc < 0) throw_native(env, rc); }
+JFN(void, setDeviceInputStable)(JNIEnv *env, jclass c, jlong ctx, jboolean stable)
+{ UNUSED(c); int32_t rc = tgpu_context_set_device_input_stable(H(tgpu_context, ctx), stable ? 1 : 0); if (rc < 0) throw_native(env, rc); }
 JFN(void, profileEnable)(JNIEnv *env, jclass c, jlong ctx, jboolean enabled)
 { UNUSED(c); int32_t rc = tgpu_profile_enable(H(tgpu_context, ctx), enabled ? 1 : 0); if (rc < 0) throw_native(env, rc); }
 /* the per-kernel timings as a JSON string (OperatorInfo of the GPU operators) */
