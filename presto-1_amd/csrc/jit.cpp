@@ -1112,11 +1112,11 @@ __device__ inline long long fj_region_base(long long b, long long tiles, long lo
 // compacts / writes the pairs of tile it-3, whose slots arrived during the previous iteration.  One memory round trip per
 // iteration instead of three (vmcnt is in-order on CDNA: a wait for a dependent load would also wait for every prefetch
 // issued before it, so "prefetch, then probe" inside one iteration cannot overlap).
-extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
+__device__ __forceinline__ void fj_probe_body(const FjArgs& J, const unsigned int bid, const unsigned int nblk) {
   const FpArgs& A = J.fp;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __shared__ int C[2][4];   // pairs of each wave, double-buffered by tile parity (one barrier per tile)
-  const long long region = fj_region_base(blockIdx.x, J.tiles, gridDim.x, J.chunk_shift);
+  const long long region = fj_region_base(bid, J.tiles, nblk, J.chunk_shift);
   long long local = 0;      // pairs this block has written so far (uniform across the block)
   unsigned int selected = 0;   // per lane: rows that passed the filter (a lane sees fewer than 2^31 rows)
   // Row layout of a tile: wave w owns the contiguous rows [w * 64 * FJ_STRIPES, (w + 1) * 64 * FJ_STRIPES) of the tile and its
@@ -1131,8 +1131,8 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
   const int csh = J.chunk_shift;
   const long long cmask = (1LL << csh) - 1;
   const long long chunks = (J.tiles + cmask) >> csh;
-  const long long my_tiles = chunks > (long long)blockIdx.x ? ((chunks - blockIdx.x + gridDim.x - 1) / gridDim.x) << csh : 0;   // incl. tiles past the end
-  auto tile_of = [&](long long j) -> long long { return ((((j >> csh) * gridDim.x) + blockIdx.x) << csh) + (j & cmask); };
+  const long long my_tiles = chunks > (long long)bid ? ((chunks - bid + nblk - 1) / nblk) << csh : 0;   // incl. tiles past the end
+  auto tile_of = [&](long long j) -> long long { return ((((j >> csh) * nblk) + bid) << csh) + (j & cmask); };
   long long chunk_local0 = 0;   // `local` at the start of the chunk being compacted
   TgRow rw[FJ_STRIPES];                                                                                            // stage A -> B
   long long pkey[FJ_STRIPES]; unsigned int psidx[FJ_STRIPES]; unsigned long long pbw[FJ_STRIPES];                      // B -> C
@@ -1420,7 +1420,7 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 #if !FJ_EPILOGUE
   if (threadIdx.x == 0) {
     const unsigned long long block_total = S[0] + S[1] + S[2] + S[3];
-    if (block_total) atomicAdd(&J.counters[(blockIdx.x % FJ_COUNT_SLOTS) * 16], block_total);
+    if (block_total) atomicAdd(&J.counters[(bid % FJ_COUNT_SLOTS) * 16], block_total);
   }
 }
 #else
@@ -1437,11 +1437,11 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
     const unsigned long long block_total = S[0] + S[1] + S[2] + S[3];
     S_last = 0;
     if (!J.host_out) {
-      if (block_total) atomicAdd(&J.counters[(blockIdx.x % FJ_COUNT_SLOTS) * 16], block_total);
+      if (block_total) atomicAdd(&J.counters[(bid % FJ_COUNT_SLOTS) * 16], block_total);
     } else {
-      const unsigned int slot = blockIdx.x % FJ_COUNT_SLOTS;
-      const unsigned int in_slot = (gridDim.x - slot + FJ_COUNT_SLOTS - 1) / FJ_COUNT_SLOTS;          // workgroups that count into this slot
-      const unsigned int live_slots = gridDim.x < FJ_COUNT_SLOTS ? gridDim.x : FJ_COUNT_SLOTS;
+      const unsigned int slot = bid % FJ_COUNT_SLOTS;
+      const unsigned int in_slot = (nblk - slot + FJ_COUNT_SLOTS - 1) / FJ_COUNT_SLOTS;          // workgroups that count into this slot
+      const unsigned int live_slots = nblk < FJ_COUNT_SLOTS ? nblk : FJ_COUNT_SLOTS;
       const unsigned long long before = atomicAdd(&J.counters[slot * 16], block_total + (1ULL << 48));
       if ((unsigned int)(before >> 48) + 1u == in_slot) S_last = (atomicAdd(J.done, 1u) + 1u == live_slots) ? 1 : 0;
     }
@@ -1497,12 +1497,14 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) {
 }
 #endif
 
+extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) { fj_probe_body(J, blockIdx.x, gridDim.x); }
+
 // pass 2: one workgroup per chunk: moves the chunk's pairs to their final position and evaluates the probe-side output
 // projections for the matching rows only
-extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
+__device__ __forceinline__ void fj_emit_body(const FjArgs& J, const unsigned int bid, const unsigned int nblk) {
   const FpArgs& A = J.fp;
   const long long chunks = (J.tiles + (1LL << J.chunk_shift) - 1) >> J.chunk_shift;
-  for (long long chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+  for (long long chunk = bid; chunk < chunks; chunk += nblk) {
     const int cnt = J.tile_cnt[chunk];
     if (cnt == 0) continue;
     const long long src = fj_region_base(chunk % J.grid1, J.tiles, J.grid1, J.chunk_shift) + J.tile_src[chunk];
@@ -1538,6 +1540,17 @@ extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) {
     }
   }
 }
+extern "C" __global__ void __launch_bounds__(256) fj_emit(FjArgs J) { fj_emit_body(J, blockIdx.x, gridDim.x); }
+#if FJ_EPILOGUE
+// One launch for two pages of a page-at-a-time probe: pass 2 of an EARLIER page (its totals have reached the host) next to pass 1 of the NEW
+// page.  Both are chains of dependent memory round trips that one page cannot fill the chip with (17.7 and 9.6 us for a 2^20-row page);
+// side by side in one grid they overlap.  The probe's workgroups come first (they run longer).
+struct FjPairArgs { FjArgs probe; FjArgs emit; unsigned int probe_blocks; unsigned int pad; };
+extern "C" __global__ void __launch_bounds__(256) fj_pair(FjPairArgs P) {
+  if (blockIdx.x < P.probe_blocks) fj_probe_body(P.probe, blockIdx.x, P.probe_blocks);
+  else fj_emit_body(P.emit, blockIdx.x - P.probe_blocks, gridDim.x - P.probe_blocks);
+}
+#endif
 )SRC";
 
 }  // namespace
@@ -1764,7 +1777,7 @@ static std::string prefilter_source(const std::string &src, int variant)
     static const char *layout[4] = {"plain", "bitmap", "bloom", "direct"};
     const std::string l = layout[variant % 4];
     return "#define FJ_PF " + std::to_string(variant % 4) + "\n#define FJ_NO_NULLS " + std::to_string((variant / 4) % 2) + "\n#define FJ_CARRY " + std::to_string((variant / 8) % 2) +
-           "\n#define FJ_EPILOGUE " + std::to_string(variant / 16) + "\n#define fj_probe fj_probe_" + l +
+           "\n#define FJ_EPILOGUE " + std::to_string(variant / 16) + "\n#define fj_pair fj_pair_" + l + "\n#define fj_probe fj_probe_" + l +
            "\n#define fj_emit fj_emit_" + l + "\n" + src;
 }
 
@@ -1800,6 +1813,8 @@ struct FusedProbeGpu::Pending {
     std::vector<BufferPtr> carry_regions;
     Context::AsyncRead read;
     Context::Signal signal;   // epilogue path: the kernel delivers the totals itself
+    int64_t grid1 = 0, emit_blocks = 0;
+    bool probe_launched = false;
 };
 
 void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions,
@@ -1810,7 +1825,7 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
     finish(ctx, p, in, probe_out, build_idx, count, selected_rows, build_cols, build_out);
 }
 
-std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions)
+std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, bool launch)
 {
     TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
     TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
@@ -1929,25 +1944,73 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
             J.carry_nulls = carry_regions.back()->as<uint8_t>();
         }
     }
+    pend->grid1 = grid1;
+    pend->tile_cnt = tile_cnt; pend->tile_src = tile_src; pend->tile_dst = tile_dst; pend->misc = misc; pend->pair_probe = pair_probe; pend->pair_build = pair_build;
+    // (launch == false: the caller puts pass 1 into one launch with another page's pass 2, launch_pair; only the page variant can)
+    if (launch || !epilogue) launch_probe(ctx, pend);
+    signal_guard.armed = false;
+    return pend;
+}
+
+void FusedProbeGpu::launch_probe(Context *ctx, const std::shared_ptr<Pending> &pend)
+{
+    static const char *probe_names[4] = {"fj_probe_plain", "fj_probe_bitmap", "fj_probe_bloom", "fj_probe_direct"};
+    if (!pend || pend->probe_launched) return;
+    FjArgs &J = pend->J;
     {
         ProfileScope ps(ctx, "fused_filter_probe");
-        launch_args(module->fn(probe_names[pf_kind]), (int)grid1, J, ctx->stream());
+        launch_args(pend->module->fn(probe_names[pend->pf_kind]), (int)pend->grid1, J, ctx->stream());
     }
-    signal_guard.armed = false;
-    pend->tile_cnt = tile_cnt; pend->tile_src = tile_src; pend->tile_dst = tile_dst; pend->misc = misc; pend->pair_probe = pair_probe; pend->pair_build = pair_build;
-    if (!epilogue) {
+    pend->probe_launched = true;
+    if (pend->signal.slot < 0) {
         {
             ProfileScope ps(ctx, "fused_probe_scan");
-            k::exclusive_scan_i32(ctx, J.tile_cnt, tile_dst->as<int32_t>(), chunks, (int64_t *)(misc->as<unsigned long long>() + 2));
+            k::exclusive_scan_i32(ctx, J.tile_cnt, pend->tile_dst->as<int32_t>(), pend->chunks, (int64_t *)(pend->misc->as<unsigned long long>() + 2));
         }
-        pend->read = ctx->begin_read(misc->ptr(), (size_t)kFjMiscWords * 8);
+        pend->read = ctx->begin_read(pend->misc->ptr(), (size_t)kFjMiscWords * 8);
     }
-    return pend;
+}
+
+bool FusedProbeGpu::can_pair(const std::shared_ptr<Pending> &emit_side, const std::shared_ptr<Pending> &probe_side) const
+{
+    return emit_side && probe_side && emit_side->module == probe_side->module && emit_side->pf_kind == probe_side->pf_kind && emit_side->emit_blocks > 0 &&
+           !probe_side->probe_launched && probe_side->signal.slot >= 0 && getenv("TGPU_DISABLE_PROBE_PAIRING") == nullptr;
+}
+
+// pass 2 of `emit_side` (prepared: finish(..., launch = false)) and pass 1 of `probe_side` (prepared: begin(..., launch = false)) in one launch
+void FusedProbeGpu::launch_pair(Context *ctx, const std::shared_ptr<Pending> &emit_side, const std::shared_ptr<Pending> &probe_side)
+{
+    static const char *pair_names[4] = {"fj_pair_plain", "fj_pair_bitmap", "fj_pair_bloom", "fj_pair_direct"};
+    TG_CHECK_STATE(can_pair(emit_side, probe_side), "these two pages cannot share a launch");
+    struct FjPairArgs {
+        FjArgs probe, emit;
+        unsigned int probe_blocks, pad;
+    } P{probe_side->J, emit_side->J, (unsigned int)probe_side->grid1, 0u};
+    {
+        ProfileScope ps(ctx, "fused_probe_pair");
+        launch_args(probe_side->module->fn(pair_names[probe_side->pf_kind]), (int)(probe_side->grid1 + emit_side->emit_blocks), P, ctx->stream());
+    }
+    probe_side->probe_launched = true;
+    emit_side->emit_blocks = 0;   // (launched)
+}
+
+void FusedProbeGpu::launch_emit(Context *ctx, const std::shared_ptr<Pending> &pend)
+{
+    static const char *emit_names[4] = {"fj_emit_plain", "fj_emit_bitmap", "fj_emit_bloom", "fj_emit_direct"};
+    if (!pend || pend->emit_blocks <= 0) return;
+    ProfileScope ps(ctx, "fused_probe_emit");
+    launch_args(pend->module->fn(emit_names[pend->pf_kind]), (int)pend->emit_blocks, pend->J, ctx->stream());
+    pend->emit_blocks = 0;
 }
 
 void FusedProbeGpu::cancel(Context *ctx, const std::shared_ptr<Pending> &pend)
 {
     if (!pend) return;
+    if (!pend->probe_launched) {   // prepared only: no kernel will ever write the slot
+        ctx->abandon_signal(pend->signal);
+        pend->signal.slot = -1;
+        return;
+    }
     if (pend->signal.slot >= 0) {
         unsigned long long words[Context::kSignalWords];
         ctx->finish_signal(pend->signal, words);   // waits: the kernel still owns the slot until it has written it
@@ -1959,18 +2022,16 @@ void FusedProbeGpu::cancel(Context *ctx, const std::shared_ptr<Pending> &pend)
 }
 
 void FusedProbeGpu::finish(Context *ctx, const std::shared_ptr<Pending> &pend, const DevicePage &in, std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count,
-                           int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols, std::vector<DeviceColumn> *build_out)
+                           int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols, std::vector<DeviceColumn> *build_out, bool launch)
 {
     count = 0;
     selected_rows = 0;
     probe_out.clear();
     if (!pend) return;
     FjArgs &J = pend->J;
-    JitModule *module = pend->module;
-    const int pf_kind = pend->pf_kind;
     const int64_t chunks = pend->chunks;
     const bool outer = pend->outer, need_build_positions = pend->need_build_positions;
-    static const char *emit_names[4] = {"fj_emit_plain", "fj_emit_bitmap", "fj_emit_bloom", "fj_emit_direct"};
+    TG_CHECK_STATE(pend->probe_launched, "pass 1 of this page has not been launched");
     if (pend->signal.slot >= 0) {
         unsigned long long words[Context::kSignalWords];
         Context::Signal sig = pend->signal;
@@ -2032,11 +2093,8 @@ void FusedProbeGpu::finish(Context *ctx, const std::shared_ptr<Pending> &pend, c
             build_out->push_back(c);
         }
     }
-    {
-        ProfileScope ps(ctx, "fused_probe_emit");
-        int64_t blocks = std::min<int64_t>(chunks, (int64_t)ctx->cu_count() * 8);
-        launch_args(module->fn(emit_names[pf_kind]), (int)blocks, J, ctx->stream());
-    }
+    pend->emit_blocks = std::min<int64_t>(chunks, (int64_t)ctx->cu_count() * 8);
+    if (launch) launch_emit(ctx, pend);   // (else: the caller launches it, alone or paired with the next page's pass 1)
     // no second error read-back: the projections evaluated by pass 2 cannot raise (the constructor keeps anything with checked
     // integer arithmetic on the unfused path), and pass 1's filter / key errors were raised above
 }

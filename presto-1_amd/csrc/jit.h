@@ -162,9 +162,15 @@ public:
     // the same in two halves: begin() launches pass 1 and the read-back of its totals, finish() waits for that read and launches pass 2.  `in`
     // and the lookup source must stay alive and unchanged in between (null from begin() = empty page)
     struct Pending;
-    std::shared_ptr<Pending> begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions);
+    std::shared_ptr<Pending> begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, bool launch = true);
     void finish(Context *ctx, const std::shared_ptr<Pending> &pending, const DevicePage &in, std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count,
-                int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols = nullptr, std::vector<DeviceColumn> *build_out = nullptr);
+                int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols = nullptr, std::vector<DeviceColumn> *build_out = nullptr, bool launch = true);
+    // launch == false leaves the pass to the caller: launch_probe / launch_emit alone, or launch_pair = an earlier page's pass 2 and a new page's
+    // pass 1 in ONE launch (page variant of the kernels only: can_pair) -- two latency-bound grids side by side instead of one after the other
+    void launch_probe(Context *ctx, const std::shared_ptr<Pending> &pending);
+    void launch_emit(Context *ctx, const std::shared_ptr<Pending> &pending);
+    bool can_pair(const std::shared_ptr<Pending> &emit_side, const std::shared_ptr<Pending> &probe_side) const;
+    void launch_pair(Context *ctx, const std::shared_ptr<Pending> &emit_side, const std::shared_ptr<Pending> &probe_side);
     void cancel(Context *ctx, const std::shared_ptr<Pending> &pending);   // a begun page nobody will finish (operator closed early)
     const std::string &source() const { return source_; }
 

@@ -1172,14 +1172,16 @@ public:
     ~FusedFilterProjectJoinOperator() override { close(); }
 
     bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
-    bool needs_input() override { return !finishing_ && ready_.empty() && (int)inflight_.size() < kDepth && !is_blocked(); }
+    bool needs_input() override { return !finishing_ && ready_.empty() && (int)inflight_.size() <= kDepth && !is_blocked(); }
 
-    // Pages of up to kAsyncBelowRows rows are probed asynchronously: add_input launches pass 1 and the read-back of its output row count,
-    // get_output hands the page's output over once a SECOND page is in flight (or the operator is finishing) -- by then the read-back has
-    // completed behind the second page's pass 1, so nobody waits for the device on the common path.  The Operator contract allows exactly
-    // this (getOutput() may return null whenever it likes; Driver.processInternal polls).  It needs the input page to stay alive between the
-    // two calls: library-owned pages (another operator's output, an ingested host page) are kept by reference, borrowed device blocks only
-    // qualify under tgpu_context_set_device_input_stable.  An expression error of page i is raised by the get_output that completes it.
+    // Pages of up to kAsyncBelowRows rows are probed asynchronously, kDepth pages deep: add_input prepares pass 1 of the new page and -- once
+    // kDepth pages are in flight -- pass 2 of the OLDEST one, whose totals reached the host (through its signal slot) while its successor ran,
+    // and puts both into ONE launch (FusedProbeGpu::launch_pair: two latency-bound grids side by side); get_output then hands out the oldest
+    // page's output.  So a page's output appears kDepth add_inputs later -- or at finish(), or when the driver polls get_output twice without
+    // bringing input (a slow source must not keep finished work back).  The Operator contract allows exactly this (getOutput() may return
+    // null whenever it likes; Driver.processInternal polls).  It needs the input pages to stay alive in between: library-owned pages (another
+    // operator's output, an ingested host page) are kept by reference, borrowed device blocks only qualify under
+    // tgpu_context_set_device_input_stable.  An expression error of a page is raised by the call that completes it.
     static constexpr int kDepth = 2;
     static constexpr int64_t kAsyncBelowRows = 1ll << 22;
 
@@ -1189,7 +1191,7 @@ public:
     void add_page(const tgpu_page *page, const DevicePage *owned)
     {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
-        TG_CHECK_STATE(ready_.empty() && (int)inflight_.size() < kDepth, "Operator still has pending output");
+        TG_CHECK_STATE(ready_.empty() && (int)inflight_.size() <= kDepth, "Operator still has pending output");
         std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
         DevicePage in = owned ? DevicePage(*owned) : ingest_page(ctx_, page);
@@ -1214,10 +1216,27 @@ public:
                 f.gather_fused = f.build_cols.back().type != TGPU_VARCHAR && f.build_cols.back().values != nullptr;
             }
             const bool async = in.n <= kAsyncBelowRows && page_is_retained(ctx_, in) && getenv("TGPU_DISABLE_ASYNC_JOIN") == nullptr;
-            f.pending = fused_->begin(ctx_, in, *source, outer, f.need_positions);
+            polls_since_input_ = 0;
+            if (!async) {
+                complete_all();
+                f.pending = fused_->begin(ctx_, in, *source, outer, f.need_positions);
+                f.in = std::move(in);
+                inflight_.push_back(std::move(f));
+                complete_all();
+                return;
+            }
+            f.pending = fused_->begin(ctx_, in, *source, outer, f.need_positions, /*launch=*/false);
             f.in = std::move(in);
+            if ((int)inflight_.size() >= kDepth) {
+                try {
+                    complete_oldest(&f.pending);   // its pass 2 shares the launch with this page's pass 1 when the two can pair
+                } catch (...) {
+                    fused_->cancel(ctx_, f.pending);
+                    throw;
+                }
+            }
+            fused_->launch_probe(ctx_, f.pending);   // (no-op when the pair launch carried it)
             inflight_.push_back(std::move(f));
-            if (!async) complete_all();
             return;
         }
         complete_all();
@@ -1230,7 +1249,9 @@ public:
 
     std::unique_ptr<OutputPage> get_output() override
     {
-        while (ready_.empty() && !inflight_.empty() && ((int)inflight_.size() >= kDepth || finishing_)) complete_oldest();
+        // in flight stays in flight while the driver keeps bringing pages; a second poll without input in between, or finish(), completes it
+        if (ready_.empty() && !inflight_.empty() && !finishing_) polls_since_input_++;
+        while (ready_.empty() && !inflight_.empty() && (finishing_ || polls_since_input_ >= 2)) complete_oldest(nullptr);
         if (ready_.empty()) return nullptr;
         std::unique_ptr<OutputPage> out = std::move(ready_.front());
         ready_.pop_front();
@@ -1271,18 +1292,21 @@ private:
     };
     void complete_all()
     {
-        while (!inflight_.empty()) complete_oldest();
+        while (!inflight_.empty()) complete_oldest(nullptr);
     }
-    void complete_oldest()
+    // pass 2 of the oldest page in flight; with `partner` (a prepared, not yet launched page) in one launch with the partner's pass 1
+    void complete_oldest(const std::shared_ptr<FusedProbeGpu::Pending> *partner)
     {
         InFlight f = std::move(inflight_.front());
         inflight_.pop_front();
         std::vector<DeviceColumn> probe_out, build_out;
         BufferPtr build_idx;
         int64_t count = 0, selected = 0;
-        fused_->finish(ctx_, f.pending, f.in, probe_out, build_idx, count, selected, f.gather_fused ? &f.build_cols : nullptr, f.gather_fused ? &build_out : nullptr);
+        fused_->finish(ctx_, f.pending, f.in, probe_out, build_idx, count, selected, f.gather_fused ? &f.build_cols : nullptr, f.gather_fused ? &build_out : nullptr, /*launch=*/false);
         probe_rows_ += selected;
         if (count == 0) return;
+        if (partner && fused_->can_pair(f.pending, *partner)) fused_->launch_pair(ctx_, f.pending, *partner);
+        else fused_->launch_emit(ctx_, f.pending);
         if (f.track) f.source->mark_visited(build_idx->as<int32_t>(), count);
         DevicePage out;
         out.n = count;
@@ -1302,6 +1326,7 @@ private:
     std::shared_ptr<FusedProbeGpu> fused_;
     std::deque<InFlight> inflight_;
     std::deque<std::unique_ptr<OutputPage>> ready_;
+    int polls_since_input_ = 0;
     int64_t probe_rows_ = 0;
     bool finishing_ = false, closed_ = false;
 };

@@ -769,9 +769,10 @@ def test_fused_filter_probe_tile_and_chunk_boundaries(pkg, ctx, oracle, n):
 
 @pytest.mark.parametrize("join_type", [0, 1])
 def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monkeypatch):
-    """Probe pages of up to 2^22 rows are probed asynchronously (operators.cpp FusedFilterProjectJoinOperator): addInput launches the probe
-    and the read-back of its counts, getOutput returns null until a second page is in flight or finish() was called.  Same rows in the same
-    order as the synchronous protocol (TGPU_DISABLE_ASYNC_JOIN) and as the oracle, empty pages and pages without a match included."""
+    """Probe pages of up to 2^22 rows are probed asynchronously, two pages deep (operators.cpp FusedFilterProjectJoinOperator): addInput
+    launches pass 1 of the new page together with pass 2 of the page before last (one launch for both), getOutput returns null until a
+    page's successors have been added or finish() was called.  Same rows in the same order as the synchronous protocol
+    (TGPU_DISABLE_ASYNC_JOIN), as separate launches (TGPU_DISABLE_PROBE_PAIRING) and as the oracle, empty pages and pages without a match included."""
     rng = np.random.default_rng(211)
     bkeys = rng.permutation(50_000)[:20_000].astype(np.int64)
     f, c = pkg.field, pkg.constant
@@ -779,10 +780,13 @@ def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monk
     pages = [pkg.Page(pkg.Block(pkg.BIGINT, rng.integers(0, 60_000, n).astype(np.int64)), pkg.Block(pkg.DATE, rng.integers(9000, 9400, n).astype(np.int32))) for n in sizes]
     pages[4] = pkg.Page(pkg.Block(pkg.BIGINT, np.full(300, 10**9, dtype=np.int64)), pkg.Block(pkg.DATE, np.full(300, 9300, dtype=np.int32)))   # no match at all
     got = {}
-    for mode in ("async", "sync"):
+    for mode in ("async", "unpaired", "sync"):
+        if mode == "unpaired":
+            monkeypatch.setenv("TGPU_DISABLE_PROBE_PAIRING", "1")
         if mode == "sync":
             monkeypatch.setenv("TGPU_DISABLE_ASYNC_JOIN", "1")
         ctx = pkg.Context(0)
+        ctx.profile_enable(True)
         bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT], [0], [0])
         b = bf.createOperator()
         b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, bkeys)))
@@ -799,7 +803,7 @@ def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monk
                 nulls_seen += 1
             else:
                 outs.append(o.to_host()); o.release()
-            if mode == "async" and i == 0:
+            if mode != "sync" and i == 0:
                 assert o is None and op.needsInput()     # one page in flight: nothing to hand over yet, room for the next page
         op.finish()
         assert not op.needsInput()
@@ -810,8 +814,9 @@ def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monk
         got[mode] = [r for pg in outs for r in pg.rows()]
         if mode == "sync":
             assert 1 <= nulls_seen <= 3       # the empty page; the one-row page if the filter drops it; inner join: the page without a match
+        assert ("fused_probe_pair" in ctx.profile()) == (mode == "async")
         op.close(); b.close(); ctx.close()
-    assert got["async"] == got["sync"]
+    assert got["async"] == got["sync"] == got["unpaired"]
     ph = oracle.PagesHash([oracle.Col(pkg.BIGINT, bkeys)])
     want = []
     for pg in pages:
@@ -847,14 +852,23 @@ def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(p
     op.addInput(good)
     assert op.getOutput() is None
     op.addInput(page)                       # second column holds a zero
+    assert op.getOutput() is None           # two pages in flight: nothing is handed out while the driver keeps bringing pages
+    op.finish()
     o = op.getOutput()
     assert o is not None and o.position_count == 50
     o.release()
-    op.finish()
     with pytest.raises(pkg.TgpuError) as e:
         op.getOutput()
     assert e.value.code == -7               # DIVISION_BY_ZERO
     assert op.isFinished()
+    op.close()
+    # a driver that polls twice without bringing a page gets what is in flight (a slow source does not hold finished work back)
+    op = jf.createOperator()
+    op.addInput(page)
+    assert op.getOutput() is None
+    o = op.getOutput()
+    assert o is not None and o.position_count == 50
+    o.release()
     op.close(); b.close()
 
 
