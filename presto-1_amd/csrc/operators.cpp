@@ -414,7 +414,7 @@ protected:
     // are appended to a device column store (ONE launch per page, no read-back: fixed-width channels only) and processed as one page once
     // kCoalesceFlushRows rows are there -- or when the operator's state is needed (finish, output, revoke).  Rows keep their order, so
     // group ids and row-order sums are those of the unmerged stream.  Not for PARTIAL steps (their memory limit is checked per page).
-    static constexpr int64_t kCoalesceBelowRows = 1 << 16, kCoalesceFlushRows = 1 << 20;
+    static constexpr int64_t kCoalesceBelowRows = 1 << 20, kCoalesceFlushRows = 1 << 22;
     bool coalesce(const DevicePage &in)
     {
         if (!gbh_ || cfg_.step == TGPU_STEP_PARTIAL || getenv("TGPU_DISABLE_COALESCE")) return false;
@@ -1174,7 +1174,7 @@ public:
     bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
     bool needs_input() override { return !finishing_ && ready_.empty() && (int)inflight_.size() <= kDepth && !is_blocked(); }
 
-    // Pages of up to kAsyncBelowRows rows are probed asynchronously, kDepth pages deep: add_input prepares pass 1 of the new page and -- once
+    // Pages of up to kAsyncBelowRows (2^25) rows are probed asynchronously, kDepth pages deep: add_input prepares pass 1 of the new page and -- once
     // kDepth pages are in flight -- pass 2 of the OLDEST one, whose totals reached the host (through its signal slot) while its successor ran,
     // and puts both into ONE launch (FusedProbeGpu::launch_pair: two latency-bound grids side by side); get_output then hands out the oldest
     // page's output.  So a page's output appears kDepth add_inputs later -- or at finish(), or when the driver polls get_output twice without
@@ -1183,7 +1183,7 @@ public:
     // operator's output, an ingested host page) are kept by reference, borrowed device blocks only qualify under
     // tgpu_context_set_device_input_stable.  An expression error of a page is raised by the call that completes it.
     static constexpr int kDepth = 2;
-    static constexpr int64_t kAsyncBelowRows = 1ll << 22;
+    static constexpr int64_t kAsyncBelowRows = 1ll << 25;
 
     void add_input(const tgpu_page *page) override { add_page(page, nullptr); }
     void add_input_owned(const DevicePage &page) override { add_page(nullptr, &page); }   // (keeps the page's buffers: it may stay in flight)
