@@ -125,11 +125,12 @@ int32_t tgpu_set_resource_dir(const char *dir);
 int32_t tgpu_context_set_max_output_page(tgpu_context *ctx, int64_t max_bytes, int64_t max_rows);
 
 /* A promise about borrowed TGPU_DEVICE input (hosts that keep their own HBM buffers; library-owned pages and host pages need none): the
- * blocks of a page stay valid and UNCHANGED until the operator's next call (add_input / finish / get_output after finish) has returned,
- * instead of "until overwritten in stream order".  It lets the fused aggregation run one launch per page without waiting for the page's
- * counters: a page that turns out to carry a new group is re-run from its blocks one call later (DESIGN.md "Page granularity").  Java
- * pages are immutable and referenced by the operator for as long as it needs them (Operator.addInput transfers a reference,
- * SURVEY.md 8b "Ownership"): this is the device-memory counterpart of that rule.  Default off. */
+ * blocks of a page stay valid and UNCHANGED until the operator they were handed to is finished (tgpu_operator_is_finished) or closed,
+ * instead of "until overwritten in stream order".  It lets the operators that keep input BY REFERENCE do so with such pages: the fused
+ * aggregation collects small pages for one launch and re-runs a page whose launch met a new group, the fused join keeps two probe pages in
+ * flight (DESIGN.md "Page granularity").  Java pages are immutable and referenced by the operator for as long as it needs them
+ * (Operator.addInput transfers a reference, SURVEY.md 8b "Ownership"): this is the device-memory counterpart of that rule.  Default off:
+ * borrowed device pages then take the synchronous protocol. */
 int32_t tgpu_context_set_device_input_stable(tgpu_context *ctx, int32_t stable);
 
 typedef enum tgpu_double_sum_order { TGPU_SUM_ORDER_EXACT = 0, TGPU_SUM_ORDER_JAVA = 1 } tgpu_double_sum_order;
@@ -270,7 +271,11 @@ int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, 
  * LocalExecutionPlanner.visitJoin would construct when the probe source is a filter/project node, M/sql/planner/
  * LocalExecutionPlanner.java:1742,2284-2311).  Behaves exactly like the two reference operators back to back:
  * `spec`'s projections form the probe page, and probe_join_channels / probe_hash_channel / probe_output_channels index
- * those projections.  Configurations the fused kernel does not cover run the two steps unfused inside the operator. */
+ * those projections.  Configurations the fused kernel does not cover run the two steps unfused inside the operator.
+ * Pages the operator may keep (library-owned pages, host pages, borrowed device pages under tgpu_context_set_device_input_stable) of up to
+ * 2^25 rows are probed asynchronously, two pages deep: tgpu_operator_get_output returns no page for a page until two more pages have been
+ * added, tgpu_operator_finish was called or get_output is polled twice without input in between (Operator.getOutput may return null,
+ * M/operator/Operator.java:53-79); an expression error of such a page is returned by the call that completes it. */
 int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge,
                                                        int32_t input_type_count, const int32_t *input_types,
                                                        const tgpu_page_processor_spec *spec,
