@@ -1084,6 +1084,10 @@ struct FjArgs {
   unsigned char* carry_nulls; // registers for every emitted pair; pass 2 moves them instead of re-reading the input columns sparsely)
   unsigned long long* host_out; // epilogue (small pages): host-visible result words, written by the LAST workgroup of pass 1 (null: none)
   unsigned int* done;           //                         workgroups that have finished (rests at 0)
+  const FpArgs* pages;          // FJ_EPILOGUE == 2 (a launch over a LIST of pages): one FpArgs per page, in device memory
+  const int* page_tile0;        //   first tile of each page in the launch's tile sequence, [n_pages] = all tiles
+  int n_pages;
+  int pad3;
 };
 #define FJ_STRIPES @FJ_STRIPES@
 #define FJ_TILE (FJ_STRIPES * 256)
@@ -1123,7 +1127,9 @@ __device__ __forceinline__ void fj_probe_body(const FjArgs& J, const unsigned in
   // lane reads row s * 64 + lane of them in stripe s (512 contiguous bytes per wave and load).  Input order inside the tile is
   // then (wave, stripe, lane): the compaction needs the other waves' TOTALS only, everything else is wave-local scalar work.
   // Rows are 32-bit here (a page has fewer than 2^31 positions).
+#if FJ_EPILOGUE != 2
   const unsigned int n_rows = (unsigned int)A.n;
+#endif
   const unsigned int wave_row = (unsigned int)w * (64u * FJ_STRIPES) + (unsigned int)lane;
   // The j-th tile this workgroup processes: chunks of 2^chunk_shift CONSECUTIVE tiles are dealt round-robin to the workgroups, so
   // the pairs a workgroup produces for one chunk are contiguous in its region AND in the final (input) order: pass 2 then moves
@@ -1133,6 +1139,26 @@ __device__ __forceinline__ void fj_probe_body(const FjArgs& J, const unsigned in
   const long long chunks = (J.tiles + cmask) >> csh;
   const long long my_tiles = chunks > (long long)bid ? ((chunks - bid + nblk - 1) / nblk) << csh : 0;   // incl. tiles past the end
   auto tile_of = [&](long long j) -> long long { return ((((j >> csh) * nblk) + bid) << csh) + (j & cmask); };
+#if FJ_EPILOGUE == 2
+  // MULTI: the launch covers a list of pages taken as one sequence of tiles (a page starts a tile: J.page_tile0[p] = its first tile); rows
+  // travel through the stages and into the pairs as VIRTUAL rows (tile * FJ_TILE + ...), loads and expressions use the page's own rows.
+  // A workgroup's tiles ascend, so the page cursors of stage A / B only move forward (workgroup-uniform: scalar loads).
+  const FpArgs* __restrict__ pgs = J.pages;
+  const int* __restrict__ pt0 = J.page_tile0;
+  // the descriptor of the page stage A will load from is fetched ONE ITERATION AHEAD (scalar loads: the search of the tile's page and the
+  // page's column pointers are two dependent round trips that would otherwise sit in front of every iteration's row loads)
+  int pN = 0;
+  long long tN = 0;   // tile of the next iteration's stage A (my_tiles == 0: unused)
+  {
+    const long long t0 = tile_of(0);
+    tN = (my_tiles > 0 && t0 < J.tiles) ? t0 : 0;
+    while (tN >= (long long)pt0[pN + 1]) pN++;
+  }
+  FpArgs AN = pgs[pN];    // next stage A's page
+  FpArgs AB = AN;         // this iteration's stage B page (= the previous iteration's stage A page)
+  long long tB0 = 0;      // first tile of that page
+  long long tN0 = pt0[pN];
+#endif
   long long chunk_local0 = 0;   // `local` at the start of the chunk being compacted
   TgRow rw[FJ_STRIPES];                                                                                            // stage A -> B
   long long pkey[FJ_STRIPES]; unsigned int psidx[FJ_STRIPES]; unsigned long long pbw[FJ_STRIPES];                      // B -> C
@@ -1284,19 +1310,25 @@ __device__ __forceinline__ void fj_probe_body(const FjArgs& J, const unsigned in
 #pragma unroll
     for (int s = 0; s < FJ_STRIPES; s++) bidx[s] = 0;
     if (doB) {
+#if FJ_EPILOGUE == 2
+      const unsigned int n_rows = (unsigned int)AB.n;
+      const unsigned int row0 = (unsigned int)((tile_of(jB) - tB0) * FJ_TILE) + wave_row;   // the page's own rows
+#else
+      const FpArgs& AB = A;
       const unsigned int row0 = (unsigned int)(tile_of(jB) * FJ_TILE) + wave_row;
+#endif
 #pragma unroll
       for (int s = 0; s < FJ_STRIPES; s++) {
         const unsigned int row = row0 + s * 64;
         bool sel = false, passed = false;
         long long key = 0;
-        if (row < n_rows && tg_filter(A, row, rw[s])) {
+        if (row < n_rows && tg_filter(AB, row, rw[s])) {
           selected++;
           passed = true;
-          const bool kn = tg_key(A, row, rw[s], key);   // JoinProbe.java:87-97: a null probe key never matches
+          const bool kn = tg_key(AB, row, rw[s], key);   // JoinProbe.java:87-97: a null probe key never matches
           sel = !kn;
 #if FJ_CARRY
-          tg_carry_eval(A, row, rw[s], pov[s]);
+          tg_carry_eval(AB, row, rw[s], pov[s]);
 #endif
         }
         bidx[s] = 0;
@@ -1349,17 +1381,38 @@ __device__ __forceinline__ void fj_probe_body(const FjArgs& J, const unsigned in
 #endif
     }
     {
+#if FJ_EPILOGUE == 2
+      // this iteration's page was fetched by the previous one (idle stage: the same page again, its first tile)
+      const FpArgs AA = AN;
+      const long long tA = doA ? tN : tN0;
+      const unsigned int n_rows = (unsigned int)AA.n;
+      const unsigned int tile_row0 = (unsigned int)((tA - tN0) * FJ_TILE);
+      const unsigned int row0 = tile_row0 + wave_row;
+      AB = AA;      // (stage B of the NEXT iteration works on the rows loaded here; this iteration's stage B has run already)
+      tB0 = tN0;
+      {             // and the page of the next iteration's tile: issued now, needed in an iteration's time
+        const long long jn = jA + 1;
+        if (jn < my_tiles && tile_of(jn) < J.tiles) {
+          tN = tile_of(jn);
+          while (tN >= (long long)pt0[pN + 1]) pN++;
+          tN0 = pt0[pN];
+          AN = pgs[pN];
+        }
+      }
+#else
+      const FpArgs& AA = A;
       const unsigned int row0 = (unsigned int)((doA ? tile_of(jA) : 0LL) * FJ_TILE) + wave_row;
       const unsigned int tile_row0 = (unsigned int)((doA ? tile_of(jA) : 0LL) * FJ_TILE);
+#endif
       if (tile_row0 + FJ_TILE <= n_rows) {   // interior tile: one address per column, the stripes are constant offsets from it
 #pragma unroll
-        for (int s = 0; s < FJ_STRIPES; s++) tg_load_row(A, row0 + s * 64, rw[s]);
+        for (int s = 0; s < FJ_STRIPES; s++) tg_load_row(AA, row0 + s * 64, rw[s]);
       }
       else {
 #pragma unroll
         for (int s = 0; s < FJ_STRIPES; s++) {
           const unsigned int row = row0 + s * 64;
-          tg_load_row(A, row < n_rows ? row : n_rows - 1, rw[s]);
+          tg_load_row(AA, row < n_rows ? row : n_rows - 1, rw[s]);
         }
       }
     }
@@ -1504,13 +1557,35 @@ extern "C" __global__ void __launch_bounds__(256) fj_probe(FjArgs J) { fj_probe_
 __device__ __forceinline__ void fj_emit_body(const FjArgs& J, const unsigned int bid, const unsigned int nblk) {
   const FpArgs& A = J.fp;
   const long long chunks = (J.tiles + (1LL << J.chunk_shift) - 1) >> J.chunk_shift;
-  for (long long chunk = bid; chunk < chunks; chunk += nblk) {
+#if FJ_EPILOGUE == 2
+  int pE = 0;   // page of the chunk (= tile: the multi variant runs one-tile chunks); a wave's chunks ascend
+#endif
+#if FJ_EPILOGUE
+  // page variants: chunks are single tiles with a few dozen pairs each -- one WAVE per chunk (four independent chains of dependent loads
+  // per workgroup instead of one, no idle lanes waiting for 38 pairs); nothing below synchronises across the workgroup
+  const long long first = (long long)bid * 4 + (threadIdx.x >> 6), stride = (long long)nblk * 4;
+  const int lane0 = threadIdx.x & 63, lanes = 64;
+#else
+  const long long first = bid, stride = nblk;
+  const int lane0 = threadIdx.x, lanes = 256;
+#endif
+  for (long long chunk = first; chunk < chunks; chunk += stride) {
     const int cnt = J.tile_cnt[chunk];
     if (cnt == 0) continue;
     const long long src = fj_region_base(chunk % J.grid1, J.tiles, J.grid1, J.chunk_shift) + J.tile_src[chunk];
     const long long dst = J.tile_dst[chunk];
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-      const long long row = J.pair_probe[src + i];
+#if FJ_EPILOGUE == 2
+    while (chunk >= (long long)J.page_tile0[pE + 1]) pE++;
+    FpArgs AE = J.pages[pE];
+#pragma unroll
+    for (int k = 0; k < TG_MAXP; k++) { AE.out_values[k] = J.fp.out_values[k]; AE.out_nulls[k] = J.fp.out_nulls[k]; }   // (allocated after the descriptors went up)
+    const long long row_base = (long long)J.page_tile0[pE] * FJ_TILE;
+#else
+    const FpArgs& AE = A;
+    const long long row_base = 0;
+#endif
+    for (int i = lane0; i < cnt; i += lanes) {
+      const long long row = (long long)J.pair_probe[src + i] - row_base;
 #if FJ_PF == 3
       if (!(J.outer & 2)) {
         const int rank = J.pair_build[src + i];   // rank of the key among the build keys (-1: unmatched row of an outer probe)
@@ -1535,7 +1610,7 @@ __device__ __forceinline__ void fj_emit_body(const FjArgs& J, const unsigned int
       (void)row;
       tg_carry_move(J, src + i, dst + i);
 #else
-      tg_emit_outputs(A, row, dst + i);
+      tg_emit_outputs(AE, row, dst + i);
 #endif
     }
   }
@@ -1786,15 +1861,16 @@ void FusedProbeGpu::precompile()
     if (!supported_) return;
     for (int variant = 0; variant < 8; variant++) {
         (void)code_object_for(prefilter_source(source_, variant));
-        (void)code_object_for(prefilter_source(source_, 16 + variant));   // the page variants (FJ_EPILOGUE)
+        (void)code_object_for(prefilter_source(source_, 16 + variant));   // the page variants (FJ_EPILOGUE 1: one page, 2: a list of pages)
+        (void)code_object_for(prefilter_source(source_, 32 + variant));
     }
     // (the opt-in carry variants, 8 + ..., are compiled on first use)
 }
 
-JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls, bool carry, bool epilogue)
+JitModule *FusedProbeGpu::module_for(int kind, bool no_nulls, bool carry, int epilogue)
 {
     std::lock_guard<std::mutex> lk(mu_);
-    const int variant = kind + (no_nulls ? 4 : 0) + (carry ? 8 : 0) + (epilogue ? 16 : 0);
+    const int variant = kind + (no_nulls ? 4 : 0) + (carry ? 8 : 0) + epilogue * 16;   // epilogue: 0 plain, 1 page, 2 list of pages
     if (!modules_[variant]) modules_[variant] = load_module(prefilter_source(source_, variant));
     return modules_[variant].get();
 }
@@ -1815,6 +1891,9 @@ struct FusedProbeGpu::Pending {
     Context::Signal signal;   // epilogue path: the kernel delivers the totals itself
     int64_t grid1 = 0, emit_blocks = 0;
     bool probe_launched = false;
+    int kernel_variant = 0;        // FJ_EPILOGUE of the module: 0 whole table, 1 one page, 2 list of pages
+    std::vector<bool> col_nulls;   // per input channel: some page of the launch carries a null vector
+    BufferPtr descriptors;         // multi-page launches: the pages' FpArgs + first tiles
 };
 
 void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions,
@@ -1827,13 +1906,31 @@ void FusedProbeGpu::process(Context *ctx, const DevicePage &in, const LookupSour
 
 std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, bool launch)
 {
+    return begin(ctx, std::vector<const DevicePage *>{&in}, source, outer, need_build_positions, launch);
+}
+
+// rows one multi-page launch may cover: 32 768 tiles (the epilogue's scan takes them 2 048 at a time)
+int64_t FusedProbeGpu::multi_page_row_limit() { return kFjMultiMaxTiles * (int64_t)fj_stripes() * 256; }
+
+// `pages`: one page, or several (each non-empty) that are probed as ONE sequence of rows in page order -- one launch, one output page: the
+// kernels' multi variant (FJ_EPILOGUE == 2) reads the pages' column pointers from an array of descriptors.  Several pages need the page
+// variant's conditions (at most kFjMultiMaxTiles tiles in all, a free signal slot); callers check can_batch() first.
+std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const std::vector<const DevicePage *> &pages, const LookupSourceGpu &source, bool outer,
+                                                             bool need_build_positions, bool launch)
+{
     TG_CHECK_STATE(supported_, "fused probe not supported for this configuration");
-    TG_CHECK_ARG(in.cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
+    TG_CHECK_ARG(!pages.empty(), "no page");
+    const DevicePage &in = *pages[0];
+    const bool multi = pages.size() > 1;
+    for (const DevicePage *pg : pages) TG_CHECK_ARG(pg->cols.size() == input_types_.size(), "page channel count differs from the operator's input types");
     if (need_build_positions) source.ensure_rank();
     IntTableView tv;
     TG_CHECK_STATE(source.int_table(tv) && tv.links == nullptr, "fused probe needs the int-key table without duplicate build keys");
     bool any_nulls = false;
-    for (const DeviceColumn &c : in.cols) any_nulls = any_nulls || c.nulls != nullptr;
+    std::vector<bool> col_nulls(in.cols.size(), false);
+    for (const DevicePage *pg : pages)
+        for (size_t i = 0; i < pg->cols.size(); i++)
+            if (pg->cols[i].nulls != nullptr) any_nulls = col_nulls[i] = true;
     // CARRY (generate(), (c)): pass 1 evaluates the probe-side outputs for every row that passes the filter and stores them with the
     // pair, pass 2 moves dense values instead of gathering the input columns at the matching rows.  Built for VERDICT r1 item 4(d) and
     // MEASURED on Q3's orders launch (1 match in 10 rows, where the gather touches 80-97 % of the output columns' lines anyway): the
@@ -1842,14 +1939,31 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // variant is opt-in (TGPU_FJ_CARRY=1; exact key bitmaps, inner joins) and stays tested; the default keeps the two-pass gather.
     bool carry = false;
     if (const char *f = getenv("TGPU_FJ_CARRY")) carry = atoi(f) != 0 && carry_supported_ && (tv.rank_base || tv.bitmap) && !output_channels_.empty() && !outer;
-    const int64_t n = in.n;
+    const int64_t tile_rows = (int64_t)fj_stripes() * 256;
+    // the launch's rows: a page's own rows, or -- several pages -- VIRTUAL rows: every page starts a tile
+    std::vector<int32_t> page_tile0;
+    int64_t n = in.n;
+    if (multi) {
+        int64_t t = 0;
+        for (const DevicePage *pg : pages) {
+            TG_CHECK_ARG(pg->n > 0, "empty page in a multi-page launch");
+            page_tile0.push_back((int32_t)t);
+            t += ceil_div(pg->n, tile_rows);
+        }
+        page_tile0.push_back((int32_t)t);
+        TG_CHECK_ARG(t <= kFjMultiMaxTiles, "too many rows for one multi-page launch");
+        n = t * tile_rows;
+        carry = false;
+    }
     if (n == 0) return nullptr;
     // pages of up to kFjEpilogueMaxChunks tiles (always one-tile chunks, see below) run the kernel variant whose pass 1 ends with the scan and
     // the hand-over of the totals; whole tables keep the variant without it (measured on the SF100 tables: the epilogue's write-through
     // count stores and its extra state cost the lineitem launch 1.50 -> 1.82 ms)
-    const bool page_variant = ceil_div(n, (int64_t)fj_stripes() * 256) <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr;
-    JitModule *module = module_for(tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls, carry, page_variant);
+    const bool page_variant = multi || (ceil_div(n, tile_rows) <= kFjEpilogueMaxChunks && getenv("TGPU_DISABLE_PROBE_EPILOGUE") == nullptr);
+    JitModule *module = module_for(tv.rank_base ? 3 : (tv.bitmap ? 1 : (tv.bloom ? 2 : 0)), !any_nulls, carry, multi ? 2 : (page_variant ? 1 : 0));
     std::shared_ptr<Pending> pend = std::make_shared<Pending>();
+    pend->col_nulls = col_nulls;
+    pend->kernel_variant = multi ? 2 : (page_variant ? 1 : 0);
     pend->module = module;
     pend->outer = outer;
     pend->need_build_positions = need_build_positions;
@@ -1860,7 +1974,7 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
         J.fp.col_nulls[i] = in.cols[i].nulls;
         J.fp.col_offsets[i] = in.cols[i].offsets;
     }
-    J.fp.n = n;
+    J.fp.n = multi ? in.n : n;
     J.slots = tv.slots;
     J.mask = tv.mask;
     J.bitmap = tv.bitmap;
@@ -1871,7 +1985,6 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     J.direct = tv.direct;
     J.rank_base = tv.rank_base;
     J.outer = (outer ? 1 : 0) | (need_build_positions ? 0 : 2);
-    const int64_t tile_rows = (int64_t)fj_stripes() * 256;
     J.tiles = ceil_div(n, tile_rows);
     TG_CHECK_ARG(n <= 0x7fffffffLL && J.tiles <= 0x7fffffffLL, "page too large");
     // persistent workgroups: exactly as many as are resident at once (a second round of workgroups would only add a tail)
@@ -1881,7 +1994,7 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // chunks of consecutive tiles per workgroup (fj_probe): up to 64 tiles, but at least ~4 chunks per resident workgroup
     int chunk_shift = 0;
     const int max_chunk_shift = getenv("TGPU_FJ_CHUNK_SHIFT") ? atoi(getenv("TGPU_FJ_CHUNK_SHIFT")) : 6;
-    while (chunk_shift < max_chunk_shift && (J.tiles >> (chunk_shift + 1)) >= 4 * resident) chunk_shift++;
+    while (!multi && chunk_shift < max_chunk_shift && (J.tiles >> (chunk_shift + 1)) >= 4 * resident) chunk_shift++;   // (multi: a chunk must not straddle pages)
     J.chunk_shift = chunk_shift;
     const int64_t chunks = (J.tiles + (1ll << chunk_shift) - 1) >> chunk_shift;
     pend->chunks = chunks;
@@ -1896,6 +2009,7 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // every launch leaves at rest
     static_assert((size_t)kFjMiscWords * 8 <= Context::kZeroedScratchBytes, "the probe's counters fit the context's scratch words");
     if (page_variant && chunk_shift == 0) pend->signal = ctx->begin_signal();   // (no slot free: host_out stays null, the scan launch and the copy do it)
+    TG_CHECK_STATE(!multi || pend->signal.slot >= 0, "no signal slot for a multi-page launch");   // (can_batch() looked: not reached in practice)
     struct SignalGuard {   // an allocation that fails between here and the launch must not leave the slot waiting for a kernel that never runs
         Context *ctx;
         Context::Signal *signal;
@@ -1921,6 +2035,28 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
         init_words_kernel<<<1, 256, 0, ctx->stream()>>>(misc->as<unsigned long long>(), 1, kMiscWords - 1);   // one launch: [0] = ~0 (no error), the rest 0
         J.fp.error = misc->as<unsigned long long>();
         J.counters = misc->as<unsigned long long>() + 16;
+    }
+    if (multi) {
+        // the pages' descriptors and their first tiles, one upload: [FpArgs x pages][int32 x (pages + 1)]
+        const size_t desc_bytes = pages.size() * sizeof(FpArgs), tile_bytes = page_tile0.size() * 4;
+        std::vector<uint8_t> host(desc_bytes + tile_bytes);
+        for (size_t i = 0; i < pages.size(); i++) {
+            FpArgs d{};
+            for (size_t c = 0; c < pages[i]->cols.size() && c < (size_t)kFpMaxCols; c++) {
+                d.col_values[c] = pages[i]->cols[c].values;
+                d.col_nulls[c] = pages[i]->cols[c].nulls;
+                d.col_offsets[c] = pages[i]->cols[c].offsets;
+            }
+            d.n = pages[i]->n;
+            d.error = J.fp.error;
+            memcpy(host.data() + i * sizeof(FpArgs), &d, sizeof(FpArgs));
+        }
+        memcpy(host.data() + desc_bytes, page_tile0.data(), tile_bytes);
+        pend->descriptors = ctx->alloc(host.size());
+        ctx->upload(pend->descriptors->ptr(), host.data(), host.size());
+        J.pages = pend->descriptors->as<FpArgs>();
+        J.page_tile0 = reinterpret_cast<const int32_t *>(pend->descriptors->as<uint8_t>() + desc_bytes);
+        J.n_pages = (int32_t)pages.size();
     }
     J.tile_cnt = tile_cnt->as<int32_t>();
     J.tile_src = tile_src->as<int32_t>();
@@ -2061,7 +2197,7 @@ void FusedProbeGpu::finish(Context *ctx, const std::shared_ptr<Pending> &pend, c
         // produced for it (what Block.mayHaveNull() == false gives the reference's downstream operators), so the build / group-by
         // kernels behind the join skip their null checks for the channel
         const tgpu_expr_node &root = nodes_[(size_t)proj_roots_[(size_t)output_channels_[i]]];
-        const bool null_free = root.kind == TGPU_EX_INPUT && root.op >= 0 && root.op < (int)in.cols.size() && in.cols[(size_t)root.op].nulls == nullptr;
+        const bool null_free = root.kind == TGPU_EX_INPUT && root.op >= 0 && root.op < (int)pend->col_nulls.size() && !pend->col_nulls[(size_t)root.op];
         if (!null_free) {
             c.nulls_buf = ctx->alloc((size_t)count);
             c.nulls = c.nulls_buf->as<uint8_t>();
@@ -2093,7 +2229,8 @@ void FusedProbeGpu::finish(Context *ctx, const std::shared_ptr<Pending> &pend, c
             build_out->push_back(c);
         }
     }
-    pend->emit_blocks = std::min<int64_t>(chunks, (int64_t)ctx->cu_count() * 8);
+    // (page variants of the kernels: one wave per chunk, four chunks per workgroup)
+    pend->emit_blocks = std::min<int64_t>(pend->kernel_variant ? ceil_div(chunks, (int64_t)4) : chunks, (int64_t)ctx->cu_count() * 8);
     if (launch) launch_emit(ctx, pend);   // (else: the caller launches it, alone or paired with the next page's pass 1)
     // no second error read-back: the projections evaluated by pass 2 cannot raise (the constructor keeps anything with checked
     // integer arithmetic on the unfused path), and pass 1's filter / key errors were raised above

@@ -135,8 +135,13 @@ struct FjArgs {  // must match the generated struct
     uint8_t *carry_nulls;   //                and of their null bits (nullptr: no output can be null)
     unsigned long long *host_out;   // small pages: pass 1's last workgroup scans the chunk counts and writes {error, pairs, selected} here
     unsigned int *done;             //              (host-visible signal slot); `done` counts finished workgroups
+    const FpArgs *pages;            // multi-page launches (kernel variant FJ_EPILOGUE == 2): the pages' column pointers, device memory
+    const int32_t *page_tile0;      //   first tile of each page, [n_pages] = all tiles
+    int32_t n_pages;
+    int32_t pad3;
 };
 constexpr int kFjMaxBuildCols = 4;
+constexpr int64_t kFjMultiMaxTiles = 32768;      // tiles of one launch over a list of pages
 constexpr int64_t kFjEpilogueMaxChunks = 2048;   // probe launches of up to 2048 tiles (1.5 M rows at 768-row tiles; always one-tile chunks) end pass 1 with the epilogue
 
 class LookupSourceGpu;
@@ -163,6 +168,11 @@ public:
     // and the lookup source must stay alive and unchanged in between (null from begin() = empty page)
     struct Pending;
     std::shared_ptr<Pending> begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, bool launch = true);
+    // several (non-empty) pages probed as one sequence of rows: one launch, one output page (rows in page order).  At most
+    // multi_page_row_limit() rows (counted in whole tiles per page); finish() takes any of the pages as `in`.
+    std::shared_ptr<Pending> begin(Context *ctx, const std::vector<const DevicePage *> &pages, const LookupSourceGpu &source, bool outer, bool need_build_positions,
+                                   bool launch = true);
+    static int64_t multi_page_row_limit();
     void finish(Context *ctx, const std::shared_ptr<Pending> &pending, const DevicePage &in, std::vector<DeviceColumn> &probe_out, BufferPtr &build_idx, int64_t &count,
                 int64_t &selected_rows, const std::vector<DeviceColumn> *build_cols = nullptr, std::vector<DeviceColumn> *build_out = nullptr, bool launch = true);
     // launch == false leaves the pass to the caller: launch_probe / launch_emit alone, or launch_pair = an earlier page's pass 2 and a new page's
@@ -176,7 +186,7 @@ public:
 
 private:
     void generate();
-    struct JitModule *module_for(int prefilter_kind, bool no_nulls, bool carry, bool epilogue);
+    struct JitModule *module_for(int prefilter_kind, bool no_nulls, bool carry, int epilogue);
     std::mutex mu_;
     std::vector<int32_t> input_types_;
     std::vector<tgpu_expr_node> nodes_;
@@ -186,7 +196,7 @@ private:
     int32_t join_channel_;
     bool supported_ = false;
     std::string source_;
-    std::shared_ptr<JitModule> modules_[32];   // layout (4) x no-null-vectors (2) x carry (2) x page variant with the epilogue (2)
+    std::shared_ptr<JitModule> modules_[48];   // layout (4) x no-null-vectors (2) x carry (2) x {whole table, one page with the epilogue, list of pages} (3)
     bool carry_supported_ = false;
 };
 

@@ -1188,6 +1188,14 @@ public:
     void add_input(const tgpu_page *page) override { add_page(page, nullptr); }
     void add_input_owned(const DevicePage &page) override { add_page(nullptr, &page); }   // (keeps the page's buffers: it may stay in flight)
 
+    // Small pages additionally SHARE launches: pages below kBatchBelowRows rows are collected (by reference) until kBatchRows rows or
+    // kBatchPages pages have come together and are probed as one sequence of rows -- one launch, one output page, rows in page order (the
+    // kernels' multi variant, FusedProbeGpu::begin over a page list).  A launch costs ~15 us of dependent round trips whatever it covers;
+    // a 2^20-row page streams in 3.  What is collected goes out like what is in flight: when enough has come together, at finish(), or when
+    // the driver polls twice without bringing a page.
+    static constexpr int64_t kBatchBelowRows = 1ll << 22, kBatchRows = 1ll << 24;
+    static constexpr int kBatchPages = 64;
+
     void add_page(const tgpu_page *page, const DevicePage *owned)
     {
         TG_CHECK_STATE(!finishing_, "Operator is already finishing");
@@ -1195,50 +1203,35 @@ public:
         std::shared_ptr<LookupSourceGpu> source = bridge_->lookup_source();
         TG_CHECK_STATE(source != nullptr, "Lookup source has not been built yet");
         DevicePage in = owned ? DevicePage(*owned) : ingest_page(ctx_, page);
+        polls_since_input_ = 0;
         if (in.n == 0) return;
-        const bool outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
-        const bool track = cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
         IntTableView tv;
         std::shared_ptr<const JoinFilter> filter = bridge_->join_filter();   // a join filter function runs on the unfused composition
         const bool fused_ok = !filter && fused_->supported() && cfg_.probe_join_channels.size() == 1 && source->int_table(tv) && tv.links == nullptr &&
                               tv.key_type == fused_->projection_types()[(size_t)cfg_.probe_join_channels[0]] && getenv("TGPU_DISABLE_FUSION") == nullptr;
         if (fused_ok) {
-            InFlight f;
-            f.source = source;
-            f.outer = outer;
-            f.track = track;
-            f.need_positions = track || !source->output_channels().empty();
-            // fixed-width build output channels are gathered by the probe's emit pass itself (no launch of their own)
-            const int nb = (int)source->output_channels().size();
-            f.gather_fused = nb > 0 && nb <= kFjMaxBuildCols;
-            for (int i = 0; i < nb && f.gather_fused; i++) {
-                f.build_cols.push_back(source->build_column(i));
-                f.gather_fused = f.build_cols.back().type != TGPU_VARCHAR && f.build_cols.back().values != nullptr;
-            }
             const bool async = in.n <= kAsyncBelowRows && page_is_retained(ctx_, in) && getenv("TGPU_DISABLE_ASYNC_JOIN") == nullptr;
-            polls_since_input_ = 0;
             if (!async) {
+                flush_batch();
                 complete_all();
-                f.pending = fused_->begin(ctx_, in, *source, outer, f.need_positions);
-                f.in = std::move(in);
+                InFlight f = describe(source);
+                f.pending = fused_->begin(ctx_, in, *source, f.outer, f.need_positions);
+                f.pages.push_back(std::move(in));
                 inflight_.push_back(std::move(f));
                 complete_all();
                 return;
             }
-            f.pending = fused_->begin(ctx_, in, *source, outer, f.need_positions, /*launch=*/false);
-            f.in = std::move(in);
-            if ((int)inflight_.size() >= kDepth) {
-                try {
-                    complete_oldest(&f.pending);   // its pass 2 shares the launch with this page's pass 1 when the two can pair
-                } catch (...) {
-                    fused_->cancel(ctx_, f.pending);
-                    throw;
-                }
-            }
-            fused_->launch_probe(ctx_, f.pending);   // (no-op when the pair launch carried it)
-            inflight_.push_back(std::move(f));
+            const bool batching = in.n < kBatchBelowRows && getenv("TGPU_DISABLE_PROBE_BATCHING") == nullptr;
+            const int64_t tiles = (in.n + batch_tile_rows() - 1) / batch_tile_rows();
+            if (!batch_.empty() && (!batching || batch_source_ != source || (batch_tiles_ + tiles) * batch_tile_rows() > FusedProbeGpu::multi_page_row_limit())) flush_batch();
+            batch_source_ = source;
+            batch_rows_ += in.n;
+            batch_tiles_ += tiles;
+            batch_.push_back(std::move(in));
+            if (!batching || batch_rows_ >= batch_rows_target() || (int)batch_.size() >= kBatchPages) flush_batch();
             return;
         }
+        flush_batch();
         complete_all();
         // unfused composition: FilterAndProject, then the probe
         DevicePage mid, out;
@@ -1249,9 +1242,12 @@ public:
 
     std::unique_ptr<OutputPage> get_output() override
     {
-        // in flight stays in flight while the driver keeps bringing pages; a second poll without input in between, or finish(), completes it
-        if (ready_.empty() && !inflight_.empty() && !finishing_) polls_since_input_++;
-        while (ready_.empty() && !inflight_.empty() && (finishing_ || polls_since_input_ >= 2)) complete_oldest(nullptr);
+        // collected / in flight stays that way while the driver keeps bringing pages; a second poll without input in between, or finish(), completes it
+        if (ready_.empty() && (!inflight_.empty() || !batch_.empty()) && !finishing_) polls_since_input_++;
+        if (ready_.empty() && (finishing_ || polls_since_input_ >= 2)) {
+            flush_batch();
+            while (ready_.empty() && !inflight_.empty()) complete_oldest(nullptr);
+        }
         if (ready_.empty()) return nullptr;
         std::unique_ptr<OutputPage> out = std::move(ready_.front());
         ready_.pop_front();
@@ -1260,7 +1256,7 @@ public:
     void finish() override { finishing_ = true; }
     bool is_finished() override
     {
-        bool done = finishing_ && ready_.empty() && inflight_.empty();
+        bool done = finishing_ && ready_.empty() && inflight_.empty() && batch_.empty();
         if (done) close();
         return done;
     }
@@ -1268,7 +1264,9 @@ public:
     {
         int64_t b = 0;
         for (const auto &o : ready_) b += o->page.size_in_bytes();
-        for (const InFlight &f : inflight_) b += f.in.size_in_bytes();
+        for (const InFlight &f : inflight_)
+            for (const DevicePage &pg : f.pages) b += pg.size_in_bytes();
+        for (const DevicePage &pg : batch_) b += pg.size_in_bytes();
         return b;
     }
     int64_t probe_rows() const { return probe_rows_; }
@@ -1278,23 +1276,69 @@ public:
             closed_ = true;
             for (InFlight &f : inflight_) fused_->cancel(ctx_, f.pending);
             inflight_.clear();
+            batch_.clear();
             bridge_->probe_closed();
         }
     }
 
 private:
     struct InFlight {
-        DevicePage in;
+        std::vector<DevicePage> pages;   // one page, or the pages of a common launch
         std::shared_ptr<FusedProbeGpu::Pending> pending;
         std::shared_ptr<LookupSourceGpu> source;
         std::vector<DeviceColumn> build_cols;
         bool outer = false, track = false, need_positions = false, gather_fused = false;
     };
+    static int64_t batch_tile_rows() { return FusedProbeGpu::multi_page_row_limit() / kFjMultiMaxTiles; }
+    static int64_t batch_rows_target()
+    {
+        const char *e = getenv("TGPU_PROBE_BATCH_ROWS");   // (kernel studies)
+        return e ? std::max<int64_t>(1, atoll(e)) : kBatchRows;
+    }
+    InFlight describe(const std::shared_ptr<LookupSourceGpu> &source) const
+    {
+        InFlight f;
+        f.source = source;
+        f.outer = cfg_.join_type == TGPU_JOIN_PROBE_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
+        f.track = cfg_.join_type == TGPU_JOIN_LOOKUP_OUTER || cfg_.join_type == TGPU_JOIN_FULL_OUTER;
+        f.need_positions = f.track || !source->output_channels().empty();
+        // fixed-width build output channels are gathered by the probe's emit pass itself (no launch of their own)
+        const int nb = (int)source->output_channels().size();
+        f.gather_fused = nb > 0 && nb <= kFjMaxBuildCols;
+        for (int i = 0; i < nb && f.gather_fused; i++) {
+            f.build_cols.push_back(source->build_column(i));
+            f.gather_fused = f.build_cols.back().type != TGPU_VARCHAR && f.build_cols.back().values != nullptr;
+        }
+        return f;
+    }
+    // what has been collected goes into the pipeline: pass 1 prepared, launched together with pass 2 of the oldest launch in flight when
+    // kDepth are in flight and the two can pair, else on its own
+    void flush_batch()
+    {
+        if (batch_.empty()) return;
+        InFlight f = describe(batch_source_);
+        f.pages = std::move(batch_);
+        batch_.clear();
+        batch_rows_ = batch_tiles_ = 0;
+        std::vector<const DevicePage *> list;
+        for (const DevicePage &pg : f.pages) list.push_back(&pg);
+        f.pending = fused_->begin(ctx_, list, *f.source, f.outer, f.need_positions, /*launch=*/false);
+        if ((int)inflight_.size() >= kDepth) {
+            try {
+                complete_oldest(&f.pending);
+            } catch (...) {
+                fused_->cancel(ctx_, f.pending);
+                throw;
+            }
+        }
+        fused_->launch_probe(ctx_, f.pending);   // (no-op when the pair launch carried it)
+        inflight_.push_back(std::move(f));
+    }
     void complete_all()
     {
         while (!inflight_.empty()) complete_oldest(nullptr);
     }
-    // pass 2 of the oldest page in flight; with `partner` (a prepared, not yet launched page) in one launch with the partner's pass 1
+    // pass 2 of the oldest launch in flight; with `partner` (prepared, not yet launched) in one launch with the partner's pass 1
     void complete_oldest(const std::shared_ptr<FusedProbeGpu::Pending> *partner)
     {
         InFlight f = std::move(inflight_.front());
@@ -1302,7 +1346,7 @@ private:
         std::vector<DeviceColumn> probe_out, build_out;
         BufferPtr build_idx;
         int64_t count = 0, selected = 0;
-        fused_->finish(ctx_, f.pending, f.in, probe_out, build_idx, count, selected, f.gather_fused ? &f.build_cols : nullptr, f.gather_fused ? &build_out : nullptr, /*launch=*/false);
+        fused_->finish(ctx_, f.pending, f.pages[0], probe_out, build_idx, count, selected, f.gather_fused ? &f.build_cols : nullptr, f.gather_fused ? &build_out : nullptr, /*launch=*/false);
         probe_rows_ += selected;
         if (count == 0) return;
         if (partner && fused_->can_pair(f.pending, *partner)) fused_->launch_pair(ctx_, f.pending, *partner);
@@ -1326,6 +1370,9 @@ private:
     std::shared_ptr<FusedProbeGpu> fused_;
     std::deque<InFlight> inflight_;
     std::deque<std::unique_ptr<OutputPage>> ready_;
+    std::vector<DevicePage> batch_;   // pages waiting for their common launch
+    std::shared_ptr<LookupSourceGpu> batch_source_;
+    int64_t batch_rows_ = 0, batch_tiles_ = 0;
     int polls_since_input_ = 0;
     int64_t probe_rows_ = 0;
     bool finishing_ = false, closed_ = false;

@@ -769,18 +769,28 @@ def test_fused_filter_probe_tile_and_chunk_boundaries(pkg, ctx, oracle, n):
 
 @pytest.mark.parametrize("join_type", [0, 1])
 def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monkeypatch):
-    """Probe pages of up to 2^22 rows are probed asynchronously, two pages deep (operators.cpp FusedFilterProjectJoinOperator): addInput
-    launches pass 1 of the new page together with pass 2 of the page before last (one launch for both), getOutput returns null until a
-    page's successors have been added or finish() was called.  Same rows in the same order as the synchronous protocol
-    (TGPU_DISABLE_ASYNC_JOIN), as separate launches (TGPU_DISABLE_PROBE_PAIRING) and as the oracle, empty pages and pages without a match included."""
+    """Probe pages the operator may keep are probed asynchronously (operators.cpp FusedFilterProjectJoinOperator).  Four protocols, same rows in
+    the same order, equal to the oracle:
+      batched  (default) small pages are collected and probed as ONE sequence of rows per launch (the kernels' multi variant over a page list);
+      async    (TGPU_DISABLE_PROBE_BATCHING) one launch per page, two pages deep: pass 1 of the new page shares its launch with pass 2 of
+               the page before last (fj_pair); getOutput returns null until a page's successors have been added or finish() was called;
+      unpaired (+ TGPU_DISABLE_PROBE_PAIRING) the same with separate launches;
+      sync     (TGPU_DISABLE_ASYNC_JOIN) a page's output is there when addInput returns.
+    Page sizes around the 768-row tile, an empty page, a page without a match, pages with and without null vectors."""
     rng = np.random.default_rng(211)
     bkeys = rng.permutation(50_000)[:20_000].astype(np.int64)
     f, c = pkg.field, pkg.constant
-    sizes = [5_000, 1, 0, 70_000, 300, 4_096, 12_345]
-    pages = [pkg.Page(pkg.Block(pkg.BIGINT, rng.integers(0, 60_000, n).astype(np.int64)), pkg.Block(pkg.DATE, rng.integers(9000, 9400, n).astype(np.int32))) for n in sizes]
+    sizes = [5_000, 1, 0, 70_000, 300, 4_096, 12_345, 767, 768, 769, 1, 1_536, 100_000, 2]
+    pages = []
+    for i, n in enumerate(sizes):
+        knulls = (rng.random(n) < 0.05).astype(np.uint8) if i % 3 == 0 else None
+        dnulls = (rng.random(n) < 0.05).astype(np.uint8) if i % 4 == 1 else None
+        pages.append(pkg.Page(pkg.Block(pkg.BIGINT, rng.integers(0, 60_000, n).astype(np.int64), knulls), pkg.Block(pkg.DATE, rng.integers(9000, 9400, n).astype(np.int32), dnulls)))
     pages[4] = pkg.Page(pkg.Block(pkg.BIGINT, np.full(300, 10**9, dtype=np.int64)), pkg.Block(pkg.DATE, np.full(300, 9300, dtype=np.int32)))   # no match at all
     got = {}
-    for mode in ("async", "unpaired", "sync"):
+    for mode in ("batched", "async", "unpaired", "sync"):
+        if mode != "batched":
+            monkeypatch.setenv("TGPU_DISABLE_PROBE_BATCHING", "1")
         if mode == "unpaired":
             monkeypatch.setenv("TGPU_DISABLE_PROBE_PAIRING", "1")
         if mode == "sync":
@@ -804,7 +814,7 @@ def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monk
             else:
                 outs.append(o.to_host()); o.release()
             if mode != "sync" and i == 0:
-                assert o is None and op.needsInput()     # one page in flight: nothing to hand over yet, room for the next page
+                assert o is None and op.needsInput()     # one page collected / in flight: nothing to hand over yet, room for the next page
         op.finish()
         assert not op.needsInput()
         while not op.isFinished():
@@ -812,24 +822,30 @@ def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monk
             if o is not None:
                 outs.append(o.to_host()); o.release()
         got[mode] = [r for pg in outs for r in pg.rows()]
+        prof = ctx.profile()
         if mode == "sync":
-            assert 1 <= nulls_seen <= 3       # the empty page; the one-row page if the filter drops it; inner join: the page without a match
-        assert ("fused_probe_pair" in ctx.profile()) == (mode == "async")
+            assert 1 <= nulls_seen <= 5       # the empty page; a tiny page the filter drops; inner join: the page without a match
+        if mode == "batched":
+            assert nulls_seen == len(pages) and len(outs) == 1 and prof["fused_filter_probe"]["count"] == 1    # one launch, one output page
+        assert ("fused_probe_pair" in prof) == (mode == "async")
         op.close(); b.close(); ctx.close()
-    assert got["async"] == got["sync"] == got["unpaired"]
+    assert got["batched"] == got["async"] == got["sync"] == got["unpaired"]
     ph = oracle.PagesHash([oracle.Col(pkg.BIGINT, bkeys)])
     want = []
     for pg in pages:
-        k, d = pg.getBlock(0).values, pg.getBlock(1).values
-        sel = np.nonzero(d > 9200)[0]
+        kb, db = pg.getBlock(0), pg.getBlock(1)
+        k, d = kb.values, db.values
+        dn = db.nulls if db.nulls is not None else np.zeros(len(d), dtype=np.uint8)
+        sel = np.nonzero((d > 9200) & (dn == 0))[0]
         if len(sel) == 0:
             continue
-        opx, obx = ph.probe([oracle.Col(pkg.BIGINT, k[sel])], probe_outer=bool(join_type))
-        want += [(int(k[sel[i]]), int(d[sel[i]]), int(bkeys[j]) if j >= 0 else None) for i, j in zip(opx, obx)]
+        kn = None if kb.nulls is None else kb.nulls[sel]
+        opx, obx = ph.probe([oracle.Col(pkg.BIGINT, k[sel], kn)], probe_outer=bool(join_type))
+        want += [(None if (kn is not None and kn[i]) else int(k[sel[i]]), int(d[sel[i]]), int(bkeys[j]) if j >= 0 else None) for i, j in zip(opx, obx)]
     assert got["async"] == want and len(want) > 10_000
 
 
-def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(pkg, ctx):
+def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(pkg, ctx, monkeypatch):
     """close() with a probe page in flight gives its read-back slot back (17 operators: more than the context has slots); an expression error
     of an in-flight page is raised by the getOutput that completes it, and the operator stays usable for close()"""
     f = pkg.field
@@ -848,10 +864,24 @@ def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(p
     jf2 = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 3, bf.lookup_source_factory, [pkg.BIGINT] * 2, (pkg.constant(100, pkg.BIGINT) / f(1, pkg.BIGINT)) > 0,
                                                       [f(0, pkg.BIGINT), f(1, pkg.BIGINT)], [0])
     good = pkg.Page(pkg.Block(pkg.BIGINT, np.arange(50, 150, dtype=np.int64)), pkg.Block(pkg.BIGINT, np.arange(1, 101, dtype=np.int64)))
+    # (a) pages that share a launch fail together: the error comes out of the call that completes the launch
     op = jf2.createOperator()
     op.addInput(good)
     assert op.getOutput() is None
     op.addInput(page)                       # second column holds a zero
+    assert op.getOutput() is None
+    op.finish()
+    with pytest.raises(pkg.TgpuError) as e:
+        op.getOutput()
+    assert e.value.code == -7               # DIVISION_BY_ZERO
+    assert op.isFinished()
+    op.close()
+    # (b) one launch per page: the good page's output first, then the error
+    monkeypatch.setenv("TGPU_DISABLE_PROBE_BATCHING", "1")
+    op = jf2.createOperator()
+    op.addInput(good)
+    assert op.getOutput() is None
+    op.addInput(page)
     assert op.getOutput() is None           # two pages in flight: nothing is handed out while the driver keeps bringing pages
     op.finish()
     o = op.getOutput()
@@ -859,9 +889,10 @@ def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(p
     o.release()
     with pytest.raises(pkg.TgpuError) as e:
         op.getOutput()
-    assert e.value.code == -7               # DIVISION_BY_ZERO
+    assert e.value.code == -7
     assert op.isFinished()
     op.close()
+    monkeypatch.delenv("TGPU_DISABLE_PROBE_BATCHING")
     # a driver that polls twice without bringing a page gets what is in flight (a slow source does not hold finished work back)
     op = jf.createOperator()
     op.addInput(page)
