@@ -1530,12 +1530,12 @@ private:
     // (order-independent), so re-running a page after its successors does not change a bit; new groups still get their ids in page order
     // because a successor that met one of them is dirty itself and is re-run after it.  An expression error of page i is raised by the call
     // that confirms it (the next add_input, finish or get_output).
-    // Pages below kOnepassBatchRows rows wait (by reference) until that many rows or kOnepassBatchPages pages have come together and go out as
+    // Pages below kOnepassBatchRows (2^24) rows wait (by reference) until that many rows or kOnepassBatchPages pages have come together and go out as
     // ONE launch over the list of pages (fq_onepass_multi): a launch costs ~18 us whatever it covers, 1.3 M rows' worth of streaming.  A dirty
     // launch re-runs its pages one by one in page order, an expression error in a launch of several pages likewise (the re-run raises the
     // error of the first failing page, like the reference).
     static constexpr int kOnepassDepth = 2, kOnepassAfter = 2, kOnepassBatchPages = 64;
-    static constexpr int64_t kOnepassBatchRows = 1ll << 23;
+    static constexpr int64_t kOnepassBatchRows = 1ll << 24;
     static int64_t onepass_batch_rows()
     {
         const char *e = getenv("TGPU_ONEPASS_BATCH_ROWS");

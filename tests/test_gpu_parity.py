@@ -1181,7 +1181,7 @@ def _onepass_program(pkg, with_division=False):
 @pytest.mark.parametrize("late", [{}, {6: "X"}, {5: "X", 6: "Y", 9: "Z"}, {4: "X", 5: "X"}])
 def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, monkeypatch, late, batch_rows):
     """once the group set has settled the fused aggregation runs ONE launch per page -- or per batch of small pages: by default pages wait until
-    2^23 rows have come together (here: all of them, launched by finish()); TGPU_ONEPASS_BATCH_ROWS=20000 makes launches of three pages, =1 one
+    2^24 rows have come together (here: all of them, launched by finish()); TGPU_ONEPASS_BATCH_ROWS=20000 makes launches of three pages, =1 one
     per page -- and reads a launch's counters a call later (FusedAggGpu::onepass): same rows, bit for bit, as the probe + accumulate path -- also
     when pages in the middle of the stream bring new groups (their totals are dropped on the device, the pages re-run through the insert
     protocol, ids in first-seen order)"""
