@@ -273,9 +273,10 @@ int32_t tgpu_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, 
  * `spec`'s projections form the probe page, and probe_join_channels / probe_hash_channel / probe_output_channels index
  * those projections.  Configurations the fused kernel does not cover run the two steps unfused inside the operator.
  * Pages the operator may keep (library-owned pages, host pages, borrowed device pages under tgpu_context_set_device_input_stable) of up to
- * 2^25 rows are probed asynchronously, two pages deep: tgpu_operator_get_output returns no page for a page until two more pages have been
- * added, tgpu_operator_finish was called or get_output is polled twice without input in between (Operator.getOutput may return null,
- * M/operator/Operator.java:53-79); an expression error of such a page is returned by the call that completes it. */
+ * 2^25 rows are probed asynchronously: pages below 2^22 rows are collected until 2^24 rows or 64 pages share one launch (one output page,
+ * rows in input order), and two launches are kept in flight.  tgpu_operator_get_output returns no page for an input page until that has
+ * happened, tgpu_operator_finish was called or get_output is polled twice without input in between (Operator.getOutput may return null,
+ * M/operator/Operator.java:53-79); an expression error of such a page is returned by the call that completes its launch. */
 int32_t tgpu_filter_project_lookup_join_factory_create(tgpu_context *ctx, int32_t operator_id, tgpu_lookup_source_factory *bridge,
                                                        int32_t input_type_count, const int32_t *input_types,
                                                        const tgpu_page_processor_spec *spec,

@@ -137,3 +137,28 @@ same = np.diff(probe_pos) == 0
 assert np.all(np.diff(build_pos)[same] < 0), "matches of one probe row come newest build position first (ArrayPositionLinks)"
 out.release(); op.close()
 print("inner join with duplicates ok:", m, "pairs")
+
+# the fused join over MANY small pages (collected into multi-page launches, two launches in flight, paired launches): 90 pages of
+# 150 K - 450 K rows against 5 M sparse-domain build keys (DIRECT layout) with a build output channel; rows and order vs numpy
+dom, nb5 = 20_000_000, 5_000_000
+bk5 = rng.permutation(dom)[:nb5].astype(np.int64)
+pos_of = np.full(dom, -1, dtype=np.int64); pos_of[bk5] = np.arange(nb5)
+f, c = pkg.field, pkg.constant
+bf = pkg.HashBuilderOperatorFactory(ctx, 8, [pkg.BIGINT, pkg.BIGINT], [1], [0])
+b = bf.createOperator(); b.addInput(pkg.Page(pkg.Block(pkg.BIGINT, bk5), pkg.Block(pkg.BIGINT, np.arange(nb5, dtype=np.int64) * 7))); b.finish()
+jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 9, bf.lookup_source_factory, [pkg.BIGINT, pkg.DATE], f(1, pkg.DATE) > c(9200, pkg.DATE), [f(0, pkg.BIGINT), f(1, pkg.DATE)], [0],
+                                                 probe_output_channels=[0, 1])
+pages = []
+for i in range(90):
+    n = int(rng.integers(150_000, 450_000))
+    pages.append(pkg.Page(pkg.Block(pkg.BIGINT, rng.integers(0, dom, n).astype(np.int64)), pkg.Block(pkg.DATE, rng.integers(9000, 9400, n).astype(np.int32))))
+outs = pkg.to_pages(jf.createOperator(), pages)
+gk = np.concatenate([o.getBlock(0).values for o in outs]); gd = np.concatenate([o.getBlock(1).values for o in outs]); gb = np.concatenate([o.getBlock(2).values for o in outs])
+wk, wd, wb = [], [], []
+for pg in pages:
+    k, d = pg.getBlock(0).values, pg.getBlock(1).values
+    m = (d > 9200) & (pos_of[k] >= 0)
+    wk.append(k[m]); wd.append(d[m]); wb.append(pos_of[k[m]] * 7)
+assert np.array_equal(gk, np.concatenate(wk)) and np.array_equal(gd, np.concatenate(wd)) and np.array_equal(gb, np.concatenate(wb))
+assert len(outs) < len(pages) // 4, len(outs)       # pages shared launches
+print("fused join over", len(pages), "small pages ok:", len(gk), "pairs in", len(outs), "output pages")
