@@ -206,7 +206,7 @@ private:
     size_t in_use_ = 0, cached_ = 0;
     void *pinned_ = nullptr;
     size_t pinned_bytes_ = 0;
-    static constexpr int kReadSlots = 16;
+    static constexpr int kReadSlots = 64;
     void *read_slots_ = nullptr;          // kReadSlots x kReadSlotBytes pinned
     void *read_events_[kReadSlots] = {};  // hipEvent_t
     bool read_busy_[kReadSlots] = {};     // owned by a begin_read whose finish_read has not run yet (under io_mu_)

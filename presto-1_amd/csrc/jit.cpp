@@ -1964,6 +1964,22 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     std::shared_ptr<Pending> pend = std::make_shared<Pending>();
     pend->col_nulls = col_nulls;
     pend->kernel_variant = multi ? 2 : (page_variant ? 1 : 0);
+    // the page variants hand their totals over through a signal slot of the context.  None free (many operators of one context inside such a
+    // launch at once): one page falls back to the scan launch and the copy; a list of pages cannot -- the caller probes them one by one
+    if (page_variant) pend->signal = ctx->begin_signal();
+    if (multi && pend->signal.slot < 0) return nullptr;
+    struct SignalGuard {   // an allocation that fails between here and the launch must not leave the slot waiting for a kernel that never runs
+        Context *ctx;
+        Context::Signal *signal;
+        bool armed = true;
+        ~SignalGuard()
+        {
+            if (armed && signal->slot >= 0) {
+                ctx->abandon_signal(*signal);
+                signal->slot = -1;
+            }
+        }
+    } signal_guard{ctx, &pend->signal};
     pend->module = module;
     pend->outer = outer;
     pend->need_build_positions = need_build_positions;
@@ -2008,20 +2024,10 @@ std::shared_ptr<FusedProbeGpu::Pending> FusedProbeGpu::begin(Context *ctx, const
     // counters live in the context's persistent scratch words ([0] error word, [1] finished workgroups, [16 + 16 i] selected rows), which
     // every launch leaves at rest
     static_assert((size_t)kFjMiscWords * 8 <= Context::kZeroedScratchBytes, "the probe's counters fit the context's scratch words");
-    if (page_variant && chunk_shift == 0) pend->signal = ctx->begin_signal();   // (no slot free: host_out stays null, the scan launch and the copy do it)
-    TG_CHECK_STATE(!multi || pend->signal.slot >= 0, "no signal slot for a multi-page launch");   // (can_batch() looked: not reached in practice)
-    struct SignalGuard {   // an allocation that fails between here and the launch must not leave the slot waiting for a kernel that never runs
-        Context *ctx;
-        Context::Signal *signal;
-        bool armed = true;
-        ~SignalGuard()
-        {
-            if (armed && signal->slot >= 0) {
-                ctx->abandon_signal(*signal);
-                signal->slot = -1;
-            }
-        }
-    } signal_guard{ctx, &pend->signal};
+    if (pend->signal.slot >= 0 && chunk_shift != 0) {   // (cannot happen for at most kFjEpilogueMaxChunks tiles: fewer than 8 x the resident workgroups)
+        ctx->abandon_signal(pend->signal);
+        pend->signal.slot = -1;
+    }
     const bool epilogue = pend->signal.slot >= 0;
     BufferPtr misc;
     if (epilogue) {

@@ -169,7 +169,8 @@ public:
     struct Pending;
     std::shared_ptr<Pending> begin(Context *ctx, const DevicePage &in, const LookupSourceGpu &source, bool outer, bool need_build_positions, bool launch = true);
     // several (non-empty) pages probed as one sequence of rows: one launch, one output page (rows in page order).  At most
-    // multi_page_row_limit() rows (counted in whole tiles per page); finish() takes any of the pages as `in`.
+    // multi_page_row_limit() rows (counted in whole tiles per page); finish() takes any of the pages as `in`.  Returns null when the
+    // context has no signal slot left for the launch: the caller then probes the pages one by one.
     std::shared_ptr<Pending> begin(Context *ctx, const std::vector<const DevicePage *> &pages, const LookupSourceGpu &source, bool outer, bool need_build_positions,
                                    bool launch = true);
     static int64_t multi_page_row_limit();

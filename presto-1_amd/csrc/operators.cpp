@@ -1323,6 +1323,18 @@ private:
         std::vector<const DevicePage *> list;
         for (const DevicePage &pg : f.pages) list.push_back(&pg);
         f.pending = fused_->begin(ctx_, list, *f.source, f.outer, f.need_positions, /*launch=*/false);
+        if (!f.pending) {
+            // no signal slot for a launch over several pages (many operators of this context are inside one): page by page, synchronously
+            complete_all();
+            for (DevicePage &pg : f.pages) {
+                InFlight one = describe(f.source);
+                one.pending = fused_->begin(ctx_, pg, *f.source, f.outer, f.need_positions);
+                one.pages.push_back(std::move(pg));
+                inflight_.push_back(std::move(one));
+                complete_all();
+            }
+            return;
+        }
         if ((int)inflight_.size() >= kDepth) {
             try {
                 complete_oldest(&f.pending);

@@ -845,8 +845,20 @@ def test_fused_join_keeps_two_small_pages_in_flight(pkg, oracle, join_type, monk
     assert got["async"] == want and len(want) > 10_000
 
 
+def _drain(ops):
+    """host rows of what finished operators still hold, page by page"""
+    pages = []
+    for op in ops:
+        while not op.isFinished():
+            o = op.getOutput()
+            if o is not None:
+                pages.append(o.to_host().rows())
+                o.release()
+    return pages
+
+
 def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(pkg, ctx, monkeypatch):
-    """close() with a probe page in flight gives its read-back slot back (17 operators: more than the context has slots); an expression error
+    """close() with a probe page in flight gives its signal slot back (100 operators: more than the context has slots); an expression error
     of an in-flight page is raised by the getOutput that completes it, and the operator stays usable for close()"""
     f = pkg.field
     bf = pkg.HashBuilderOperatorFactory(ctx, 1, [pkg.BIGINT], [], [0])
@@ -855,11 +867,13 @@ def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(p
     b.finish()
     jf = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, [pkg.BIGINT] * 2, None, [f(0, pkg.BIGINT), f(1, pkg.BIGINT)], [0])
     page = pkg.Page(pkg.Block(pkg.BIGINT, np.arange(50, 150, dtype=np.int64)), pkg.Block(pkg.BIGINT, np.arange(100, dtype=np.int64)))
-    for _ in range(40):
+    monkeypatch.setenv("TGPU_DISABLE_PROBE_BATCHING", "1")    # (every page gets its own launch: it is in flight when the operator is closed)
+    for _ in range(100):
         op = jf.createOperator()
         op.addInput(page)
         assert op.getOutput() is None
         op.close()
+    monkeypatch.delenv("TGPU_DISABLE_PROBE_BATCHING")
     # the filter divides by zero on a selected row of the SECOND page: raised when that page is completed, after the first page's output
     jf2 = pkg.FilterProjectLookupJoinOperatorFactory(ctx, 3, bf.lookup_source_factory, [pkg.BIGINT] * 2, (pkg.constant(100, pkg.BIGINT) / f(1, pkg.BIGINT)) > 0,
                                                       [f(0, pkg.BIGINT), f(1, pkg.BIGINT)], [0])
@@ -900,7 +914,28 @@ def test_fused_join_closed_with_a_page_in_flight_and_errors_of_in_flight_pages(p
     o = op.getOutput()
     assert o is not None and o.position_count == 50
     o.release()
-    op.close(); b.close()
+    op.close()
+    # every signal slot of the context taken (64 operators with a launch in flight): a further operator's single page falls back to the scan
+    # launch + copy, its collected pages are probed one by one -- same rows
+    monkeypatch.setenv("TGPU_DISABLE_PROBE_BATCHING", "1")
+    holders = [jf.createOperator() for _ in range(64)]
+    for h in holders:
+        h.addInput(page)
+    one = jf.createOperator()
+    one.addInput(page)
+    monkeypatch.delenv("TGPU_DISABLE_PROBE_BATCHING")
+    many = jf.createOperator()
+    for _ in range(3):
+        many.addInput(page)
+    for o_ in (one, many):
+        o_.finish()
+    rows_one = [r for pg in _drain(o_ for o_ in [one]) for r in pg]
+    rows_many = [r for pg in _drain(o_ for o_ in [many]) for r in pg]
+    want = [(k, k - 50) for k in range(50, 100)]
+    assert rows_one == want and rows_many == want * 3
+    for h in holders:
+        h.close()
+    one.close(); many.close(); b.close()
 
 
 @pytest.mark.parametrize("layout", ["clustered", "spread", "duplicates"])
