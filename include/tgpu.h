@@ -528,6 +528,11 @@ int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t enco
                                                  const void *data, int64_t data_len, int32_t dictionary_size, const void *length_stream, int64_t length_len,
                                                  const void *dictionary_data, int64_t dictionary_data_len, tgpu_output_page **out);
 
+/* STRING / VARCHAR / CHAR columns in DIRECT_V2 encoding (reader/SliceDirectColumnReader.java:100-232): LENGTH = unsigned RLEv2 lengths of the
+ * non-null rows, DATA = their bytes back to back; the result is a flat VARCHAR block */
+int32_t tgpu_orc_decode_direct_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len,
+                                             const void *data, int64_t data_len, const void *length_stream, int64_t length_len, tgpu_output_page **out);
+
 /* ---- exchange between the GPUs of one node ---- */
 /* What replaces PartitionedOutputOperator -> OutputBuffer -> HTTP -> ExchangeOperator (M/operator/PartitionedOutputOperator.java:406-476,
  * M/operator/ExchangeOperator.java) when the consumers of a FIXED_HASH_DISTRIBUTION / FIXED_BROADCAST_DISTRIBUTION stage

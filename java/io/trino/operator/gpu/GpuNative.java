@@ -137,6 +137,9 @@ public final class GpuNative
     public static native long orcDecodeDictionaryStringColumn(long context, int encoding, int positionCount, byte[] present, byte[] data, int dictionarySize, byte[] lengthStream,
             byte[] dictionaryData);
 
+    /** SliceDirectColumnReader: LENGTH (one length per non-null row) + DATA (their bytes) */
+    public static native long orcDecodeDirectStringColumn(long context, int encoding, int positionCount, byte[] present, byte[] data, byte[] lengthStream);
+
     // ---- exchange between the GPUs of one node (tgpu_exchange_*); pages are output-page handles: they never leave HBM ----
     public static native byte[] exchangeUniqueId();
     public static native long createExchange(long context, byte[] uniqueId, int rank, int world);

@@ -914,6 +914,16 @@ JFN(jlong, orcDecodeDictionaryStringColumn)(JNIEnv *env, jclass c, jlong ctx, ji
     return page_result(env, rc, out);
 }
 
+JFN(jlong, orcDecodeDirectStringColumn)(JNIEnv *env, jclass c, jlong ctx, jint encoding, jint positionCount, jbyteArray present, jbyteArray data, jbyteArray lengthStream)
+{
+    UNUSED(c);
+    bytes_arg p = bytes_get(env, present), d = bytes_get(env, data), l = bytes_get(env, lengthStream);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_orc_decode_direct_string_column(H(tgpu_context, ctx), encoding, positionCount, p.p, p.n, d.p, d.n, l.p, l.n, &out);
+    bytes_release(env, &l); bytes_release(env, &d); bytes_release(env, &p);
+    return page_result(env, rc, out);
+}
+
 /* ---- exchange between the GPUs of one node (tgpu_exchange_*): pages stay in HBM, so the page arguments are output-page handles ---- */
 JFN(jbyteArray, exchangeUniqueId)(JNIEnv *env, jclass c)
 {

@@ -1269,6 +1269,16 @@ int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t enco
     });
 }
 
+int32_t tgpu_orc_decode_direct_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len, const void *data,
+                                             int64_t data_len, const void *length_stream, int64_t length_len, tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && present_len >= 0 && data_len >= 0 && length_len >= 0 && (data || data_len == 0), "bad argument");
+        *out = one_column_page(ctx->ctx.get(), orc::decode_direct_string_column(ctx->ctx.get(), encoding, position_count, (const uint8_t *)present, present_len, (const uint8_t *)data,
+                                                                              data_len, (const uint8_t *)length_stream, length_len));
+    });
+}
+
 int64_t tgpu_exchange_bytes_sent(tgpu_exchange *ex) { return ex ? ex->ex->bytes_sent() : TGPU_ERR_INVALID_ARGUMENT; }
 
 }  // extern "C"

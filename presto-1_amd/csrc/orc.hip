@@ -350,6 +350,14 @@ __global__ void __launch_bounds__(256) lengths_to_i32_kernel(const long long *__
     }
 }
 
+// lengths of the non-null rows -> a length per row (0 for a null row)
+__global__ void __launch_bounds__(256) place_lengths_kernel(const int32_t *__restrict__ compact, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n,
+                                                            int32_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (nulls && nulls[i]) ? 0 : compact[rank ? rank[i] : i];
+}
+
 int grid_for(Context *ctx, int64_t n)
 {
     int64_t blocks = ceil_div(n, 256);
@@ -547,6 +555,57 @@ DeviceColumn decode_dictionary_string_column(Context *ctx, int32_t encoding, int
     raise_if(ctx, error);
     ProfileScope ps(ctx, "orc_dictionary_gather");
     return k::gather_column(ctx, dict, ids->as<int32_t>(), n, /*negative_is_null=*/p.nulls != nullptr && p.non_null < n);
+}
+
+// STRING / VARCHAR columns in DIRECT_V2 encoding (SliceDirectColumnReader.java:100-232): LENGTH = one unsigned RLEv2 length per NON-NULL row,
+// DATA = those rows' bytes back to back.  The lengths go to their rows (a null row has none), an exclusive scan makes the offsets, the bytes
+// are the block's bytes as they are.
+DeviceColumn decode_direct_string_column(Context *ctx, int32_t encoding, int64_t n, const uint8_t *present, int64_t present_len, const uint8_t *data, int64_t data_len,
+                                         const uint8_t *length_stream, int64_t length_len)
+{
+    TG_CHECK_ARG(n >= 0 && n <= 0x7fffffffLL && data_len >= 0 && data_len <= 0x7fffffffLL, "bad argument");
+    check_encoding(encoding, false);
+    DeviceColumn col;
+    col.type = TGPU_VARCHAR;
+    col.n = n;
+    col.offsets_buf = ctx->alloc((size_t)(n + 1) * 4);
+    col.offsets = col.offsets_buf->as<int32_t>();
+    col.values_buf = ctx->alloc((size_t)(data_len > 0 ? data_len : 1));
+    col.values = col.values_buf->ptr();
+    if (data_len) ctx->upload(col.values_buf->ptr(), data, (size_t)data_len);
+    col.pool_bytes = data_len;
+    col.pool_exact = true;
+    if (n == 0) {
+        HIP_CHECK(hipMemsetAsync(col.offsets_buf->ptr(), 0, 4, ctx->stream()));
+        return col;
+    }
+    BufferPtr error = ctx->alloc_zero(4);
+    Present p = decode_present(ctx, present, present_len, n);
+    BufferPtr lens = ctx->alloc((size_t)n * 4), total = ctx->alloc(8);
+    if (p.non_null > 0) {
+        int64_t count = 0;
+        BufferPtr lens64 = decode_rle_v2(ctx, length_stream, length_len, false, count);
+        TG_CHECK_ARG(count >= p.non_null, "ORC LENGTH stream holds fewer lengths than the column has non-null positions");
+        BufferPtr compact = ctx->alloc((size_t)p.non_null * 4);
+        lengths_to_i32_kernel<<<grid_for(ctx, p.non_null), 256, 0, ctx->stream()>>>(lens64->as<long long>(), p.non_null, compact->as<int32_t>(), error->as<unsigned int>());
+        check_launch("orc_lengths");
+        place_lengths_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(compact->as<int32_t>(), p.rank ? p.rank->as<int32_t>() : nullptr,
+                                                                         p.nulls ? p.nulls->as<uint8_t>() : nullptr, n, lens->as<int32_t>());
+        check_launch("orc_place_lengths");
+    }
+    else HIP_CHECK(hipMemsetAsync(lens->ptr(), 0, (size_t)n * 4, ctx->stream()));
+    k::exclusive_scan_i32(ctx, lens->as<int32_t>(), const_cast<int32_t *>(col.offsets), n, total->as<int64_t>());
+    const int64_t bytes = ctx->read_scalar(total->as<int64_t>());
+    raise_if(ctx, error);
+    TG_CHECK_ARG(bytes == data_len, "ORC string lengths do not add up to the DATA stream");
+    const int32_t end = (int32_t)bytes;
+    ctx->upload(const_cast<int32_t *>(col.offsets) + n, &end, 4);
+    ctx->sync();
+    if (p.nulls && p.non_null < n) {
+        col.nulls_buf = p.nulls;
+        col.nulls = p.nulls->as<uint8_t>();
+    }
+    return col;
 }
 
 }  // namespace orc

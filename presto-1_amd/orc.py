@@ -40,3 +40,13 @@ def decode_dictionary_string_column(ctx, position_count, data, dictionary_size, 
     out = C.c_void_p()
     _lib.check(_lib.lib().tgpu_orc_decode_dictionary_string_column(ctx.handle, encoding, position_count, pb, pl, db, dl, dictionary_size, lb, ll, xb, xl, C.byref(out)))
     return OutputPage(out)
+
+
+def decode_direct_string_column(ctx, position_count, data, length_stream, present=None, encoding=DIRECT_V2) -> OutputPage:
+    """SliceDirectColumnReader: LENGTH (one length per non-null row) + DATA (their bytes) -> a flat VARCHAR block"""
+    pb, pl = _buf(present)
+    db, dl = _buf(data)
+    lb, ll = _buf(length_stream)
+    out = C.c_void_p()
+    _lib.check(_lib.lib().tgpu_orc_decode_direct_string_column(ctx.handle, encoding, position_count, pb, pl, db, dl, lb, ll, C.byref(out)))
+    return OutputPage(out)

@@ -139,3 +139,29 @@ def test_boolean_and_dictionary_string_columns(pkg, ctx, gorc, orc):
     assert got.to_list() == want
     with pytest.raises(pkg.TgpuError):             # an id outside the dictionary
         gorc.decode_dictionary_string_column(ctx, 3, orc.rle_v2_direct([0, 9, 1], False), 2, orc.rle_v2_direct([1, 1], False), b"ab")
+
+
+def test_direct_string_column(pkg, ctx, gorc, orc):
+    """SliceDirectColumnReader.java:100-232: LENGTH = one unsigned RLEv2 length per NON-NULL row, DATA = those rows' bytes; with and without a
+    PRESENT stream, empty strings, an all-null column, a stream whose lengths do not add up to the data"""
+    rng = np.random.default_rng(17)
+    n = 20_000
+    words = ["", "a", "BUILDING", "MACHINERY", "x" * 300, "AUTOMOBILE", "héllo wörld"]
+    for with_present in (False, True):
+        present = (rng.random(n) < 0.85).astype(np.uint8) if with_present else np.ones(n, dtype=np.uint8)
+        pick = rng.integers(0, len(words), int(present.sum()))
+        enc = [words[i].encode("utf-8") for i in pick]
+        lens = [len(b) for b in enc]
+        length_stream = b"".join(orc.rle_v2_direct(lens[i:i + 512], False) for i in range(0, len(lens), 512))
+        got = gorc.decode_direct_string_column(ctx, n, b"".join(enc), length_stream, present=orc.boolean_encode(present.tolist()) if with_present else None).to_host().getBlock(0)
+        it = iter(pick.tolist())
+        want = [words[next(it)] if p_ else None for p_ in present]
+        assert got.to_list() == want
+    none = gorc.decode_direct_string_column(ctx, 100, b"", b"", present=orc.boolean_encode([0] * 100)).to_host().getBlock(0)
+    assert none.to_list() == [None] * 100
+    assert gorc.decode_direct_string_column(ctx, 0, b"", b"").position_count == 0
+    with pytest.raises(pkg.TgpuError):
+        gorc.decode_direct_string_column(ctx, 3, b"abcdef", orc.rle_v2_direct([1, 1, 1], False))
+    with pytest.raises(pkg.TgpuError) as e:        # RLEv1
+        gorc.decode_direct_string_column(ctx, 3, b"abc", orc.rle_v2_direct([1, 1, 1], False), encoding=gorc.DIRECT)
+    assert e.value.code == -8
