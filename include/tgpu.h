@@ -348,6 +348,24 @@ int32_t tgpu_scan_filter_project_factory_create(tgpu_context *ctx, int32_t opera
 /* SourceOperator.addSplit (:232-263: the split's page source; one at a time, the next one after the current is finished) / noMoreSplits */
 int32_t tgpu_scan_operator_add_page_source(tgpu_operator *op, const tgpu_page_source *source);
 int32_t tgpu_scan_operator_no_more_splits(tgpu_operator *op);
+/* The record-cursor flavour (processColumnSource / RecordCursorToPages, :267-273,290-351; S/connector/RecordCursor.java): the split's source
+ * is a row cursor.  The reference runs a compiled CursorProcessor over it row by row into a PageBuilder; here the rows are read through the
+ * callbacks into host columns, up to 65 536 rows at a time (what RecordPageSource does, S/connector/RecordPageSource.java:70-135), and take
+ * the page path from there -- the same rows in the same order, cut into other pages (page cuts are not part of the contract).  `types` =
+ * the cursor's fields: BIGINT / INTEGER / DATE fields are read with get_long, DOUBLE with get_double, BOOLEAN with get_boolean, VARCHAR
+ * with get_slice (bytes valid until the next advance).  close may be NULL. */
+typedef struct tgpu_record_cursor {
+    void *user;
+    int32_t (*advance_next_position)(void *user);      /* RecordCursor.advanceNextPosition: 1 = positioned on a row, 0 = no more rows, < 0 error */
+    int32_t (*is_null)(void *user, int32_t field);
+    int32_t (*get_boolean)(void *user, int32_t field);
+    int64_t (*get_long)(void *user, int32_t field);
+    double (*get_double)(void *user, int32_t field);
+    int32_t (*get_slice)(void *user, int32_t field, const void **bytes, int32_t *length);   /* 0 = ok, < 0 error */
+    int64_t (*completed_bytes)(void *user);            /* RecordCursor.getCompletedBytes; NULL = not tracked */
+    void (*close)(void *user);
+} tgpu_record_cursor;
+int32_t tgpu_scan_operator_add_record_cursor(tgpu_operator *op, const tgpu_record_cursor *cursor, int32_t type_count, const int32_t *types);
 /* OperatorStats the scan side feeds (:354-397): positions pulled from the page sources, lazy blocks loaded / skipped */
 int32_t tgpu_scan_operator_stats(tgpu_operator *op, int64_t *processed_positions, int64_t *lazy_blocks_loaded, int64_t *lazy_blocks_skipped);
 

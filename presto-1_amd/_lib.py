@@ -71,6 +71,18 @@ class PageSource(C.Structure):
                 ("close", SOURCE_CLOSE_FN)]
 
 
+CURSOR_FIELD_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32)
+CURSOR_LONG_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_int32)
+CURSOR_DOUBLE_FN = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_int32)
+CURSOR_SLICE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32))
+CURSOR_BYTES_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p)
+
+
+class RecordCursor(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("advance_next_position", SOURCE_FLAG_FN), ("is_null", CURSOR_FIELD_FN), ("get_boolean", CURSOR_FIELD_FN), ("get_long", CURSOR_LONG_FN),
+                ("get_double", CURSOR_DOUBLE_FN), ("get_slice", CURSOR_SLICE_FN), ("completed_bytes", CURSOR_BYTES_FN), ("close", SOURCE_CLOSE_FN)]
+
+
 class AggSpec(C.Structure):
     _fields_ = [("function", C.c_int32), ("input_channel", C.c_int32), ("mask_channel", C.c_int32)]
 
@@ -115,6 +127,7 @@ SYMBOLS = {
     "tgpu_filter_project_hash_aggregation_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), i32, P(i32), P(i32), i32, i32, i32, P(AggSpec), i32, P(vp)]),
     "tgpu_scan_filter_project_factory_create": (i32, [vp, i32, i32, P(i32), P(PageProcessorSpec), P(vp)]),
     "tgpu_scan_operator_add_page_source": (i32, [vp, P(PageSource)]),
+    "tgpu_scan_operator_add_record_cursor": (i32, [vp, P(RecordCursor), i32, P(i32)]),
     "tgpu_scan_operator_no_more_splits": (i32, [vp]),
     "tgpu_scan_operator_stats": (i32, [vp, P(i64), P(i64), P(i64)]),
     "tgpu_operator_factory_create_operator": (i32, [vp, P(vp)]),

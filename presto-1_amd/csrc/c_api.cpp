@@ -264,6 +264,122 @@ int32_t tgpu_scan_operator_add_page_source(tgpu_operator *op, const tgpu_page_so
     });
 }
 
+namespace {
+// RecordCursor -> pages (the library's RecordPageSource): rows are pulled through the cursor's callbacks into host columns, kBatchRows at a
+// time, and handed to the scan operator as an ordinary page source; the operator closes it (which closes the cursor and frees this object)
+struct CursorPageSource {
+    static constexpr int32_t kBatchRows = 1 << 16;
+    tgpu_record_cursor cur;
+    std::vector<int32_t> types;
+    bool finished = false, closed = false;
+    std::vector<std::vector<uint8_t>> values, nulls;
+    std::vector<std::vector<int32_t>> offsets;
+    std::vector<tgpu_block> blocks;
+
+    static int32_t get_next_page(void *u, tgpu_page *page)
+    {
+        CursorPageSource *s = static_cast<CursorPageSource *>(u);
+        if (s->finished) return 0;
+        const size_t nf = s->types.size();
+        s->values.assign(nf, {});
+        s->nulls.assign(nf, {});
+        s->offsets.assign(nf, {});
+        for (size_t f = 0; f < nf; f++)
+            if (s->types[f] == TGPU_VARCHAR) s->offsets[f].push_back(0);
+        std::vector<bool> any_null(nf, false);
+        int32_t rows = 0;
+        while (rows < kBatchRows) {
+            const int32_t a = s->cur.advance_next_position(s->cur.user);
+            if (a < 0) return a;
+            if (a == 0) {
+                s->finished = true;
+                break;
+            }
+            for (size_t f = 0; f < nf; f++) {
+                const int32_t t = s->types[f];
+                const bool is_null = s->cur.is_null(s->cur.user, (int32_t)f) != 0;
+                s->nulls[f].push_back(is_null ? 1 : 0);
+                any_null[f] = any_null[f] || is_null;
+                if (t == TGPU_VARCHAR) {
+                    const void *b = nullptr;
+                    int32_t len = 0;
+                    if (!is_null) {
+                        const int32_t rc = s->cur.get_slice(s->cur.user, (int32_t)f, &b, &len);
+                        if (rc < 0) return rc;
+                        if (len < 0 || (len > 0 && !b)) return TGPU_ERR_INVALID_ARGUMENT;
+                    }
+                    const uint8_t *bytes = static_cast<const uint8_t *>(b);
+                    s->values[f].insert(s->values[f].end(), bytes, bytes + len);
+                    if (s->values[f].size() > 0x7fffffffu) return TGPU_ERR_INSUFFICIENT_RESOURCES;
+                    s->offsets[f].push_back((int32_t)s->values[f].size());
+                    continue;
+                }
+                const size_t w = (size_t)type_width(t), at = s->values[f].size();
+                s->values[f].resize(at + w);
+                if (is_null) continue;   // (zero bytes)
+                if (t == TGPU_DOUBLE) {
+                    const double v = s->cur.get_double(s->cur.user, (int32_t)f);
+                    memcpy(&s->values[f][at], &v, 8);
+                } else if (t == TGPU_BOOLEAN) s->values[f][at] = s->cur.get_boolean(s->cur.user, (int32_t)f) ? 1 : 0;
+                else {
+                    const int64_t v = s->cur.get_long(s->cur.user, (int32_t)f);
+                    if (w == 8) memcpy(&s->values[f][at], &v, 8);
+                    else {
+                        const int32_t v32 = (int32_t)v;
+                        memcpy(&s->values[f][at], &v32, 4);
+                    }
+                }
+            }
+            rows++;
+        }
+        if (rows == 0) return 0;
+        s->blocks.assign(nf, tgpu_block{});
+        for (size_t f = 0; f < nf; f++) {
+            tgpu_block &b = s->blocks[f];
+            b.type = s->types[f];
+            b.encoding = TGPU_FLAT;
+            b.memory = TGPU_HOST;
+            b.position_count = rows;
+            if (s->types[f] == TGPU_VARCHAR && s->values[f].empty()) s->values[f].push_back(0);   // (a non-null byte pool for a column of empty strings)
+            b.values = s->values[f].data();
+            b.nulls = any_null[f] ? s->nulls[f].data() : nullptr;
+            b.offsets = s->types[f] == TGPU_VARCHAR ? s->offsets[f].data() : nullptr;
+        }
+        page->position_count = rows;
+        page->channel_count = (int32_t)nf;
+        page->blocks = s->blocks.data();
+        return 1;
+    }
+    static int32_t is_finished(void *u) { return static_cast<CursorPageSource *>(u)->finished ? 1 : 0; }
+    static void close(void *u)
+    {
+        CursorPageSource *s = static_cast<CursorPageSource *>(u);
+        if (s->cur.close) s->cur.close(s->cur.user);
+        delete s;
+    }
+};
+}  // namespace
+
+int32_t tgpu_scan_operator_add_record_cursor(tgpu_operator *op, const tgpu_record_cursor *cursor, int32_t type_count, const int32_t *types)
+{
+    return guard_on(ctx_of(op), [&] {
+        TG_CHECK_ARG(op != nullptr && op->op && cursor && type_count >= 0 && (types || type_count == 0), "null argument");
+        TG_CHECK_ARG(cursor->advance_next_position && cursor->is_null && cursor->get_boolean && cursor->get_long && cursor->get_double && cursor->get_slice,
+                     "a record cursor implements advance_next_position, is_null and the four getters");
+        for (int32_t i = 0; i < type_count; i++) TG_CHECK_ARG(valid_type(types[i]), "unknown field type");
+        std::unique_ptr<CursorPageSource> s = std::make_unique<CursorPageSource>();
+        s->cur = *cursor;
+        s->types.assign(types, types + type_count);
+        tgpu_page_source ps{};
+        ps.user = s.get();
+        ps.get_next_page = &CursorPageSource::get_next_page;
+        ps.is_finished = &CursorPageSource::is_finished;
+        ps.close = &CursorPageSource::close;
+        scan_add_page_source(op->op.get(), &ps);   // (copies the callbacks; from here on the operator owns the source and closes it)
+        s.release();
+    });
+}
+
 int32_t tgpu_scan_operator_no_more_splits(tgpu_operator *op)
 {
     return guard_on(ctx_of(op), [&] {

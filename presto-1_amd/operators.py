@@ -68,7 +68,7 @@ class Context:
         _lib.check(_lib.lib().tgpu_context_set_double_sum_order(self.handle, order))
 
     def set_device_input_stable(self, stable=True):
-        """the promise of tgpu_context_set_device_input_stable: borrowed device blocks stay valid and unchanged until the operator's next call returns"""
+        """the promise of tgpu_context_set_device_input_stable: borrowed device blocks stay valid and unchanged until the operator they were given to has finished"""
         _lib.check(_lib.lib().tgpu_context_set_device_input_stable(self.handle, int(bool(stable))))
 
     def profile_enable(self, on=True):
@@ -294,11 +294,64 @@ class PageSource:
         self.closed = True
 
 
+class RecordCursor:
+    """a RecordCursor (S/connector/RecordCursor.java) over Python rows (tuples; None = null), as the callbacks of tgpu_record_cursor"""
+
+    def __init__(self, types, rows):
+        self.types = list(types)
+        self.rows = list(rows)
+        self.at = -1
+        self.closed = False
+        self.error = None
+        self._slice_keep = None
+        self.struct = _lib.RecordCursor(None, _lib.SOURCE_FLAG_FN(self._advance), _lib.CURSOR_FIELD_FN(self._is_null), _lib.CURSOR_FIELD_FN(self._boolean),
+                                        _lib.CURSOR_LONG_FN(self._long), _lib.CURSOR_DOUBLE_FN(self._double), _lib.CURSOR_SLICE_FN(self._slice),
+                                        _lib.CURSOR_BYTES_FN(self._bytes), _lib.SOURCE_CLOSE_FN(self._close))
+
+    def _advance(self, user):
+        self.at += 1
+        return 1 if self.at < len(self.rows) else 0
+
+    def _is_null(self, user, field):
+        return 1 if self.rows[self.at][field] is None else 0
+
+    def _boolean(self, user, field):
+        return 1 if self.rows[self.at][field] else 0
+
+    def _long(self, user, field):
+        return int(self.rows[self.at][field])
+
+    def _double(self, user, field):
+        return float(self.rows[self.at][field])
+
+    def _slice(self, user, field, out_bytes, out_len):
+        try:
+            v = self.rows[self.at][field]
+            b = v.encode("utf-8") if isinstance(v, str) else bytes(v)
+            self._slice_keep = C.create_string_buffer(b, len(b)) if b else None   # valid until the next advance
+            out_bytes[0] = C.cast(self._slice_keep, C.c_void_p).value if b else None
+            out_len[0] = len(b)
+            return 0
+        except Exception as e:   # must not unwind through the C frames
+            self.error = e
+            return -1
+
+    def _bytes(self, user):
+        return 0
+
+    def _close(self, user):
+        self.closed = True
+
+
 class ScanOperator(Operator):
-    def addSplit(self, page_source: PageSource):
-        """SourceOperator.addSplit: the split's page source"""
-        self._sources = getattr(self, "_sources", []) + [page_source]
-        _lib.check(_lib.lib().tgpu_scan_operator_add_page_source(self.handle, C.byref(page_source.struct)))
+    def addSplit(self, source):
+        """SourceOperator.addSplit: the split's page source (PageSource) or record cursor (RecordCursor)"""
+        self._sources = getattr(self, "_sources", []) + [source]
+        if isinstance(source, RecordCursor):
+            t, n = _i32(source.types)
+            _lib.check(_lib.lib().tgpu_scan_operator_add_record_cursor(self.handle, C.byref(source.struct), n, t))
+            return
+        _lib.check(_lib.lib().tgpu_scan_operator_add_page_source(self.handle, C.byref(source.struct)))
 
     def noMoreSplits(self):
         _lib.check(_lib.lib().tgpu_scan_operator_no_more_splits(self.handle))

@@ -2589,6 +2589,54 @@ def test_scan_filter_project_page_source_golden(pkg, ctx):
     assert [r[0] for pg in _drain_source_operator(op2) for r in pg.rows()] == [10, 10, 10, 10]
 
 
+def test_scan_filter_project_record_cursor_golden_and_mixed_types(pkg, ctx, oracle):
+    # T/operator/TestScanFilterAndProjectOperator.java:221-253 testRecordCursorSource: the split's source is a RecordCursor over the VARCHAR
+    # sequence page of 10 000 rows, projection field(0): every row comes out, in order (tgpu_scan_operator_add_record_cursor)
+    V, B, D, BO, DT = pkg.VARCHAR, pkg.BIGINT, pkg.DOUBLE, pkg.BOOLEAN, pkg.DATE
+    f, c = pkg.field, pkg.constant
+    vals = sequence_values(V, 0, 10_000)
+    fac = pkg.ScanFilterAndProjectOperatorFactory(ctx, 0, [V], None, [f(0, V)])
+    op = fac.createOperator()
+    cur = pkg.RecordCursor([V], [(v,) for v in vals])
+    op.addSplit(cur)
+    op.noMoreSplits()
+    pages = _drain_source_operator(op)
+    assert [r[0] for pg in pages for r in pg.rows()] == vals
+    assert cur.closed and op.stats()["processedPositions"] == 10_000
+    # every getter, nulls, more rows than one batch of the adapter (65 536), a filter and computed projections: equal to the oracle's
+    # filter / project over the same rows as one page
+    rng = np.random.default_rng(223)
+    n = 150_000
+    rows = []
+    words = ["", "a", "BUILDING", "héllo", "x" * 50]
+    for i in range(n):
+        rows.append((None if i % 97 == 0 else int(rng.integers(-10**12, 10**12)), None if i % 89 == 0 else float(rng.standard_normal()),
+                     None if i % 83 == 0 else bool(rng.integers(0, 2)), None if i % 79 == 0 else words[int(rng.integers(0, len(words)))],
+                     None if i % 73 == 0 else int(rng.integers(9000, 9400))))
+    T = [B, D, BO, V, DT]
+    filt = pkg.and_(f(4, DT) > c(9100, DT), pkg.not_(pkg.is_null(f(0, B))))
+    projs = [f(0, B) + c(1, B), f(1, D) * c(2.0, D), f(2, BO), f(3, V), f(4, DT)]
+    op = pkg.ScanFilterAndProjectOperatorFactory(ctx, 1, T, filt, projs).createOperator()
+    cur = pkg.RecordCursor(T, rows)
+    op.addSplit(cur)
+    op.noMoreSplits()
+    got = [r for pg in _drain_source_operator(op) for r in pg.rows()]
+    page = pkg.Page(*[pkg.Block(t, [r[i] for r in rows]) for i, t in enumerate(T)])
+    prog = pkg.expressions.FlatProgram(filt, projs)
+    cols = [ocol(oracle, b) for b in page.blocks]
+    pos = oracle.filter_positions(prog.nodes, prog.filter_root, bytes(prog.pool), cols)
+    want_cols = []
+    for root in prog.projection_roots[:3] + prog.projection_roots[4:]:
+        v, nl = oracle.project(prog.nodes, root, bytes(prog.pool), cols, pos)
+        want_cols.append([None if nl[i] else v[i] for i in range(len(pos))])
+    assert len(got) == len(pos) and cur.closed
+    assert [r[0] for r in got] == [None if x is None else int(x) for x in want_cols[0]]
+    assert [None if r[1] is None else np.float64(r[1]).tobytes() for r in got] == [None if x is None else np.float64(x).tobytes() for x in want_cols[1]]
+    assert [r[2] for r in got] == [None if x is None else bool(x) for x in want_cols[2]]
+    assert [r[3] for r in got] == [rows[p][3] for p in pos]
+    assert [r[4] for r in got] == [None if x is None else int(x) for x in want_cols[3]]
+
+
 def test_scan_filter_project_lazy_blocks(pkg, ctx):
     """T/operator/project/TestPageProcessor.java:156-184 (SelectAll: filter block loaded, projection block loaded for the output),
     :219-234 testSelectNoneFilterLazyLoad (a projection-only lazy channel is NOT loaded when the filter selects nothing),
