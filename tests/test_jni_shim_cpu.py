@@ -68,7 +68,8 @@ def test_shim_only_calls_functions_the_header_declares_and_binds_every_operator_
                "tgpu_group_by_hash_group_count", "tgpu_group_by_hash_capacity", "tgpu_group_by_hash_estimated_size", "tgpu_group_by_hash_rehash_count",
                "tgpu_group_by_hash_append_values", "tgpu_hash_page", "tgpu_partition_page", "tgpu_profile_reset", "tgpu_version", "tgpu_set_resource_dir",
                "tgpu_pinned_alloc", "tgpu_pinned_free", "tgpu_output_page_copy_block",
-               "tgpu_scan_operator_add_record_cursor",   # (Java keeps a RecordPageSource as the page source it is: INTEGRATION.md) "tgpu_exchange_create_with_transport", "tgpu_partitioned_join_position_encode",
+               "tgpu_exchange_create_with_transport", "tgpu_partitioned_join_position_encode",
+               "tgpu_scan_operator_add_record_cursor",   # (Java keeps a RecordPageSource as the page source it is: INTEGRATION.md)
                "tgpu_partitioned_join_position_decode", "tgpu_lookup_source_factory_destroy"}
     assert unbound <= allowed | {"tgpu_lookup_source_factory_destroy"}, unbound - allowed
 
