@@ -339,7 +339,10 @@ void Context::finish_signal(const Signal &s, unsigned long long out[kSignalWords
             c->read_busy_[slot] = false;
         }
     } release{this, s.slot};
-    // the flag word arrives while the stream keeps running; a stream that has drained without it means the kernel never ran to its end
+    // the flag word arrives while the stream keeps running; a stream that has drained without it means the kernel never ran to its end.
+    // TGPU_BLOCKING_WAIT=1 (an embedding that must not spin a core): wait for the stream instead of polling the word
+    static const bool blocking = getenv("TGPU_BLOCKING_WAIT") != nullptr;
+    if (blocking && __atomic_load_n(const_cast<unsigned long long *>(&s.host[kSignalWords - 1]), __ATOMIC_ACQUIRE) == 0) HIP_CHECK(hipStreamSynchronize(stream_));
     for (uint64_t spins = 1;; spins++) {
         if (__atomic_load_n(const_cast<unsigned long long *>(&s.host[kSignalWords - 1]), __ATOMIC_ACQUIRE) != 0) break;
         if ((spins & 0xfffff) == 0) {
