@@ -1048,6 +1048,34 @@ class Bench:
 #   group_by_hash    : T/operator/BenchmarkGroupByHash.java:65-74,119-137 bigintGroupByHash: addPage of BIGINT keys uniform in
 #                      [0, groups) + appendValuesTo of every group (10 M rows / 3 M groups as in the reference, and 100 M / 40 M)
 # ---------------------------------------------------------------------------------------------------------------------
+# What bounds the open-address tables is not HBM bytes but the rate at which this part serves RANDOM accesses to tables beyond its caches,
+# measured in isolation by tools/exp_random_access.hip (G accesses per second, whole chip): loads 56 / 55 / 54 and returning
+# atomics (CAS / atomicMin) 27 / 22 / 18 for tables of <= 128 MB / 512 MB / >= 2 GB.  The byte roofline of these kernels stays in `roofline`;
+# this object prices them in requests.
+def random_access_rates(table_bytes):
+    """(G random loads/s, G returning atomics/s) of tools/exp_random_access.hip for a table of this size: Infinity-Cache-sized, 512 MB, DRAM-sized"""
+    if table_bytes <= (128 << 20):
+        return 56.0, 27.0
+    if table_bytes <= (512 << 20):
+        return 55.0, 22.0
+    return 54.0, 18.0
+
+
+def request_roofline(profile, steps, kernel, rows, loads_per_row, atomics_per_row, table_bytes, note):
+    st = profile.get(kernel)
+    if not st or st["count"] == 0:
+        return None
+    ms = st["total_ms"] / steps
+    achieved = rows / (ms * 1e-3) / 1e9
+    RANDOM_LOADS_G_PER_S, RANDOM_ATOMICS_G_PER_S = random_access_rates(table_bytes)
+    # (loads are served by the cache hierarchy, returning atomics at the memory side: the two streams overlap, the slower one bounds)
+    peak = 1.0 / max(loads_per_row / RANDOM_LOADS_G_PER_S, atomics_per_row / RANDOM_ATOMICS_G_PER_S)
+    return {"bound": "random_access", "kernel": kernel, "achieved": achieved, "peak": peak, "unit": "G rows/s", "frac": achieved / peak, "kernel_ms_per_step": ms,
+            "rows_per_step": rows, "random_loads_per_row": loads_per_row, "returning_atomics_per_row": atomics_per_row, "table_bytes": table_bytes,
+            "peak_source": f"tools/exp_random_access.hip on MI355X (DESIGN.md 4a): {RANDOM_LOADS_G_PER_S:g} G random loads/s, {RANDOM_ATOMICS_G_PER_S:g} G returning atomics/s "
+                           "for a table of this size; a measured ceiling of the isolated access pattern, not a datasheet number", "note": note}
+
+
 def sub_join_hash_layout(b, steps, warmup, sf):
     p, ctx, dev = b.pkg, b.ctx, b.dev
     B, D, I = p.BIGINT, p.DOUBLE, p.INTEGER
@@ -1097,7 +1125,9 @@ def sub_join_hash_layout(b, steps, warmup, sf):
     roof = dominant(prof, steps, {"fused_filter_probe": n}, {"fused_filter_probe": alg / n}, pmc_prefix="sub_join_hash_layout:")
     return {"workload": "fused filter + probe, sparse random 64-bit build keys (open-address TgSlot16 table + Bloom pre-filter)", "build_rows": nb, "input_rows": n,
             "probe_rows": n_pass, "pairs": want_pairs, "table_slots": res["stats"]["hash_size"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n_pass / step_s,
-            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
+            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
+            "request_roofline": request_roofline(prof, steps, "fused_filter_probe", n_pass, 1.0 + want_pairs / max(n_pass, 1), 0.0, res["stats"]["hash_size"] * 16,
+                                                 "one Bloom word per row that passes the filter (29 MB filter: beyond the L2) + one table slot per survivor"), "ok": bool(ok)}
 
 
 def sub_join_duplicate_keys(b, steps, warmup, sf):
@@ -1134,7 +1164,9 @@ def sub_join_duplicate_keys(b, steps, warmup, sf):
     roof = dominant(prof, steps, {"join_probe_count": n}, {"join_probe_count": 32.0}, pmc_prefix="sub_join_duplicate_keys:")
     return {"workload": "LookupJoinOperator over a table with every build key twice (position links, newest -> oldest chains)", "build_rows": nb, "probe_rows": n,
             "pairs": want_pairs, "link_count": res["stats"]["link_count"], "ms_per_step": step_s * 1e3, "probe_rows_per_sec": n / step_s,
-            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof, "ok": bool(ok)}
+            "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
+            "request_roofline": request_roofline(prof, steps, "join_probe_count", n, 1.0, 0.0, res["stats"]["hash_size"] * 16,
+                                                 "one table slot per probe row (the chain length sits in the slot)"), "ok": bool(ok)}
 
 
 def sub_group_by_hash(b, steps, warmup, rows, groups):
@@ -1150,17 +1182,25 @@ def sub_group_by_hash(b, steps, warmup, rows, groups):
         g.addPage(page)
         out = g.appendValuesDevice()
         res["groups"] = out.position_count
+        res["capacity"] = g.getCapacity()
         out.release()
         g.close()
 
     step_s, prof = b.timed(step, steps, warmup)
     want = int(torch.unique(keys).numel())
+    # rows that pay the returning atomic: those whose key has not been published by an EARLIER sub-batch of 2^24 rows
+    batch = i >> 24
+    first_batch = torch.full((groups,), 1 << 40, device=dev, dtype=torch.int64).scatter_reduce_(0, keys, batch, "amin")
+    atomic_rows = int((first_batch[keys] == batch).sum().item())
     # gbh_insert per row: key 8 B + one 8-byte table word + the 4-byte group id it answers with
     shape = f"{rows // 1_000_000}M_{groups // 1_000_000}M"
     roof = dominant(prof, steps, {"gbh_insert": rows}, {"gbh_insert": 20.0}, pmc_prefix=f"sub_group_by_hash_{shape}:")
     return {"workload": f"BenchmarkGroupByHash.bigintGroupByHash shape: addPage of {rows} BIGINT keys uniform in [0, {groups}) + appendValuesTo of every group",
             "rows": rows, "groups": want, "ms_per_step": step_s * 1e3, "rows_per_sec": rows / step_s, "ns_per_row": step_s * 1e9 / rows,
             "kernels_ms_per_step": {k: v["total_ms"] / steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])}, "roofline": roof,
+            "request_roofline": request_roofline(prof, steps, "gbh_insert", rows, 1.0, atomic_rows / rows, res["capacity"] * 16,
+                                                 "one slot load per row; one returning atomicMin per row whose group is new in its 2^24-row sub-batch (counted from the keys: "
+                                                 f"{atomic_rows} of {rows} rows), rows of groups published by an earlier sub-batch only read"),
             "ok": bool(res["groups"] == want)}
 
 
