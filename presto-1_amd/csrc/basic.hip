@@ -56,41 +56,72 @@ template <typename T> __device__ __forceinline__ T block_exclusive_scan(T v, T *
     return prefix;
 }
 
-__global__ void __launch_bounds__(kBlock) scan_tile_sums_i32(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ tile_sums)
+// the 8 consecutive items of a thread: two 16-byte loads when the array is 16-byte aligned (it is for every buffer of the context's
+// allocator; callers may pass interior pointers), else eight 4-byte ones
+__device__ __forceinline__ void scan_load8(const int32_t *__restrict__ in, int64_t idx, int64_t n, bool aligned, int32_t v[kScanItems])
+{
+    if (aligned && idx + kScanItems <= n) {
+        const int4 a = *reinterpret_cast<const int4 *>(in + idx), b = *reinterpret_cast<const int4 *>(in + idx + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < kScanItems; i++) v[i] = idx + i < n ? in[idx + i] : 0;
+}
+
+// Every workgroup owns a contiguous RANGE of tiles (range = a multiple of the tile, at most kScanMaxBlocks ranges): the scan of the range
+// sums in the middle is then a few hundred values whatever n is (one tile per workgroup made it 48 828 values for 100 M elements, scanned
+// by a single workgroup in 191 rounds: 0.4 ms of the join's 0.74 ms probe scan).
+constexpr int kScanMaxBlocks = 2048;
+
+__global__ void __launch_bounds__(kBlock) scan_range_sums_i32(const int32_t *__restrict__ in, int64_t n, int64_t range, int64_t *__restrict__ range_sums)
 {
     __shared__ int64_t lds[kWaves + 1];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    const int64_t a = (int64_t)blockIdx.x * range, z = a + range < n ? a + range : n;
     int64_t s = 0;
+    for (int64_t base = a; base < z; base += kScanTile) {
+        int32_t v[kScanItems];
+        scan_load8(in, base + (int64_t)threadIdx.x * kScanItems, z, aligned, v);
 #pragma unroll
-    for (int i = 0; i < kScanItems; i++) {
-        int64_t idx = base + i;
-        if (idx < n) s += in[idx];
+        for (int i = 0; i < kScanItems; i++) s += v[i];
     }
     int64_t total;
     block_exclusive_scan<int64_t>(s, &total, lds);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+    if (threadIdx.x == 0) range_sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(kBlock) scan_tiles_i32(const int32_t *__restrict__ in, int32_t *__restrict__ out, int64_t n,
-                                                          const int64_t *__restrict__ tile_prefix)
+__global__ void __launch_bounds__(kBlock) scan_ranges_i32(const int32_t *__restrict__ in, int32_t *__restrict__ out, int64_t n, int64_t range,
+                                                           const int64_t *__restrict__ range_prefix)
 {
     __shared__ int64_t lds[kWaves + 1];
-    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    int32_t v[kScanItems];
-    int64_t s = 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15) == 0, out_aligned = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    const int64_t a = (int64_t)blockIdx.x * range, z = a + range < n ? a + range : n;
+    int64_t carry = range_prefix[blockIdx.x];
+    for (int64_t base = a; base < z; base += kScanTile) {
+        const int64_t idx = base + (int64_t)threadIdx.x * kScanItems;
+        int32_t v[kScanItems];
+        scan_load8(in, idx, z, aligned, v);
+        int64_t s = 0;
 #pragma unroll
-    for (int i = 0; i < kScanItems; i++) {
-        int64_t idx = base + i;
-        v[i] = idx < n ? in[idx] : 0;
-        s += v[i];
-    }
-    int64_t total;
-    int64_t prefix = block_exclusive_scan<int64_t>(s, &total, lds) + tile_prefix[blockIdx.x];
+        for (int i = 0; i < kScanItems; i++) s += v[i];
+        int64_t total;
+        int64_t prefix = carry + block_exclusive_scan<int64_t>(s, &total, lds);
+        int32_t o[kScanItems];
 #pragma unroll
-    for (int i = 0; i < kScanItems; i++) {
-        int64_t idx = base + i;
-        if (idx < n) out[idx] = (int32_t)prefix;
-        prefix += v[i];
+        for (int i = 0; i < kScanItems; i++) {
+            o[i] = (int32_t)prefix;
+            prefix += v[i];
+        }
+        if (out_aligned && idx + kScanItems <= z) {
+            *reinterpret_cast<int4 *>(out + idx) = make_int4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<int4 *>(out + idx + 4) = make_int4(o[4], o[5], o[6], o[7]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kScanItems; i++)
+                if (idx + i < z) out[idx + i] = o[i];
+        }
+        carry += total;
     }
 }
 
@@ -144,12 +175,13 @@ void exclusive_scan_i32(Context *ctx, const int32_t *in, int32_t *out, int64_t n
         check_launch("exclusive_scan_i32");
         return;
     }
-    int64_t tiles = ceil_div(n, kScanTile);
-    BufferPtr sums = ctx->alloc((size_t)tiles * 8);
-    BufferPtr prefix = ctx->alloc((size_t)tiles * 8);
-    scan_tile_sums_i32<<<(int)tiles, kBlock, 0, ctx->stream()>>>(in, n, sums->as<int64_t>());
-    scan_small_i64<<<1, kBlock, 0, ctx->stream()>>>(sums->as<int64_t>(), prefix->as<int64_t>(), tiles, total_dev);
-    scan_tiles_i32<<<(int)tiles, kBlock, 0, ctx->stream()>>>(in, out, n, prefix->as<int64_t>());
+    const int64_t tiles = ceil_div(n, kScanTile);
+    const int64_t tiles_per_range = ceil_div(tiles, (int64_t)kScanMaxBlocks), range = tiles_per_range * kScanTile, ranges = ceil_div(n, range);
+    BufferPtr sums = ctx->alloc((size_t)ranges * 8);
+    BufferPtr prefix = ctx->alloc((size_t)ranges * 8);
+    scan_range_sums_i32<<<(int)ranges, kBlock, 0, ctx->stream()>>>(in, n, range, sums->as<int64_t>());
+    scan_small_i64<<<1, kBlock, 0, ctx->stream()>>>(sums->as<int64_t>(), prefix->as<int64_t>(), ranges, total_dev);
+    scan_ranges_i32<<<(int)ranges, kBlock, 0, ctx->stream()>>>(in, out, n, range, prefix->as<int64_t>());
     check_launch("exclusive_scan_i32");
 }
 
