@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 2; } } while (0)
 __global__ void spin(unsigned long long cycles, int *sink)
 {
@@ -23,13 +24,16 @@ int main()
         CK(hipMalloc(&dev, bytes));
         memset(src, 0xA5, bytes);
         spin<<<1, 1, 0, s>>>(2000000ull, nullptr);   // ~20 ms at 100 MHz
+        const auto t0 = std::chrono::steady_clock::now();
         CK(hipMemcpyAsync(dev, src, bytes, hipMemcpyHostToDevice, s));
+        const double call_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         memset(src, 0x3C, bytes);                     // the caller reuses its array
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(back, dev, bytes, hipMemcpyDeviceToHost));
         size_t wrong = 0;
         for (size_t i = 0; i < bytes; i++) wrong += back[i] != 0xA5;
-        printf("bytes %10zu: %s (%zu bytes saw the overwritten source)\n", bytes, wrong ? "SOURCE READ LATER" : "source consumed at return", wrong);
+        printf("bytes %10zu: %s (%zu bytes saw the overwritten source); the call took %.0f us behind a ~20 ms kernel\n", bytes,
+               wrong ? "SOURCE READ LATER" : "source consumed at return", wrong, call_us);
         bad += wrong != 0;
         CK(hipFree(dev));
         free(src);
