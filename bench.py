@@ -1540,8 +1540,10 @@ def main():
                      "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(p1.items(), key=lambda kv: -kv[1]["total_ms"])}}
         # roofline of Q1's dominant kernel: the fused project+accumulate pass reads the group id (one byte per row in the
         # low-cardinality mode Q1 runs in, int32 otherwise) + four 8-byte inputs per row
-        out["q1"]["roofline"] = dominant(p1, args.steps, {"fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
-                                         {"fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
+        # (the table-sized page: three leading slices through probe + accumulate, the rest -- n - 1.5 M rows -- in ONE one-pass launch that reads
+        # every input byte once: 4 + 2 x (4 + 1) + 32 = 46 B per row; TGPU_DISABLE_PAGE_SPLIT: the two-launch path, 1 + 32 B per row in the accumulate)
+        out["q1"]["roofline"] = dominant(p1, args.steps, {"fused_filter_group_accumulate_onepass": n - 1_572_864, "fused_project_accumulate_lowcard": n, "fused_project_accumulate": n},
+                                         {"fused_filter_group_accumulate_onepass": 46.0, "fused_project_accumulate_lowcard": 33.0, "fused_project_accumulate": 36.0})
         out["checks"]["q1"] = b.check_q1(java_order_distance=(b.world == 1 and not args.no_cpu_baseline))
         out["q1"]["step_stats"] = b.step_stats(b.step_q1, min(args.steps, 20))
         out["q1"]["double_sum_order"] = "EXACT"

@@ -1465,6 +1465,29 @@ public:
             if (processor_->process(ctx_, in, mid)) process_page(mid);
             return;
         }
+        // A table-sized page does not need two passes either: its first rows go through the insert protocol in three slices -- they bring
+        // the groups and decide the DOUBLE mode -- and if the group set has settled by then (it has for the few-group aggregations this path
+        // is for) the REST of the page is one one-pass launch: every input byte read once instead of the key columns twice.  The rest is
+        // judged like any one-pass launch: a row of an unknown group makes it dirty and it is re-run through the two-launch path.
+        if (in.n >= kSplitAboveRows && pending_.empty() && batch_.empty() && clean_streak_ < kOnepassAfter && retained(in) && getenv("TGPU_DISABLE_ONEPASS") == nullptr &&
+            getenv("TGPU_DISABLE_SPECULATION") == nullptr && getenv("TGPU_DISABLE_PAGE_SPLIT") == nullptr) {
+            static constexpr int64_t kSlices[3] = {1 << 18, 1 << 18, 1 << 20};
+            int64_t at = 0;
+            for (int64_t len : kSlices) {
+                process_fused(slice_of(in, at, len));
+                at += len;
+            }
+            DevicePage rest = slice_of(in, at, in.n - at);
+            if (onepass_ready(rest)) {
+                batch_rows_ += rest.n;
+                batch_.push_back(std::move(rest));
+                launch_onepass();
+            } else {
+                drain_onepass();
+                process_fused(rest);
+            }
+            return;
+        }
         if (onepass_ready(in)) {
             // the operator is blocking (nothing leaves it before finish): small pages are collected, by reference, into one launch
             batch_rows_ += in.n;
@@ -1547,6 +1570,14 @@ private:
     // launch re-runs its pages one by one in page order, an expression error in a launch of several pages likewise (the re-run raises the
     // error of the first failing page, like the reference).
     static constexpr int kOnepassDepth = 2, kOnepassAfter = 2, kOnepassBatchPages = 64;
+    static constexpr int64_t kSplitAboveRows = 1ll << 23;   // pages from here on are split into three leading slices + the rest (add_page)
+    DevicePage slice_of(const DevicePage &in, int64_t at, int64_t len) const
+    {
+        DevicePage out;
+        out.n = len;
+        for (const DeviceColumn &c : in.cols) out.cols.push_back(k::region_of(ctx_, c, at, len));   // views: the buffers are shared
+        return out;
+    }
     static constexpr int64_t kOnepassBatchRows = 1ll << 24;
     static int64_t onepass_batch_rows()
     {

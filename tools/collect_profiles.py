@@ -19,7 +19,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OURS = ("fj_", "fg_", "fa_", "fp_", "fq_", "tgpu::", "void tgpu::")   # rocPRIM kernels (scan / radix sort) are shared with torch: left out
 PROFILE_NAME = {"fj_probe_direct": "fused_filter_probe", "fj_emit_direct": "fused_probe_emit", "fg_probe": "fused_filter_group_probe",
-                "fa_accumulate_lowcard": "fused_project_accumulate_lowcard", "fp_count": "filter_count", "fp_emit": "filter_project_emit",
+                "fa_accumulate_lowcard": "fused_project_accumulate_lowcard", "fq_onepass": "fused_filter_group_accumulate_onepass", "fp_count": "filter_count",
+                "fp_emit": "filter_project_emit",
                 # sub-benchmarks (bench.py looks them up under these keys: their kernels share profile names with the headline's)
                 "fj_probe_bloom": "sub_join_hash_layout:fused_filter_probe",
                 "void tgpu::(anonymous namespace)::probe_count_kernel<true>": "sub_join_duplicate_keys:join_probe_count"}
