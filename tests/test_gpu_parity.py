@@ -1286,6 +1286,45 @@ def test_fused_aggregation_launch_over_ragged_pages_with_and_without_null_vector
         assert ulp_diff([np.nan if x is None else x for x in ra[2:6]], [np.nan if x is None else x for x in rb[2:6]]).max() == 0
 
 
+@pytest.mark.parametrize("late_group", [False, True])
+def test_fused_aggregation_splits_a_table_sized_page(pkg, monkeypatch, late_group):
+    """a page of 9 M rows (>= 2^23): three leading slices through the insert protocol, the rest in ONE one-pass launch; with a group that first
+    appears deep inside the rest the launch is dirty and the rest is re-run through the two-launch path.  Bit for bit the unsplit path
+    (TGPU_DISABLE_PAGE_SPLIT), group order included."""
+    rng = np.random.default_rng(61)
+    n = 9_000_000
+    V, D, DT, B = pkg.VARCHAR, pkg.DOUBLE, pkg.DATE, pkg.BIGINT
+    k1 = np.frombuffer(b"ANR", dtype=np.uint8)[rng.integers(0, 3, n)].copy()
+    k2 = np.frombuffer(b"FO", dtype=np.uint8)[rng.integers(0, 2, n)].copy()
+    if late_group:
+        k1[7_000_003] = ord("X")
+    off = np.arange(n + 1, dtype=np.int32)
+    qty = rng.integers(1, 51, n).astype(np.float64)
+    price = qty * rng.integers(90000, 210000, n) / 100.0
+    disc = rng.integers(0, 11, n) / 100.0
+    ship = rng.integers(8036, 10562, n).astype(np.int32)
+    page = pkg.Page(pkg.Block(V, k1, None, off), pkg.Block(V, k2, None, off), pkg.Block(D, qty), pkg.Block(D, price), pkg.Block(D, disc), pkg.Block(DT, ship),
+                    pkg.Block(B, np.ones(n, dtype=np.int64)))
+    T, filt, projs, aggs = _onepass_program(pkg)
+    rows = {}
+    for mode in ("split", "unsplit"):
+        if mode == "unsplit":
+            monkeypatch.setenv("TGPU_DISABLE_PAGE_SPLIT", "1")
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [V, V], [0, 1], aggs)
+        out = pkg.to_pages(fac.createOperator(), [page])
+        rows[mode] = [r for p_ in out for r in p_.rows()]
+        launches = ctx.profile().get("fused_filter_group_accumulate_onepass", {"count": 0})["count"]
+        assert launches == (1 if mode == "split" else 0)
+        ctx.close()
+    a, b = rows["split"], rows["unsplit"]
+    assert [r[:2] for r in a] == [r[:2] for r in b] and len(a) == (7 if late_group else 6)
+    for ra, rb in zip(a, b):
+        assert ra[6] == rb[6] and ra[7] == rb[7]
+        assert ulp_diff([np.nan if x is None else x for x in ra[2:6]], [np.nan if x is None else x for x in rb[2:6]]).max() == 0
+
+
 @pytest.mark.parametrize("batch_rows", ["1", "12000", None])
 def test_fused_aggregation_one_launch_per_page_raises_expression_errors_a_call_later(pkg, monkeypatch, batch_rows):
     """a filter that divides by zero on a page of the one-pass stream: the page's error word comes back with its counters, one call later; a
