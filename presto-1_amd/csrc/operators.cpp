@@ -1515,6 +1515,15 @@ public:
         drain_onepass();
         HashAggregationOperator::start_memory_revoke();
     }
+    // (the builder's bytes + the library-owned pages this operator keeps alive: collected for a common launch, or launched and not yet confirmed)
+    int64_t memory_bytes() override
+    {
+        int64_t b = HashAggregationOperator::memory_bytes();
+        for (const DevicePage &pg : batch_) b += owned_bytes(pg);
+        for (const PendingPage &p : pending_)
+            for (const DevicePage &pg : p.pages) b += owned_bytes(pg);
+        return b;
+    }
 
 private:
     // the two-launch path: group probe (insert protocol when a page brings new groups) + accumulate, one read-back per page
@@ -1571,6 +1580,12 @@ private:
     // error of the first failing page, like the reference).
     static constexpr int kOnepassDepth = 2, kOnepassAfter = 2, kOnepassBatchPages = 64;
     static constexpr int64_t kSplitAboveRows = 1ll << 23;   // pages from here on are split into three leading slices + the rest (add_page)
+    static int64_t owned_bytes(const DevicePage &pg)
+    {
+        for (const DeviceColumn &c : pg.cols)
+            if (c.n > 0 && !c.values_buf) return 0;   // borrowed device blocks are the embedding's memory, not this operator's
+        return pg.size_in_bytes();
+    }
     DevicePage slice_of(const DevicePage &in, int64_t at, int64_t len) const
     {
         DevicePage out;
