@@ -540,6 +540,9 @@ int32_t tgpu_orc_decode_long_column(tgpu_context *ctx, int32_t type, int32_t enc
 /* BOOLEAN columns: DATA = a boolean stream */
 int32_t tgpu_orc_decode_boolean_column(tgpu_context *ctx, int32_t position_count, const void *present, int64_t present_len, const void *data, int64_t data_len,
                                        tgpu_output_page **out);
+/* DOUBLE columns (reader/DoubleColumnReader.java:92-175): DATA = the non-null rows' doubles, 8 little-endian bytes each */
+int32_t tgpu_orc_decode_double_column(tgpu_context *ctx, int32_t position_count, const void *present, int64_t present_len, const void *data, int64_t data_len,
+                                      tgpu_output_page **out);
 /* STRING / VARCHAR / CHAR columns in DICTIONARY_V2 encoding: DATA = unsigned RLEv2 ids, LENGTH = unsigned RLEv2 lengths of the dictionary_size
  * entries, DICTIONARY_DATA = their bytes; the result is a flat VARCHAR block */
 int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len,

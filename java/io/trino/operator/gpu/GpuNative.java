@@ -137,6 +137,8 @@ public final class GpuNative
     public static native long orcDecodeDictionaryStringColumn(long context, int encoding, int positionCount, byte[] present, byte[] data, int dictionarySize, byte[] lengthStream,
             byte[] dictionaryData);
 
+    /** DoubleColumnReader: DATA = the non-null rows' doubles, 8 little-endian bytes each */
+    public static native long orcDecodeDoubleColumn(long context, int positionCount, byte[] present, byte[] data);
     /** SliceDirectColumnReader: LENGTH (one length per non-null row) + DATA (their bytes) */
     public static native long orcDecodeDirectStringColumn(long context, int encoding, int positionCount, byte[] present, byte[] data, byte[] lengthStream);
 

@@ -914,6 +914,15 @@ JFN(jlong, orcDecodeDictionaryStringColumn)(JNIEnv *env, jclass c, jlong ctx, ji
     return page_result(env, rc, out);
 }
 
+JFN(jlong, orcDecodeDoubleColumn)(JNIEnv *env, jclass c, jlong ctx, jint positionCount, jbyteArray present, jbyteArray data)
+{
+    UNUSED(c);
+    bytes_arg p = bytes_get(env, present), d = bytes_get(env, data);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_orc_decode_double_column(H(tgpu_context, ctx), positionCount, p.p, p.n, d.p, d.n, &out);
+    bytes_release(env, &d); bytes_release(env, &p);
+    return page_result(env, rc, out);
+}
 JFN(jlong, orcDecodeDirectStringColumn)(JNIEnv *env, jclass c, jlong ctx, jint encoding, jint positionCount, jbyteArray present, jbyteArray data, jbyteArray lengthStream)
 {
     UNUSED(c);

@@ -1373,6 +1373,15 @@ int32_t tgpu_orc_decode_boolean_column(tgpu_context *ctx, int32_t position_count
     });
 }
 
+int32_t tgpu_orc_decode_double_column(tgpu_context *ctx, int32_t position_count, const void *present, int64_t present_len, const void *data, int64_t data_len,
+                                      tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && (data || data_len == 0) && present_len >= 0 && data_len >= 0, "bad argument");
+        *out = one_column_page(ctx->ctx.get(), orc::decode_double_column(ctx->ctx.get(), position_count, (const uint8_t *)present, present_len, (const uint8_t *)data, data_len));
+    });
+}
+
 int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len, const void *data,
                                                  int64_t data_len, int32_t dictionary_size, const void *length_stream, int64_t length_len, const void *dictionary_data,
                                                  int64_t dictionary_data_len, tgpu_output_page **out)

@@ -15,6 +15,7 @@ DeviceColumn decode_boolean_column(Context *ctx, int64_t n, const uint8_t *prese
 // DICTIONARY_DATA (the entries' bytes back to back) -> a flat VARCHAR column
 DeviceColumn decode_direct_string_column(Context *ctx, int32_t encoding, int64_t n, const uint8_t *present, int64_t present_len, const uint8_t *data, int64_t data_len,
                                          const uint8_t *length_stream, int64_t length_len);
+DeviceColumn decode_double_column(Context *ctx, int64_t n, const uint8_t *present, int64_t present_len, const uint8_t *data, int64_t data_len);
 DeviceColumn decode_dictionary_string_column(Context *ctx, int32_t encoding, int64_t n, const uint8_t *present, int64_t present_len, const uint8_t *data, int64_t data_len,
                                              int32_t dictionary_size, const uint8_t *length_stream, int64_t length_len, const uint8_t *dictionary_data, int64_t dictionary_data_len);
 

@@ -510,6 +510,33 @@ DeviceColumn decode_boolean_column(Context *ctx, int64_t n, const uint8_t *prese
     return col;
 }
 
+// DOUBLE columns (DoubleColumnReader.java:92-175, stream/DoubleInputStream.java): DATA = the non-null rows' IEEE-754 doubles, 8 little-endian
+// bytes each -- the bit patterns go to their rows as they are
+DeviceColumn decode_double_column(Context *ctx, int64_t n, const uint8_t *present, int64_t present_len, const uint8_t *data, int64_t data_len)
+{
+    TG_CHECK_ARG(n >= 0 && n <= 0x7fffffffLL && data_len >= 0, "bad argument");
+    DeviceColumn col;
+    col.type = TGPU_DOUBLE;
+    col.n = n;
+    col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1) * 8);
+    col.values = col.values_buf->ptr();
+    if (n == 0) return col;
+    Present p = decode_present(ctx, present, present_len, n);
+    TG_CHECK_ARG(data_len >= p.non_null * 8, "ORC DATA stream holds fewer doubles than the column has non-null positions");
+    if (!p.nulls || p.non_null == n) {
+        ctx->upload(col.values_buf->ptr(), data, (size_t)n * 8);
+        return col;
+    }
+    BufferPtr compact = ctx->alloc((size_t)(p.non_null > 0 ? p.non_null : 1) * 8), error = ctx->alloc_zero(4);
+    if (p.non_null > 0) ctx->upload(compact->ptr(), data, (size_t)p.non_null * 8);
+    place_values_kernel<long long><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(compact->as<long long>(), p.rank->as<int32_t>(), p.nulls->as<uint8_t>(), n,
+                                                                              (long long *)col.values_buf->ptr(), error->as<unsigned int>());
+    check_launch("orc_place_values");
+    col.nulls_buf = p.nulls;
+    col.nulls = p.nulls->as<uint8_t>();
+    return col;
+}
+
 DeviceColumn decode_dictionary_string_column(Context *ctx, int32_t encoding, int64_t n, const uint8_t *present, int64_t present_len, const uint8_t *data, int64_t data_len,
                                              int32_t dictionary_size, const uint8_t *length_stream, int64_t length_len, const uint8_t *dictionary_data, int64_t dictionary_data_len)
 {

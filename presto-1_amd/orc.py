@@ -50,3 +50,12 @@ def decode_direct_string_column(ctx, position_count, data, length_stream, presen
     out = C.c_void_p()
     _lib.check(_lib.lib().tgpu_orc_decode_direct_string_column(ctx.handle, encoding, position_count, pb, pl, db, dl, lb, ll, C.byref(out)))
     return OutputPage(out)
+
+
+def decode_double_column(ctx, position_count, data, present=None) -> OutputPage:
+    """DoubleColumnReader: DATA = the non-null rows' doubles (8 little-endian bytes each)"""
+    pb, pl = _buf(present)
+    db, dl = _buf(data)
+    out = C.c_void_p()
+    _lib.check(_lib.lib().tgpu_orc_decode_double_column(ctx.handle, position_count, pb, pl, db, dl, C.byref(out)))
+    return OutputPage(out)

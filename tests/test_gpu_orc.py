@@ -165,3 +165,23 @@ def test_direct_string_column(pkg, ctx, gorc, orc):
     with pytest.raises(pkg.TgpuError) as e:        # RLEv1
         gorc.decode_direct_string_column(ctx, 3, b"abc", orc.rle_v2_direct([1, 1, 1], False), encoding=gorc.DIRECT)
     assert e.value.code == -8
+
+
+def test_double_column(pkg, ctx, gorc, orc):
+    """DoubleColumnReader.java:92-175: DATA = the non-null rows' doubles as 8 little-endian bytes; bit patterns (NaN payloads, -0.0, infinities,
+    denormals) arrive unchanged, null rows hold 0"""
+    rng = np.random.default_rng(19)
+    n = 50_000
+    vals = rng.standard_normal(n)
+    vals[:6] = [np.nan, -0.0, np.inf, -np.inf, 5e-324, np.float64(np.frombuffer(np.uint64(0x7ff8000000000123).tobytes(), dtype=np.float64)[0])]
+    got = gorc.decode_double_column(ctx, n, vals.astype("<f8").tobytes()).to_host().getBlock(0)
+    assert got.nulls is None and np.array_equal(got.values.view(np.uint64), vals.view(np.uint64))
+    present = (rng.random(n) < 0.8).astype(np.uint8)
+    present[:8] = 1
+    nn = vals[: int(present.sum())]
+    got = gorc.decode_double_column(ctx, n, nn.astype("<f8").tobytes(), present=orc.boolean_encode(present.tolist())).to_host().getBlock(0)
+    assert np.array_equal(got.nulls.astype(bool), present == 0)
+    assert np.array_equal(got.values[present == 1].view(np.uint64), nn.view(np.uint64)) and not got.values[present == 0].any()
+    with pytest.raises(pkg.TgpuError):             # a truncated DATA stream
+        gorc.decode_double_column(ctx, 10, b"\x00" * 72)
+    assert gorc.decode_double_column(ctx, 0, b"").position_count == 0
