@@ -531,7 +531,8 @@ int32_t tgpu_deserialize_page(tgpu_context *ctx, const void *bytes, int64_t len,
  * BooleanColumnReader.java, SliceDictionaryColumnReader.java:120-330 over stream/LongInputStreamV2.java:59-312, LongBitPacker.java:82-108,
  * ByteInputStream.java:43-75, BooleanInputStream.java:36-58), on the device: the streams are handed over DECOMPRESSED in host memory (the
  * chunk framing and its codecs stay with the file reader), `present` = the PRESENT stream or NULL (no nulls); *out = a one-channel page.
- * `encoding` = the column's ColumnEncoding kind; RLEv1 encodings (DIRECT / DICTIONARY, files written before Hive 0.12): TGPU_ERR_NOT_SUPPORTED. */
+ * `encoding` = the column's ColumnEncoding kind: the integer streams of DIRECT / DICTIONARY columns (files written before Hive 0.12) are RLEv1
+ * (stream/LongInputStreamV1.java:47-103), those of DIRECT_V2 / DICTIONARY_V2 columns RLEv2. */
 typedef enum tgpu_orc_encoding { TGPU_ORC_DIRECT = 0, TGPU_ORC_DICTIONARY = 1, TGPU_ORC_DIRECT_V2 = 2, TGPU_ORC_DICTIONARY_V2 = 3 } tgpu_orc_encoding;
 /* SHORT / INT / LONG / DATE columns: DATA = signed RLEv2; type = TGPU_BIGINT, TGPU_INTEGER or TGPU_DATE (32-bit types check the range like
  * LongInputStreamV2.next(int[]) :356-364) */

@@ -155,6 +155,38 @@ def rle_v2_patched_base(values, base, fb, patch_width, patches):
     return bytes(out)
 
 
+def rle_v1_encode(values, signed):
+    """an RLEv1 stream (LongInputStreamV1.java:47-103 read backwards): runs of 3..130 values with a constant delta in [-128, 127], else literal
+    groups of up to 128 varints"""
+    vals = [int(v) for v in values]
+    out, lit, i = bytearray(), [], 0
+
+    def flush():
+        nonlocal lit
+        while lit:
+            chunk, lit = lit[:128], lit[128:]
+            out.append(0x100 - len(chunk))
+            for v in chunk:
+                out.extend(write_vlong(v, signed))
+    while i < len(vals):
+        j = i + 1
+        if j < len(vals) and -128 <= vals[j] - vals[i] <= 127:
+            d = vals[j] - vals[i]
+            while j + 1 < len(vals) and j + 1 - i < 130 and vals[j + 1] - vals[j] == d:
+                j += 1
+            if j + 1 - i >= 3:
+                flush()
+                out.append(j + 1 - i - 3)
+                out.append(d & 0xff)
+                out.extend(write_vlong(vals[i], signed))
+                i = j + 1
+                continue
+        lit.append(vals[i])
+        i += 1
+    flush()
+    return bytes(out)
+
+
 def byte_rle_encode(data):
     out, i = bytearray(), 0
     data = bytes(data)

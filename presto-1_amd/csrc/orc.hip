@@ -23,7 +23,7 @@ namespace {
 
 constexpr int kWave = 64;
 
-enum RunKind : int32_t { SHORT_REPEAT = 0, DIRECT = 1, PATCHED_BASE = 2, DELTA = 3 };
+enum RunKind : int32_t { SHORT_REPEAT = 0, DIRECT = 1, PATCHED_BASE = 2, DELTA = 3, V1_RUN = 4, V1_LITERALS = 5 };
 
 struct Run {
     int64_t in_off;       // first byte of the run's PACKED payload (behind the header fields the host has read)
@@ -375,6 +375,76 @@ BufferPtr upload_padded(Context *ctx, const uint8_t *src, int64_t bytes)
 }
 
 // every value of an RLEv2 stream as int64 on the device
+// RLEv1 (LongInputStreamV1.java:47-103; files written before Hive 0.12): a control byte < 0x80 = a run of control + 3 values base + i * delta
+// (delta a signed byte, base a varint); else 0x100 - control literal varints.  The host reads the control bytes and walks the varints'
+// continuation bits (it must, to find the next control byte); the device decodes: one lane per run -- a run is at most 130 values.
+std::vector<Run> scan_rle_v1(const uint8_t *bytes, int64_t len, bool is_signed, int64_t &total)
+{
+    std::vector<Run> runs;
+    HostReader in{bytes, len};
+    total = 0;
+    while (in.at < in.len) {
+        Run r{};
+        const int control = in.read();
+        r.out_off = total;
+        if (control < 0x80) {
+            r.kind = V1_RUN;
+            r.count = control + 3;
+            r.delta = (int8_t)in.read();
+            const uint64_t v = in.vint();
+            r.base = is_signed ? zigzag(v) : (int64_t)v;
+            r.in_off = in.at;
+        } else {
+            r.kind = V1_LITERALS;
+            r.count = 0x100 - control;
+            r.in_off = in.at;
+            for (int i = 0; i < r.count; i++) (void)in.vint();
+        }
+        total += r.count;
+        if (total > 0x7fffffffLL) fail(TGPU_ERR_INVALID_ARGUMENT, "ORC stream holds more than 2^31 values");
+        runs.push_back(r);
+    }
+    return runs;
+}
+
+__global__ void __launch_bounds__(256) rle_v1_decode_kernel(const uint8_t *__restrict__ bytes, const Run *__restrict__ runs, int64_t n_runs, int is_signed, long long *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (int64_t)gridDim.x * blockDim.x) {
+        const Run r = runs[i];
+        long long *o = out + r.out_off;
+        if (r.kind == V1_RUN) {
+            for (int k = 0; k < r.count; k++) o[k] = (long long)((unsigned long long)r.base + (unsigned long long)((long long)k * r.delta));
+            continue;
+        }
+        const uint8_t *p = bytes + r.in_off;
+        for (int k = 0; k < r.count; k++) {   // LongDecode.readVInt :117-141
+            unsigned long long v = 0;
+            int off = 0, b;
+            do {
+                b = *p++;
+                if (off < 64) v |= (unsigned long long)(b & 0x7f) << off;
+                off += 7;
+            } while (b & 0x80);
+            o[k] = is_signed ? (long long)((v >> 1) ^ (unsigned long long)(-(long long)(v & 1))) : (long long)v;
+        }
+    }
+}
+
+BufferPtr decode_rle_v1(Context *ctx, const uint8_t *bytes, int64_t len, bool is_signed, int64_t &count)
+{
+    std::vector<Run> runs = scan_rle_v1(bytes, len, is_signed, count);
+    BufferPtr out = ctx->alloc((size_t)(count > 0 ? count : 1) * 8);
+    if (runs.empty()) return out;
+    BufferPtr dbytes = upload_padded(ctx, bytes, len), druns = ctx->alloc(runs.size() * sizeof(Run));
+    ctx->upload(druns->ptr(), runs.data(), runs.size() * sizeof(Run));
+    ProfileScope ps(ctx, "orc_rle_v1_decode");
+    rle_v1_decode_kernel<<<grid_for(ctx, (int64_t)runs.size()), 256, 0, ctx->stream()>>>(dbytes->as<uint8_t>(), druns->as<Run>(), (int64_t)runs.size(), is_signed ? 1 : 0,
+                                                                                       out->as<long long>());
+    check_launch("orc_rle_v1_decode");
+    ctx->sync();   // `runs` (host) backs the upload
+    return out;
+}
+
 BufferPtr decode_rle_v2(Context *ctx, const uint8_t *bytes, int64_t len, bool is_signed, int64_t &count)
 {
     std::vector<Run> runs = scan_rle_v2(bytes, len, is_signed, count);
@@ -439,11 +509,16 @@ void raise_if(Context *ctx, BufferPtr &error)
     if (e & 4u) fail(TGPU_ERR_INVALID_ARGUMENT, "ORC dictionary entry length out of range");
 }
 
-void check_encoding(int32_t encoding, bool dictionary)
+// the column's integer streams: RLEv1 for the DIRECT / DICTIONARY encodings (files written before Hive 0.12), RLEv2 for the _V2 ones
+bool integer_streams_are_v1(int32_t encoding, bool dictionary)
 {
-    if (encoding == (dictionary ? TGPU_ORC_DICTIONARY : TGPU_ORC_DIRECT))
-        fail(TGPU_ERR_NOT_SUPPORTED, "ORC RLEv1 integer streams (files written before Hive 0.12) are not decoded on the device");
+    if (encoding == (dictionary ? TGPU_ORC_DICTIONARY : TGPU_ORC_DIRECT)) return true;
     TG_CHECK_ARG(encoding == (dictionary ? TGPU_ORC_DICTIONARY_V2 : TGPU_ORC_DIRECT_V2), "unexpected ORC column encoding for this reader");
+    return false;
+}
+BufferPtr decode_rle(Context *ctx, bool v1, const uint8_t *bytes, int64_t len, bool is_signed, int64_t &count)
+{
+    return v1 ? decode_rle_v1(ctx, bytes, len, is_signed, count) : decode_rle_v2(ctx, bytes, len, is_signed, count);
 }
 
 }  // namespace
@@ -452,7 +527,7 @@ DeviceColumn decode_long_column(Context *ctx, int32_t type, int32_t encoding, in
 {
     TG_CHECK_ARG(type == TGPU_BIGINT || type == TGPU_INTEGER || type == TGPU_DATE, "ORC integer columns decode to BIGINT, INTEGER or DATE");
     TG_CHECK_ARG(n >= 0 && n <= 0x7fffffffLL, "bad position count");
-    check_encoding(encoding, false);
+    const bool v1 = integer_streams_are_v1(encoding, false);
     DeviceColumn col;
     col.type = type;
     col.n = n;
@@ -462,7 +537,7 @@ DeviceColumn decode_long_column(Context *ctx, int32_t type, int32_t encoding, in
     if (n == 0) return col;
     Present p = decode_present(ctx, present, present_len, n);
     int64_t count = 0;
-    BufferPtr compact = decode_rle_v2(ctx, data, data_len, true, count);
+    BufferPtr compact = decode_rle(ctx, v1, data, data_len, true, count);
     TG_CHECK_ARG(count >= p.non_null, "ORC DATA stream holds fewer values than the column has non-null positions");
     BufferPtr error = ctx->alloc_zero(4);
     const uint8_t *nulls = p.nulls ? p.nulls->as<uint8_t>() : nullptr;
@@ -541,7 +616,7 @@ DeviceColumn decode_dictionary_string_column(Context *ctx, int32_t encoding, int
                                              int32_t dictionary_size, const uint8_t *length_stream, int64_t length_len, const uint8_t *dictionary_data, int64_t dictionary_data_len)
 {
     TG_CHECK_ARG(n >= 0 && n <= 0x7fffffffLL && dictionary_size >= 0 && dictionary_data_len >= 0 && dictionary_data_len <= 0x7fffffffLL, "bad argument");
-    check_encoding(encoding, true);
+    const bool v1 = integer_streams_are_v1(encoding, true);
     // the dictionary: entry lengths (unsigned RLEv2) -> offsets by an exclusive scan; bytes as they are (SliceDictionaryColumnReader.java:260-300)
     DeviceColumn dict;
     dict.type = TGPU_VARCHAR;
@@ -556,7 +631,7 @@ DeviceColumn decode_dictionary_string_column(Context *ctx, int32_t encoding, int
     dict.pool_exact = true;
     if (dictionary_size > 0) {
         int64_t count = 0;
-        BufferPtr lens64 = decode_rle_v2(ctx, length_stream, length_len, false, count);
+        BufferPtr lens64 = decode_rle(ctx, v1, length_stream, length_len, false, count);
         TG_CHECK_ARG(count >= dictionary_size, "ORC LENGTH stream holds fewer lengths than the dictionary has entries");
         BufferPtr lens = ctx->alloc((size_t)dictionary_size * 4), total = ctx->alloc(8);
         lengths_to_i32_kernel<<<grid_for(ctx, dictionary_size), 256, 0, ctx->stream()>>>(lens64->as<long long>(), dictionary_size, lens->as<int32_t>(), error->as<unsigned int>());
@@ -573,7 +648,7 @@ DeviceColumn decode_dictionary_string_column(Context *ctx, int32_t encoding, int
     // the ids (unsigned RLEv2, one per non-null row) at their row positions, then the library's dictionary gather
     Present p = decode_present(ctx, present, present_len, n);
     int64_t count = 0;
-    BufferPtr ids64 = decode_rle_v2(ctx, data, data_len, false, count);
+    BufferPtr ids64 = decode_rle(ctx, v1, data, data_len, false, count);
     TG_CHECK_ARG(count >= p.non_null, "ORC DATA stream holds fewer ids than the column has non-null positions");
     BufferPtr ids = ctx->alloc((size_t)n * 4);
     place_ids_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(ids64->as<long long>(), p.rank ? p.rank->as<int32_t>() : nullptr, p.nulls ? p.nulls->as<uint8_t>() : nullptr, n,
@@ -591,7 +666,7 @@ DeviceColumn decode_direct_string_column(Context *ctx, int32_t encoding, int64_t
                                          const uint8_t *length_stream, int64_t length_len)
 {
     TG_CHECK_ARG(n >= 0 && n <= 0x7fffffffLL && data_len >= 0 && data_len <= 0x7fffffffLL, "bad argument");
-    check_encoding(encoding, false);
+    const bool v1 = integer_streams_are_v1(encoding, false);
     DeviceColumn col;
     col.type = TGPU_VARCHAR;
     col.n = n;
@@ -611,7 +686,7 @@ DeviceColumn decode_direct_string_column(Context *ctx, int32_t encoding, int64_t
     BufferPtr lens = ctx->alloc((size_t)n * 4), total = ctx->alloc(8);
     if (p.non_null > 0) {
         int64_t count = 0;
-        BufferPtr lens64 = decode_rle_v2(ctx, length_stream, length_len, false, count);
+        BufferPtr lens64 = decode_rle(ctx, v1, length_stream, length_len, false, count);
         TG_CHECK_ARG(count >= p.non_null, "ORC LENGTH stream holds fewer lengths than the column has non-null positions");
         BufferPtr compact = ctx->alloc((size_t)p.non_null * 4);
         lengths_to_i32_kernel<<<grid_for(ctx, p.non_null), 256, 0, ctx->stream()>>>(lens64->as<long long>(), p.non_null, compact->as<int32_t>(), error->as<unsigned int>());

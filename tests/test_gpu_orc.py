@@ -108,9 +108,6 @@ def test_present_stream_expands_values_to_their_rows(pkg, ctx, gorc, orc):
     with pytest.raises(pkg.TgpuError) as e:        # LongInputStreamV2.next(int[]): "Decoded value out of range for a 32bit number"
         gorc.decode_long_column(ctx, pkg.INTEGER, 3, orc.rle_v2_direct([1, 2**31, 3], True))
     assert "32bit" in str(e.value)
-    with pytest.raises(pkg.TgpuError) as e:        # RLEv1 is not decoded
-        gorc.decode_long_column(ctx, pkg.BIGINT, 3, b"\x00\x01\x02", encoding=gorc.DIRECT)
-    assert e.value.code == -8
     with pytest.raises(pkg.TgpuError):             # a truncated run
         gorc.decode_long_column(ctx, pkg.BIGINT, 512, orc.rle_v2_direct(list(range(512)), True)[:-5])
 
@@ -162,9 +159,6 @@ def test_direct_string_column(pkg, ctx, gorc, orc):
     assert gorc.decode_direct_string_column(ctx, 0, b"", b"").position_count == 0
     with pytest.raises(pkg.TgpuError):
         gorc.decode_direct_string_column(ctx, 3, b"abcdef", orc.rle_v2_direct([1, 1, 1], False))
-    with pytest.raises(pkg.TgpuError) as e:        # RLEv1
-        gorc.decode_direct_string_column(ctx, 3, b"abc", orc.rle_v2_direct([1, 1, 1], False), encoding=gorc.DIRECT)
-    assert e.value.code == -8
 
 
 def test_double_column(pkg, ctx, gorc, orc):
@@ -185,3 +179,37 @@ def test_double_column(pkg, ctx, gorc, orc):
     with pytest.raises(pkg.TgpuError):             # a truncated DATA stream
         gorc.decode_double_column(ctx, 10, b"\x00" * 72)
     assert gorc.decode_double_column(ctx, 0, b"").position_count == 0
+
+
+def test_rle_v1_columns(pkg, ctx, gorc, orc):
+    """the DIRECT / DICTIONARY column encodings of files written before Hive 0.12: integer streams are RLEv1 (LongInputStreamV1.java:47-103: runs of
+    3..130 values with a byte delta, literal groups of up to 128 varints).  Streams written by the test encoder (oracle/orc.py, checked against
+    the oracle's decoder) through the long, dictionary-string and direct-string readers; a stream cut inside a varint is refused."""
+    rng = np.random.default_rng(23)
+    vals = np.concatenate([np.arange(0, 3000, 3), rng.integers(-10**15, 10**15, 5000), np.full(1000, -7), np.arange(5000, 0, -5), rng.integers(-3, 3, 777),
+                           np.array([np.iinfo(np.int64).max, np.iinfo(np.int64).min, 0, -1, 1])]).astype(np.int64)
+    stream = orc.rle_v1_encode(vals.tolist(), True)
+    assert np.array_equal(orc.rle_v1(stream, True, cap=len(vals) + 10), vals)
+    got = gorc.decode_long_column(ctx, pkg.BIGINT, len(vals), stream, encoding=gorc.DIRECT).to_host().getBlock(0)
+    assert got.nulls is None and np.array_equal(got.values, vals)
+    n = len(vals) + 4000
+    present = np.ones(n, dtype=np.uint8)
+    present[rng.choice(n, 4000, replace=False)] = 0
+    got = gorc.decode_long_column(ctx, pkg.BIGINT, n, stream, present=orc.boolean_encode(present.tolist()), encoding=gorc.DIRECT).to_host().getBlock(0)
+    assert np.array_equal(got.nulls.astype(bool), present == 0) and np.array_equal(got.values[present == 1], vals)
+    small = rng.integers(-(2**31), 2**31, 3000).astype(np.int64)
+    got = gorc.decode_long_column(ctx, pkg.INTEGER, len(small), orc.rle_v1_encode(small.tolist(), True), encoding=gorc.DIRECT).to_host().getBlock(0)
+    assert np.array_equal(got.values, small.astype(np.int32))
+    with pytest.raises(pkg.TgpuError):             # cut inside a literal's varint
+        gorc.decode_long_column(ctx, pkg.BIGINT, 2, bytes([0xfe, 0x80, 0x80]), encoding=gorc.DIRECT)
+    # strings: DICTIONARY (ids + lengths RLEv1) and DIRECT (lengths RLEv1)
+    words = ["", "a", "BUILDING", "MACHINERY", "x" * 200, "héllo"]
+    m = 20_000
+    ids = rng.integers(0, len(words), m)
+    enc = [w.encode("utf-8") for w in words]
+    got = gorc.decode_dictionary_string_column(ctx, m, orc.rle_v1_encode(ids.tolist(), False), len(words), orc.rle_v1_encode([len(b) for b in enc], False), b"".join(enc),
+                                               encoding=gorc.DICTIONARY).to_host().getBlock(0)
+    assert got.to_list() == [words[i] for i in ids]
+    rows = [enc[i] for i in ids]
+    got = gorc.decode_direct_string_column(ctx, m, b"".join(rows), orc.rle_v1_encode([len(b) for b in rows], False), encoding=gorc.DIRECT).to_host().getBlock(0)
+    assert got.to_list() == [words[i] for i in ids]
