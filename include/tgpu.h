@@ -555,6 +555,19 @@ int32_t tgpu_orc_decode_dictionary_string_column(tgpu_context *ctx, int32_t enco
 int32_t tgpu_orc_decode_direct_string_column(tgpu_context *ctx, int32_t encoding, int32_t position_count, const void *present, int64_t present_len,
                                              const void *data, int64_t data_len, const void *length_stream, int64_t length_len, tgpu_output_page **out);
 
+/* ---- scan-side decode, the second columnar format: Parquet data pages -> device-resident blocks ---- */
+/* What a Parquet page source does per data page of a FLAT column (lib/trino-parquet/src/main/java/io/trino/parquet/reader/PrimitiveColumnReader.java
+ * readPageV1 / readPageV2 / initDataReader, LevelRLEReader.java, ParquetEncoding.java, the dictionary package, reader/{Int,Long,Double,Boolean,Binary}ColumnReader.java;
+ * the byte-level decoders are parquet-mr's, restated from the Parquet format specification), on the device.  The page arrives DECOMPRESSED and
+ * taken apart by the file reader (thrift page headers and codecs stay there): `definition_levels` = the levels' RLE / bit-packed hybrid of bit
+ * width 1 WITHOUT the 4-byte length a V1 page carries in front of it, NULL for a required column; `values` = the value section;
+ * `dictionary` / `dictionary_count` = the column chunk's PLAIN dictionary page for the dictionary encodings, else NULL / 0.
+ * `physical` = parquet.thrift Type (0 BOOLEAN, 1 INT32, 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY) with `type` INTEGER / DATE, BIGINT, DOUBLE, BOOLEAN, VARCHAR;
+ * `encoding` = parquet.thrift Encoding (0 PLAIN, 2 PLAIN_DICTIONARY, 8 RLE_DICTIONARY; 3 RLE for BOOLEAN values); anything else: TGPU_ERR_NOT_SUPPORTED.  *out = a one-channel page. */
+int32_t tgpu_parquet_decode_data_page(tgpu_context *ctx, int32_t type, int32_t physical, int32_t encoding, int32_t position_count, const void *definition_levels,
+                                      int64_t definition_levels_len, const void *values, int64_t values_len, const void *dictionary, int64_t dictionary_len,
+                                      int32_t dictionary_count, tgpu_output_page **out);
+
 /* ---- exchange between the GPUs of one node ---- */
 /* What replaces PartitionedOutputOperator -> OutputBuffer -> HTTP -> ExchangeOperator (M/operator/PartitionedOutputOperator.java:406-476,
  * M/operator/ExchangeOperator.java) when the consumers of a FIXED_HASH_DISTRIBUTION / FIXED_BROADCAST_DISTRIBUTION stage

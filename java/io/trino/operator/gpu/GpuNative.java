@@ -142,6 +142,14 @@ public final class GpuNative
     /** SliceDirectColumnReader: LENGTH (one length per non-null row) + DATA (their bytes) */
     public static native long orcDecodeDirectStringColumn(long context, int encoding, int positionCount, byte[] present, byte[] data, byte[] lengthStream);
 
+    /**
+     * PrimitiveColumnReader.readPageV1 / readPageV2 of a flat Parquet column: the page's definition levels (RLE / bit-packed hybrid, no length prefix;
+     * null for a required column), its value section and, for the dictionary encodings, the chunk's PLAIN dictionary page.  physical / encoding =
+     * the parquet.thrift ordinals (Type: 0 BOOLEAN, 1 INT32, 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY; Encoding: 0 PLAIN, 2 PLAIN_DICTIONARY, 3 RLE, 8 RLE_DICTIONARY)
+     */
+    public static native long parquetDecodeDataPage(long context, int type, int physical, int encoding, int positionCount, byte[] definitionLevels, byte[] values,
+            byte[] dictionary, int dictionaryCount);
+
     // ---- exchange between the GPUs of one node (tgpu_exchange_*); pages are output-page handles: they never leave HBM ----
     public static native byte[] exchangeUniqueId();
     public static native long createExchange(long context, byte[] uniqueId, int rank, int world);

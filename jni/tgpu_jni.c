@@ -933,6 +933,19 @@ JFN(jlong, orcDecodeDirectStringColumn)(JNIEnv *env, jclass c, jlong ctx, jint e
     return page_result(env, rc, out);
 }
 
+/* one data page of a flat Parquet column (tgpu_parquet_decode_data_page): definition levels without their length prefix (null: a required column), the
+ * value section, the chunk's PLAIN dictionary page for the dictionary encodings (else null) */
+JFN(jlong, parquetDecodeDataPage)(JNIEnv *env, jclass c, jlong ctx, jint type, jint physical, jint encoding, jint positionCount, jbyteArray definitionLevels, jbyteArray values,
+                                  jbyteArray dictionary, jint dictionaryCount)
+{
+    UNUSED(c);
+    bytes_arg l = bytes_get(env, definitionLevels), v = bytes_get(env, values), d = bytes_get(env, dictionary);
+    tgpu_output_page *out = NULL;
+    int32_t rc = tgpu_parquet_decode_data_page(H(tgpu_context, ctx), type, physical, encoding, positionCount, l.p, l.n, v.p, v.n, d.p, d.n, dictionaryCount, &out);
+    bytes_release(env, &d); bytes_release(env, &v); bytes_release(env, &l);
+    return page_result(env, rc, out);
+}
+
 /* ---- exchange between the GPUs of one node (tgpu_exchange_*): pages stay in HBM, so the page arguments are output-page handles ---- */
 JFN(jbyteArray, exchangeUniqueId)(JNIEnv *env, jclass c)
 {

@@ -106,6 +106,7 @@ SYMBOLS = {
     "tgpu_orc_decode_dictionary_string_column": (i32, [vp, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp]),
     "tgpu_orc_decode_direct_string_column": (i32, [vp, i32, i32, vp, i64, vp, i64, vp, i64, vp]),
     "tgpu_orc_decode_double_column": (i32, [vp, i32, vp, i64, vp, i64, vp]),
+    "tgpu_parquet_decode_data_page": (i32, [vp, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, i32, vp]),
     "tgpu_context_set_max_output_page": (i32, [vp, i64, i64]),
     "tgpu_pinned_alloc": (i32, [vp, i64, P(vp)]),
     "tgpu_pinned_free": (i32, [vp, vp]),

@@ -9,6 +9,7 @@
 #include "operators.h"
 #include "serde.h"
 #include "orc.h"
+#include "parquet.h"
 
 namespace tgpu {
 const std::string &last_error();
@@ -1401,6 +1402,17 @@ int32_t tgpu_orc_decode_direct_string_column(tgpu_context *ctx, int32_t encoding
         TG_CHECK_ARG(ctx && out && present_len >= 0 && data_len >= 0 && length_len >= 0 && (data || data_len == 0), "bad argument");
         *out = one_column_page(ctx->ctx.get(), orc::decode_direct_string_column(ctx->ctx.get(), encoding, position_count, (const uint8_t *)present, present_len, (const uint8_t *)data,
                                                                               data_len, (const uint8_t *)length_stream, length_len));
+    });
+}
+
+int32_t tgpu_parquet_decode_data_page(tgpu_context *ctx, int32_t type, int32_t physical, int32_t encoding, int32_t position_count, const void *definition_levels,
+                                      int64_t definition_levels_len, const void *values, int64_t values_len, const void *dictionary, int64_t dictionary_len,
+                                      int32_t dictionary_count, tgpu_output_page **out)
+{
+    return guard_on(ctx_of(ctx), [&] {
+        TG_CHECK_ARG(ctx && out && (values || values_len == 0) && (dictionary || dictionary_len == 0) && (definition_levels || definition_levels_len == 0), "bad argument");
+        *out = one_column_page(ctx->ctx.get(), parquet::decode_data_page(ctx->ctx.get(), type, physical, encoding, position_count, (const uint8_t *)definition_levels, definition_levels_len,
+                                                                         (const uint8_t *)values, values_len, (const uint8_t *)dictionary, dictionary_len, dictionary_count));
     });
 }
 

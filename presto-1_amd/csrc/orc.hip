@@ -9,7 +9,7 @@
 // bytes per run: control bytes, run lengths, the two vints of a DELTA run) while it stages the bytes, and uploads a run directory; every value
 // is decoded on the device, one wave per run -- bit unpacking at lane-computed bit offsets, zigzag, the prefix sums of DELTA runs as a wave scan,
 // the patch list of PATCHED_BASE runs as a scan of its gaps.  PRESENT bits become the null vector, the values are expanded to row positions
-// through an exclusive scan of the not-null flags.  RLEv1 (files written before Hive 0.12) is not decoded: TGPU_ERR_NOT_SUPPORTED.
+// through an exclusive scan of the not-null flags.  RLEv1 streams (files written before Hive 0.12): one lane per run.
 #include "orc.h"
 
 #include "kernels.h"

@@ -1,0 +1,379 @@
+// parquet.hip -- scan-side decode, the second columnar format the reference reads: the data pages of a flat Parquet column
+// decoded on the device into flat HBM columns.  Reference (lib/trino-parquet/src/main/java/io/trino/parquet/): reader/PrimitiveColumnReader.java
+// (readPageV1 / readPageV2 / initDataReader: levels, then the value reader of the page's encoding), reader/LevelRLEReader.java,
+// ParquetEncoding.java (PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY -> value readers and dictionaries), dictionary/*.java (PLAIN dictionary
+// pages), reader/{Int,Long,Double,Boolean,Binary}ColumnReader.java.  The byte-level decoders those classes call are NOT in the reference tree:
+// org.apache.parquet (parquet-mr) classes out of io.prestosql.hive:hive-apache 3.1.2-6, the shaded bundle the reference's root pom.xml:537-538 pins
+// -- RunLengthBitPackingHybridDecoder, the Plain*ValuesReaders -- so their algorithm is restated from the public Parquet format specification (Encodings.md: "RLE / bit-packing
+// hybrid", "PLAIN") and pinned on Apache Arrow's independent writer and reader of the same format (tests) and on the one Parquet data file the
+// reference's own tests hold that these types can read (single_int_column/data.parquet).
+//
+// Pages arrive DECOMPRESSED in host memory (codecs and the thrift page headers stay with the file reader).  Like the ORC streams, a hybrid
+// stream is a sequence of runs whose headers are variable length: the host walks the headers (a varint per run), the device decodes the values
+// -- one wave per run, bit-packed values at lane-computed bit offsets (least significant bit first, little-endian bytes).
+#include "parquet.h"
+
+#include "kernels.h"
+
+#include <cstring>
+
+namespace tgpu {
+namespace parquet {
+
+namespace {
+
+constexpr int kWave = 64;
+enum Physical : int32_t { PQ_BOOLEAN = 0, PQ_INT32 = 1, PQ_INT64 = 2, PQ_DOUBLE = 5, PQ_BYTE_ARRAY = 6 };          // parquet.thrift Type
+enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
+
+struct Run {
+    int64_t in_off;    // bit-packed run: first byte of the packed values
+    int64_t out_off;   // index of the run's first value
+    int32_t count;     // values of the run (the last bit-packed run is cut at the number of values wanted: its tail is padding)
+    int32_t packed;    // 1 = bit-packed, 0 = RLE
+    int64_t value;     // RLE: the repeated value
+};
+
+// the run directory of an RLE / bit-packed hybrid stream (Encodings.md; RunLengthBitPackingHybridDecoder.readNext): header = ULEB128;
+// bit 0 set: (header >> 1) groups of 8 bit-packed values; clear: a run of header >> 1 copies of one value of ceil(bit_width / 8) bytes
+std::vector<Run> scan_hybrid(const uint8_t *bytes, int64_t len, int bit_width, int64_t want)
+{
+    TG_CHECK_ARG(bit_width >= 0 && bit_width <= 32, "Parquet hybrid stream: bit width out of range");
+    std::vector<Run> runs;
+    int64_t at = 0, total = 0;
+    while (total < want) {
+        if (at >= len) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet hybrid stream ends before the page's values do");
+        uint64_t header = 0;
+        for (int shift = 0;; shift += 7) {
+            if (at >= len || shift > 35) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet hybrid stream: bad run header");
+            const int b = bytes[at++];
+            header |= (uint64_t)(b & 0x7f) << shift;
+            if (!(b & 0x80)) break;
+        }
+        Run r{};
+        r.out_off = total;
+        if (header & 1) {
+            const int64_t values = (int64_t)(header >> 1) * 8, packed_bytes = (int64_t)(header >> 1) * bit_width;
+            r.packed = 1;
+            r.in_off = at;
+            r.count = (int32_t)std::min<int64_t>(values, want - total);
+            // (writers may cut the padding of the LAST group short: only the bytes the wanted values occupy must be there)
+            if (at + ((int64_t)r.count * bit_width + 7) / 8 > len) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet hybrid stream: a bit-packed run is longer than the stream");
+            at = std::min<int64_t>(at + packed_bytes, len);
+        } else {
+            const int64_t count = (int64_t)(header >> 1);
+            const int width_bytes = (bit_width + 7) / 8;
+            if (count == 0 || at + width_bytes > len) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet hybrid stream: bad RLE run");
+            uint64_t v = 0;
+            for (int i = 0; i < width_bytes; i++) v |= (uint64_t)bytes[at++] << (8 * i);
+            r.value = (int64_t)v;
+            r.count = (int32_t)std::min<int64_t>(count, want - total);
+        }
+        total += r.count;
+        runs.push_back(r);
+    }
+    return runs;
+}
+
+__global__ void __launch_bounds__(256) hybrid_decode_kernel(const uint8_t *__restrict__ bytes, const Run *__restrict__ runs, int64_t n_runs, int bit_width, int32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mask = bit_width >= 64 ? ~0ull : ((1ull << bit_width) - 1ull);
+    for (int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; w < n_runs; w += ((int64_t)gridDim.x * blockDim.x) >> 6) {
+        const Run r = runs[w];
+        for (int i = lane; i < r.count; i += kWave) {
+            long long v = r.value;
+            if (r.packed) {
+                const long long bit = (long long)i * bit_width;
+                const uint8_t *p = bytes + r.in_off + (bit >> 3);
+                unsigned long long word = 0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) word |= (unsigned long long)p[k] << (8 * k);   // 32 bits at any bit offset span at most 5 bytes (the buffer is padded)
+                v = (long long)((word >> (bit & 7)) & mask);
+            }
+            out[r.out_off + i] = (int32_t)v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) levels_to_flags_kernel(const int32_t *__restrict__ levels, int64_t n, uint8_t *__restrict__ nulls, int32_t *__restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int present = levels[i] != 0;
+        nulls[i] = present ? 0 : 1;
+        flags[i] = present;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) place_kernel(const T *__restrict__ compact, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n, T *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (nulls && nulls[i]) ? (T)0 : compact[rank ? rank[i] : i];
+}
+
+// int32 values (0 / 1) of the non-null rows -> a byte per row
+__global__ void __launch_bounds__(256) place_narrow_kernel(const int32_t *__restrict__ compact, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n, uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (nulls && nulls[i]) ? (uint8_t)0 : (uint8_t)(compact[rank ? rank[i] : i] != 0);
+}
+
+// PLAIN BOOLEAN: one bit per value, least significant bit first
+__global__ void __launch_bounds__(256) place_bits_kernel(const uint8_t *__restrict__ bits, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n, uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (nulls && nulls[i]) {
+            out[i] = 0;
+            continue;
+        }
+        const int64_t j = rank ? rank[i] : i;
+        out[i] = (bits[j >> 3] >> (j & 7)) & 1;
+    }
+}
+
+// dictionary ids of the non-null rows -> an id per row (-1 for a null row); an id outside the dictionary raises the error flag
+__global__ void __launch_bounds__(256) place_ids_kernel(const int32_t *__restrict__ compact, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n,
+                                                        int32_t dictionary_size, int32_t *__restrict__ out, unsigned int *error)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (nulls && nulls[i]) {
+            out[i] = -1;
+            continue;
+        }
+        const int32_t id = compact[rank ? rank[i] : i];
+        if (id < 0 || id >= dictionary_size) {
+            atomicOr(error, 1u);
+            out[i] = -1;
+        } else out[i] = id;
+    }
+}
+
+// PLAIN BYTE_ARRAY: the values' bytes (behind their 4-byte length prefixes in the page) to their place in the block's byte pool
+__global__ void __launch_bounds__(256) copy_strings_kernel(const uint8_t *__restrict__ page, const int32_t *__restrict__ src_off, const int32_t *__restrict__ rank,
+                                                           const uint8_t *__restrict__ nulls, const int32_t *__restrict__ offsets, int64_t n, uint8_t *__restrict__ pool)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (nulls && nulls[i]) continue;
+        const uint8_t *s = page + src_off[rank ? rank[i] : i];
+        uint8_t *d = pool + offsets[i];
+        const int len = offsets[i + 1] - offsets[i];
+        for (int k = 0; k < len; k++) d[k] = s[k];
+    }
+}
+
+int grid_for(Context *ctx, int64_t n)
+{
+    int64_t blocks = ceil_div(n, 256);
+    const int64_t cap = (int64_t)ctx->cu_count() * 8;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(blocks, cap));
+}
+
+BufferPtr upload_padded(Context *ctx, const uint8_t *src, int64_t bytes)
+{
+    BufferPtr b = ctx->alloc((size_t)bytes + 16);
+    if (bytes) ctx->upload(b->ptr(), src, (size_t)bytes);
+    HIP_CHECK(hipMemsetAsync(static_cast<uint8_t *>(b->ptr()) + bytes, 0, 16, ctx->stream()));
+    return b;
+}
+
+// `want` values of a hybrid stream as int32 on the device
+BufferPtr decode_hybrid(Context *ctx, const uint8_t *bytes, int64_t len, int bit_width, int64_t want)
+{
+    BufferPtr out = ctx->alloc((size_t)(want > 0 ? want : 1) * 4);
+    if (want == 0) return out;
+    if (bit_width == 0) {   // (a dictionary of one entry: every id is 0 and the stream may be empty)
+        HIP_CHECK(hipMemsetAsync(out->ptr(), 0, (size_t)want * 4, ctx->stream()));
+        return out;
+    }
+    std::vector<Run> runs = scan_hybrid(bytes, len, bit_width, want);
+    BufferPtr dbytes = upload_padded(ctx, bytes, len), druns = ctx->alloc(runs.size() * sizeof(Run));
+    ctx->upload(druns->ptr(), runs.data(), runs.size() * sizeof(Run));
+    ProfileScope ps(ctx, "parquet_hybrid_decode");
+    hybrid_decode_kernel<<<grid_for(ctx, (int64_t)runs.size() * kWave), 256, 0, ctx->stream()>>>(dbytes->as<uint8_t>(), druns->as<Run>(), (int64_t)runs.size(), bit_width, out->as<int32_t>());
+    check_launch("parquet_hybrid_decode");
+    ctx->sync();   // `runs` (host) backs the upload
+    return out;
+}
+
+struct Present {
+    BufferPtr nulls, rank;
+    int64_t non_null = 0;
+};
+Present decode_levels(Context *ctx, const uint8_t *def_levels, int64_t def_len, int64_t n)
+{
+    Present p;
+    p.non_null = n;
+    if (!def_levels || n == 0) return p;
+    BufferPtr levels = decode_hybrid(ctx, def_levels, def_len, 1, n);
+    p.nulls = ctx->alloc((size_t)n);
+    p.rank = ctx->alloc((size_t)n * 4);
+    BufferPtr flags = ctx->alloc((size_t)n * 4), total = ctx->alloc(8);
+    levels_to_flags_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(levels->as<int32_t>(), n, p.nulls->as<uint8_t>(), flags->as<int32_t>());
+    check_launch("parquet_levels");
+    k::exclusive_scan_i32(ctx, flags->as<int32_t>(), p.rank->as<int32_t>(), n, total->as<int64_t>());
+    p.non_null = ctx->read_scalar(total->as<int64_t>());
+    return p;
+}
+
+// PLAIN BYTE_ARRAY values: where each value's bytes start in `bytes` and how long it is (a 4-byte little-endian length in front of each)
+void scan_byte_arrays(const uint8_t *bytes, int64_t len, int64_t count, std::vector<int32_t> &src_off, std::vector<int32_t> &lengths)
+{
+    src_off.resize((size_t)count);
+    lengths.resize((size_t)count);
+    int64_t at = 0;
+    for (int64_t i = 0; i < count; i++) {
+        if (at + 4 > len) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet PLAIN BYTE_ARRAY section ends inside a length");
+        uint32_t l;
+        memcpy(&l, bytes + at, 4);
+        at += 4;
+        if (l > 0x7fffffffu || at + (int64_t)l > len) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet PLAIN BYTE_ARRAY value is longer than its section");
+        src_off[(size_t)i] = (int32_t)at;
+        lengths[(size_t)i] = (int32_t)l;
+        at += l;
+    }
+}
+
+int width_of(int32_t physical)
+{
+    return physical == PQ_INT32 ? 4 : (physical == PQ_INT64 || physical == PQ_DOUBLE) ? 8 : 0;
+}
+
+// `count` PLAIN values (no nulls among them) placed at the non-null rows of an n-row column
+DeviceColumn plain_column(Context *ctx, int32_t type, int32_t physical, const uint8_t *bytes, int64_t len, int64_t n, const Present &p)
+{
+    DeviceColumn col;
+    col.type = type;
+    col.n = n;
+    const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+    const int32_t *rank = nulls ? p.rank->as<int32_t>() : nullptr;
+    if (nulls) {
+        col.nulls_buf = p.nulls;
+        col.nulls = nulls;
+    }
+    if (physical == PQ_BYTE_ARRAY) {
+        std::vector<int32_t> src_off, lengths;
+        scan_byte_arrays(bytes, len, p.non_null, src_off, lengths);
+        int64_t total_bytes = 0;
+        for (int32_t l : lengths) total_bytes += l;
+        TG_CHECK_ARG(total_bytes <= 0x7fffffffLL, "Parquet page holds more than 2 GB of string bytes");
+        col.offsets_buf = ctx->alloc((size_t)(n + 1) * 4);
+        col.offsets = col.offsets_buf->as<int32_t>();
+        col.values_buf = ctx->alloc((size_t)(total_bytes > 0 ? total_bytes : 1));
+        col.values = col.values_buf->ptr();
+        col.pool_bytes = total_bytes;
+        col.pool_exact = true;
+        if (n == 0) {
+            HIP_CHECK(hipMemsetAsync(col.offsets_buf->ptr(), 0, 4, ctx->stream()));
+            return col;
+        }
+        BufferPtr dlen = ctx->alloc((size_t)std::max<int64_t>(p.non_null, 1) * 4), dsrc = ctx->alloc((size_t)std::max<int64_t>(p.non_null, 1) * 4), row_len = ctx->alloc((size_t)n * 4),
+                  total = ctx->alloc(8), page = upload_padded(ctx, bytes, len);
+        if (p.non_null > 0) {
+            ctx->upload(dlen->ptr(), lengths.data(), (size_t)p.non_null * 4);
+            ctx->upload(dsrc->ptr(), src_off.data(), (size_t)p.non_null * 4);
+        }
+        place_kernel<int32_t><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(dlen->as<int32_t>(), rank, nulls, n, row_len->as<int32_t>());
+        check_launch("parquet_place_lengths");
+        k::exclusive_scan_i32(ctx, row_len->as<int32_t>(), const_cast<int32_t *>(col.offsets), n, total->as<int64_t>());
+        const int32_t end = (int32_t)total_bytes;
+        ctx->upload(const_cast<int32_t *>(col.offsets) + n, &end, 4);
+        copy_strings_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(page->as<uint8_t>(), dsrc->as<int32_t>(), rank, nulls, col.offsets, n, col.values_buf->as<uint8_t>());
+        check_launch("parquet_copy_strings");
+        ctx->sync();   // the host vectors back the uploads
+        return col;
+    }
+    if (physical == PQ_BOOLEAN) {
+        TG_CHECK_ARG(len >= (p.non_null + 7) / 8, "Parquet PLAIN BOOLEAN section holds fewer bits than the page has non-null values");
+        col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1));
+        col.values = col.values_buf->ptr();
+        if (n == 0) return col;
+        BufferPtr bits = upload_padded(ctx, bytes, len);
+        place_bits_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(bits->as<uint8_t>(), rank, nulls, n, col.values_buf->as<uint8_t>());
+        check_launch("parquet_place_bits");
+        return col;
+    }
+    const int w = width_of(physical);
+    TG_CHECK_ARG(len >= p.non_null * w, "Parquet PLAIN section holds fewer values than the page has non-null positions");
+    col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1) * (size_t)w);
+    col.values = col.values_buf->ptr();
+    if (n == 0) return col;
+    if (!nulls) {
+        ctx->upload(col.values_buf->ptr(), bytes, (size_t)n * (size_t)w);
+        return col;
+    }
+    BufferPtr compact = ctx->alloc((size_t)std::max<int64_t>(p.non_null, 1) * (size_t)w);
+    if (p.non_null > 0) ctx->upload(compact->ptr(), bytes, (size_t)p.non_null * (size_t)w);
+    if (w == 8) place_kernel<long long><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(compact->as<long long>(), rank, nulls, n, (long long *)col.values_buf->ptr());
+    else place_kernel<int32_t><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(compact->as<int32_t>(), rank, nulls, n, (int32_t *)col.values_buf->ptr());
+    check_launch("parquet_place_values");
+    return col;
+}
+
+void check_types(int32_t type, int32_t physical)
+{
+    const bool ok = (physical == PQ_INT32 && (type == TGPU_INTEGER || type == TGPU_DATE)) || (physical == PQ_INT64 && type == TGPU_BIGINT) || (physical == PQ_DOUBLE && type == TGPU_DOUBLE) ||
+                    (physical == PQ_BOOLEAN && type == TGPU_BOOLEAN) || (physical == PQ_BYTE_ARRAY && type == TGPU_VARCHAR);
+    if (!ok) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet physical type / column type pair not decoded on the device (INT32 -> INTEGER / DATE, INT64 -> BIGINT, DOUBLE, BOOLEAN, BYTE_ARRAY -> VARCHAR)");
+}
+
+}  // namespace
+
+DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int32_t encoding, int64_t n, const uint8_t *def_levels, int64_t def_len, const uint8_t *values,
+                              int64_t values_len, const uint8_t *dictionary, int64_t dictionary_len, int32_t dictionary_count)
+{
+    TG_CHECK_ARG(n >= 0 && n <= 0x7fffffffLL && def_len >= 0 && values_len >= 0 && dictionary_len >= 0 && dictionary_count >= 0, "bad argument");
+    check_types(type, physical);
+    Present p = decode_levels(ctx, def_levels, def_len, n);
+    if (encoding == PQ_PLAIN) return plain_column(ctx, type, physical, values, values_len, n, p);
+    if (encoding == PQ_RLE) {
+        // ParquetEncoding.RLE as a VALUE encoding exists for BOOLEAN only (ParquetEncoding.java:105-115,198-212: bit width 1): a 4-byte length, then
+        // the non-null rows' booleans as a hybrid stream
+        if (physical != PQ_BOOLEAN) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet RLE value encoding is for BOOLEAN columns");
+        DeviceColumn col;
+        col.type = type;
+        col.n = n;
+        col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1));
+        col.values = col.values_buf->ptr();
+        if (n == 0) return col;
+        const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+        if (nulls) {
+            col.nulls_buf = p.nulls;
+            col.nulls = nulls;
+        }
+        BufferPtr compact;
+        if (p.non_null > 0) {
+            TG_CHECK_ARG(values_len >= 4, "Parquet RLE value section without its length");
+            uint32_t length;
+            memcpy(&length, values, 4);
+            TG_CHECK_ARG((int64_t)length <= values_len - 4, "Parquet RLE value section shorter than its length says");
+            compact = decode_hybrid(ctx, values + 4, (int64_t)length, 1, p.non_null);
+        } else compact = ctx->alloc(4);
+        place_narrow_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(compact->as<int32_t>(), nulls ? p.rank->as<int32_t>() : nullptr, nulls, n, col.values_buf->as<uint8_t>());
+        check_launch("parquet_place_booleans");
+        return col;
+    }
+    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY; RLE for BOOLEAN)");
+    TG_CHECK_ARG(physical != PQ_BOOLEAN, "BOOLEAN columns have no dictionary encoding");
+    // the dictionary page: PLAIN values without nulls (dictionary/*.java); the page: one byte of bit width, then the ids as a hybrid stream
+    Present all;
+    all.non_null = dictionary_count;
+    DeviceColumn dict = plain_column(ctx, type, physical, dictionary, dictionary_len, dictionary_count, all);
+    if (n == 0) return k::region_of(ctx, dict, 0, 0);
+    BufferPtr ids = ctx->alloc((size_t)n * 4), error = ctx->alloc_zero(4);
+    if (p.non_null > 0) {
+        TG_CHECK_ARG(values_len >= 1, "Parquet dictionary-encoded page without its bit width byte");
+        const int bit_width = values[0];
+        BufferPtr compact = decode_hybrid(ctx, values + 1, values_len - 1, bit_width, p.non_null);
+        const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+        place_ids_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(compact->as<int32_t>(), nulls ? p.rank->as<int32_t>() : nullptr, nulls, n, dictionary_count, ids->as<int32_t>(),
+                                                                      error->as<unsigned int>());
+        check_launch("parquet_place_ids");
+        if (ctx->read_scalar(error->as<unsigned int>()) != 0) fail(TGPU_ERR_INVALID_ARGUMENT, "Parquet dictionary id outside the dictionary");
+    } else HIP_CHECK(hipMemsetAsync(ids->ptr(), 0xff, (size_t)n * 4, ctx->stream()));
+    ProfileScope ps(ctx, "parquet_dictionary_gather");
+    return k::gather_column(ctx, dict, ids->as<int32_t>(), n, /*negative_is_null=*/p.non_null < n);
+}
+
+}  // namespace parquet
+}  // namespace tgpu

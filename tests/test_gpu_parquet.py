@@ -1,0 +1,110 @@
+"""-m gpu: the Parquet data-page decoders of libtgpu.so (csrc/parquet.hip, tgpu_parquet_decode_data_page) against the reference's own Parquet file,
+against files written and read back by Apache Arrow in every page layout the decoders cover, and against the oracle on pages of chosen shapes."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parquet_cases as cases   # noqa: E402
+import parquet_pages as pp      # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("presto-1_amd")
+
+
+@pytest.fixture(scope="module")
+def gpq():
+    return importlib.import_module("presto-1_amd.parquet")
+
+
+@pytest.fixture(scope="module")
+def opq():
+    from oracle import parquet as m
+    return m
+
+
+@pytest.fixture()
+def ctx(pkg):
+    c = pkg.Context(0)
+    yield c
+    c.close()
+
+
+def device_page(pkg, gpq, ctx, type_name, chunk, page, dictionary, dcount):
+    dl, vals = pp.split_data_page(chunk, page)
+    blk = gpq.decode_data_page(ctx, getattr(pkg, type_name), chunk["physical"], page["encoding"], page["num_values"], vals, dl, dictionary, dcount).to_host().getBlock(0)
+    out = blk.to_list()
+    return [v.encode("utf-8") if isinstance(v, str) else v for v in out]
+
+
+def same(a, b):
+    return len(a) == len(b) and all((x is None and y is None) or (x is not None and y is not None and (x == y or (isinstance(x, float) and np.float64(x).tobytes() == np.float64(y).tobytes())))
+                                    for x, y in zip(a, b))
+
+
+def test_the_references_own_parquet_file(pkg, gpq, ctx):
+    fx = cases.reference_fixture()
+    rows = []
+    for c, page, (dl, vals) in cases.fixture_pages(fx):
+        rows += gpq.decode_data_page(ctx, pkg.INTEGER, c["physical"], page["encoding"], page["num_values"], vals, dl).to_host().getBlock(0).to_list()
+    assert [[v] for v in rows] == fx["asserted_rows"]        # TestParquetSymlinkInputFormat.java:63: row(42)
+
+
+def test_pages_written_by_arrow_decode_to_what_arrow_reads(pkg, gpq, ctx, tmp_path):
+    pages = 0
+    for label, path, table in cases.write_cases(tmp_path):
+        for chunk in pp.column_chunks(path):
+            dictionary, dcount, got = None, 0, []
+            for page in chunk["pages"]:
+                if page["kind"] == "DICTIONARY":
+                    dictionary, dcount = page["bytes"], page["num_values"]
+                    continue
+                got += device_page(pkg, gpq, ctx, cases.TYPE_OF[chunk["name"]], chunk, page, dictionary, dcount)
+                pages += 1
+            want = cases.expected_column(table, chunk["name"], chunk["physical"])
+            assert same(got, want), (label, chunk["name"])
+    assert pages > 60
+
+
+def test_pages_of_chosen_shapes_against_the_oracle(pkg, gpq, opq, ctx):
+    rng = np.random.default_rng(29)
+    # dictionary ids at every bit width a dictionary of up to 2^20 entries needs, long RLE runs, runs that end inside a group of 8
+    for dcount in (1, 2, 3, 17, 300, 70_000, 1 << 20):
+        bw = max(0, int(dcount - 1).bit_length())
+        n = 50_000
+        present = (rng.random(n) < 0.9).astype(np.int32)
+        nn = int(present.sum())
+        ids = np.concatenate([rng.integers(0, dcount, nn // 2), np.full(nn - nn // 2 - 5, dcount - 1), rng.integers(0, dcount, 5)])
+        dict_vals = rng.integers(-10**12, 10**12, dcount)
+        page = bytes([bw]) + opq.hybrid_encode(ids.tolist(), bw)
+        dl = opq.hybrid_encode(present.tolist(), 1)
+        dpage = opq.plain_encode(opq.INT64, dict_vals)
+        want = opq.decode_data_page(opq.INT64, opq.RLE_DICTIONARY, n, page, dl, dpage, dcount)
+        got = gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.RLE_DICTIONARY, n, page, dl, dpage, dcount).to_host().getBlock(0).to_list()
+        assert got == want, dcount
+    # strings: empty values, long values, every row null, no row at all
+    words = [b"", b"a", b"x" * 5000, "héllo".encode("utf-8")]
+    for n, frac in ((0, 1.0), (1, 1.0), (1000, 0.0), (30_000, 0.7)):
+        present = (rng.random(n) < frac).astype(np.int32)
+        vals = [words[int(x)] for x in rng.integers(0, len(words), int(present.sum()))]
+        page, dl = opq.plain_encode(opq.BYTE_ARRAY, vals), opq.hybrid_encode(present.tolist(), 1) if n else b""
+        want = opq.decode_data_page(opq.BYTE_ARRAY, opq.PLAIN, n, page, dl if n else None)
+        blk = gpq.decode_data_page(ctx, pkg.VARCHAR, gpq.BYTE_ARRAY, gpq.PLAIN, n, page, dl if n else None).to_host().getBlock(0)
+        assert [None if v is None else v.encode("utf-8") for v in blk.to_list()] == want, (n, frac)
+    # failure modes: a stream that ends early, an id outside the dictionary, a type the decoders do not cover
+    with pytest.raises(pkg.TgpuError):
+        gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.PLAIN, 10, b"\x00" * 72)
+    with pytest.raises(pkg.TgpuError):
+        gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.RLE_DICTIONARY, 8, bytes([2]) + opq.hybrid_encode([0, 1, 3, 1, 0, 0, 0, 0], 2), None, opq.plain_encode(opq.INT64, [1, 2, 3]), 3)
+    with pytest.raises(pkg.TgpuError):
+        gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.PLAIN, 8, b"\x00" * 64, opq.hybrid_encode([1] * 8, 1)[:0] + b"\x10")      # definition levels cut short
+    with pytest.raises(pkg.TgpuError) as e:
+        gpq.decode_data_page(ctx, pkg.DOUBLE, gpq.INT64, gpq.PLAIN, 1, b"\x00" * 8)
+    assert e.value.code == -8

@@ -242,4 +242,4 @@ def test_the_glue_calls_only_natives_gpu_native_declares_and_uses_the_fused_fact
                  "setDoubleSumOrder", "scanAddPageSource"):
         assert must in called, must
     unused = declared - called
-    assert unused <= {"synchronizeContext", "destroyContext", "profileEnable", "profileDump", "spillStats", "partitionedOutputInfo", "scanStats", "destroyFactory", "orcDecodeLongColumn", "orcDecodeBooleanColumn", "orcDecodeDictionaryStringColumn", "orcDecodeDirectStringColumn", "orcDecodeDoubleColumn"}, unused
+    assert unused <= {"synchronizeContext", "destroyContext", "profileEnable", "profileDump", "spillStats", "partitionedOutputInfo", "scanStats", "destroyFactory", "orcDecodeLongColumn", "orcDecodeBooleanColumn", "orcDecodeDictionaryStringColumn", "orcDecodeDirectStringColumn", "orcDecodeDoubleColumn", "parquetDecodeDataPage"}, unused

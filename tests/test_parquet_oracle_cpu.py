@@ -1,0 +1,75 @@
+"""The Parquet page decoders' CPU restatement (oracle/parquet_oracle.c + oracle/parquet.py) against (a) the one Parquet file of the reference these
+types cover, with the row its own test asserts, and (b) files written and read back by Apache Arrow in every page layout the decoders cover."""
+import sys
+import os
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parquet_cases as cases   # noqa: E402
+import parquet_pages as pp      # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def opq():
+    from oracle import parquet as m
+    return m
+
+
+def test_the_references_own_parquet_file_decodes_to_the_row_its_test_asserts(opq):
+    fx = cases.reference_fixture()
+    rows = []
+    for c, page, (dl, vals) in cases.fixture_pages(fx):
+        assert page["kind"] == "DATA_V1" and c["physical"] == pp.INT32
+        rows += opq.decode_data_page(c["physical"], page["encoding"], page["num_values"], vals, dl)
+    assert [[v] for v in rows] == fx["asserted_rows"]        # TestParquetSymlinkInputFormat.java:63: row(42)
+
+
+def decode_chunk(opq, chunk):
+    dictionary, dcount, out = None, 0, []
+    for page in chunk["pages"]:
+        if page["kind"] == "DICTIONARY":
+            dictionary, dcount = page["bytes"], page["num_values"]
+            continue
+        dl, vals = pp.split_data_page(chunk, page)
+        out += opq.decode_data_page(chunk["physical"], page["encoding"], page["num_values"], vals, dl, dictionary, dcount)
+    return out
+
+
+def same(a, b):
+    return len(a) == len(b) and all((x is None and y is None) or (x is not None and y is not None and (x == y or (isinstance(x, float) and np.float64(x).tobytes() == np.float64(y).tobytes())))
+                                    for x, y in zip(a, b))
+
+
+def test_pages_written_by_arrow_decode_to_what_arrow_reads(opq, tmp_path):
+    seen = set()
+    for label, path, table in cases.write_cases(tmp_path):
+        for chunk in pp.column_chunks(path):
+            got = decode_chunk(opq, chunk)
+            want = cases.expected_column(table, chunk["name"], chunk["physical"])
+            assert same(got, want), (label, chunk["name"])
+            seen |= {(p["kind"], p["encoding"]) for p in chunk["pages"]}
+    # every layout occurred: PLAIN and dictionary data pages of both versions, PLAIN dictionary pages
+    assert {("DATA_V1", pp.PLAIN), ("DATA_V2", pp.PLAIN), ("DICTIONARY", pp.PLAIN)} <= seen
+    assert any(k == "DATA_V1" and e in (pp.PLAIN_DICTIONARY, pp.RLE_DICTIONARY) for k, e in seen) and any(k == "DATA_V2" and e in (pp.PLAIN_DICTIONARY, pp.RLE_DICTIONARY) for k, e in seen)
+
+
+def test_hybrid_streams_of_every_width_and_their_failure_modes(opq):
+    rng = np.random.default_rng(5)
+    for bw in list(range(1, 33)):
+        hi = 1 << min(bw, 31)
+        v = np.concatenate([rng.integers(0, hi, 200), np.full(100, hi - 1), rng.integers(0, hi, 13), np.zeros(64, dtype=np.int64), rng.integers(0, hi, 1)])
+        s = opq.hybrid_encode(v.tolist(), bw)
+        assert np.array_equal(opq.hybrid(s, bw, len(v)), v.astype(np.int64).astype(np.uint32).view(np.int32) if bw == 32 else v)
+        assert np.array_equal(opq.hybrid(s, bw, 150), opq.hybrid(s, bw, len(v))[:150])      # fewer values wanted than the stream holds
+        with pytest.raises(ValueError):
+            opq.hybrid(s[: len(s) // 2], bw, len(v))                                         # the stream ends before the values do
+    assert np.array_equal(opq.hybrid(b"", 0, 7), np.zeros(7))                                # a one-entry dictionary: bit width 0
+    with pytest.raises(ValueError):
+        opq.hybrid(bytes([0x00]), 3, 1)                                                      # an RLE run of length 0
+    assert opq.plain_values(pp.BYTE_ARRAY, opq.plain_encode(pp.BYTE_ARRAY, [b"", b"ab", b"x" * 70]), 3) == [b"", b"ab", b"x" * 70]
+    with pytest.raises(ValueError):
+        opq.plain_values(pp.BYTE_ARRAY, b"\x05\x00\x00\x00ab", 1)                            # a value longer than its section
+    bits = [bool(x) for x in rng.integers(0, 2, 77)]
+    assert opq.plain_values(pp.BOOLEAN, opq.plain_encode(pp.BOOLEAN, bits), 77) == bits
