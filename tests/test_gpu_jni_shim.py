@@ -307,3 +307,21 @@ def test_orc_column_decode_through_the_shim(pkg, jvm, jctx):
     assert np.array_equal(nulls, present == 0) and np.array_equal(got[present == 1], vals)
     jvm.call("releasePage", None, I64(page))
     clean(jvm)
+
+
+def test_parquet_page_decode_through_the_shim(pkg, jvm, jctx):
+    """GpuNative.parquetDecodeDataPage: definition levels + a dictionary-encoded value section + the chunk's dictionary page -> a device page"""
+    from oracle import parquet as opq
+    rng = np.random.default_rng(5)
+    n, dcount = 4000, 300
+    present = (rng.random(n) < 0.85).astype(np.int32)
+    ids = rng.integers(0, dcount, int(present.sum()))
+    dict_vals = rng.integers(-10**12, 10**12, dcount)
+    bw = int(dcount - 1).bit_length()
+    as_i8 = lambda b: jvm.array(np.frombuffer(bytes(b), dtype=np.int8))   # noqa: E731
+    page = jvm.checked("parquetDecodeDataPage", I64, jctx, I32(pkg.BIGINT), I32(opq.INT64), I32(opq.RLE_DICTIONARY), I32(n), as_i8(opq.hybrid_encode(present.tolist(), 1)),
+                       as_i8(bytes([bw]) + opq.hybrid_encode(ids.tolist(), bw)), as_i8(opq.plain_encode(opq.INT64, dict_vals)), I32(dcount))
+    got, nulls = heap_blocks(jvm, page)[0]
+    assert np.array_equal(nulls, present == 0) and np.array_equal(got[present == 1], dict_vals[ids])
+    jvm.call("releasePage", None, I64(page))
+    clean(jvm)
