@@ -815,6 +815,26 @@ class Bench:
         self.q1_result = None
         return out
 
+    def q1_java_order_at_line_size(self, n):
+        """the strict mode on the line's own table: Q1 under TGPU_SUM_ORDER_JAVA -- every group's rows sorted out of the page and added in row
+        order, one workgroup per group (`fa_ordered_chain`: the additions of one sum are a dependent chain, ~7.5 ns per row of the largest group)
+        -- timed, and sum(extendedprice) compared BIT FOR BIT with the sequential sums check_q1 computed on the host (numpy cumsum)"""
+        p = self.pkg
+        self.ctx.set_double_sum_order(p.SUM_ORDER_JAVA)
+        try:
+            s, prof = self.timed(self.step_q1, 2, 1)
+            rows = [r for pg in self.q1_result for r in pg]
+        finally:
+            self.ctx.set_double_sum_order(p.SUM_ORDER_EXACT)
+        out = {"rows": n, "ms_per_step": s * 1e3, "rows_per_sec": n / s,
+               "kernels_ms_per_step": {k: v["total_ms"] / 2 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["total_ms"])[:3]}}
+        java = getattr(self, "q1_java_price", None)
+        if java:
+            out["sum_extendedprice_bit_identical_to_java_order"] = bool(len(rows) == len(java) and all(
+                np.float64(r[3]).view(np.int64) == np.float64(java.get(r[0] + r[1], np.nan)).view(np.int64) for r in rows))
+        self.q1_result = None
+        return out
+
     def setup_q1_dist(self):
         """Q1 on N ranks: every rank aggregates its own row-range shard with the fused PARTIAL operator, the 4-row
         partial pages are all-gathered in rank order (tgpu_exchange_all_gather) and a FINAL HashAggregationOperator combines them on every
@@ -1010,9 +1030,11 @@ class Bench:
             price = t["extendedprice"].cpu().numpy()
             rf, ls, sd = t["returnflag"].cpu().numpy(), t["linestatus"].cpu().numpy(), t["shipdate"].cpu().numpy()
             dist = {}
+            self.q1_java_price = {}
             for r in rows:
                 m = (sd <= 10471) & (rf == ord(r[0])) & (ls == ord(r[1]))
                 java = float(np.cumsum(price[m])[-1])
+                self.q1_java_price[r[0] + r[1]] = java
                 a, b = np.float64(r[3]).view(np.int64), np.float64(java).view(np.int64)
                 dist[r[0] + r[1]] = int(abs(int(a) - int(b)))
             out["sum_extendedprice_ulp_distance_to_java_order"] = dist
@@ -1548,7 +1570,11 @@ def main():
         out["q1"]["step_stats"] = b.step_stats(b.step_q1, min(args.steps, 20))
         out["q1"]["double_sum_order"] = "EXACT"
         if b.world == 1:
+            strict = b.q1_java_order_at_line_size(n)
             out["q1"]["double_sum_modes"] = b.q1_double_sum_modes(args.steps, args.warmup)
+            out["q1"]["double_sum_modes"]["java_order_at_line_size"] = strict
+            if strict.get("sum_extendedprice_bit_identical_to_java_order") is False:
+                out["checks"]["q1"]["ok"] = False
         if b.world == 1 and "paged" in only:
             # the engine hands over pages, not tables: the same program fed as 2^20-row pages (573 of them at SF100) directly and through MergePages
             out["q1"]["paged"] = {"direct_2^20": b.q1_paged(args.steps, args.warmup, 1 << 20), "merged_2^20_1GB": b.q1_paged(args.steps, args.warmup, 1 << 20, merge_mb=1024),

@@ -58,6 +58,15 @@ __device__ inline void tg_i128_add(unsigned long long *acc, long long v)
     if (hi_add) atomicAdd(&acc[1], hi_add);
 }
 
+// acc (128-bit, two words) += v, v a partial sum of many rows
+__device__ inline void tg_i128_add_wide(unsigned long long *acc, __int128 v)
+{
+    const unsigned long long lo = (unsigned long long)v, hi = (unsigned long long)((unsigned __int128)v >> 64);
+    const unsigned long long old = atomicAdd(&acc[0], lo);
+    const unsigned long long hi_add = hi + ((old + lo) < old ? 1ULL : 0ULL);
+    if (hi_add) atomicAdd(&acc[1], hi_add);
+}
+
 // double-double add (hi, lo) += (h2, l2)
 __device__ inline void tg_dd_add(double &hi, double &lo, double h2, double l2)
 {

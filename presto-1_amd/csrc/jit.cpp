@@ -283,11 +283,11 @@ static __global__ void init_words_kernel(unsigned long long *p, int n_ones, int 
     for (int i = (int)threadIdx.x; i < n_ones + n_zeros; i += (int)blockDim.x) p[i] = i < n_ones ? ~0ull : 0ull;
 }
 
-template <typename Args> static void launch_args(hipFunction_t f, int grid, Args &args, hipStream_t stream)
+template <typename Args> static void launch_args(hipFunction_t f, int grid, Args &args, hipStream_t stream, int block = 256)
 {
     size_t size = sizeof(Args);
     void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-    HIP_CHECK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, 256, 1, 1, 0, stream, nullptr, config));
+    HIP_CHECK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, 0, stream, nullptr, config));
 }
 
 
@@ -2359,6 +2359,21 @@ extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F)
   fa_accumulate_body<false>(F, (unsigned char*)0);
 }
 
+// ORDERED mode, few groups: workgroup b adds the rows of group b (its stretch of the sorted keys: two binary searches)
+extern "C" __global__ void __launch_bounds__(FA_ORD_WAVES * 64) fa_ordered_chain(FaArgs F) {
+  __shared__ __attribute__((aligned(16))) double vals[2 * FA_ORD_DOUBLES * FA_ORD_STRIDE];   // (stride even: 16-byte reads; lanes 4 banks apart)
+  const FpArgs& A = F.fp;
+  if (FA_GATE_CLOSED(F)) return;
+  const unsigned int key = blockIdx.x + 1u;
+  long long lo = 0, hi = A.n;            // first index with ord_keys >= key
+  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (F.ord_keys[mid] < key) lo = mid + 1; else hi = mid; }
+  const long long s = lo;
+  hi = A.n;                              // first index with ord_keys > key
+  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (F.ord_keys[mid] <= key) lo = mid + 1; else hi = mid; }
+  if (lo == s) return;
+  tg_accumulate_group_chained(F, A, (long long)blockIdx.x, s, lo, vals);
+}
+
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_ordered(FaArgs F) {
   const FpArgs& A = F.fp;
   if (FA_GATE_CLOSED(F)) return;
@@ -2737,7 +2752,8 @@ void FusedAggGpu::generate()
     Gen gr(nodes_, pool_, input_types_);
     gr.reg_mode = true;
     gr.tmp = gm.tmp;
-    std::ostringstream eval, lc_read, lc_upd, lc_write, gl, nf_any, nf_slow, nf_clear, ord_decl, ord_upd, ord_write;
+    std::ostringstream eval, lc_read, lc_upd, lc_write, gl, nf_any, nf_slow, nf_clear, ord_decl, ord_upd, ord_write, ch_decl, ch_upd, ch_write, ch_sum;
+    int ord_doubles = 0;   // DOUBLE sums = sequential chains of the ORDERED mode's few-group kernel (fa_ordered_chain)
     for (size_t k = 0; k < aggs_.size(); k++) {
         const tgpu_agg_spec &a = aggs_[k];
         const int w = wide_slot_[k];
@@ -2809,6 +2825,21 @@ void FusedAggGpu::generate()
         if (is_big)
             ord_write << "    if (ob" << k << " != 0) { unsigned long long* p_ = &F.st[" << k << "].i128[(size_t)g * 2]; const unsigned __int128 n_ = (((unsigned __int128)p_[1] << 64) | p_[0]) + (unsigned __int128)ob"
                       << k << "; p_[0] = (unsigned long long)n_; p_[1] = (unsigned long long)(n_ >> 64); }\n";
+        // ORDERED mode, few groups (fa_ordered_chain): the producer lanes count and add the integers (any order gives the same bits) and
+        // hand the doubles to the chain lane of the aggregate -- a row the aggregate skips travels as -0.0, the identity of IEEE addition
+        ch_decl << "  long long oc" << k << " = 0;";
+        if (is_big) ch_decl << " __int128 ob" << k << " = 0;";
+        ch_decl << "\n";
+        ch_upd << "      oc" << k << " += t" << k << " ? 1 : 0;";
+        if (is_big) ch_upd << " if (t" << k << ") ob" << k << " += y" << k << ";";
+        if (is_dbl) ch_upd << " out[" << ord_doubles << " * FA_ORD_STRIDE] = t" << k << " ? x" << k << " : -0.0;";
+        ch_upd << "\n";
+        ch_write << "    if (oc" << k << ") atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], (unsigned long long)oc" << k << ");\n";
+        if (is_big) ch_write << "    if (ob" << k << " != 0) tg_i128_add_wide(&F.st[" << k << "].i128[(size_t)g * 2], ob" << k << ");\n";
+        if (is_dbl) {
+            ch_sum << "    if (lane == " << ord_doubles << ") sum = F.st[" << k << "].dsum;\n";
+            ord_doubles++;
+        }
         // global: exact atomics per row
         gl << "  if (t" << k << ") {\n    atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], 1ULL);\n";
         if (is_dbl) gl << "    tg_kulisch_add(&F.st[" << k << "].limbs[(size_t)g * TG_LIMBS], &F.st[" << k << "].special[g], x" << k << ");\n";
@@ -3222,6 +3253,38 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
         << "  const unsigned int key = F.ord_keys[i];\n  const long long g = (long long)key - 1;\n" << ord_decl.str()
         << "  for (long long j = i; j < n && F.ord_keys[j] == key; j++) {\n    const long long row = F.ord_rows[j];\n    TgRow R;\n    tg_load_row(A, row, R);\n"
         << eval.str() << ord_upd.str() << "  }\n" << ord_write.str() << "}\n";
+    // few groups, ORDERED mode: one workgroup per group.  Waves 1..15 evaluate the group's rows, 960 at a time, into LDS; wave 0 holds one
+    // chain per DOUBLE sum (lane d = the d-th such aggregate) and adds the tile before, value after value in row order, while the next one
+    // is produced.  The additions of one sum are a dependent chain whatever the machine: this keeps that chain free of loads and
+    // expression work (the old lane-per-group loop paid a row load and the projections between two additions).
+    ord_doubles_ = ord_doubles;
+    if (const char *w = getenv("TGPU_ORD_WAVES")) ord_waves_ = std::max(2, std::min(16, atoi(w)));   // kernel study only
+    src << "#define FA_ORD_DOUBLES " << std::max(1, std::min(ord_doubles, kOrdChainMaxDoubles)) << "\n#define FA_ORD_WAVES " << ord_waves_
+        << "\n#define FA_ORD_TILE ((FA_ORD_WAVES - 1) * 64)\n#define FA_ORD_STRIDE (FA_ORD_TILE + 2)\n"
+        << "__device__ inline void tg_accumulate_group_chained(const FaArgs& F, const FpArgs& A, long long g, long long s, long long e, double* vals) {\n" << cols_decl(gr)
+        << "  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n" << ch_decl.str()
+        << "  double* sum = (double*)0;\n  if (wave == 0) {\n    __builtin_amdgcn_s_setprio(3);\n" << ch_sum.str() << "  }\n  double os = sum ? sum[g] : 0.0;\n"
+        << "  const long long tiles = (e - s + FA_ORD_TILE - 1) / FA_ORD_TILE;\n"
+        << "  const int r = (wave - 1) * 64 + lane;\n"
+        << "  long long row_next = (wave > 0 && s + r < e) ? F.ord_rows[s + r] : 0;   // (the row number of the next tile is on its way while this one is evaluated)\n"
+        << "  for (long long t = 0; t <= tiles; t++) {\n"
+        << "    if (wave > 0 && t < tiles) {\n      const long long j = s + t * FA_ORD_TILE + r;\n      const long long row = row_next;\n"
+        << "      if (j + FA_ORD_TILE < e) row_next = F.ord_rows[j + FA_ORD_TILE];\n"
+        << "      double* out = vals + (t & 1) * (FA_ORD_DOUBLES * FA_ORD_STRIDE) + r; (void)out;\n"
+        << "      if (j < e) {\n      TgRow R;\n      tg_load_row(A, row, R);\n" << eval.str() << ch_upd.str() << "      }\n    }\n"
+        << "    else if (wave == 0 && t > 0 && sum) {\n      const long long left = e - (s + (t - 1) * FA_ORD_TILE);\n      const int cnt = left < FA_ORD_TILE ? (int)left : FA_ORD_TILE;\n"
+        << "      const double* in = vals + ((t - 1) & 1) * (FA_ORD_DOUBLES * FA_ORD_STRIDE) + lane * FA_ORD_STRIDE;\n      int j = 0;\n"
+        // 16 values per batch (8 x 16-byte LDS reads), the next batch's reads issued before this batch's additions: the chain waits for
+        // the adder, not for the LDS
+        << "      if (cnt >= 16) {\n        const double2* in2 = (const double2*)in;\n        double2 a[8], b[8];\n"
+        << "#pragma unroll\n        for (int u = 0; u < 8; u++) a[u] = in2[u];\n"
+        << "        for (; j + 32 <= cnt; j += 16) {\n"
+        << "#pragma unroll\n          for (int u = 0; u < 8; u++) b[u] = in2[(j >> 1) + 8 + u];\n"
+        << "#pragma unroll\n          for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }\n"
+        << "#pragma unroll\n          for (int u = 0; u < 8; u++) a[u] = b[u];\n        }\n"
+        << "#pragma unroll\n        for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }\n        j += 16;\n      }\n"
+        << "      for (; j < cnt; j++) os += in[j];\n    }\n"
+        << "    __syncthreads();\n  }\n  if (sum) sum[g] = os;\n  if (wave > 0) {\n" << ch_write.str() << "  }\n}\n";
     std::string tail = kernels.substr(split);
     const std::string tag = "@FA_STRIPES@";
     tail.replace(tail.find(tag), tag.size(), std::to_string(fa_stripes()));
@@ -3493,6 +3556,14 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
     if (ordered) {
         F.ord_keys = ord_keys->as<unsigned int>();
         F.ord_rows = ord_rows->as<int>();
+        // few groups with many rows each: one workgroup per group, the sums as chains fed from LDS (same bits as the lane-per-group kernel)
+        const int64_t ids = groups > 0 ? groups : 1;
+        if (ord_doubles_ <= kOrdChainMaxDoubles && ids <= kOrdChainMaxGroups && in.n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr) {
+            ProfileScope ps(ctx, "fused_project_accumulate_ordered_chain");
+            launch_args(module->fn("fa_ordered_chain"), (int)ids, F, ctx->stream(), ord_waves_ * 64);
+            if (accumulate_can_raise_) raise_if_error(ctx, err);
+            return;
+        }
         ProfileScope ps(ctx, "fused_project_accumulate_ordered");
         const int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8);
         launch_args(module->fn("fa_accumulate_ordered"), (int)blocks, F, ctx->stream());

@@ -1177,6 +1177,93 @@ def test_double_sums_do_not_depend_on_how_the_rows_are_cut_into_pages(pkg, shape
         assert [r[3] for r in rows] == [r[3] for r in base], name
 
 
+@pytest.mark.parametrize("groups,n", [(1, 5_000), (4, 70_000), (300, 90_000), (4096, 300_000)])
+def test_fused_aggregation_java_order_chained_few_groups(pkg, oracle, groups, n, monkeypatch):
+    """SUM_ORDER_JAVA with few groups: one workgroup per group, the DOUBLE sums as chains fed from LDS (fa_ordered_chain) -- bit-identical to the
+    Java-order oracle (DoubleSumAggregation.java:34-38, per-position loop AccumulatorCompiler.java:487-566) and to the lane-per-group kernel,
+    over several pages, with filtered rows, nulls, masks, NaN / infinities, skewed group sizes (groups without rows in a page, groups of one
+    row, tiles that end inside the 448-row stretch); counts and BIGINT sums exact"""
+    rng = np.random.default_rng(101 + groups)
+    B, D, BO = pkg.BIGINT, pkg.DOUBLE, pkg.BOOLEAN
+    f, c = pkg.field, pkg.constant
+    T = [B, D, BO, B, D]
+    filt = f(4, D) < 0.9
+    projs = [f(0, B), f(1, D), f(2, BO), f(3, B), f(1, D) * (c(1.0, D) - f(4, D))]
+    aggs = [(pkg.SUM_DOUBLE, 1), (pkg.AVG_DOUBLE, 1), (pkg.SUM_DOUBLE, 1, 2), (pkg.COUNT_ALL, -1), (pkg.SUM_BIGINT, 3), (pkg.AVG_BIGINT, 3), (pkg.SUM_DOUBLE, 4), (pkg.COUNT_COLUMN, 1)]
+    cols = []
+    for page in range(3):
+        m = n if page != 1 else n // 3 + 449
+        keys = np.minimum((rng.pareto(1.2, m) * max(1, groups // 8)).astype(np.int64), groups - 1)      # skewed: some groups huge, some of one row
+        if page == 0:
+            keys[:groups] = np.arange(groups)            # (every group known after the first page: the ids of the oracle and the table agree)
+        vals = rng.standard_normal(m) * 10.0 ** rng.integers(-8, 9, m)
+        vals[rng.integers(0, m, 4)] = np.inf
+        vals[rng.integers(0, m, 2)] = np.nan
+        vals[rng.integers(0, m, 4)] = -0.0
+        cols.append((keys, vals, (rng.random(m) < 0.1).astype(np.uint8), rng.integers(0, 2, m).astype(np.uint8), rng.integers(-10**15, 10**15, m).astype(np.int64), rng.random(m)))
+
+    def run(disable):
+        if disable:
+            monkeypatch.setenv("TGPU_DISABLE_ORDERED_CHAIN", "1")
+        else:
+            monkeypatch.delenv("TGPU_DISABLE_ORDERED_CHAIN", raising=False)
+        ctx = pkg.Context(0)
+        ctx.profile_enable(True)
+        ctx.set_double_sum_order(pkg.SUM_ORDER_JAVA)
+        pages = [pkg.Page(pkg.Block(B, k), pkg.Block(D, v, nl), pkg.Block(BO, m_), pkg.Block(B, i_), pkg.Block(D, d_)) for k, v, nl, m_, i_, d_ in cols]
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [B], [0], aggs)
+        out = pkg.to_pages(fac.createOperator(), pages)
+        prof = ctx.profile()
+        ctx.close()
+        return [r for p_ in out for r in p_.rows()], prof
+
+    rows, prof = run(False)
+    assert "fused_project_accumulate_ordered_chain" in prof
+    rows_lane, prof_lane = run(True)
+    assert "fused_project_accumulate_ordered_chain" not in prof_lane and "fused_project_accumulate_ordered" in prof_lane
+
+    def bits(rs):
+        return [[None if x is None else (np.float64(x).view(np.int64).item() if isinstance(x, float) else x) for x in r] for r in rs]
+    assert bits(rows) == bits(rows_lane)
+    keys, vals, nulls, mask, ints, disc = (np.concatenate([cl[i] for cl in cols]) for i in range(6))
+    sel = np.nonzero(disc < 0.9)[0]
+    keys, vals, nulls, mask, ints, disc = (a[sel] for a in (keys, vals, nulls, mask, ints, disc))
+    o = oracle.BigintGroupByHash(groups)
+    gids = o.get_group_ids(oracle.Col(pkg.BIGINT, keys))
+    ng = o.group_count
+    assert len(rows) == ng
+    by_key = {r[0]: r for r in rows}
+    first = {}
+    for k_, g_ in zip(keys.tolist(), gids.tolist()):
+        first.setdefault(g_, k_)
+    got = [by_key[first[g_]] for g_ in range(ng)]
+    with np.errstate(invalid="ignore", over="ignore"):
+        cnt, java = oracle.agg_double_sum(gids, vals, ng, nulls=nulls)
+        cnt_m, java_m = oracle.agg_double_sum(gids, vals, ng, nulls=nulls, mask=mask)
+        cnt_d, java_d = oracle.agg_double_sum(gids, vals * (1.0 - disc), ng, nulls=nulls)
+        cnt_i, java_i = oracle.agg_long_avg(gids, ints, ng)
+        cnt_l, exact = oracle.agg_long_sum(gids, ints, ng)
+
+    def same(col, want, have_rows):
+        for g_ in range(ng):
+            x = got[g_][col]
+            if not have_rows[g_]:
+                assert x is None, (col, g_)
+            else:
+                w = want[g_]
+                assert (np.isnan(x) and np.isnan(w)) or np.float64(x).view(np.int64) == np.float64(w).view(np.int64), (col, g_, x, w)
+    with np.errstate(invalid="ignore", over="ignore", divide="ignore"):
+        same(1, java, cnt > 0)
+        same(2, java / np.maximum(cnt, 1), cnt > 0)
+        same(3, java_m, cnt_m > 0)
+        same(6, java_i / np.maximum(cnt_i, 1), cnt_i > 0)
+        same(7, java_d, cnt_d > 0)
+    rows_of = np.bincount(gids, minlength=ng)
+    for g_ in range(ng):
+        assert got[g_][4] == rows_of[g_] and got[g_][5] == exact[g_], g_
+        assert got[g_][8] == cnt[g_], g_
+
+
 def _onepass_pages(pkg, rng, npages, rows, late_groups, error_page=None):
     """pages of a Q1-like program: 2 varchar(1) keys (3 x 2 values), some pages add a new key value late in the stream"""
     pages = []
