@@ -3274,15 +3274,21 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
         << "      if (j < e) {\n      TgRow R;\n      tg_load_row(A, row, R);\n" << eval.str() << ch_upd.str() << "      }\n    }\n"
         << "    else if (wave == 0 && t > 0 && sum) {\n      const long long left = e - (s + (t - 1) * FA_ORD_TILE);\n      const int cnt = left < FA_ORD_TILE ? (int)left : FA_ORD_TILE;\n"
         << "      const double* in = vals + ((t - 1) & 1) * (FA_ORD_DOUBLES * FA_ORD_STRIDE) + lane * FA_ORD_STRIDE;\n      int j = 0;\n"
-        // 16 values per batch (8 x 16-byte LDS reads), the next batch's reads issued before this batch's additions: the chain waits for
-        // the adder, not for the LDS
+        // 16 values per batch (8 x 16-byte LDS reads); the reads of the next batch are issued BETWEEN this batch's additions (one read after
+        // every second addition: a dependent v_add_f64 waits ~12 cycles for its input, tools/exp_dep_add.hip, and a read fits in that shadow),
+        // two batches per loop trip so that no registers are copied
+        << "#define FA_ORD_ADDS(a) _Pragma(\"unroll\") for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }\n"
+        << "#define FA_ORD_MIX() _Pragma(\"unroll\") for (int u = 0; u < 8; u++) { __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }\n"
         << "      if (cnt >= 16) {\n        const double2* in2 = (const double2*)in;\n        double2 a[8], b[8];\n"
         << "#pragma unroll\n        for (int u = 0; u < 8; u++) a[u] = in2[u];\n"
-        << "        for (; j + 32 <= cnt; j += 16) {\n"
+        << "        for (; j + 48 <= cnt; j += 32) {\n"
         << "#pragma unroll\n          for (int u = 0; u < 8; u++) b[u] = in2[(j >> 1) + 8 + u];\n"
-        << "#pragma unroll\n          for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }\n"
-        << "#pragma unroll\n          for (int u = 0; u < 8; u++) a[u] = b[u];\n        }\n"
-        << "#pragma unroll\n        for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }\n        j += 16;\n      }\n"
+        << "          FA_ORD_ADDS(a)\n          FA_ORD_MIX()\n"
+        << "#pragma unroll\n          for (int u = 0; u < 8; u++) a[u] = in2[(j >> 1) + 16 + u];\n"
+        << "          FA_ORD_ADDS(b)\n          FA_ORD_MIX()\n        }\n"
+        << "        FA_ORD_ADDS(a)\n        j += 16;\n"
+        << "        for (; j + 16 <= cnt; j += 16) {\n"
+        << "#pragma unroll\n          for (int u = 0; u < 8; u++) a[u] = in2[(j >> 1) + u];\n          FA_ORD_ADDS(a)\n        }\n      }\n"
         << "      for (; j < cnt; j++) os += in[j];\n    }\n"
         << "    __syncthreads();\n  }\n  if (sum) sum[g] = os;\n  if (wave > 0) {\n" << ch_write.str() << "  }\n}\n";
     std::string tail = kernels.substr(split);
