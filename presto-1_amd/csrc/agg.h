@@ -20,6 +20,8 @@ namespace tgpu {
 
 constexpr int kLimbs = 68;       // 32-bit limbs covering 2^-1074 .. 2^2101
 constexpr int kMaxAggs = 16;
+// ORDERED mode: the chained kernels (one workgroup per group) are chosen up to this many groups and from this many rows per group on average
+constexpr int64_t kOrdChainMaxGroups = 4096, kOrdChainMinRows = 64;
 
 class GroupedAccumulators {
 public:

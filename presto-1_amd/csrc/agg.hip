@@ -149,6 +149,105 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
     (void)error;
 }
 
+// ORDERED mode with few groups (many rows per group): one workgroup per group, see device_agg.h "strict row-order sums".  Waves 1..15 take
+// the group's rows 960 at a time: counts and BIGINT sums are reduced per wave and added to LDS words (any order gives the same bits), the
+// DOUBLE addends go to the LDS tile -- a row an aggregate skips travels as -0.0, the identity of IEEE addition; wave 0, lane d, adds the
+// tile before to the d-th DOUBLE sum, value after value in row order.  Same bits as agg_ordered_kernel<false> (tested against it).
+struct OrdChainPlan {
+    int32_t slot[kMaxAggs];   // aggregate -> its chain (lane of wave 0), or -1
+};
+
+__device__ inline long long wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(TG_ORD_WAVES * 64) agg_ordered_chain_kernel(AggArgs args, OrdChainPlan plan, const unsigned int *__restrict__ keys,
+                                                                               const int *__restrict__ rows, int64_t n)
+{
+    __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
+    __shared__ unsigned long long cnt_lds[kMaxAggs], lo_lds[kMaxAggs];
+    __shared__ long long hi_lds[kMaxAggs];
+    long long s, e;
+    tg_ord_stretch(keys, n, blockIdx.x + 1u, s, e);
+    if (e == s) return;
+    const int64_t g = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < kMaxAggs) {
+        cnt_lds[threadIdx.x] = 0;
+        lo_lds[threadIdx.x] = 0;
+        hi_lds[threadIdx.x] = 0;
+    }
+    double *sum = nullptr;
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int k = 0; k < kMaxAggs; k++)
+            if (k < args.n_aggs && plan.slot[k] == lane) sum = args.a[k].dsum;
+    }
+    double os = sum ? sum[g] : 0.0;
+    __syncthreads();
+    const long long tiles = (e - s + TG_ORD_TILE - 1) / TG_ORD_TILE;
+    const int r = (wave - 1) * 64 + lane;
+    long long row_next = (wave > 0 && s + r < e) ? rows[s + r] : 0;
+    for (long long t = 0; t <= tiles; t++) {
+        if (wave > 0 && t < tiles) {
+            const long long j = s + t * TG_ORD_TILE + r;
+            const long long row = row_next;
+            if (j + TG_ORD_TILE < e) row_next = rows[j + TG_ORD_TILE];
+            double *out = vals + (t & 1) * (TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE) + r;
+            const bool live = j < e;
+#pragma unroll
+            for (int k = 0; k < kMaxAggs; k++) {   // constant indices into the by-value argument block (no scratch copy)
+                if (k >= args.n_aggs) break;
+                const AggView &a = args.a[k];
+                bool take = live;
+                if (take && a.mask && ((a.mask_nulls && a.mask_nulls[row]) || !a.mask[row])) take = false;
+                if (take && a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[row]) take = false;
+                const unsigned long long taken = __ballot(take);
+                if (lane == 0 && taken) atomicAdd(&cnt_lds[k], (unsigned long long)__popcll(taken));
+                if (a.function == TGPU_AGG_SUM_BIGINT) {
+                    // sum = 2^32 x (sum of the signed high halves) + (sum of the unsigned low halves): neither leaves 64 bits below 2^31 rows
+                    const long long v = take ? ((const long long *)a.input)[row] : 0;
+                    const long long lo = wave_sum_i64((long long)(unsigned int)v), hi = wave_sum_i64(v >> 32);
+                    if (lane == 0 && taken) {
+                        atomicAdd(&lo_lds[k], (unsigned long long)lo);
+                        atomicAdd((unsigned long long *)&hi_lds[k], (unsigned long long)hi);
+                    }
+                }
+                else if (plan.slot[k] >= 0 && live) {
+                    double x = -0.0;
+                    if (take) x = a.function == TGPU_AGG_AVG_BIGINT ? (double)((const long long *)a.input)[row] : ((const double *)a.input)[row];
+                    out[plan.slot[k] * TG_ORD_STRIDE] = x;
+                }
+            }
+        }
+        else if (wave == 0 && t > 0 && sum) {
+            const long long left = e - (s + (t - 1) * TG_ORD_TILE);
+            os = tg_chain_add_tile(vals + ((t - 1) & 1) * (TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE) + lane * TG_ORD_STRIDE, left < TG_ORD_TILE ? (int)left : TG_ORD_TILE, os);
+        }
+        __syncthreads();
+    }
+    if (sum) sum[g] = os;
+    if (threadIdx.x == 64) {
+#pragma unroll
+        for (int k = 0; k < kMaxAggs; k++) {
+            if (k >= args.n_aggs) break;
+            const AggView &a = args.a[k];
+            if (cnt_lds[k]) a.counts[g] += (long long)cnt_lds[k];
+            if (a.function == TGPU_AGG_SUM_BIGINT && a.i128) {
+                const __int128 big = (__int128)hi_lds[k] * ((__int128)1 << 32) + (__int128)lo_lds[k];
+                const unsigned __int128 cur = ((unsigned __int128)a.i128[g * 2 + 1] << 64) | a.i128[g * 2];
+                const unsigned __int128 nxt = cur + (unsigned __int128)big;
+                a.i128[g * 2] = (unsigned long long)nxt;
+                a.i128[g * 2 + 1] = (unsigned long long)(nxt >> 64);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Low-cardinality path (TPCH Q1: 4 groups x 8 aggregates over 600 M rows).  With a handful of groups every lane of the
 // chip would hammer the same few accumulators, so the accumulators are privatised PER LANE in LDS (device_agg.h):
@@ -771,9 +870,20 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
     }
     if (mode_ == Mode::ORDERED) {
         TG_CHECK_STATE(gids != nullptr, "ordered accumulation needs group ids");
-        ProfileScope ps(ctx_, "agg_accumulate_ordered");
+        // few groups with many rows each: one workgroup per group, the DOUBLE sums as chains fed from LDS
+        OrdChainPlan plan{};
+        int doubles = 0;
+        for (int k = 0; k < kMaxAggs; k++) plan.slot[k] = (k < args.n_aggs && args.a[k].dsum) ? doubles++ : -1;
+        const int64_t ids = group_count > 0 ? group_count : 1;
+        const bool chained = doubles <= TG_ORD_MAX_DOUBLES && ids <= kOrdChainMaxGroups && n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr;
+        ProfileScope ps(ctx_, chained ? "agg_accumulate_ordered_chain" : "agg_accumulate_ordered");
         BufferPtr keys, rows;
         sort_rows_by_group(gids, n, group_count, keys, rows);
+        if (chained) {
+            agg_ordered_chain_kernel<<<(int)ids, TG_ORD_WAVES * 64, 0, ctx_->stream()>>>(args, plan, keys->as<unsigned int>(), rows->as<int>(), n);
+            check_launch("agg_accumulate_ordered_chain");
+            return;
+        }
         agg_ordered_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>());
         check_launch("agg_accumulate_ordered");
         return;

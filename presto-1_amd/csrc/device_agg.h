@@ -67,6 +67,60 @@ __device__ inline void tg_i128_add_wide(unsigned long long *acc, __int128 v)
     if (hi_add) atomicAdd(&acc[1], hi_add);
 }
 
+// ---- strict row-order sums (ORDERED mode with few groups: jit.cpp fa_ordered_chain, agg.hip agg_ordered_chain_kernel) -----------------------
+// One workgroup of TG_ORD_WAVES waves per group: waves 1.. produce the DOUBLE addends of TG_ORD_TILE rows into one of two LDS tiles
+// ([chain][TG_ORD_STRIDE] doubles each), wave 0 adds the tile before -- lane d = the d-th DOUBLE sum of the operator.
+#define TG_ORD_WAVES 16
+#define TG_ORD_TILE ((TG_ORD_WAVES - 1) * 64)
+#define TG_ORD_STRIDE (TG_ORD_TILE + 2)      // even: 16-byte LDS reads; neighbouring lanes' chains lie 4 banks apart
+#define TG_ORD_MAX_DOUBLES 8
+// os + in[0] + in[1] + ... + in[cnt - 1], strictly left to right (`in`: 16-byte aligned LDS).  16 values per batch (8 x 16-byte reads); the
+// reads of the next batch are issued BETWEEN this batch's additions (one read after every second addition: a dependent v_add_f64 waits
+// ~12 cycles for its input, tools/exp_dep_add.hip, and a read fits in that shadow); two batches per trip so that no registers are copied
+__device__ inline double tg_chain_add_tile(const double *in, int cnt, double os)
+{
+#define TG_ORD_ADDS(a) _Pragma("unroll") for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }
+#define TG_ORD_MIX() _Pragma("unroll") for (int u = 0; u < 8; u++) { __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+    int j = 0;
+    if (cnt >= 16) {
+        const double2 *in2 = (const double2 *)in;
+        double2 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = in2[u];
+        for (; j + 48 <= cnt; j += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) b[u] = in2[(j >> 1) + 8 + u];
+            TG_ORD_ADDS(a)
+            TG_ORD_MIX()
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = in2[(j >> 1) + 16 + u];
+            TG_ORD_ADDS(b)
+            TG_ORD_MIX()
+        }
+        TG_ORD_ADDS(a)
+        j += 16;
+        for (; j + 16 <= cnt; j += 16) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = in2[(j >> 1) + u];
+            TG_ORD_ADDS(a)
+        }
+    }
+    for (; j < cnt; j++) os += in[j];
+    return os;
+#undef TG_ORD_ADDS
+#undef TG_ORD_MIX
+}
+// the stretch [s, e) of key in the page's sorted keys (ascending; 0 = filtered rows in front)
+__device__ inline void tg_ord_stretch(const unsigned int *keys, long long n, unsigned int key, long long &s, long long &e)
+{
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
+    s = lo;
+    hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
+    e = lo;
+}
+
 // double-double add (hi, lo) += (h2, l2)
 __device__ inline void tg_dd_add(double &hi, double &lo, double h2, double l2)
 {

@@ -2359,19 +2359,15 @@ extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F)
   fa_accumulate_body<false>(F, (unsigned char*)0);
 }
 
-// ORDERED mode, few groups: workgroup b adds the rows of group b (its stretch of the sorted keys: two binary searches)
-extern "C" __global__ void __launch_bounds__(FA_ORD_WAVES * 64) fa_ordered_chain(FaArgs F) {
-  __shared__ __attribute__((aligned(16))) double vals[2 * FA_ORD_DOUBLES * FA_ORD_STRIDE];   // (stride even: 16-byte reads; lanes 4 banks apart)
+// ORDERED mode, few groups: workgroup b adds the rows of group b (its stretch of the sorted keys)
+extern "C" __global__ void __launch_bounds__(TG_ORD_WAVES * 64) fa_ordered_chain(FaArgs F) {
+  __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
   const FpArgs& A = F.fp;
   if (FA_GATE_CLOSED(F)) return;
-  const unsigned int key = blockIdx.x + 1u;
-  long long lo = 0, hi = A.n;            // first index with ord_keys >= key
-  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (F.ord_keys[mid] < key) lo = mid + 1; else hi = mid; }
-  const long long s = lo;
-  hi = A.n;                              // first index with ord_keys > key
-  while (lo < hi) { const long long mid = (lo + hi) >> 1; if (F.ord_keys[mid] <= key) lo = mid + 1; else hi = mid; }
-  if (lo == s) return;
-  tg_accumulate_group_chained(F, A, (long long)blockIdx.x, s, lo, vals);
+  long long s, e;
+  tg_ord_stretch(F.ord_keys, A.n, blockIdx.x + 1u, s, e);
+  if (e == s) return;
+  tg_accumulate_group_chained(F, A, (long long)blockIdx.x, s, e, vals);
 }
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_ordered(FaArgs F) {
@@ -2832,7 +2828,7 @@ void FusedAggGpu::generate()
         ch_decl << "\n";
         ch_upd << "      oc" << k << " += t" << k << " ? 1 : 0;";
         if (is_big) ch_upd << " if (t" << k << ") ob" << k << " += y" << k << ";";
-        if (is_dbl) ch_upd << " out[" << ord_doubles << " * FA_ORD_STRIDE] = t" << k << " ? x" << k << " : -0.0;";
+        if (is_dbl) ch_upd << " out[" << ord_doubles << " * TG_ORD_STRIDE] = t" << k << " ? x" << k << " : -0.0;";
         ch_upd << "\n";
         ch_write << "    if (oc" << k << ") atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], (unsigned long long)oc" << k << ");\n";
         if (is_big) ch_write << "    if (ob" << k << " != 0) tg_i128_add_wide(&F.st[" << k << "].i128[(size_t)g * 2], ob" << k << ");\n";
@@ -3258,38 +3254,19 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     // is produced.  The additions of one sum are a dependent chain whatever the machine: this keeps that chain free of loads and
     // expression work (the old lane-per-group loop paid a row load and the projections between two additions).
     ord_doubles_ = ord_doubles;
-    if (const char *w = getenv("TGPU_ORD_WAVES")) ord_waves_ = std::max(2, std::min(16, atoi(w)));   // kernel study only
-    src << "#define FA_ORD_DOUBLES " << std::max(1, std::min(ord_doubles, kOrdChainMaxDoubles)) << "\n#define FA_ORD_WAVES " << ord_waves_
-        << "\n#define FA_ORD_TILE ((FA_ORD_WAVES - 1) * 64)\n#define FA_ORD_STRIDE (FA_ORD_TILE + 2)\n"
-        << "__device__ inline void tg_accumulate_group_chained(const FaArgs& F, const FpArgs& A, long long g, long long s, long long e, double* vals) {\n" << cols_decl(gr)
+    src << "__device__ inline void tg_accumulate_group_chained(const FaArgs& F, const FpArgs& A, long long g, long long s, long long e, double* vals) {\n" << cols_decl(gr)
         << "  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;\n" << ch_decl.str()
         << "  double* sum = (double*)0;\n  if (wave == 0) {\n    __builtin_amdgcn_s_setprio(3);\n" << ch_sum.str() << "  }\n  double os = sum ? sum[g] : 0.0;\n"
-        << "  const long long tiles = (e - s + FA_ORD_TILE - 1) / FA_ORD_TILE;\n"
+        << "  const long long tiles = (e - s + TG_ORD_TILE - 1) / TG_ORD_TILE;\n"
         << "  const int r = (wave - 1) * 64 + lane;\n"
         << "  long long row_next = (wave > 0 && s + r < e) ? F.ord_rows[s + r] : 0;   // (the row number of the next tile is on its way while this one is evaluated)\n"
         << "  for (long long t = 0; t <= tiles; t++) {\n"
-        << "    if (wave > 0 && t < tiles) {\n      const long long j = s + t * FA_ORD_TILE + r;\n      const long long row = row_next;\n"
-        << "      if (j + FA_ORD_TILE < e) row_next = F.ord_rows[j + FA_ORD_TILE];\n"
-        << "      double* out = vals + (t & 1) * (FA_ORD_DOUBLES * FA_ORD_STRIDE) + r; (void)out;\n"
+        << "    if (wave > 0 && t < tiles) {\n      const long long j = s + t * TG_ORD_TILE + r;\n      const long long row = row_next;\n"
+        << "      if (j + TG_ORD_TILE < e) row_next = F.ord_rows[j + TG_ORD_TILE];\n"
+        << "      double* out = vals + (t & 1) * (TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE) + r; (void)out;\n"
         << "      if (j < e) {\n      TgRow R;\n      tg_load_row(A, row, R);\n" << eval.str() << ch_upd.str() << "      }\n    }\n"
-        << "    else if (wave == 0 && t > 0 && sum) {\n      const long long left = e - (s + (t - 1) * FA_ORD_TILE);\n      const int cnt = left < FA_ORD_TILE ? (int)left : FA_ORD_TILE;\n"
-        << "      const double* in = vals + ((t - 1) & 1) * (FA_ORD_DOUBLES * FA_ORD_STRIDE) + lane * FA_ORD_STRIDE;\n      int j = 0;\n"
-        // 16 values per batch (8 x 16-byte LDS reads); the reads of the next batch are issued BETWEEN this batch's additions (one read after
-        // every second addition: a dependent v_add_f64 waits ~12 cycles for its input, tools/exp_dep_add.hip, and a read fits in that shadow),
-        // two batches per loop trip so that no registers are copied
-        << "#define FA_ORD_ADDS(a) _Pragma(\"unroll\") for (int u = 0; u < 8; u++) { os += a[u].x; os += a[u].y; }\n"
-        << "#define FA_ORD_MIX() _Pragma(\"unroll\") for (int u = 0; u < 8; u++) { __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }\n"
-        << "      if (cnt >= 16) {\n        const double2* in2 = (const double2*)in;\n        double2 a[8], b[8];\n"
-        << "#pragma unroll\n        for (int u = 0; u < 8; u++) a[u] = in2[u];\n"
-        << "        for (; j + 48 <= cnt; j += 32) {\n"
-        << "#pragma unroll\n          for (int u = 0; u < 8; u++) b[u] = in2[(j >> 1) + 8 + u];\n"
-        << "          FA_ORD_ADDS(a)\n          FA_ORD_MIX()\n"
-        << "#pragma unroll\n          for (int u = 0; u < 8; u++) a[u] = in2[(j >> 1) + 16 + u];\n"
-        << "          FA_ORD_ADDS(b)\n          FA_ORD_MIX()\n        }\n"
-        << "        FA_ORD_ADDS(a)\n        j += 16;\n"
-        << "        for (; j + 16 <= cnt; j += 16) {\n"
-        << "#pragma unroll\n          for (int u = 0; u < 8; u++) a[u] = in2[(j >> 1) + u];\n          FA_ORD_ADDS(a)\n        }\n      }\n"
-        << "      for (; j < cnt; j++) os += in[j];\n    }\n"
+        << "    else if (wave == 0 && t > 0 && sum) {\n      const long long left = e - (s + (t - 1) * TG_ORD_TILE);\n"
+        << "      os = tg_chain_add_tile(vals + ((t - 1) & 1) * (TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE) + lane * TG_ORD_STRIDE, left < TG_ORD_TILE ? (int)left : TG_ORD_TILE, os);\n    }\n"
         << "    __syncthreads();\n  }\n  if (sum) sum[g] = os;\n  if (wave > 0) {\n" << ch_write.str() << "  }\n}\n";
     std::string tail = kernels.substr(split);
     const std::string tag = "@FA_STRIPES@";
@@ -3566,7 +3543,7 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
         const int64_t ids = groups > 0 ? groups : 1;
         if (ord_doubles_ <= kOrdChainMaxDoubles && ids <= kOrdChainMaxGroups && in.n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr) {
             ProfileScope ps(ctx, "fused_project_accumulate_ordered_chain");
-            launch_args(module->fn("fa_ordered_chain"), (int)ids, F, ctx->stream(), ord_waves_ * 64);
+            launch_args(module->fn("fa_ordered_chain"), (int)ids, F, ctx->stream(), kOrdChainWaves * 64);
             if (accumulate_can_raise_) raise_if_error(ctx, err);
             return;
         }

@@ -271,9 +271,8 @@ private:
     // ORDERED mode's chained kernel (fa_ordered_chain): DOUBLE sums of the operator, and when the kernel is chosen -- at most
     // kOrdChainMaxDoubles chains (one lane of wave 0 each, LDS for two tiles of them), one workgroup per group, >= kOrdChainMinRows rows per
     // group on average (below that the lane-per-group kernel has more lanes at work)
-    int ord_doubles_ = 0, ord_waves_ = 16;   // (waves per workgroup: one adds, the others evaluate rows)
-    static constexpr int kOrdChainMaxDoubles = 8;
-    static constexpr int64_t kOrdChainMaxGroups = 4096, kOrdChainMinRows = 64;
+    int ord_doubles_ = 0;
+    static constexpr int kOrdChainMaxDoubles = 8, kOrdChainWaves = 16;   // = TG_ORD_MAX_DOUBLES, TG_ORD_WAVES (device_agg.h)
     int wide_slot_[16], cnt_slot_[16];
     std::vector<std::vector<int>> cnt_inputs_;   // per count slot: the raw input channels its (mask, input) expressions read
     std::vector<bool> cnt_masked_;

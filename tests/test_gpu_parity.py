@@ -1085,7 +1085,7 @@ def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle
         if mode == "fused":
             assert ("fused_project_accumulate_lowcard" in prof) == (ngroups == 4)
         else:
-            assert ("agg_accumulate_ordered" in prof) == (ngroups != 4)
+            assert ("agg_accumulate_ordered" in prof or "agg_accumulate_ordered_chain" in prof) == (ngroups != 4)
         ctx.close()
     a, b = results["fused"], results["unfused"]
     assert len(a) == len(b) and [r[:2] for r in a] == [r[:2] for r in b]        # same groups in the same (first-seen) order
@@ -1178,9 +1178,11 @@ def test_double_sums_do_not_depend_on_how_the_rows_are_cut_into_pages(pkg, shape
         assert [r[3] for r in rows] == [r[3] for r in base], name
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("groups,n", [(1, 5_000), (4, 70_000), (300, 90_000), (4096, 300_000)])
-def test_fused_aggregation_java_order_chained_few_groups(pkg, oracle, groups, n, monkeypatch):
-    """SUM_ORDER_JAVA with few groups: one workgroup per group, the DOUBLE sums as chains fed from LDS (fa_ordered_chain) -- bit-identical to the
+def test_aggregation_java_order_chained_few_groups(pkg, oracle, groups, n, fused, monkeypatch):
+    """SUM_ORDER_JAVA with few groups: one workgroup per group, the DOUBLE sums as chains fed from LDS (fused operator: the generated
+    fa_ordered_chain; plain HashAggregationOperator over the already filtered and projected rows: agg_ordered_chain_kernel) -- bit-identical to the
     Java-order oracle (DoubleSumAggregation.java:34-38, per-position loop AccumulatorCompiler.java:487-566) and to the lane-per-group kernel,
     over several pages, with filtered rows, nulls, masks, NaN / infinities, skewed group sizes (groups without rows in a page, groups of one
     row, tiles that end inside the 448-row stretch); counts and BIGINT sums exact"""
@@ -1211,17 +1213,27 @@ def test_fused_aggregation_java_order_chained_few_groups(pkg, oracle, groups, n,
         ctx = pkg.Context(0)
         ctx.profile_enable(True)
         ctx.set_double_sum_order(pkg.SUM_ORDER_JAVA)
-        pages = [pkg.Page(pkg.Block(B, k), pkg.Block(D, v, nl), pkg.Block(BO, m_), pkg.Block(B, i_), pkg.Block(D, d_)) for k, v, nl, m_, i_, d_ in cols]
-        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [B], [0], aggs)
+        if fused:
+            pages = [pkg.Page(pkg.Block(B, k), pkg.Block(D, v, nl), pkg.Block(BO, m_), pkg.Block(B, i_), pkg.Block(D, d_)) for k, v, nl, m_, i_, d_ in cols]
+            fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, filt, projs, [B], [0], aggs)
+        else:
+            pages = []
+            for k, v, nl, m_, i_, d_ in cols:
+                keep = d_ < 0.9
+                with np.errstate(invalid="ignore", over="ignore"):
+                    prod = v * (1.0 - d_)
+                pages.append(pkg.Page(pkg.Block(B, k[keep]), pkg.Block(D, v[keep], nl[keep]), pkg.Block(BO, m_[keep]), pkg.Block(B, i_[keep]), pkg.Block(D, prod[keep], nl[keep])))
+            fac = pkg.HashAggregationOperatorFactory(ctx, 0, [B], [0], aggs, expected_groups=groups)
         out = pkg.to_pages(fac.createOperator(), pages)
         prof = ctx.profile()
         ctx.close()
         return [r for p_ in out for r in p_.rows()], prof
 
+    names = ("fused_project_accumulate_ordered_chain", "fused_project_accumulate_ordered") if fused else ("agg_accumulate_ordered_chain", "agg_accumulate_ordered")
     rows, prof = run(False)
-    assert "fused_project_accumulate_ordered_chain" in prof
+    assert names[0] in prof
     rows_lane, prof_lane = run(True)
-    assert "fused_project_accumulate_ordered_chain" not in prof_lane and "fused_project_accumulate_ordered" in prof_lane
+    assert names[0] not in prof_lane and names[1] in prof_lane
 
     def bits(rs):
         return [[None if x is None else (np.float64(x).view(np.int64).item() if isinstance(x, float) else x) for x in r] for r in rs]
