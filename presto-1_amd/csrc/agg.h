@@ -13,6 +13,7 @@
 // lane per group adds its rows sequentially, in row order, into a plain double per group -- the very order of the
 // reference's per-position loop (AccumulatorCompiler.java:487-566), so the sums are bit-identical to the Java operator's.
 #pragma once
+#include <cstdlib>
 
 #include "common.h"
 
@@ -21,7 +22,10 @@ namespace tgpu {
 constexpr int kLimbs = 68;       // 32-bit limbs covering 2^-1074 .. 2^2101
 constexpr int kMaxAggs = 16;
 // ORDERED mode: the chained kernels (one workgroup per group) are chosen up to this many groups and from this many rows per group on average
-constexpr int64_t kOrdChainMaxGroups = 4096, kOrdChainMinRows = 64;
+// (a workgroup costs ~14 us before its first addition, 55 ns per group with 256 CUs at work; one lane per group costs 0.2-0.3 ns per ROW:
+// tools/exp_medium_groups.py, 50 M rows -- 65 536 groups 5.7 against 14.5 ms, 262 144 groups 14.5 against 10.0 ms)
+constexpr int64_t kOrdChainMaxGroups = 65536, kOrdChainMinRows = 256;
+inline int64_t ord_chain_max_groups() { const char *e = getenv("TGPU_ORD_CHAIN_MAX_GROUPS"); return e ? atoll(e) : kOrdChainMaxGroups; }   // (the variable: kernel study)
 
 class GroupedAccumulators {
 public:
@@ -48,6 +52,8 @@ public:
     // low-cardinality capacity; when the accumulators are (now) ORDERED, reserves the states and returns the page's
     // (group id + 1, row) pairs in (group, row) order -- the caller then adds the rows of every group in that order.
     bool begin_ordered(const int32_t *gids, int64_t n, int64_t groups, int64_t lowcard_max_groups, BufferPtr &keys, BufferPtr &rows);
+    // the chained kernels' input: {first, end} index of every group id's stretch of the sorted keys (ids pairs of int32; {0, 0} = no rows)
+    BufferPtr group_stretches(const unsigned int *keys, int64_t n, int64_t ids);
     // the JIT-fused accumulate kernels address the exact (limb) state directly: they keep the accumulators out of ORDERED mode
     void set_allow_ordered(bool on) { allow_ordered_ = on; }
     // TGPU_SUM_ORDER_JAVA: ORDERED whatever the number of groups (every group's rows are added in row order)

@@ -99,6 +99,17 @@ __global__ void __launch_bounds__(kBlock) ordered_keys_kernel(const int32_t *__r
     if (__any(bad) && (threadIdx.x & 63) == 0) *unsorted = 1u;   // idempotent plain store
 }
 
+// {first, end} of every group's stretch of the sorted keys (the words start at 0)
+__global__ void __launch_bounds__(kBlock) ordered_stretches_kernel(const unsigned int *__restrict__ keys, int64_t n, int *__restrict__ stretches)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const unsigned int k = keys[i];
+        if (k == 0) continue;
+        if (i == 0 || keys[i - 1] != k) stretches[(size_t)(k - 1) * 2] = (int)i;
+        if (i == n - 1 || keys[i + 1] != k) stretches[(size_t)(k - 1) * 2 + 1] = (int)(i + 1);
+    }
+}
+
 template <bool INTERMEDIATE>
 __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const unsigned int *__restrict__ keys, const int *__restrict__ rows, int64_t n,
                                                               unsigned int *error)
@@ -164,14 +175,13 @@ __device__ inline long long wave_sum_i64(long long v)
     return v;
 }
 
-__global__ void __launch_bounds__(TG_ORD_WAVES * 64) agg_ordered_chain_kernel(AggArgs args, OrdChainPlan plan, const unsigned int *__restrict__ keys,
-                                                                               const int *__restrict__ rows, int64_t n)
+__global__ void __launch_bounds__(TG_ORD_WAVES * 64) agg_ordered_chain_kernel(AggArgs args, OrdChainPlan plan, const int *__restrict__ stretches,
+                                                                               const int *__restrict__ rows)
 {
     __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
     __shared__ unsigned long long cnt_lds[kMaxAggs], lo_lds[kMaxAggs];
     __shared__ long long hi_lds[kMaxAggs];
-    long long s, e;
-    tg_ord_stretch(keys, n, blockIdx.x + 1u, s, e);
+    const long long s = stretches[(size_t)blockIdx.x * 2], e = stretches[(size_t)blockIdx.x * 2 + 1];
     if (e == s) return;
     const int64_t g = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -802,6 +812,14 @@ bool GroupedAccumulators::begin_ordered(const int32_t *gids, int64_t n, int64_t 
     return true;
 }
 
+BufferPtr GroupedAccumulators::group_stretches(const unsigned int *keys, int64_t n, int64_t ids)
+{
+    BufferPtr st = ctx_->alloc_zero((size_t)ids * 8);
+    ordered_stretches_kernel<<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(keys, n, st->as<int>());
+    check_launch("ordered_stretches");
+    return st;
+}
+
 // (group id + 1, row) pairs of the page in (group, row) order: stable LSD radix sort on the bits the group ids use
 void GroupedAccumulators::sort_rows_by_group(const int32_t *gids, int64_t n, int64_t groups, BufferPtr &keys, BufferPtr &rows)
 {
@@ -875,12 +893,13 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         int doubles = 0;
         for (int k = 0; k < kMaxAggs; k++) plan.slot[k] = (k < args.n_aggs && args.a[k].dsum) ? doubles++ : -1;
         const int64_t ids = group_count > 0 ? group_count : 1;
-        const bool chained = doubles <= TG_ORD_MAX_DOUBLES && ids <= kOrdChainMaxGroups && n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr;
+        const bool chained = doubles <= TG_ORD_MAX_DOUBLES && ids <= ord_chain_max_groups() && n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr;
         ProfileScope ps(ctx_, chained ? "agg_accumulate_ordered_chain" : "agg_accumulate_ordered");
         BufferPtr keys, rows;
         sort_rows_by_group(gids, n, group_count, keys, rows);
         if (chained) {
-            agg_ordered_chain_kernel<<<(int)ids, TG_ORD_WAVES * 64, 0, ctx_->stream()>>>(args, plan, keys->as<unsigned int>(), rows->as<int>(), n);
+            BufferPtr stretches = group_stretches(keys->as<unsigned int>(), n, ids);
+            agg_ordered_chain_kernel<<<(int)ids, TG_ORD_WAVES * 64, 0, ctx_->stream()>>>(args, plan, stretches->as<int>(), rows->as<int>());
             check_launch("agg_accumulate_ordered_chain");
             return;
         }

@@ -110,17 +110,6 @@ __device__ inline double tg_chain_add_tile(const double *in, int cnt, double os)
 #undef TG_ORD_ADDS
 #undef TG_ORD_MIX
 }
-// the stretch [s, e) of key in the page's sorted keys (ascending; 0 = filtered rows in front)
-__device__ inline void tg_ord_stretch(const unsigned int *keys, long long n, unsigned int key, long long &s, long long &e)
-{
-    long long lo = 0, hi = n;
-    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys[mid] < key) lo = mid + 1; else hi = mid; }
-    s = lo;
-    hi = n;
-    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys[mid] <= key) lo = mid + 1; else hi = mid; }
-    e = lo;
-}
-
 // double-double add (hi, lo) += (h2, l2)
 __device__ inline void tg_dd_add(double &hi, double &lo, double h2, double l2)
 {

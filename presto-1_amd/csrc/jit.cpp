@@ -2271,6 +2271,7 @@ struct FaArgs {
   const unsigned char* gids8;     // compact group ids (id + 1, 0 = filtered row) instead of gids
   TgFoldScratch fold;             // low-cardinality launches: the workgroups' folded partials
   const unsigned long long* gate; // speculative launch behind a group-by probe: its counters; anything but clean = do nothing
+  const int* ord_stretch;         // ORDERED mode, chained kernel: {first, end} of every group's stretch of ord_keys
 };
 // clean = no row met a new group ([0]), no table overflow ([2]), no expression error ([7] == ~0): groupby.h GbhSpeculateFn
 #define FA_GATE_CLOSED(F) ((F).gate && (((F).gate[0] | (F).gate[2] | ~(F).gate[7]) != 0ULL))
@@ -2364,8 +2365,7 @@ extern "C" __global__ void __launch_bounds__(TG_ORD_WAVES * 64) fa_ordered_chain
   __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
   const FpArgs& A = F.fp;
   if (FA_GATE_CLOSED(F)) return;
-  long long s, e;
-  tg_ord_stretch(F.ord_keys, A.n, blockIdx.x + 1u, s, e);
+  const long long s = F.ord_stretch[(size_t)blockIdx.x * 2], e = F.ord_stretch[(size_t)blockIdx.x * 2 + 1];
   if (e == s) return;
   tg_accumulate_group_chained(F, A, (long long)blockIdx.x, s, e, vals);
 }
@@ -2566,6 +2566,7 @@ struct FaArgsHost {
         unsigned long long *pending;
     } fold;
     const unsigned long long *gate;
+    const int *ord_stretch;
 };
 // host mirror of the generated FqArgs (fq_onepass)
 struct FqArgsHost {
@@ -3541,7 +3542,9 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
         F.ord_rows = ord_rows->as<int>();
         // few groups with many rows each: one workgroup per group, the sums as chains fed from LDS (same bits as the lane-per-group kernel)
         const int64_t ids = groups > 0 ? groups : 1;
-        if (ord_doubles_ <= kOrdChainMaxDoubles && ids <= kOrdChainMaxGroups && in.n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr) {
+        if (ord_doubles_ <= kOrdChainMaxDoubles && ids <= ord_chain_max_groups() && in.n >= ids * kOrdChainMinRows && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr) {
+            BufferPtr stretches = accs.group_stretches(F.ord_keys, in.n, ids);
+            F.ord_stretch = stretches->as<int>();
             ProfileScope ps(ctx, "fused_project_accumulate_ordered_chain");
             launch_args(module->fn("fa_ordered_chain"), (int)ids, F, ctx->stream(), kOrdChainWaves * 64);
             if (accumulate_can_raise_) raise_if_error(ctx, err);

@@ -1080,7 +1080,7 @@ def test_fused_filter_project_aggregation_matches_unfused_and_oracle(pkg, oracle
         out = pkg.to_pages(fac.createOperator(), [page, pkg.Page(*[pkg.Block(t, []) for t in T]), page])
         results[mode] = [r for p in out for r in p.rows()]
         prof = ctx.profile()
-        # (ORDERED with >= 64 rows per group on average: the chained kernel, fa_ordered_chain; below that one lane per group)
+        # (ORDERED with >= 256 rows per group on average: the chained kernel, fa_ordered_chain; below that one lane per group)
         assert ("fused_project_accumulate_lowcard" in prof or "fused_project_accumulate_ordered_chain" in prof or "fused_project_accumulate_ordered" in prof) == (mode == "fused")
         if mode == "fused":
             assert ("fused_project_accumulate_lowcard" in prof) == (ngroups == 4)
@@ -1179,7 +1179,7 @@ def test_double_sums_do_not_depend_on_how_the_rows_are_cut_into_pages(pkg, shape
 
 
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("groups,n", [(1, 5_000), (4, 70_000), (300, 90_000), (4096, 300_000)])
+@pytest.mark.parametrize("groups,n", [(1, 5_000), (4, 70_000), (300, 90_000), (4096, 1_300_000)])
 def test_aggregation_java_order_chained_few_groups(pkg, oracle, groups, n, fused, monkeypatch):
     """SUM_ORDER_JAVA with few groups: one workgroup per group, the DOUBLE sums as chains fed from LDS (fused operator: the generated
     fa_ordered_chain; plain HashAggregationOperator over the already filtered and projected rows: agg_ordered_chain_kernel) -- bit-identical to the
