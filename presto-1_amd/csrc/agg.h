@@ -25,6 +25,8 @@ constexpr int kMaxAggs = 16;
 // (a workgroup costs ~14 us before its first addition, 55 ns per group with 256 CUs at work; one lane per group costs 0.2-0.3 ns per ROW:
 // tools/exp_medium_groups.py, 50 M rows -- 65 536 groups 5.7 against 14.5 ms, 262 144 groups 14.5 against 10.0 ms)
 constexpr int64_t kOrdChainMaxGroups = 65536, kOrdChainMinRows = 256;
+// one lane per group: a lane hands its group over to the chained kernel after this many rows (0.5 ms of a lane's time)
+constexpr int64_t kOrdHandoffRows = 4096;
 inline int64_t ord_chain_max_groups() { const char *e = getenv("TGPU_ORD_CHAIN_MAX_GROUPS"); return e ? atoll(e) : kOrdChainMaxGroups; }   // (the variable: kernel study)
 
 class GroupedAccumulators {

@@ -110,14 +110,22 @@ __global__ void __launch_bounds__(kBlock) ordered_stretches_kernel(const unsigne
     }
 }
 
+// handoff > 0: a lane walks at most that many rows of its group and leaves the rest ({group, next index} appended to list) to
+// agg_ordered_chain_kernel -- a group far longer than the others would otherwise be the whole launch
 template <bool INTERMEDIATE>
 __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const unsigned int *__restrict__ keys, const int *__restrict__ rows, int64_t n,
-                                                              unsigned int *error)
+                                                              unsigned int *error, int64_t handoff, long long *list, unsigned int *list_count)
 {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const unsigned int key = keys[i];
         if (key == 0 || (i > 0 && keys[i - 1] == key)) continue;
         const int64_t g = (int64_t)key - 1;
+        const int64_t stop = handoff > 0 ? (i + handoff < n ? i + handoff : n) : n;   // (the walk ends there at the latest)
+        if (handoff > 0 && stop < n && keys[stop] == key) {
+            const unsigned int at = atomicAdd(list_count, 1u);
+            list[(size_t)at * 2] = g;
+            list[(size_t)at * 2 + 1] = stop;
+        }
 #pragma unroll
         for (int k = 0; k < kMaxAggs; k++) {   // constant indices into the by-value argument block (no scratch copy)
             if (k >= args.n_aggs) break;
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
             long long cnt = 0;
             double s = a.dsum ? a.dsum[g] : 0.0;
             __int128 big = 0;
-            for (int64_t j = i; j < n && keys[j] == key; j++) {
+            for (int64_t j = i; j < stop && keys[j] == key; j++) {
                 const int64_t r = rows[j];
                 if (INTERMEDIATE) {
                     // combine(): DoubleSumAggregation.java:48-52, AverageAggregations.java:63-67, CountAggregation.java:46-49
@@ -175,15 +183,9 @@ __device__ inline long long wave_sum_i64(long long v)
     return v;
 }
 
-__global__ void __launch_bounds__(TG_ORD_WAVES * 64) agg_ordered_chain_kernel(AggArgs args, OrdChainPlan plan, const int *__restrict__ stretches,
-                                                                               const int *__restrict__ rows)
+__device__ inline void ordered_chain_group(const AggArgs &args, const OrdChainPlan &plan, const int *__restrict__ rows, int64_t g, long long s, long long e, double *vals,
+                                           unsigned long long *cnt_lds, unsigned long long *lo_lds, long long *hi_lds)
 {
-    __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
-    __shared__ unsigned long long cnt_lds[kMaxAggs], lo_lds[kMaxAggs];
-    __shared__ long long hi_lds[kMaxAggs];
-    const long long s = stretches[(size_t)blockIdx.x * 2], e = stretches[(size_t)blockIdx.x * 2 + 1];
-    if (e == s) return;
-    const int64_t g = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (threadIdx.x < kMaxAggs) {
         cnt_lds[threadIdx.x] = 0;
@@ -255,6 +257,29 @@ __global__ void __launch_bounds__(TG_ORD_WAVES * 64) agg_ordered_chain_kernel(Ag
                 a.i128[g * 2 + 1] = (unsigned long long)(nxt >> 64);
             }
         }
+    }
+    __syncthreads();   // (the LDS words are reset by the next group of this workgroup)
+}
+
+// stretches: workgroup b = group b (every group of the page); else the workgroups share the list the lane-per-group kernel handed over
+__global__ void __launch_bounds__(TG_ORD_WAVES * 64) agg_ordered_chain_kernel(AggArgs args, OrdChainPlan plan, const int *__restrict__ stretches,
+                                                                               const unsigned int *__restrict__ keys, const int *__restrict__ rows, int64_t n,
+                                                                               const long long *__restrict__ list, const unsigned int *__restrict__ list_count)
+{
+    __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
+    __shared__ unsigned long long cnt_lds[kMaxAggs], lo_lds[kMaxAggs];
+    __shared__ long long hi_lds[kMaxAggs];
+    if (stretches) {
+        const long long s = stretches[(size_t)blockIdx.x * 2], e = stretches[(size_t)blockIdx.x * 2 + 1];
+        if (e > s) ordered_chain_group(args, plan, rows, blockIdx.x, s, e, vals, cnt_lds, lo_lds, hi_lds);
+        return;
+    }
+    const unsigned int count = *list_count;
+    for (unsigned int b = blockIdx.x; b < count; b += gridDim.x) {
+        const long long g = list[(size_t)b * 2], s = list[(size_t)b * 2 + 1];
+        long long lo = s, hi = n;            // the end of the group's stretch: first index whose key is larger
+        while (lo < hi) { const long long mid = (lo + hi) >> 1; if (keys[mid] <= (unsigned int)(g + 1)) lo = mid + 1; else hi = mid; }
+        if (lo > s) ordered_chain_group(args, plan, rows, g, s, lo, vals, cnt_lds, lo_lds, hi_lds);
     }
 }
 
@@ -899,12 +924,25 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         sort_rows_by_group(gids, n, group_count, keys, rows);
         if (chained) {
             BufferPtr stretches = group_stretches(keys->as<unsigned int>(), n, ids);
-            agg_ordered_chain_kernel<<<(int)ids, TG_ORD_WAVES * 64, 0, ctx_->stream()>>>(args, plan, stretches->as<int>(), rows->as<int>());
+            agg_ordered_chain_kernel<<<(int)ids, TG_ORD_WAVES * 64, 0, ctx_->stream()>>>(args, plan, stretches->as<int>(), keys->as<unsigned int>(), rows->as<int>(), n, nullptr,
+                                                                                          nullptr);
             check_launch("agg_accumulate_ordered_chain");
             return;
         }
-        agg_ordered_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>());
+        // one lane per group; a group of more than kOrdHandoffRows rows (one key far more frequent than the others) goes to the chained
+        // kernel after that many rows
+        const int64_t long_groups = n / kOrdHandoffRows;   // at most this many groups can be that long
+        const bool handoff = long_groups > 0 && doubles <= TG_ORD_MAX_DOUBLES && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr;
+        BufferPtr list = handoff ? ctx_->alloc((size_t)long_groups * 16) : nullptr, list_count = handoff ? ctx_->alloc_zero(8) : nullptr;
+        agg_ordered_kernel<false><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>(),
+                                                                                      handoff ? kOrdHandoffRows : 0, handoff ? list->as<long long>() : nullptr,
+                                                                                      handoff ? list_count->as<unsigned int>() : nullptr);
         check_launch("agg_accumulate_ordered");
+        if (handoff) {
+            agg_ordered_chain_kernel<<<(int)std::min<int64_t>(long_groups, ctx_->cu_count()), TG_ORD_WAVES * 64, 0, ctx_->stream()>>>(
+                args, plan, nullptr, keys->as<unsigned int>(), rows->as<int>(), n, list->as<long long>(), list_count->as<unsigned int>());
+            check_launch("agg_accumulate_ordered_handoff");
+        }
         return;
     }
     // low-cardinality path: lane-private LDS accumulators when all groups x states fit in one CU's LDS
@@ -987,7 +1025,8 @@ void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const
         ProfileScope ps(ctx_, "agg_combine_ordered");
         BufferPtr keys, rows;
         sort_rows_by_group(gids, n, group_count, keys, rows);
-        agg_ordered_kernel<true><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>());
+        agg_ordered_kernel<true><<<grid_for(ctx_, n), kBlock, 0, ctx_->stream()>>>(args, keys->as<unsigned int>(), rows->as<int>(), n, error_->as<unsigned int>(), 0, nullptr,
+                                                                                     nullptr);
         check_launch("agg_combine_ordered");
         return;
     }

@@ -2271,7 +2271,11 @@ struct FaArgs {
   const unsigned char* gids8;     // compact group ids (id + 1, 0 = filtered row) instead of gids
   TgFoldScratch fold;             // low-cardinality launches: the workgroups' folded partials
   const unsigned long long* gate; // speculative launch behind a group-by probe: its counters; anything but clean = do nothing
-  const int* ord_stretch;         // ORDERED mode, chained kernel: {first, end} of every group's stretch of ord_keys
+  const int* ord_stretch;         // ORDERED mode, chained kernel over all groups: {first, end} of every group's stretch of ord_keys; or
+  long long* ord_list;            // the groups the lane-per-group kernel handed over after ord_handoff rows: {group, next index} pairs,
+  unsigned int* ord_list_count;   // their number (starts at 0); ord_handoff 0 = lanes walk their groups to the end
+  int ord_handoff;
+  int pad4;
 };
 // clean = no row met a new group ([0]), no table overflow ([2]), no expression error ([7] == ~0): groupby.h GbhSpeculateFn
 #define FA_GATE_CLOSED(F) ((F).gate && (((F).gate[0] | (F).gate[2] | ~(F).gate[7]) != 0ULL))
@@ -2360,14 +2364,26 @@ extern "C" __global__ void __launch_bounds__(256) fa_accumulate_global(FaArgs F)
   fa_accumulate_body<false>(F, (unsigned char*)0);
 }
 
-// ORDERED mode, few groups: workgroup b adds the rows of group b (its stretch of the sorted keys)
+// ORDERED mode, row order through chains (device_agg.h): workgroup b adds the rows of group b (ord_stretch: every group of the page), or the
+// workgroups share the list of groups that fa_accumulate_ordered's lanes handed over after their first ord_handoff rows (a group far
+// longer than the others: its lane would be the whole launch)
 extern "C" __global__ void __launch_bounds__(TG_ORD_WAVES * 64) fa_ordered_chain(FaArgs F) {
   __shared__ __attribute__((aligned(16))) double vals[2 * TG_ORD_MAX_DOUBLES * TG_ORD_STRIDE];
   const FpArgs& A = F.fp;
   if (FA_GATE_CLOSED(F)) return;
-  const long long s = F.ord_stretch[(size_t)blockIdx.x * 2], e = F.ord_stretch[(size_t)blockIdx.x * 2 + 1];
-  if (e == s) return;
-  tg_accumulate_group_chained(F, A, (long long)blockIdx.x, s, e, vals);
+  if (F.ord_stretch) {
+    const long long s = F.ord_stretch[(size_t)blockIdx.x * 2], e = F.ord_stretch[(size_t)blockIdx.x * 2 + 1];
+    if (e == s) return;
+    tg_accumulate_group_chained(F, A, (long long)blockIdx.x, s, e, vals);
+    return;
+  }
+  const unsigned int count = *F.ord_list_count;
+  for (unsigned int b = blockIdx.x; b < count; b += gridDim.x) {
+    const long long g = F.ord_list[(size_t)b * 2], s = F.ord_list[(size_t)b * 2 + 1];
+    long long lo = s, hi = A.n;          // the end of the group's stretch: first index whose key is larger
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (F.ord_keys[mid] <= (unsigned int)(g + 1)) lo = mid + 1; else hi = mid; }
+    if (lo > s) tg_accumulate_group_chained(F, A, g, s, lo, vals);
+  }
 }
 
 extern "C" __global__ void __launch_bounds__(256) fa_accumulate_ordered(FaArgs F) {
@@ -2567,6 +2583,10 @@ struct FaArgsHost {
     } fold;
     const unsigned long long *gate;
     const int *ord_stretch;
+    long long *ord_list;
+    unsigned int *ord_list_count;
+    int32_t ord_handoff;
+    int32_t pad4;
 };
 // host mirror of the generated FqArgs (fq_onepass)
 struct FqArgsHost {
@@ -3248,7 +3268,10 @@ extern "C" __global__ void __launch_bounds__(256) fg_probe(FgArgs G) {
     // the additions as in Java: no special flags here)
     src << "__device__ inline void tg_accumulate_group_ordered(const FaArgs& F, const FpArgs& A, long long i, long long n) {\n" << cols_decl(gr)
         << "  const unsigned int key = F.ord_keys[i];\n  const long long g = (long long)key - 1;\n" << ord_decl.str()
-        << "  for (long long j = i; j < n && F.ord_keys[j] == key; j++) {\n    const long long row = F.ord_rows[j];\n    TgRow R;\n    tg_load_row(A, row, R);\n"
+        << "  for (long long j = i; j < n && F.ord_keys[j] == key; j++) {\n"
+        << "    if (F.ord_handoff && j - i == F.ord_handoff) {   // a long group: the rest goes to a workgroup of fa_ordered_chain (state so far: below)\n"
+        << "      const unsigned int at = atomicAdd(F.ord_list_count, 1u);\n      F.ord_list[(size_t)at * 2] = g;\n      F.ord_list[(size_t)at * 2 + 1] = j;\n      break;\n    }\n"
+        << "    const long long row = F.ord_rows[j];\n    TgRow R;\n    tg_load_row(A, row, R);\n"
         << eval.str() << ord_upd.str() << "  }\n" << ord_write.str() << "}\n";
     // few groups, ORDERED mode: one workgroup per group.  Waves 1..15 evaluate the group's rows, 960 at a time, into LDS; wave 0 holds one
     // chain per DOUBLE sum (lane d = the d-th such aggregate) and adds the tile before, value after value in row order, while the next one
@@ -3550,9 +3573,27 @@ void FusedAggGpu::accumulate(Context *ctx, const DevicePage &in, const int32_t *
             if (accumulate_can_raise_) raise_if_error(ctx, err);
             return;
         }
-        ProfileScope ps(ctx, "fused_project_accumulate_ordered");
-        const int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8);
-        launch_args(module->fn("fa_accumulate_ordered"), (int)blocks, F, ctx->stream());
+        // one lane per group; a group of more than kOrdHandoffRows rows (skew: one key far more frequent than the others) is handed over to
+        // the chained kernel after that many rows -- its lane would otherwise be the whole launch (128 ns per row)
+        BufferPtr list, list_count;
+        const int64_t long_groups = in.n / kOrdHandoffRows;   // at most this many groups can be that long
+        const bool handoff = long_groups > 0 && ord_doubles_ <= kOrdChainMaxDoubles && getenv("TGPU_DISABLE_ORDERED_CHAIN") == nullptr;
+        if (handoff) {
+            list = ctx->alloc((size_t)long_groups * 16);
+            list_count = ctx->alloc_zero(8);
+            F.ord_list = list->as<long long>();
+            F.ord_list_count = list_count->as<unsigned int>();
+            F.ord_handoff = (int32_t)kOrdHandoffRows;
+        }
+        {
+            ProfileScope ps(ctx, "fused_project_accumulate_ordered");
+            const int64_t blocks = std::min<int64_t>(ceil_div(in.n, 256), (int64_t)ctx->cu_count() * 8);
+            launch_args(module->fn("fa_accumulate_ordered"), (int)blocks, F, ctx->stream());
+        }
+        if (handoff) {
+            ProfileScope ps(ctx, "fused_project_accumulate_ordered_handoff");
+            launch_args(module->fn("fa_ordered_chain"), (int)std::min<int64_t>(long_groups, ctx->cu_count()), F, ctx->stream(), kOrdChainWaves * 64);
+        }
         if (accumulate_can_raise_) raise_if_error(ctx, err);
         return;
     }

@@ -23,6 +23,8 @@ def main():
     disc = bench.rnd(8, i, 11).to(torch.float64) / 100.0
     for groups in [int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (64, 1000, 4096):
         keys = bench.rnd(3, i, groups)
+        if len(sys.argv) > 3 and sys.argv[3] == "skew":      # 30 % of the rows in one group
+            keys = torch.where(bench.rnd(4, i, 10) < 3, torch.zeros_like(keys), keys)
         page = p.Page(b.dblock(B, keys), b.dblock(D, price), b.dblock(D, disc))
         fac = p.FilterProjectHashAggregationOperatorFactory(b.ctx, 77, [B, D, D], f(2, D) < 0.095, [f(0, B), f(1, D), f(1, D) * (c(1.0, D) - f(2, D))], [B], [0],
                                                             [(p.SUM_DOUBLE, 1), (p.SUM_DOUBLE, 2), (p.AVG_DOUBLE, 2), (p.COUNT_ALL, -1)], expected_groups=groups)
