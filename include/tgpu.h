@@ -197,7 +197,9 @@ typedef enum tgpu_agg_function {
     TGPU_AGG_SUM_BIGINT = 3,    /* sum(bigint)     LongSumAggregation.java:34-63 */
     TGPU_AGG_SUM_DOUBLE = 4,    /* sum(double)     DoubleSumAggregation.java:34-63 */
     TGPU_AGG_AVG_BIGINT = 5,    /* avg(bigint)     AverageAggregations.java:35-80 */
-    TGPU_AGG_AVG_DOUBLE = 6     /* avg(double)     AverageAggregations.java:42-80 */
+    TGPU_AGG_AVG_DOUBLE = 6,    /* avg(double)     AverageAggregations.java:42-80 */
+    TGPU_AGG_MIN_BIGINT = 7,    /* min(bigint)     AbstractMinMaxAggregationFunction.java:233-289 (LONG_INPUT / LONG_COMBINE, NullableLongState) */
+    TGPU_AGG_MAX_BIGINT = 8     /* max(bigint)     the same with the comparison turned round (MaxAggregationFunction.java) */
 } tgpu_agg_function;
 
 typedef struct tgpu_agg_spec {

@@ -70,6 +70,7 @@ def lib():
             "o_agg_double_sum": (None, [vp, vp, vp, vp, i32, vp, vp]),
             "o_agg_long_avg": (None, [vp, vp, vp, vp, i32, vp, vp]),
             "o_agg_long_sum": (i32, [vp, vp, vp, vp, i32, vp, vp]),
+            "o_agg_long_minmax": (None, [vp, vp, vp, vp, i32, i32, vp, vp]),
             "o_agg_count": (None, [vp, vp, vp, i32, vp]),
             "o_exact_sum": (f64, [vp, i64]),
             "o_agg_double_sum_exact": (None, [vp, vp, vp, vp, i64, i32, vp, vp]),
@@ -297,6 +298,16 @@ def agg_long_sum(gids, values, ngroups, nulls=None, mask=None):
     if rc != 0:
         raise OracleError(rc)
     return counts, sums
+
+
+def agg_long_minmax(gids, values, ngroups, is_min, nulls=None, mask=None):
+    """(counts, extremes): extremes[g] is meaningful where counts[g] > 0 (the state is null otherwise)"""
+    counts = np.zeros(ngroups, dtype=np.int64)
+    out = np.zeros(ngroups, dtype=np.int64)
+    v = np.ascontiguousarray(values, dtype=np.int64)
+    g = _gid(gids)
+    lib().o_agg_long_minmax(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), 1 if is_min else 0, _ptr(counts), _ptr(out))
+    return counts, out
 
 
 def agg_count(gids, n, ngroups, nulls=None, mask=None):

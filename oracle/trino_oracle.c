@@ -625,6 +625,22 @@ int32_t o_agg_long_sum(const int64_t *gids, const int64_t *v, const uint8_t *nul
     return O_OK;
 }
 
+/* min(bigint) / max(bigint): M/operator/aggregation/AbstractMinMaxAggregationFunction.java:233-236 (input) -> :274-289 compareAndUpdateState on a
+ * NullableLongState: the first value is taken, then every value the comparison prefers (MinAggregationFunction: value < state,
+ * MaxAggregationFunction: value > state).  counts[g] > 0 <=> the state is not null; values[g] is meaningful only then. */
+void o_agg_long_minmax(const int64_t *gids, const int64_t *v, const uint8_t *nulls, const uint8_t *mask, int32_t n, int32_t is_min,
+                       int64_t *counts, int64_t *values)
+{
+    for (int32_t i = 0; i < n; i++) {
+        if (mask && !mask[i]) continue;
+        if (nulls && nulls[i]) continue;
+        int64_t g = gids ? gids[i] : 0;
+        if (counts[g] == 0) values[g] = v[i];                                   /* state.isNull(): setNull(false), setLong(value) */
+        else if (is_min ? v[i] < values[g] : v[i] > values[g]) values[g] = v[i];
+        counts[g] += 1;
+    }
+}
+
 void o_agg_count(const int64_t *gids, const uint8_t *nulls, const uint8_t *mask, int32_t n, int64_t *counts)
 {
     for (int32_t i = 0; i < n; i++) {

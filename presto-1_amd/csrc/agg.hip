@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
                 if (cnt == 0) continue;  // empty partial state
                 atomicAdd((unsigned long long *)&a.counts[g], (unsigned long long)cnt);
                 if (a.function == TGPU_AGG_SUM_BIGINT) i128_add(&a.i128[g * 2], ((const long long *)a.input2)[r]);
+                else if (tg_is_minmax(a.function)) tg_minmax_update(&a.i128[g * 2], tg_minmax_code(((const long long *)a.input2)[r], a.function == TGPU_AGG_MIN_BIGINT));
                 else kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input2)[r]);
                 continue;
             }
@@ -69,6 +70,8 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
             atomicAdd((unsigned long long *)&a.counts[g], 1ULL);
             switch (a.function) {
             case TGPU_AGG_SUM_BIGINT: i128_add(&a.i128[g * 2], ((const long long *)a.input)[r]); break;
+            case TGPU_AGG_MIN_BIGINT:
+            case TGPU_AGG_MAX_BIGINT: tg_minmax_update(&a.i128[g * 2], tg_minmax_code(((const long long *)a.input)[r], a.function == TGPU_AGG_MIN_BIGINT)); break;
             case TGPU_AGG_SUM_DOUBLE:
             case TGPU_AGG_AVG_DOUBLE: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input)[r]); break;
             case TGPU_AGG_AVG_BIGINT: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], (double)((const long long *)a.input)[r]); break;
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
             long long cnt = 0;
             double s = a.dsum ? a.dsum[g] : 0.0;
             __int128 big = 0;
+            unsigned long long best = 0;   // min / max: the best code among the rows walked (0 = none)
             for (int64_t j = i; j < stop && keys[j] == key; j++) {
                 const int64_t r = rows[j];
                 if (INTERMEDIATE) {
@@ -141,6 +145,10 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
                     if (c == 0) continue;   // empty partial state
                     cnt += c;
                     if (a.function == TGPU_AGG_SUM_BIGINT) big += ((const long long *)a.input2)[r];
+                    else if (tg_is_minmax(a.function)) {
+                        const unsigned long long c_ = tg_minmax_code(((const long long *)a.input2)[r], a.function == TGPU_AGG_MIN_BIGINT);
+                        best = c_ > best ? c_ : best;
+                    }
                     else if (a.function != TGPU_AGG_COUNT_ALL && a.function != TGPU_AGG_COUNT_COLUMN) s += ((const double *)a.input2)[r];
                     continue;
                 }
@@ -149,6 +157,12 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
                 cnt++;
                 switch (a.function) {
                 case TGPU_AGG_SUM_BIGINT: big += ((const long long *)a.input)[r]; break;
+                case TGPU_AGG_MIN_BIGINT:
+                case TGPU_AGG_MAX_BIGINT: {
+                    const unsigned long long c_ = tg_minmax_code(((const long long *)a.input)[r], a.function == TGPU_AGG_MIN_BIGINT);
+                    best = c_ > best ? c_ : best;
+                    break;
+                }
                 case TGPU_AGG_SUM_DOUBLE:
                 case TGPU_AGG_AVG_DOUBLE: s += ((const double *)a.input)[r]; break;
                 case TGPU_AGG_AVG_BIGINT: s += (double)((const long long *)a.input)[r]; break;
@@ -157,6 +171,7 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
             }
             if (cnt) a.counts[g] += cnt;
             if (a.dsum) a.dsum[g] = s;
+            if (best) tg_minmax_update(&a.i128[g * 2], best);
             if (a.i128 && big != 0) {
                 const unsigned __int128 cur = ((unsigned __int128)a.i128[g * 2 + 1] << 64) | a.i128[g * 2];
                 const unsigned __int128 nxt = cur + (unsigned __int128)big;
@@ -228,6 +243,9 @@ __device__ inline void ordered_chain_group(const AggArgs &args, const OrdChainPl
                         atomicAdd(&lo_lds[k], (unsigned long long)lo);
                         atomicAdd((unsigned long long *)&hi_lds[k], (unsigned long long)hi);
                     }
+                }
+                else if (tg_is_minmax(a.function)) {
+                    if (take) tg_minmax_update(&a.i128[g * 2], tg_minmax_code(((const long long *)a.input)[row], a.function == TGPU_AGG_MIN_BIGINT));
                 }
                 else if (plan.slot[k] >= 0 && live) {
                     double x = -0.0;
@@ -313,6 +331,10 @@ __global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCa
             if (a.mask && ((a.mask_nulls && a.mask_nulls[r]) || !a.mask[r])) continue;
             if (a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[r]) continue;
             cnt_base[plan.cnt_slot[k] * kBlock + threadIdx.x] += 1u;
+            if (tg_is_minmax(a.function)) {   // (no lane-private slot: almost no row improves a group's extreme, see tg_minmax_update)
+                tg_minmax_update(&a.i128[(size_t)g * 2], tg_minmax_code(((const long long *)a.input)[r], a.function == TGPU_AGG_MIN_BIGINT));
+                continue;
+            }
             const int w = plan.wide_slot[k];
             if (w < 0) continue;
             if (a.function == TGPU_AGG_SUM_BIGINT) {
@@ -437,7 +459,8 @@ __global__ void __launch_bounds__(kBlock) agg_evaluate_kernel(EvalArgs args, int
         }
         double dsum = 0.0;
         long long lsum = 0;
-        if (a.function == TGPU_AGG_SUM_BIGINT) {
+        if (tg_is_minmax(a.function)) lsum = tg_minmax_value(a.i128[g * 2], a.function == TGPU_AGG_MIN_BIGINT);
+        else if (a.function == TGPU_AGG_SUM_BIGINT) {
             const unsigned long long lo = a.i128[g * 2], hi = a.i128[g * 2 + 1];
             lsum = (long long)lo;
             const unsigned long long expect_hi = lsum < 0 ? ~0ULL : 0ULL;
@@ -449,11 +472,14 @@ __global__ void __launch_bounds__(kBlock) agg_evaluate_kernel(EvalArgs args, int
         if (a.partial) {
             ((long long *)a.out0)[g] = cnt;
             if (a.function == TGPU_AGG_SUM_BIGINT) ((long long *)a.out1)[g] = lsum;
+            else if (tg_is_minmax(a.function)) ((long long *)a.out1)[g] = cnt ? lsum : 0;
             else ((double *)a.out1)[g] = dsum;
             continue;
         }
         a.out0_nulls[g] = cnt == 0 ? 1 : 0;  // DoubleSumAggregation.java:54-63, AverageAggregations.java:69-80
         switch (a.function) {
+        case TGPU_AGG_MIN_BIGINT:
+        case TGPU_AGG_MAX_BIGINT:
         case TGPU_AGG_SUM_BIGINT: ((long long *)a.out0)[g] = cnt ? lsum : 0; break;
         case TGPU_AGG_SUM_DOUBLE: ((double *)a.out0)[g] = cnt ? dsum : 0.0; break;
         default: ((double *)a.out0)[g] = cnt ? dsum / (double)cnt : 0.0; break;
@@ -471,6 +497,8 @@ int grid_for(Context *ctx, int64_t n)
 
 bool is_double_state(int32_t f) { return f == TGPU_AGG_SUM_DOUBLE || f == TGPU_AGG_AVG_DOUBLE || f == TGPU_AGG_AVG_BIGINT; }
 bool is_count(int32_t f) { return f == TGPU_AGG_COUNT_ALL || f == TGPU_AGG_COUNT_COLUMN; }
+bool is_minmax(int32_t f) { return f == TGPU_AGG_MIN_BIGINT || f == TGPU_AGG_MAX_BIGINT; }
+bool is_bigint_state(int32_t f) { return f == TGPU_AGG_SUM_BIGINT || is_minmax(f); }   // two 64-bit words per group (128-bit sum / extreme code)
 
 // the regions a round of state growth has to clear, zeroed by ONE launch (an operator with 8 aggregates grows ~24 arrays: one
 // memset each would cost more in launch gaps than the clearing itself)
@@ -506,7 +534,7 @@ GroupedAccumulators::GroupedAccumulators(Context *ctx, std::vector<tgpu_agg_spec
 {
     TG_CHECK_ARG((int)specs.size() <= kMaxAggs, "at most 16 aggregates per operator");
     for (auto &s : specs) {
-        TG_CHECK_ARG(s.function >= TGPU_AGG_COUNT_ALL && s.function <= TGPU_AGG_AVG_DOUBLE, "unknown aggregate function");
+        TG_CHECK_ARG(s.function >= TGPU_AGG_COUNT_ALL && s.function <= TGPU_AGG_MAX_BIGINT, "unknown aggregate function");
         State st;
         st.spec = s;
         states_.push_back(st);
@@ -644,7 +672,10 @@ __global__ void __launch_bounds__(kBlock) agg_merge_states_kernel(MergeArgs args
                 if (!(fabs(v) <= 1.7976931348623157e308)) tg_flag_special(&a.special[g], v);
                 else tg_kulisch_add(&a.limbs[g * kLimbs], &a.special[g], v);   // (atomic adds: lane l == 0 of this group races with the limb lanes above)
             }
-            if (a.r_i128) {
+            if (a.r_i128 && tg_is_minmax(a.function)) {   // combine(): the better of the two extremes (AbstractMinMaxAggregationFunction.java:251-254)
+                if (a.r_i128[i * 2] > a.i128[g * 2]) a.i128[g * 2] = a.r_i128[i * 2];
+            }
+            else if (a.r_i128) {
                 const unsigned long long lo = a.i128[g * 2], add = a.r_i128[i * 2];
                 a.i128[g * 2] = lo + add;
                 a.i128[g * 2 + 1] += a.r_i128[i * 2 + 1] + ((lo + add) < lo ? 1ULL : 0ULL);
@@ -761,7 +792,7 @@ void GroupedAccumulators::ensure(int64_t groups)
                 st.special = grow(ctx_, st.special, st.cap, cap, 4, zeros);
             }
         }
-        if (st.spec.function == TGPU_AGG_SUM_BIGINT) st.i128 = grow(ctx_, st.i128, st.cap * 2, cap * 2, 8, zeros);
+        if (is_bigint_state(st.spec.function)) st.i128 = grow(ctx_, st.i128, st.cap * 2, cap * 2, 8, zeros);
         st.cap = cap;
     }
     if (zeros.n) {
@@ -782,7 +813,7 @@ static void check_channel(const DevicePage &page, int ch, int32_t want_type, con
 static int64_t lowcard_bytes_per_group(const std::vector<tgpu_agg_spec> &specs)
 {
     int64_t wide = 0;
-    for (auto &s : specs) wide += is_count(s.function) ? 0 : 1;
+    for (auto &s : specs) wide += (is_count(s.function) || is_minmax(s.function)) ? 0 : 1;
     return wide * 2 * kBlock * 8 + (int64_t)specs.size() * kBlock * 4;
 }
 
@@ -894,7 +925,7 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         a.function = st.spec.function;
         if (st.spec.function != TGPU_AGG_COUNT_ALL) {
             int32_t want = 0;
-            if (st.spec.function == TGPU_AGG_SUM_BIGINT || st.spec.function == TGPU_AGG_AVG_BIGINT) want = TGPU_BIGINT;
+            if (is_bigint_state(st.spec.function) || st.spec.function == TGPU_AGG_AVG_BIGINT) want = TGPU_BIGINT;
             if (st.spec.function == TGPU_AGG_SUM_DOUBLE || st.spec.function == TGPU_AGG_AVG_DOUBLE) want = TGPU_DOUBLE;
             check_channel(page, st.spec.input_channel, want, "aggregate input");
             a.input = page.cols[st.spec.input_channel].values;
@@ -949,7 +980,7 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
     LowCardPlan plan{};
     plan.n_aggs = args.n_aggs;
     for (int k = 0; k < args.n_aggs; k++) {
-        plan.wide_slot[k] = is_count(args.a[k].function) ? -1 : plan.n_wide++;
+        plan.wide_slot[k] = (is_count(args.a[k].function) || is_minmax(args.a[k].function)) ? -1 : plan.n_wide++;   // (min / max: straight to the state word)
         plan.cnt_slot[k] = k;
         plan.count_from_rows[k] = 0;
     }
@@ -1010,7 +1041,7 @@ void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const
         a.input = page.cols[ch].values;
         ch++;
         if (!is_count(st.spec.function)) {
-            check_channel(page, ch, st.spec.function == TGPU_AGG_SUM_BIGINT ? TGPU_BIGINT : TGPU_DOUBLE, "intermediate sum");
+            check_channel(page, ch, is_bigint_state(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE, "intermediate sum");
             a.input2 = page.cols[ch].values;
             ch++;
         }
@@ -1065,7 +1096,7 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
             if (partial && !is_count(st.spec.function)) {
                 DeviceColumn c1;
                 c1.n = groups;
-                c1.type = st.spec.function == TGPU_AGG_SUM_BIGINT ? TGPU_BIGINT : TGPU_DOUBLE;
+                c1.type = is_bigint_state(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE;
                 c1.values_buf = ctx_->alloc((size_t)alloc_n * 8);
                 c1.values = c1.values_buf->ptr();
                 a.out1 = c1.values_buf->ptr();
@@ -1073,7 +1104,7 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
             }
         }
         else {
-            c0.type = st.spec.function == TGPU_AGG_SUM_BIGINT ? TGPU_BIGINT : TGPU_DOUBLE;
+            c0.type = is_bigint_state(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE;
             c0.nulls_buf = ctx_->alloc((size_t)alloc_n);
             c0.nulls = c0.nulls_buf->as<uint8_t>();
             a.out0_nulls = c0.nulls_buf->as<uint8_t>();

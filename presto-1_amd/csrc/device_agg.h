@@ -13,6 +13,8 @@
 #define TG_AGG_SUM_DOUBLE 4
 #define TG_AGG_AVG_BIGINT 5
 #define TG_AGG_AVG_DOUBLE 6
+#define TG_AGG_MIN_BIGINT 7
+#define TG_AGG_MAX_BIGINT 8
 
 // per-aggregate state arrays in HBM, indexed by group id
 struct TgAggState {
@@ -56,6 +58,26 @@ __device__ inline void tg_i128_add(unsigned long long *acc, long long v)
     const unsigned long long carry = (old + uv) < old ? 1ULL : 0ULL;
     const unsigned long long hi_add = (v < 0 ? ~0ULL : 0ULL) + carry;
     if (hi_add) atomicAdd(&acc[1], hi_add);
+}
+
+// min(bigint) / max(bigint) (AbstractMinMaxAggregationFunction.java:274-289: keep the value the comparison prefers).  The state word --
+// word 0 of the aggregate's two i128 words -- holds the running extreme in an unsigned code that preserves (max) or reverses (min) the
+// order, so one unsigned atomicMax serves both and a zero word is the identity (no value yet; the count says whether there is one).
+// Order independent and exact: every path (lane-private, global, row-order, one-pass re-runs) may apply a row any number of times.
+__device__ inline bool tg_is_minmax(int function) { return function == TG_AGG_MIN_BIGINT || function == TG_AGG_MAX_BIGINT; }
+__device__ inline unsigned long long tg_minmax_code(long long v, bool is_min)
+{
+    const unsigned long long u = (unsigned long long)v ^ 0x8000000000000000ULL;
+    return is_min ? ~u : u;
+}
+__device__ inline long long tg_minmax_value(unsigned long long code, bool is_min)
+{
+    return (long long)((is_min ? ~code : code) ^ 0x8000000000000000ULL);
+}
+// (the plain read first: after a group's first few rows almost no row improves the extreme, and a stale read can only be too small)
+__device__ inline void tg_minmax_update(unsigned long long *word, unsigned long long code)
+{
+    if (code > *(volatile unsigned long long *)word) atomicMax(word, code);
 }
 
 // acc (128-bit, two words) += v, v a partial sum of many rows
@@ -328,7 +350,7 @@ __device__ inline void tg_fold_flush(TgFoldScratch fs, int rows, int n_aggs, con
     tg_fold_wave(bigint, c, a0, a1);
     if (lane != 0 || c == 0) return;
     atomicAdd((unsigned long long *)&a.counts[g], c);
-    if (a.function == TG_AGG_COUNT_ALL || a.function == TG_AGG_COUNT_COLUMN) return;
+    if (a.function == TG_AGG_COUNT_ALL || a.function == TG_AGG_COUNT_COLUMN || tg_is_minmax(a.function)) return;   // (min / max: the rows went to the state word)
     if (bigint) {
         if (a0 || a1) {
             const unsigned long long old = atomicAdd(&a.i128[g * 2], a0);

@@ -2622,11 +2622,11 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
     supported_ = true;
     const int np = (int)proj_roots_.size();
     for (auto &a : aggs_) {
-        TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_AVG_DOUBLE, "unknown aggregate function");
+        TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_MAX_BIGINT, "unknown aggregate function");
         if (a.function != TGPU_AGG_COUNT_ALL) {
             TG_CHECK_ARG(a.input_channel >= 0 && a.input_channel < np, "aggregate input channel out of range");
             const int32_t t = proj_types_[(size_t)a.input_channel];
-            const bool want_bigint = a.function == TGPU_AGG_SUM_BIGINT || a.function == TGPU_AGG_AVG_BIGINT;
+            const bool want_bigint = a.function == TGPU_AGG_SUM_BIGINT || a.function == TGPU_AGG_AVG_BIGINT || a.function == TGPU_AGG_MIN_BIGINT || a.function == TGPU_AGG_MAX_BIGINT;
             const bool want_double = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE;
             TG_CHECK_ARG(!(want_bigint && t != TGPU_BIGINT) && !(want_double && t != TGPU_DOUBLE), "aggregate input type mismatch");
             if (a.function == TGPU_AGG_COUNT_COLUMN && t == TGPU_VARCHAR) supported_ = supported_ && nodes_[(size_t)proj_roots_[(size_t)a.input_channel]].kind == TGPU_EX_INPUT;
@@ -2691,7 +2691,8 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
     };
     for (size_t k = 0; k < aggs_.size(); k++) {
         const tgpu_agg_spec &a = aggs_[k];
-        const bool count_only = a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN;
+        // (min / max keep no lane-private sum either: their rows go straight to the state word, device_agg.h tg_minmax_update)
+        const bool count_only = a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN || a.function == TGPU_AGG_MIN_BIGINT || a.function == TGPU_AGG_MAX_BIGINT;
         const int in_root = a.function == TGPU_AGG_COUNT_ALL ? -1 : proj_roots_[(size_t)a.input_channel];
         const int mask_root = a.mask_channel >= 0 ? proj_roots_[(size_t)a.mask_channel] : -1;
         const int kind = a.function == TGPU_AGG_SUM_BIGINT ? 1 : (a.function == TGPU_AGG_AVG_BIGINT ? 2 : 0);
@@ -2776,6 +2777,9 @@ void FusedAggGpu::generate()
         const int w = wide_slot_[k];
         const bool is_dbl = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE || a.function == TGPU_AGG_AVG_BIGINT;
         const bool is_big = a.function == TGPU_AGG_SUM_BIGINT;
+        const bool is_mm = a.function == TGPU_AGG_MIN_BIGINT || a.function == TGPU_AGG_MAX_BIGINT;
+        const std::string mm_word = "&F.st[" + std::to_string(k) + "].i128[(size_t)g * 2]";
+        const std::string mm_code = "tg_minmax_code(y" + std::to_string(k) + ", " + (a.function == TGPU_AGG_MIN_BIGINT ? "true" : "false") + ")";
         eval << "  bool t" << k << " = true; double x" << k << " = 0.0; long long y" << k << " = 0; (void)x" << k << "; (void)y" << k << ";\n  {\n";
         gr.os.str("");
         if (a.mask_channel >= 0) {
@@ -2790,7 +2794,7 @@ void FusedAggGpu::generate()
             gr.os.str("");
             eval << "      if (" << v.n << ") t" << k << " = false;\n";
             if (is_dbl) eval << "      else x" << k << " = " << (a.function == TGPU_AGG_AVG_BIGINT ? "(double)" : "") << v.v << ";\n";
-            else if (is_big) eval << "      else y" << k << " = " << v.v << ";\n";
+            else if (is_big || is_mm) eval << "      else y" << k << " = " << v.v << ";\n";
             eval << "    }\n";
         }
         eval << "  }\n";
@@ -2815,6 +2819,7 @@ void FusedAggGpu::generate()
             lc_upd << "  c" << cs << " += t" << k << " ? 1u : 0u;\n";
             lc_write << "  if (!" << cfr << ") cnt_base[" << cs << " * 256 + threadIdx.x] = c" << cs << ";\n";
         }
+        if (is_mm) lc_upd << "  if (t" << k << ") tg_minmax_update(" << mm_word << ", " << mm_code << ");\n";
         if (is_dbl && first_wide) {
             lc_read << "  double h" << w << " = hi_base[" << w << " * 256 + threadIdx.x], l" << w << " = lo_base[" << w << " * 256 + threadIdx.x];\n";
             lc_upd << "  { const double v_ = t" << k << " ? x" << k << " : 0.0; const double s_ = h" << w << " + v_; const double bb_ = s_ - h" << w << "; l" << w
@@ -2832,13 +2837,16 @@ void FusedAggGpu::generate()
         ord_decl << "    long long oc" << k << " = 0;";
         if (is_dbl) ord_decl << " double os" << k << " = F.st[" << k << "].dsum[g];";
         if (is_big) ord_decl << " __int128 ob" << k << " = 0;";
+        if (is_mm) ord_decl << " unsigned long long om" << k << " = 0;";
         ord_decl << "\n";
         ord_upd << "      if (t" << k << ") { oc" << k << "++;";
         if (is_dbl) ord_upd << " os" << k << " += x" << k << ";";
         if (is_big) ord_upd << " ob" << k << " += y" << k << ";";
+        if (is_mm) ord_upd << " { const unsigned long long c_ = " << mm_code << "; om" << k << " = c_ > om" << k << " ? c_ : om" << k << "; }";
         ord_upd << " }\n";
         ord_write << "    if (oc" << k << ") F.st[" << k << "].counts[g] += oc" << k << ";\n";
         if (is_dbl) ord_write << "    F.st[" << k << "].dsum[g] = os" << k << ";\n";
+        if (is_mm) ord_write << "    if (om" << k << ") tg_minmax_update(" << mm_word << ", om" << k << ");\n";
         if (is_big)
             ord_write << "    if (ob" << k << " != 0) { unsigned long long* p_ = &F.st[" << k << "].i128[(size_t)g * 2]; const unsigned __int128 n_ = (((unsigned __int128)p_[1] << 64) | p_[0]) + (unsigned __int128)ob"
                       << k << "; p_[0] = (unsigned long long)n_; p_[1] = (unsigned long long)(n_ >> 64); }\n";
@@ -2846,13 +2854,16 @@ void FusedAggGpu::generate()
         // hand the doubles to the chain lane of the aggregate -- a row the aggregate skips travels as -0.0, the identity of IEEE addition
         ch_decl << "  long long oc" << k << " = 0;";
         if (is_big) ch_decl << " __int128 ob" << k << " = 0;";
+        if (is_mm) ch_decl << " unsigned long long om" << k << " = 0;";
         ch_decl << "\n";
         ch_upd << "      oc" << k << " += t" << k << " ? 1 : 0;";
         if (is_big) ch_upd << " if (t" << k << ") ob" << k << " += y" << k << ";";
+        if (is_mm) ch_upd << " if (t" << k << ") { const unsigned long long c_ = " << mm_code << "; om" << k << " = c_ > om" << k << " ? c_ : om" << k << "; }";
         if (is_dbl) ch_upd << " out[" << ord_doubles << " * TG_ORD_STRIDE] = t" << k << " ? x" << k << " : -0.0;";
         ch_upd << "\n";
         ch_write << "    if (oc" << k << ") atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], (unsigned long long)oc" << k << ");\n";
         if (is_big) ch_write << "    if (ob" << k << " != 0) tg_i128_add_wide(&F.st[" << k << "].i128[(size_t)g * 2], ob" << k << ");\n";
+        if (is_mm) ch_write << "    if (om" << k << ") tg_minmax_update(" << mm_word << ", om" << k << ");\n";
         if (is_dbl) {
             ch_sum << "    if (lane == " << ord_doubles << ") sum = F.st[" << k << "].dsum;\n";
             ord_doubles++;
@@ -2861,6 +2872,7 @@ void FusedAggGpu::generate()
         gl << "  if (t" << k << ") {\n    atomicAdd((unsigned long long*)&F.st[" << k << "].counts[g], 1ULL);\n";
         if (is_dbl) gl << "    tg_kulisch_add(&F.st[" << k << "].limbs[(size_t)g * TG_LIMBS], &F.st[" << k << "].special[g], x" << k << ");\n";
         else if (is_big) gl << "    tg_i128_add(&F.st[" << k << "].i128[(size_t)g * 2], y" << k << ");\n";
+        else if (is_mm) gl << "    tg_minmax_update(" << mm_word << ", " << mm_code << ");\n";
         gl << "  }\n";
     }
 

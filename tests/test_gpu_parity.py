@@ -1282,6 +1282,85 @@ def test_aggregation_java_order_chained_few_groups(pkg, oracle, groups, n, fused
         assert got[g_][8] == cnt[g_], g_
 
 
+@pytest.mark.parametrize("plan", ["single", "partial_final", "fused", "fused_java_order", "spilled"])
+@pytest.mark.parametrize("groups", [3, 300, 50_000])
+def test_min_max_bigint_every_path(pkg, oracle, groups, plan):
+    """min(bigint) / max(bigint) (AbstractMinMaxAggregationFunction.java:233-289) next to sums and counts, through every accumulation path:
+    few groups (lane-private LDS counts, the extremes straight to the state word; the fused operator's one-pass launches from the fourth
+    page on), a few hundred and 50 000 groups (row-order modes: chained kernel / one lane per group), PARTIAL -> FINAL (the (count, value)
+    pair as intermediate state), the fused filter/project operator in both DOUBLE orders, and spilled runs merged at the end.  Nulls,
+    masks, groups whose rows are all null (-> null), int64 extremes; bit-exact against the oracle's row-at-a-time restatement"""
+    rng = np.random.default_rng(500 + groups)
+    B, D, BO = pkg.BIGINT, pkg.DOUBLE, pkg.BOOLEAN
+    n, npages = 40_000, 6
+    cols = []
+    for page in range(npages):
+        keys = rng.integers(0, groups, n).astype(np.int64)
+        vals = rng.integers(-2**62, 2**62, n).astype(np.int64)
+        vals[rng.integers(0, n, 3)] = -(2**63)
+        vals[rng.integers(0, n, 3)] = 2**63 - 1
+        small = rng.integers(-1000, 1000, n).astype(np.int64)
+        nulls = (rng.random(n) < 0.2).astype(np.uint8)
+        if groups > 3:
+            nulls[keys == 1] = 1                     # a group whose values are all null
+        mask = rng.integers(0, 2, n).astype(np.uint8)
+        dbl = rng.standard_normal(n)
+        cols.append((keys, vals, nulls, mask, small, dbl))
+    aggs = [(pkg.MIN_BIGINT, 1), (pkg.MAX_BIGINT, 1), (pkg.MIN_BIGINT, 1, 2), (pkg.SUM_BIGINT, 3), (pkg.MAX_BIGINT, 3), (pkg.COUNT_ALL, -1), (pkg.SUM_DOUBLE, 4), (pkg.COUNT_COLUMN, 1)]
+    pages = [pkg.Page(pkg.Block(B, k), pkg.Block(B, v, nl), pkg.Block(BO, m), pkg.Block(B, sm), pkg.Block(D, d)) for k, v, nl, m, sm, d in cols]
+    ctx = pkg.Context(0)
+    ctx.profile_enable(True)
+    f = pkg.field
+    if plan == "single":
+        rows = run_agg(pkg, ctx, pages, [B], [0], aggs, expected=groups)
+    elif plan == "partial_final":
+        partials = []
+        for pg in pages:
+            op = pkg.HashAggregationOperatorFactory(ctx, 0, [B], [0], aggs, step=pkg.PARTIAL, expected_groups=groups).createOperator()
+            partials += pkg.to_pages(op, [pg])
+            op.close()
+        fin, ch = [], 1
+        for a in aggs:
+            fin.append((a[0], ch))
+            ch += 1 if a[0] in (pkg.COUNT_ALL, pkg.COUNT_COLUMN) else 2
+        rows = run_agg(pkg, ctx, partials, [B], [0], fin, step=pkg.FINAL, expected=groups)
+    elif plan in ("fused", "fused_java_order"):
+        if plan == "fused_java_order":
+            ctx.set_double_sum_order(pkg.SUM_ORDER_JAVA)
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, [B, B, BO, B, D], None, [f(0, B), f(1, B), f(2, BO), f(3, B), f(4, D)], [B], [0], aggs)
+        rows = [r for p_ in pkg.to_pages(fac.createOperator(), pages) for r in p_.rows()]
+        if groups == 3 and plan == "fused":
+            assert "fused_filter_group_accumulate_onepass" in ctx.profile()
+    else:
+        op = pkg.HashAggregationOperatorFactory(ctx, 0, [B], [0], aggs, expected_groups=groups, spill_enabled=True).createOperator()
+        rows = _drive_with_revokes(op, pages, True)
+        assert op.spillStats()[0] >= 1
+        op.close()
+    ctx.close()
+    keys, vals, nulls, mask, small, dbl = (np.concatenate([c[i] for c in cols]) for i in range(6))
+    o = oracle.BigintGroupByHash(groups)
+    gids = o.get_group_ids(oracle.Col(B, keys))
+    ng = o.group_count
+    assert len(rows) == ng
+    by_key = {r[0]: r for r in rows}
+    first = {}
+    for k_, g_ in zip(keys.tolist(), gids.tolist()):
+        first.setdefault(g_, k_)
+    got = [by_key[first[g_]] for g_ in range(ng)]
+    c_min, mins = oracle.agg_long_minmax(gids, vals, ng, True, nulls=nulls)
+    c_max, maxs = oracle.agg_long_minmax(gids, vals, ng, False, nulls=nulls)
+    c_mm, mmin = oracle.agg_long_minmax(gids, vals, ng, True, nulls=nulls, mask=mask)
+    c_s, sums = oracle.agg_long_sum(gids, small, ng)
+    c_sm, smax = oracle.agg_long_minmax(gids, small, ng, False)
+    for g_ in range(ng):
+        r = got[g_]
+        assert r[1] == (int(mins[g_]) if c_min[g_] else None) and r[2] == (int(maxs[g_]) if c_max[g_] else None), (g_, r)
+        assert r[3] == (int(mmin[g_]) if c_mm[g_] else None), (g_, r)
+        assert r[4] == int(sums[g_]) and r[5] == int(smax[g_]) and r[6] == int(c_s[g_]) and r[8] == int(c_min[g_]), (g_, r)
+    if groups > 3:
+        assert by_key[1][1] is None and by_key[1][2] is None and by_key[1][8] == 0
+
+
 def _onepass_pages(pkg, rng, npages, rows, late_groups, error_page=None):
     """pages of a Q1-like program: 2 varchar(1) keys (3 x 2 values), some pages add a new key value late in the stream"""
     pages = []
@@ -3136,7 +3215,7 @@ def test_spill_fused_aggregation_final_step_and_unsupported_factories(pkg, ctx, 
 
 @pytest.mark.parametrize("hash_enabled", [True, False])
 def test_multiple_partial_flushes_golden(pkg, ctx, oracle, hash_enabled):
-    """T/operator/TestHashAggregationOperator.java:512-591 testMultiplePartialFlushes (SUM_BIGINT stands in for LONG_MIN, see the fixture):
+    """T/operator/TestHashAggregationOperator.java:512-591 testMultiplePartialFlushes (LONG_MIN as written):
     a PARTIAL aggregation with a 1 kB limit fills up, stops taking input, drains, and takes input again"""
     case = GOLD["hash_aggregation"]["testMultiplePartialFlushes"]
     pages = []
@@ -3146,7 +3225,7 @@ def test_multiple_partial_flushes_golden(pkg, ctx, oracle, hash_enabled):
         if hash_enabled:
             blocks.append(pkg.Block(pkg.BIGINT, oracle.hash_rows([oracle.Col(pkg.BIGINT, keys)])))
         pages.append(pkg.Page(*blocks))
-    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [(pkg.SUM_BIGINT, 0)], step=pkg.PARTIAL, hash_channel=1 if hash_enabled else -1, expected_groups=100_000)
+    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [(pkg.MIN_BIGINT, 0)], step=pkg.PARTIAL, hash_channel=1 if hash_enabled else -1, expected_groups=100_000)
     fac.setMaxPartialMemory(case["max_partial_memory_bytes"])
     op = fac.createOperator()
     it = iter(pages)
@@ -3177,19 +3256,19 @@ def test_multiple_partial_flushes_golden(pkg, ctx, oracle, hash_enabled):
         if o is not None:
             out.append(o.to_host())
     rows = [r for p in out for r in p.rows()]
-    # PARTIAL output of sum(bigint): (key, [hash], count, sum) -- the reference's LONG_MIN state is the value itself; compare keys and sums
+    # PARTIAL output of min(bigint): (key, [hash], count, value) -- the reference's NullableLongState is the value itself; compare keys and values
     assert sorted((r[0], r[-1]) for r in rows) == [(i, i) for i in range(case["rows"])]
     assert op.memoryBytes() >= 0
     op.close()
 
 
 def test_merge_with_memory_spill_golden(pkg, oracle):
-    """T/operator/TestHashAggregationOperator.java:594-634 testMergeWithMemorySpill (SUM_BIGINT stands in for LONG_MIN): 150 000 groups
+    """T/operator/TestHashAggregationOperator.java:594-634 testMergeWithMemorySpill (LONG_MIN as written): 150 000 groups
     spilled by the driver's revokes, 10 more in memory, merged when the output is built"""
     case = GOLD["hash_aggregation"]["testMergeWithMemorySpill"]
     ctx = pkg.Context(0)
     pages = [pkg.Page(pkg.Block(pkg.BIGINT, np.arange(0, 150_000, dtype=np.int64))), pkg.Page(pkg.Block(pkg.BIGINT, np.arange(150_000, 150_010, dtype=np.int64)))]
-    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [(pkg.SUM_BIGINT, 0)], expected_groups=1, spill_enabled=True)
+    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [(pkg.MIN_BIGINT, 0)], expected_groups=1, spill_enabled=True)
     op = fac.createOperator()
     rows = _drive_with_revokes(op, pages, True)
     assert op.spillStats()[0] >= 1

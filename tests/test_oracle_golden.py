@@ -222,19 +222,35 @@ def test_hash_aggregation_golden(oracle):
 
 @pytest.mark.parametrize("name,pages", [("testMultiplePartialFlushes", [(0, 500), (500, 500), (1000, 500), (1500, 500)]), ("testMergeWithMemorySpill", [(0, 150_000), (150_000, 10)])])
 def test_hash_aggregation_sequence_fixtures(oracle, name, pages):
-    # T/operator/TestHashAggregationOperator.java:512-591, :594-634: every key occurs once, the expected rows are (i, i) -- min in the
-    # reference, sum here (fixture "substitution"); the oracle's group-by + long sum over the same sequence pages
+    # T/operator/TestHashAggregationOperator.java:512-591, :594-634: LONG_MIN(ch0) over sequence pages, every key occurs once, the expected
+    # rows are (i, i): the oracle's group-by + min (o_agg_long_minmax), states combined page after page as the operator does
     case = GOLD["hash_aggregation"][name]
     n = case["rows"]
     g = oracle.BigintGroupByHash(100_000 if name == "testMultiplePartialFlushes" else 1)
-    sums = np.zeros(n, dtype=np.int64)
+    mins = np.full(n, np.iinfo(np.int64).max, dtype=np.int64)
+    seen = np.zeros(n, dtype=np.int64)
     for start, rows in pages:
         keys = np.arange(start, start + rows, dtype=np.int64)
         gids = g.get_group_ids(oracle.Col(BIGINT, keys))
-        c, s = oracle.agg_long_sum(gids, keys, n)
-        sums += s
+        c, m = oracle.agg_long_minmax(gids, keys, n, True)
+        mins = np.where(c > 0, np.minimum(mins, m), mins)
+        seen += c
     assert g.group_count == n
-    assert np.array_equal(g.values()[0], np.arange(n)) and np.array_equal(sums, np.arange(n))
+    assert np.array_equal(g.values()[0], np.arange(n)) and np.array_equal(mins, np.arange(n)) and np.all(seen == 1)
+
+
+def test_long_min_max_restates_compare_and_update_state(oracle):
+    # AbstractMinMaxAggregationFunction.java:274-289 on a few rows by hand: nulls and masked rows leave the state alone, the first value is
+    # taken whatever it is, ties keep the state; a group without values stays null (count 0)
+    gids = np.array([0, 1, 0, 1, 2, 0, 1], dtype=np.int64)
+    vals = np.array([5, -3, 7, -3, 99, -(2**63), 2**63 - 1], dtype=np.int64)
+    nulls = np.array([0, 0, 0, 0, 1, 0, 0], dtype=np.uint8)
+    c, mn = oracle.agg_long_minmax(gids, vals, 3, True, nulls=nulls)
+    c2, mx = oracle.agg_long_minmax(gids, vals, 3, False, nulls=nulls)
+    assert c.tolist() == [3, 3, 0] and c2.tolist() == [3, 3, 0]
+    assert mn[:2].tolist() == [-(2**63), -3] and mx[:2].tolist() == [7, 2**63 - 1]
+    c3, m3 = oracle.agg_long_minmax(gids, vals, 3, True, mask=np.array([0, 1, 1, 1, 1, 0, 1], dtype=np.uint8))
+    assert c3.tolist() == [1, 3, 1] and m3.tolist() == [7, -3, 99]
 
 
 def test_exact_sum_matches_fsum(oracle):
