@@ -8,14 +8,15 @@ import numpy as np
 from . import oracle as _o
 
 BOOLEAN, INT32, INT64, DOUBLE, BYTE_ARRAY = 0, 1, 2, 5, 6
-PLAIN, PLAIN_DICTIONARY, RLE, RLE_DICTIONARY = 0, 2, 3, 8
+PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, RLE_DICTIONARY = 0, 2, 3, 5, 8
 
 
 def _lib():
     L = _o.lib()
     if not getattr(L, "_pq_ready", False):
         i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
-        for name, res, args in (("o_pq_hybrid", i64, [vp, i64, i32, vp, i64]), ("o_pq_plain_byte_array", i64, [vp, i64, i64, vp, vp, i64]), ("o_pq_plain_boolean", i64, [vp, i64, i64, vp])):
+        for name, res, args in (("o_pq_hybrid", i64, [vp, i64, i32, vp, i64]), ("o_pq_plain_byte_array", i64, [vp, i64, i64, vp, vp, i64]), ("o_pq_plain_boolean", i64, [vp, i64, i64, vp]),
+                                ("o_pq_delta_binary_packed", i64, [vp, i64, i64, i32, vp])):
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         L._pq_ready = True
@@ -34,6 +35,18 @@ def hybrid(data, bit_width, want):
     if n < 0:
         raise ValueError("corrupt hybrid stream")
     return out[:n].copy()
+
+
+def delta_binary_packed(physical, data, count):
+    """`count` DELTA_BINARY_PACKED values (INT32 / INT64) as a python list"""
+    if physical not in (INT32, INT64):
+        raise ValueError("DELTA_BINARY_PACKED is for INT32 and INT64 columns")     # ParquetEncoding.java:151
+    a, p = _bytes(data)
+    out = np.zeros(max(count, 1), dtype=np.int64)
+    n = _lib().o_pq_delta_binary_packed(p, len(data), count, 32 if physical == INT32 else 64, out.ctypes.data_as(C.c_void_p))
+    if n < 0:
+        raise ValueError("corrupt DELTA_BINARY_PACKED section")
+    return out[:n].tolist()
 
 
 def plain_values(physical, data, count):
@@ -65,6 +78,8 @@ def decode_data_page(physical, encoding, n, values, definition_levels=None, dict
     nn = sum(present)
     if encoding == PLAIN:
         vals = plain_values(physical, values, nn)
+    elif encoding == DELTA_BINARY_PACKED:
+        vals = delta_binary_packed(physical, values, nn)
     elif encoding == RLE:   # ParquetEncoding.RLE for VALUES: BOOLEAN only (bit width 1), a 4-byte length in front of the hybrid stream (ParquetEncoding.java:105-115,198-212)
         if physical != BOOLEAN:
             raise ValueError("RLE value encoding is for BOOLEAN columns")
@@ -130,6 +145,49 @@ def hybrid_encode(values, bit_width, rng=None):
             pend.append(vals[i])
             i += 1
     flush(True)
+    return bytes(out)
+
+
+def zigzag_uleb(v):
+    return uleb(((v << 1) ^ (v >> 63)) & ((1 << 64) - 1))
+
+
+def delta_encode(values, physical, block_size=128, miniblocks=4):
+    """a DELTA_BINARY_PACKED section over `values` (wrapping arithmetic of the physical type's width, like the writers)"""
+    bits = 32 if physical == INT32 else 64
+    mask = (1 << bits) - 1
+
+    def signed(u, b=64):
+        u &= (1 << b) - 1
+        return u - (1 << b) if u >> (b - 1) else u
+    vals = [int(v) for v in values]
+    out = bytearray(uleb(block_size) + uleb(miniblocks) + uleb(len(vals)) + zigzag_uleb(vals[0] if vals else 0))
+    mini = block_size // miniblocks
+    deltas = [signed((vals[i] - vals[i - 1]) & mask, bits) for i in range(1, len(vals))]
+    for b0 in range(0, len(deltas), block_size):
+        block = deltas[b0:b0 + block_size]
+        md = min(block)
+        out += zigzag_uleb(md)
+        rel = [(d - md) & ((1 << 64) - 1) for d in block]
+        widths, chunks = [], []
+        for m in range(miniblocks):
+            part = rel[m * mini:(m + 1) * mini]
+            if not part:
+                widths.append(0)
+                continue
+            w = max(x.bit_length() for x in part)
+            widths.append(w)
+            part = part + [0] * (mini - len(part))
+            acc, nb, by = 0, 0, bytearray()
+            for x in part:
+                acc |= x << nb
+                nb += w
+                while nb >= 8:
+                    by.append(acc & 0xff)
+                    acc >>= 8
+                    nb -= 8
+            chunks.append(bytes(by))
+        out += bytes(widths) + b"".join(chunks)
     return bytes(out)
 
 

@@ -83,3 +83,60 @@ int64_t o_pq_plain_boolean(const uint8_t *bytes, int64_t len, int64_t count, uin
     for (int64_t i = 0; i < count; i++) out[i] = (bytes[i >> 3] >> (i & 7)) & 1;
     return count;
 }
+
+/* DELTA_BINARY_PACKED (Encodings.md "Delta Encoding"; parquet-mr DeltaBinaryPackingValuesReader, which ParquetEncoding.java:146-154 hands INT32 /
+ * INT64 pages to): header = block size, miniblocks per block, total value count (ULEB128), first value (zigzag ULEB128); then blocks: min delta
+ * (zigzag ULEB128), one bit-width byte per miniblock, the miniblocks' deltas minus the min delta, bit-packed least significant bit first (a
+ * miniblock is always written whole; miniblocks past the last value are not written).  value[i] = value[i - 1] + min delta + packed delta, in
+ * wrapping 64-bit arithmetic (`bits` = 32: the INT32 reader keeps the low 32 bits).  Returns the number of values or -1. */
+static int pq_uleb(const uint8_t *bytes, int64_t len, int64_t *at, uint64_t *out)
+{
+    uint64_t v = 0;
+    int shift = 0;
+    for (;;) {
+        if (*at >= len || shift > 63) return -1;
+        const int b = bytes[(*at)++];
+        v |= (uint64_t)(b & 0x7f) << shift;
+        shift += 7;
+        if (!(b & 0x80)) break;
+    }
+    *out = v;
+    return 0;
+}
+
+int64_t o_pq_delta_binary_packed(const uint8_t *bytes, int64_t len, int64_t want, int32_t bits, int64_t *out)
+{
+    int64_t at = 0;
+    uint64_t block_size, miniblocks, total, zz;
+    if (pq_uleb(bytes, len, &at, &block_size) || pq_uleb(bytes, len, &at, &miniblocks) || pq_uleb(bytes, len, &at, &total) || pq_uleb(bytes, len, &at, &zz)) return -1;
+    if (miniblocks == 0 || miniblocks > 4096 || block_size == 0 || block_size % 128 || block_size % miniblocks || (block_size / miniblocks) % 32) return -1;
+    if ((int64_t)total < want) return -1;
+    if (want == 0) return 0;
+    const int64_t mini = (int64_t)(block_size / miniblocks);
+    uint64_t value = (zz >> 1) ^ (~(zz & 1) + 1);   /* zigzag */
+    int64_t n = 0;
+    out[n++] = bits == 32 ? (int64_t)(int32_t)value : (int64_t)value;
+    while (n < want) {
+        uint64_t zmin;
+        if (pq_uleb(bytes, len, &at, &zmin)) return -1;
+        const uint64_t min_delta = (zmin >> 1) ^ (~(zmin & 1) + 1);
+        if (at + (int64_t)miniblocks > len) return -1;
+        const uint8_t *widths = bytes + at;
+        at += (int64_t)miniblocks;
+        for (uint64_t m = 0; m < miniblocks && n < want; m++) {
+            const int w = widths[m];
+            if (w > 64 || at + mini * w / 8 > len) return -1;
+            for (int64_t i = 0; i < mini && n < want; i++) {
+                uint64_t d = 0;
+                for (int k = 0; k < w; k++) {
+                    const int64_t b = i * w + k;
+                    d |= (uint64_t)((bytes[at + (b >> 3)] >> (b & 7)) & 1) << k;
+                }
+                value += min_delta + d;
+                out[n++] = bits == 32 ? (int64_t)(int32_t)value : (int64_t)value;
+            }
+            at += mini * w / 8;
+        }
+    }
+    return n;
+}

@@ -1,7 +1,7 @@
 // parquet.hip -- scan-side decode, the second columnar format the reference reads: the data pages of a flat Parquet column
 // decoded on the device into flat HBM columns.  Reference (lib/trino-parquet/src/main/java/io/trino/parquet/): reader/PrimitiveColumnReader.java
 // (readPageV1 / readPageV2 / initDataReader: levels, then the value reader of the page's encoding), reader/LevelRLEReader.java,
-// ParquetEncoding.java (PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY -> value readers and dictionaries), dictionary/*.java (PLAIN dictionary
+// ParquetEncoding.java (PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY / DELTA_BINARY_PACKED -> value readers and dictionaries), dictionary/*.java (PLAIN dictionary
 // pages), reader/{Int,Long,Double,Boolean,Binary}ColumnReader.java.  The byte-level decoders those classes call are NOT in the reference tree:
 // org.apache.parquet (parquet-mr) classes out of io.prestosql.hive:hive-apache 3.1.2-6, the shaded bundle the reference's root pom.xml:537-538 pins
 // -- RunLengthBitPackingHybridDecoder, the Plain*ValuesReaders -- so their algorithm is restated from the public Parquet format specification (Encodings.md: "RLE / bit-packing
@@ -15,6 +15,8 @@
 
 #include "kernels.h"
 
+#include <rocprim/rocprim.hpp>
+
 #include <cstring>
 
 namespace tgpu {
@@ -24,7 +26,7 @@ namespace {
 
 constexpr int kWave = 64;
 enum Physical : int32_t { PQ_BOOLEAN = 0, PQ_INT32 = 1, PQ_INT64 = 2, PQ_DOUBLE = 5, PQ_BYTE_ARRAY = 6 };          // parquet.thrift Type
-enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
+enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_DELTA_BINARY_PACKED = 5, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
 
 struct Run {
     int64_t in_off;    // bit-packed run: first byte of the packed values
@@ -310,6 +312,138 @@ DeviceColumn plain_column(Context *ctx, int32_t type, int32_t physical, const ui
     return col;
 }
 
+// ---- DELTA_BINARY_PACKED (Encodings.md "Delta Encoding"; parquet-mr DeltaBinaryPackingValuesReader behind ParquetEncoding.java:146-154) -------
+// header: block size, miniblocks per block, total count (ULEB128), first value (zigzag); blocks: min delta (zigzag), one bit-width byte per
+// miniblock, the miniblocks' (delta - min delta) bit-packed least significant bit first.  The host walks the block headers (three varints per
+// 128 values), the device unpacks every miniblock -- one lane per value -- and a prefix sum turns the deltas into values (wrapping 64-bit
+// arithmetic; INT32 keeps the low half).
+struct Mini {
+    int64_t in_off;      // first byte of the miniblock's packed deltas
+    int64_t out_off;     // index of the value its first delta produces (>= 1: value 0 is the header's first value)
+    int64_t min_delta;
+    int32_t count;       // deltas of the miniblock that are values of the page (the last one may be padded)
+    int32_t width;
+};
+
+__global__ void __launch_bounds__(256) delta_unpack_kernel(const uint8_t *__restrict__ bytes, const Mini *__restrict__ minis, int64_t n_minis, unsigned long long *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    for (int64_t m = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); m < n_minis; m += (int64_t)gridDim.x * 4) {
+        const Mini mb = minis[m];
+        const unsigned long long mask = mb.width >= 64 ? ~0ULL : ((1ULL << mb.width) - 1ULL);
+        for (int i = lane; i < mb.count; i += 64) {
+            const int64_t bit = (int64_t)i * mb.width;
+            const uint8_t *p = bytes + mb.in_off + (bit >> 3);
+            const int sh = (int)(bit & 7);
+            unsigned long long lo = 0;
+            memcpy(&lo, p, 8);                                   // (the page is uploaded with 16 bytes of padding)
+            unsigned long long v = lo >> sh;
+            if (sh && mb.width + sh > 64) v |= (unsigned long long)p[8] << (64 - sh);
+            out[mb.out_off + i] = (v & mask) + (unsigned long long)mb.min_delta;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) place_low_half_kernel(const long long *__restrict__ compact, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n,
+                                                             int32_t *__restrict__ out)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) out[r] = (nulls && nulls[r]) ? 0 : (int32_t)compact[rank ? rank[r] : r];
+}
+
+static bool read_uleb(const uint8_t *bytes, int64_t len, int64_t &at, uint64_t &out)
+{
+    uint64_t v = 0;
+    for (int shift = 0;; shift += 7) {
+        if (at >= len || shift > 63) return false;
+        const int b = bytes[at++];
+        v |= (uint64_t)(b & 0x7f) << shift;
+        if (!(b & 0x80)) break;
+    }
+    out = v;
+    return true;
+}
+
+DeviceColumn delta_column(Context *ctx, int32_t type, int32_t physical, const uint8_t *bytes, int64_t len, int64_t n, const Present &p)
+{
+    if (physical != PQ_INT32 && physical != PQ_INT64) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet DELTA_BINARY_PACKED is for INT32 and INT64 columns");   // ParquetEncoding.java:151
+    DeviceColumn col;
+    col.type = type;
+    col.n = n;
+    const int w = width_of(physical);
+    col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1) * (size_t)w);
+    col.values = col.values_buf->ptr();
+    if (n == 0) return col;
+    const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+    const int32_t *rank = nulls ? p.rank->as<int32_t>() : nullptr;
+    if (nulls) {
+        col.nulls_buf = p.nulls;
+        col.nulls = nulls;
+    }
+    const int64_t want = p.non_null;
+    if (want == 0) {
+        HIP_CHECK(hipMemsetAsync(col.values_buf->ptr(), 0, (size_t)n * (size_t)w, ctx->stream()));
+        return col;
+    }
+    int64_t at = 0;
+    uint64_t block_size, miniblocks, total, zz;
+    TG_CHECK_ARG(read_uleb(bytes, len, at, block_size) && read_uleb(bytes, len, at, miniblocks) && read_uleb(bytes, len, at, total) && read_uleb(bytes, len, at, zz),
+                 "Parquet DELTA_BINARY_PACKED header cut short");
+    TG_CHECK_ARG(miniblocks > 0 && miniblocks <= 4096 && block_size > 0 && block_size % 128 == 0 && block_size % miniblocks == 0 && (block_size / miniblocks) % 32 == 0,
+                 "Parquet DELTA_BINARY_PACKED block shape outside the specification");
+    TG_CHECK_ARG((int64_t)total >= want, "Parquet DELTA_BINARY_PACKED section holds fewer values than the page has non-null positions");
+    const int64_t mini = (int64_t)(block_size / miniblocks);
+    const uint64_t first = (zz >> 1) ^ (~(zz & 1) + 1);
+    std::vector<Mini> minis;
+    for (int64_t done = 1; done < want;) {
+        uint64_t zmin;
+        TG_CHECK_ARG(read_uleb(bytes, len, at, zmin) && at + (int64_t)miniblocks <= len, "Parquet DELTA_BINARY_PACKED block header cut short");
+        const uint64_t min_delta = (zmin >> 1) ^ (~(zmin & 1) + 1);
+        const uint8_t *widths = bytes + at;
+        at += (int64_t)miniblocks;
+        for (uint64_t m = 0; m < miniblocks && done < want; m++) {
+            const int width = widths[m];
+            TG_CHECK_ARG(width <= 64 && at + mini * width / 8 <= len, "Parquet DELTA_BINARY_PACKED miniblock cut short");
+            Mini mb;
+            mb.in_off = at;
+            mb.out_off = done;
+            mb.min_delta = (int64_t)min_delta;
+            mb.count = (int32_t)std::min<int64_t>(mini, want - done);
+            mb.width = width;
+            minis.push_back(mb);
+            done += mb.count;
+            at += mini * width / 8;
+        }
+    }
+    // deltas (slot 0: the first value) -> inclusive prefix sum = the values
+    BufferPtr seq = ctx->alloc((size_t)want * 8), sums = ctx->alloc((size_t)want * 8);
+    ctx->upload(seq->ptr(), &first, 8);
+    BufferPtr page, dminis;
+    if (!minis.empty()) {
+        page = upload_padded(ctx, bytes, len);
+        dminis = ctx->alloc(minis.size() * sizeof(Mini));
+        ctx->upload(dminis->ptr(), minis.data(), minis.size() * sizeof(Mini));
+        ProfileScope ps(ctx, "parquet_delta_unpack");
+        delta_unpack_kernel<<<(int)std::min<int64_t>(ceil_div((int64_t)minis.size(), 4), (int64_t)ctx->cu_count() * 8), 256, 0, ctx->stream()>>>(page->as<uint8_t>(), dminis->as<Mini>(),
+                                                                                                                                           (int64_t)minis.size(), seq->as<unsigned long long>());
+        check_launch("parquet_delta_unpack");
+    }
+    {
+        ProfileScope ps(ctx, "parquet_delta_scan");
+        size_t temp_bytes = 0;
+        HIP_CHECK(rocprim::inclusive_scan(nullptr, temp_bytes, seq->as<unsigned long long>(), sums->as<unsigned long long>(), (size_t)want, rocprim::plus<unsigned long long>(), ctx->stream()));
+        BufferPtr temp = ctx->alloc(temp_bytes ? temp_bytes : 1);
+        HIP_CHECK(rocprim::inclusive_scan(temp->ptr(), temp_bytes, seq->as<unsigned long long>(), sums->as<unsigned long long>(), (size_t)want, rocprim::plus<unsigned long long>(), ctx->stream()));
+    }
+    if (w == 8) {
+        if (!nulls) HIP_CHECK(hipMemcpyAsync(col.values_buf->ptr(), sums->ptr(), (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream()));
+        else place_kernel<long long><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(sums->as<long long>(), rank, nulls, n, (long long *)col.values_buf->ptr());
+    }
+    else place_low_half_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(sums->as<long long>(), rank, nulls, n, (int32_t *)col.values_buf->ptr());
+    check_launch("parquet_place_delta_values");
+    ctx->sync();   // the host vectors back the uploads
+    return col;
+}
+
 void check_types(int32_t type, int32_t physical)
 {
     const bool ok = (physical == PQ_INT32 && (type == TGPU_INTEGER || type == TGPU_DATE)) || (physical == PQ_INT64 && type == TGPU_BIGINT) || (physical == PQ_DOUBLE && type == TGPU_DOUBLE) ||
@@ -326,6 +460,7 @@ DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int3
     check_types(type, physical);
     Present p = decode_levels(ctx, def_levels, def_len, n);
     if (encoding == PQ_PLAIN) return plain_column(ctx, type, physical, values, values_len, n, p);
+    if (encoding == PQ_DELTA_BINARY_PACKED) return delta_column(ctx, type, physical, values, values_len, n, p);
     if (encoding == PQ_RLE) {
         // ParquetEncoding.RLE as a VALUE encoding exists for BOOLEAN only (ParquetEncoding.java:105-115,198-212: bit width 1): a 4-byte length, then
         // the non-null rows' booleans as a hybrid stream
@@ -353,7 +488,7 @@ DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int3
         check_launch("parquet_place_booleans");
         return col;
     }
-    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY; RLE for BOOLEAN)");
+    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY, DELTA_BINARY_PACKED; RLE for BOOLEAN)");
     TG_CHECK_ARG(physical != PQ_BOOLEAN, "BOOLEAN columns have no dictionary encoding");
     // the dictionary page: PLAIN values without nulls (dictionary/*.java); the page: one byte of bit width, then the ids as a hybrid stream
     Present all;

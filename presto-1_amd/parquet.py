@@ -7,7 +7,7 @@ from . import _lib
 from .spi import OutputPage
 
 BOOLEAN, INT32, INT64, DOUBLE, BYTE_ARRAY = 0, 1, 2, 5, 6          # parquet.thrift Type
-PLAIN, PLAIN_DICTIONARY, RLE, RLE_DICTIONARY = 0, 2, 3, 8           # parquet.thrift Encoding (RLE as a value encoding: BOOLEAN)
+PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, RLE_DICTIONARY = 0, 2, 3, 5, 8   # parquet.thrift Encoding (RLE as a value encoding: BOOLEAN; DELTA_BINARY_PACKED: INT32 / INT64)
 
 
 def _buf(b):

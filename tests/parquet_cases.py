@@ -59,6 +59,31 @@ def write_cases(tmp_dir, n=20_000):
     return out
 
 
+def write_delta_cases(tmp_dir, n=20_000):
+    """INT32 / INT64 columns written DELTA_BINARY_PACKED (ParquetEncoding.java:146-154), both data page versions: random values (wide miniblocks), a
+    sorted key column (narrow ones), dates, nullable and required, an all-null column"""
+    import pyarrow as pa
+    import pyarrow.parquet as pq
+    out = []
+    for seed, ver in enumerate(("1.0", "2.0")):
+        rng = np.random.default_rng(300 + seed)
+
+        def nullable(vals, every):
+            return [None if every and i % every == 0 else v for i, v in enumerate(vals)]
+        t = pa.table({
+            "i64": pa.array(nullable(rng.integers(-2**63, 2**63 - 1, n).tolist(), 7), type=pa.int64()),
+            "i64_runs": pa.array((np.cumsum(rng.integers(0, 9, n)) + 10**12).tolist(), type=pa.int64()),
+            "i32": pa.array(nullable(rng.integers(-2**31, 2**31, n).tolist(), 5), type=pa.int32()),
+            "date": pa.array(nullable(rng.integers(8000, 11000, n).tolist(), 11), type=pa.date32()),
+            "all_null": pa.array([None] * n, type=pa.int32()),
+        })
+        path = os.path.join(str(tmp_dir), f"delta_{ver}.parquet")
+        pq.write_table(t, path, compression="NONE", use_dictionary=False, data_page_version=ver, write_statistics=False, data_page_size=16384,
+                       column_encoding={c: "DELTA_BINARY_PACKED" for c in t.column_names})
+        out.append((f"delta pages=V{ver[0]}", path, pq.read_table(path)))
+    return out
+
+
 def expected_column(table, name, physical):
     col = table.column(name).to_pylist()
     if physical == pp.BYTE_ARRAY:

@@ -108,3 +108,39 @@ def test_pages_of_chosen_shapes_against_the_oracle(pkg, gpq, opq, ctx):
     with pytest.raises(pkg.TgpuError) as e:
         gpq.decode_data_page(ctx, pkg.DOUBLE, gpq.INT64, gpq.PLAIN, 1, b"\x00" * 8)
     assert e.value.code == -8
+
+
+def test_delta_binary_packed_pages(pkg, gpq, opq, ctx, tmp_path):
+    """DELTA_BINARY_PACKED (ParquetEncoding.java:146-154 -> parquet-mr's DeltaBinaryPackingValuesReader): pages written by Arrow decode to what
+    Arrow reads, sections of chosen shapes (every miniblock width, wrapping deltas, block / miniblock edges, nulls) to what the oracle decodes;
+    a truncated section and a non-integer column are refused"""
+    pages = 0
+    for label, path, table in cases.write_delta_cases(tmp_path):
+        for chunk in pp.column_chunks(path):
+            got = []
+            for page in chunk["pages"]:
+                got += device_page(pkg, gpq, ctx, cases.TYPE_OF[chunk["name"]], chunk, page, None, 0)
+                pages += 1
+            assert same(got, cases.expected_column(table, chunk["name"], chunk["physical"])), (label, chunk["name"])
+    assert pages >= 20
+    rng = np.random.default_rng(13)
+    for n, frac in ((1, 1.0), (2, 1.0), (33, 1.0), (129, 0.5), (130, 1.0), (4000, 0.8), (100_000, 0.95)):
+        for physical, bits, tname in ((gpq.INT64, 64, "BIGINT"), (gpq.INT32, 32, "INTEGER")):
+            present = (rng.random(n) < frac).astype(np.int32)
+            nn = int(present.sum())
+            lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+            for vals in (rng.integers(lo, hi, nn, endpoint=True).tolist(), (np.cumsum(rng.integers(0, 1 << int(rng.integers(0, 20)), nn)) % (1 << 30)).tolist()):
+                sec, dl = opq.delta_encode(vals, physical), (opq.hybrid_encode(present.tolist(), 1) if frac < 1.0 else None)
+                want = opq.decode_data_page(physical, opq.DELTA_BINARY_PACKED, n, sec, dl)
+                got = gpq.decode_data_page(ctx, getattr(pkg, tname), physical, gpq.DELTA_BINARY_PACKED, n, sec, dl).to_host().getBlock(0).to_list()
+                assert got == want, (n, frac, bits)
+    for w in range(0, 62):
+        vals = np.cumsum([0] + [int(x) for x in rng.integers(0, 1 << w, 300)]).tolist()
+        sec = opq.delta_encode(vals, gpq.INT64, 256, 8)
+        assert gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_BINARY_PACKED, len(vals), sec).to_host().getBlock(0).to_list() == vals, w
+    sec = opq.delta_encode(list(range(300)), gpq.INT64)
+    with pytest.raises(pkg.TgpuError):
+        gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_BINARY_PACKED, 300, sec[:len(sec) // 2])
+    with pytest.raises(pkg.TgpuError) as e:
+        gpq.decode_data_page(ctx, pkg.DOUBLE, gpq.DOUBLE, gpq.DELTA_BINARY_PACKED, 300, sec)
+    assert e.value.code == -8

@@ -55,6 +55,37 @@ def test_pages_written_by_arrow_decode_to_what_arrow_reads(opq, tmp_path):
     assert any(k == "DATA_V1" and e in (pp.PLAIN_DICTIONARY, pp.RLE_DICTIONARY) for k, e in seen) and any(k == "DATA_V2" and e in (pp.PLAIN_DICTIONARY, pp.RLE_DICTIONARY) for k, e in seen)
 
 
+def test_delta_binary_packed_pages_written_by_arrow_and_of_chosen_shapes(opq, tmp_path):
+    """DELTA_BINARY_PACKED (INT32 / INT64): Arrow's writer against Arrow's reader through the restatement, then sections of chosen shapes through
+    the test encoder (the specification read backwards): every miniblock width 0..64, wrapping deltas, counts around the block and miniblock
+    edges, a different block shape, and the failure modes"""
+    pages = 0
+    for label, path, table in cases.write_delta_cases(tmp_path):
+        for chunk in pp.column_chunks(path):
+            assert same(decode_chunk(opq, chunk), cases.expected_column(table, chunk["name"], chunk["physical"])), (label, chunk["name"])
+            assert all(p_["encoding"] == opq.DELTA_BINARY_PACKED for p_ in chunk["pages"])
+            pages += len(chunk["pages"])
+    assert pages >= 20
+    rng = np.random.default_rng(11)
+    for n in (0, 1, 2, 32, 33, 34, 128, 129, 130, 257, 1000):
+        for physical, bits in ((opq.INT64, 64), (opq.INT32, 32)):
+            lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+            vals = rng.integers(lo, hi, n, endpoint=True).tolist()                      # deltas wrap around the type's range
+            assert opq.delta_binary_packed(physical, opq.delta_encode(vals, physical), n) == vals
+            assert opq.delta_binary_packed(physical, opq.delta_encode(vals, physical, 256, 8), n) == vals
+    for w in range(0, 64):       # a miniblock whose packed deltas need exactly w bits
+        vals = np.cumsum([0] + [int(x) for x in rng.integers(0, 1 << w, 200, dtype=np.uint64 if w == 63 else np.int64)]).tolist() if w < 62 else None
+        if vals is not None:
+            assert opq.delta_binary_packed(opq.INT64, opq.delta_encode(vals, opq.INT64), len(vals)) == vals, w
+    sec = opq.delta_encode(list(range(300)), opq.INT64)
+    with pytest.raises(ValueError):
+        opq.delta_binary_packed(opq.INT64, sec[:len(sec) // 2], 300)                     # cut short
+    with pytest.raises(ValueError):
+        opq.delta_binary_packed(opq.INT64, sec, 301)                                     # fewer values than wanted
+    with pytest.raises(ValueError):
+        opq.delta_binary_packed(opq.DOUBLE, sec, 300)                                    # ParquetEncoding.java:151
+
+
 def test_hybrid_streams_of_every_width_and_their_failure_modes(opq):
     rng = np.random.default_rng(5)
     for bw in list(range(1, 33)):
