@@ -8,7 +8,7 @@ import numpy as np
 from . import oracle as _o
 
 BOOLEAN, INT32, INT64, DOUBLE, BYTE_ARRAY = 0, 1, 2, 5, 6
-PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, RLE_DICTIONARY = 0, 2, 3, 5, 8
+PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY, RLE_DICTIONARY = 0, 2, 3, 5, 6, 8
 
 
 def _lib():
@@ -16,7 +16,7 @@ def _lib():
     if not getattr(L, "_pq_ready", False):
         i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
         for name, res, args in (("o_pq_hybrid", i64, [vp, i64, i32, vp, i64]), ("o_pq_plain_byte_array", i64, [vp, i64, i64, vp, vp, i64]), ("o_pq_plain_boolean", i64, [vp, i64, i64, vp]),
-                                ("o_pq_delta_binary_packed", i64, [vp, i64, i64, i32, vp])):
+                                ("o_pq_delta_binary_packed", i64, [vp, i64, i64, i32, vp, vp])):
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         L._pq_ready = True
@@ -37,16 +37,29 @@ def hybrid(data, bit_width, want):
     return out[:n].copy()
 
 
-def delta_binary_packed(physical, data, count):
-    """`count` DELTA_BINARY_PACKED values (INT32 / INT64) as a python list"""
+def delta_binary_packed(physical, data, count, with_end=False):
+    """`count` DELTA_BINARY_PACKED values (INT32 / INT64) as a python list (with_end: and the bytes the section takes)"""
     if physical not in (INT32, INT64):
         raise ValueError("DELTA_BINARY_PACKED is for INT32 and INT64 columns")     # ParquetEncoding.java:151
     a, p = _bytes(data)
     out = np.zeros(max(count, 1), dtype=np.int64)
-    n = _lib().o_pq_delta_binary_packed(p, len(data), count, 32 if physical == INT32 else 64, out.ctypes.data_as(C.c_void_p))
+    end = C.c_int64(0)
+    n = _lib().o_pq_delta_binary_packed(p, len(data), count, 32 if physical == INT32 else 64, out.ctypes.data_as(C.c_void_p), C.byref(end))
     if n < 0:
         raise ValueError("corrupt DELTA_BINARY_PACKED section")
-    return out[:n].tolist()
+    return (out[:n].tolist(), end.value) if with_end else out[:n].tolist()
+
+
+def delta_length_byte_array(data, count):
+    """DELTA_LENGTH_BYTE_ARRAY (Encodings.md; ParquetEncoding.java:156-163): the lengths as a DELTA_BINARY_PACKED section, then the bytes back to back"""
+    lengths, at = delta_binary_packed(INT32, data, count, with_end=True)
+    out = []
+    for l in lengths:
+        if l < 0 or at + l > len(data):
+            raise ValueError("DELTA_LENGTH_BYTE_ARRAY lengths do not fit the bytes that follow them")
+        out.append(bytes(data[at:at + l]))
+        at += l
+    return out
 
 
 def plain_values(physical, data, count):
@@ -80,6 +93,10 @@ def decode_data_page(physical, encoding, n, values, definition_levels=None, dict
         vals = plain_values(physical, values, nn)
     elif encoding == DELTA_BINARY_PACKED:
         vals = delta_binary_packed(physical, values, nn)
+    elif encoding == DELTA_LENGTH_BYTE_ARRAY:
+        if physical != BYTE_ARRAY:
+            raise ValueError("DELTA_LENGTH_BYTE_ARRAY is for BYTE_ARRAY columns")     # ParquetEncoding.java:160
+        vals = delta_length_byte_array(values, nn)
     elif encoding == RLE:   # ParquetEncoding.RLE for VALUES: BOOLEAN only (bit width 1), a 4-byte length in front of the hybrid stream (ParquetEncoding.java:105-115,198-212)
         if physical != BOOLEAN:
             raise ValueError("RLE value encoding is for BOOLEAN columns")
@@ -189,6 +206,10 @@ def delta_encode(values, physical, block_size=128, miniblocks=4):
             chunks.append(bytes(by))
         out += bytes(widths) + b"".join(chunks)
     return bytes(out)
+
+
+def delta_length_encode(values):
+    return delta_encode([len(b) for b in values], INT32) + b"".join(bytes(b) for b in values)
 
 
 def plain_encode(physical, values):

@@ -104,13 +104,15 @@ static int pq_uleb(const uint8_t *bytes, int64_t len, int64_t *at, uint64_t *out
     return 0;
 }
 
-int64_t o_pq_delta_binary_packed(const uint8_t *bytes, int64_t len, int64_t want, int32_t bits, int64_t *out)
+/* *consumed (may be null) = the bytes the section takes when it holds exactly `want` values: what DELTA_LENGTH_BYTE_ARRAY needs to find the strings */
+int64_t o_pq_delta_binary_packed(const uint8_t *bytes, int64_t len, int64_t want, int32_t bits, int64_t *out, int64_t *consumed)
 {
     int64_t at = 0;
     uint64_t block_size, miniblocks, total, zz;
     if (pq_uleb(bytes, len, &at, &block_size) || pq_uleb(bytes, len, &at, &miniblocks) || pq_uleb(bytes, len, &at, &total) || pq_uleb(bytes, len, &at, &zz)) return -1;
     if (miniblocks == 0 || miniblocks > 4096 || block_size == 0 || block_size % 128 || block_size % miniblocks || (block_size / miniblocks) % 32) return -1;
     if ((int64_t)total < want) return -1;
+    if (consumed) *consumed = at;
     if (want == 0) return 0;
     const int64_t mini = (int64_t)(block_size / miniblocks);
     uint64_t value = (zz >> 1) ^ (~(zz & 1) + 1);   /* zigzag */
@@ -138,5 +140,6 @@ int64_t o_pq_delta_binary_packed(const uint8_t *bytes, int64_t len, int64_t want
             at += mini * w / 8;
         }
     }
+    if (consumed) *consumed = at;
     return n;
 }

@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kWave = 64;
 enum Physical : int32_t { PQ_BOOLEAN = 0, PQ_INT32 = 1, PQ_INT64 = 2, PQ_DOUBLE = 5, PQ_BYTE_ARRAY = 6 };          // parquet.thrift Type
-enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_DELTA_BINARY_PACKED = 5, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
+enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_DELTA_BINARY_PACKED = 5, PQ_DELTA_LENGTH_BYTE_ARRAY = 6, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
 
 struct Run {
     int64_t in_off;    // bit-packed run: first byte of the packed values
@@ -363,27 +363,9 @@ static bool read_uleb(const uint8_t *bytes, int64_t len, int64_t &at, uint64_t &
     return true;
 }
 
-DeviceColumn delta_column(Context *ctx, int32_t type, int32_t physical, const uint8_t *bytes, int64_t len, int64_t n, const Present &p)
+// `want` DELTA_BINARY_PACKED values on the device as wrapping 64-bit integers (want >= 1); *end = the bytes the section takes
+BufferPtr delta_values(Context *ctx, const uint8_t *bytes, int64_t len, int64_t want, int64_t *end)
 {
-    if (physical != PQ_INT32 && physical != PQ_INT64) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet DELTA_BINARY_PACKED is for INT32 and INT64 columns");   // ParquetEncoding.java:151
-    DeviceColumn col;
-    col.type = type;
-    col.n = n;
-    const int w = width_of(physical);
-    col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1) * (size_t)w);
-    col.values = col.values_buf->ptr();
-    if (n == 0) return col;
-    const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
-    const int32_t *rank = nulls ? p.rank->as<int32_t>() : nullptr;
-    if (nulls) {
-        col.nulls_buf = p.nulls;
-        col.nulls = nulls;
-    }
-    const int64_t want = p.non_null;
-    if (want == 0) {
-        HIP_CHECK(hipMemsetAsync(col.values_buf->ptr(), 0, (size_t)n * (size_t)w, ctx->stream()));
-        return col;
-    }
     int64_t at = 0;
     uint64_t block_size, miniblocks, total, zz;
     TG_CHECK_ARG(read_uleb(bytes, len, at, block_size) && read_uleb(bytes, len, at, miniblocks) && read_uleb(bytes, len, at, total) && read_uleb(bytes, len, at, zz),
@@ -414,12 +396,13 @@ DeviceColumn delta_column(Context *ctx, int32_t type, int32_t physical, const ui
             at += mini * width / 8;
         }
     }
+    if (end) *end = at;
     // deltas (slot 0: the first value) -> inclusive prefix sum = the values
     BufferPtr seq = ctx->alloc((size_t)want * 8), sums = ctx->alloc((size_t)want * 8);
     ctx->upload(seq->ptr(), &first, 8);
     BufferPtr page, dminis;
     if (!minis.empty()) {
-        page = upload_padded(ctx, bytes, len);
+        page = upload_padded(ctx, bytes, at);
         dminis = ctx->alloc(minis.size() * sizeof(Mini));
         ctx->upload(dminis->ptr(), minis.data(), minis.size() * sizeof(Mini));
         ProfileScope ps(ctx, "parquet_delta_unpack");
@@ -434,13 +417,98 @@ DeviceColumn delta_column(Context *ctx, int32_t type, int32_t physical, const ui
         BufferPtr temp = ctx->alloc(temp_bytes ? temp_bytes : 1);
         HIP_CHECK(rocprim::inclusive_scan(temp->ptr(), temp_bytes, seq->as<unsigned long long>(), sums->as<unsigned long long>(), (size_t)want, rocprim::plus<unsigned long long>(), ctx->stream()));
     }
+    ctx->sync();   // the host vectors back the uploads
+    return sums;
+}
+
+DeviceColumn delta_column(Context *ctx, int32_t type, int32_t physical, const uint8_t *bytes, int64_t len, int64_t n, const Present &p)
+{
+    if (physical != PQ_INT32 && physical != PQ_INT64) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet DELTA_BINARY_PACKED is for INT32 and INT64 columns");   // ParquetEncoding.java:151
+    DeviceColumn col;
+    col.type = type;
+    col.n = n;
+    const int w = width_of(physical);
+    col.values_buf = ctx->alloc((size_t)(n > 0 ? n : 1) * (size_t)w);
+    col.values = col.values_buf->ptr();
+    if (n == 0) return col;
+    const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+    const int32_t *rank = nulls ? p.rank->as<int32_t>() : nullptr;
+    if (nulls) {
+        col.nulls_buf = p.nulls;
+        col.nulls = nulls;
+    }
+    if (p.non_null == 0) {
+        HIP_CHECK(hipMemsetAsync(col.values_buf->ptr(), 0, (size_t)n * (size_t)w, ctx->stream()));
+        return col;
+    }
+    BufferPtr sums = delta_values(ctx, bytes, len, p.non_null, nullptr);
     if (w == 8) {
         if (!nulls) HIP_CHECK(hipMemcpyAsync(col.values_buf->ptr(), sums->ptr(), (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream()));
         else place_kernel<long long><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(sums->as<long long>(), rank, nulls, n, (long long *)col.values_buf->ptr());
     }
     else place_low_half_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(sums->as<long long>(), rank, nulls, n, (int32_t *)col.values_buf->ptr());
     check_launch("parquet_place_delta_values");
-    ctx->sync();   // the host vectors back the uploads
+    ctx->sync();   // (sums is released on return)
+    return col;
+}
+
+// DELTA_LENGTH_BYTE_ARRAY (Encodings.md "Delta-length byte array"; ParquetEncoding.java:156-163 -> parquet-mr's DeltaLengthByteArrayValuesReader): the
+// non-null values' lengths as a DELTA_BINARY_PACKED section, then their bytes back to back -- which IS the column's pool (a null row has no
+// bytes): one upload, and the offsets are the prefix sum of the row lengths
+__global__ void __launch_bounds__(256) place_lengths_kernel(const long long *__restrict__ compact, const int32_t *__restrict__ rank, const uint8_t *__restrict__ nulls, int64_t n,
+                                                            int64_t pool_bytes, int32_t *__restrict__ out, unsigned int *__restrict__ error)
+{
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        long long l = (nulls && nulls[r]) ? 0 : compact[rank ? rank[r] : r];
+        if (l < 0 || l > pool_bytes) {
+            *error = 1u;
+            l = 0;
+        }
+        out[r] = (int32_t)l;
+    }
+}
+
+DeviceColumn delta_length_strings(Context *ctx, int32_t type, int32_t physical, const uint8_t *bytes, int64_t len, int64_t n, const Present &p)
+{
+    if (physical != PQ_BYTE_ARRAY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet DELTA_LENGTH_BYTE_ARRAY is for BYTE_ARRAY columns");   // ParquetEncoding.java:160
+    DeviceColumn col;
+    col.type = type;
+    col.n = n;
+    const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+    const int32_t *rank = nulls ? p.rank->as<int32_t>() : nullptr;
+    if (nulls) {
+        col.nulls_buf = p.nulls;
+        col.nulls = nulls;
+    }
+    col.offsets_buf = ctx->alloc((size_t)(n + 1) * 4);
+    col.offsets = col.offsets_buf->as<int32_t>();
+    if (n == 0 || p.non_null == 0) {
+        HIP_CHECK(hipMemsetAsync(col.offsets_buf->ptr(), 0, (size_t)(n + 1) * 4, ctx->stream()));
+        col.values_buf = ctx->alloc(1);
+        col.values = col.values_buf->ptr();
+        col.pool_bytes = 0;
+        col.pool_exact = true;
+        return col;
+    }
+    int64_t at = 0;
+    BufferPtr lengths = delta_values(ctx, bytes, len, p.non_null, &at);
+    const int64_t pool_bytes = len - at;
+    TG_CHECK_ARG(pool_bytes <= 0x7fffffffLL, "Parquet page holds more than 2 GB of string bytes");
+    col.values_buf = ctx->alloc((size_t)(pool_bytes > 0 ? pool_bytes : 1));
+    col.values = col.values_buf->ptr();
+    if (pool_bytes > 0) ctx->upload(col.values_buf->ptr(), bytes + at, (size_t)pool_bytes);
+    BufferPtr row_len = ctx->alloc((size_t)n * 4), total = ctx->alloc(8), error = ctx->alloc_zero(4);
+    place_lengths_kernel<<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(lengths->as<long long>(), rank, nulls, n, pool_bytes, row_len->as<int32_t>(), error->as<unsigned int>());
+    check_launch("parquet_place_lengths");
+    k::exclusive_scan_i32(ctx, row_len->as<int32_t>(), const_cast<int32_t *>(col.offsets), n, total->as<int64_t>());
+    // the lengths must add up to no more than the bytes that follow them (the last offset = their sum)
+    const int64_t sum = ctx->read_scalar(total->as<int64_t>());
+    TG_CHECK_ARG(ctx->read_scalar(error->as<unsigned int>()) == 0 && sum <= pool_bytes, "Parquet DELTA_LENGTH_BYTE_ARRAY lengths do not fit the bytes that follow them");
+    const int32_t end = (int32_t)sum;
+    ctx->upload(const_cast<int32_t *>(col.offsets) + n, &end, 4);
+    col.pool_bytes = sum;
+    col.pool_exact = true;
+    ctx->sync();
     return col;
 }
 
@@ -461,6 +529,7 @@ DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int3
     Present p = decode_levels(ctx, def_levels, def_len, n);
     if (encoding == PQ_PLAIN) return plain_column(ctx, type, physical, values, values_len, n, p);
     if (encoding == PQ_DELTA_BINARY_PACKED) return delta_column(ctx, type, physical, values, values_len, n, p);
+    if (encoding == PQ_DELTA_LENGTH_BYTE_ARRAY) return delta_length_strings(ctx, type, physical, values, values_len, n, p);
     if (encoding == PQ_RLE) {
         // ParquetEncoding.RLE as a VALUE encoding exists for BOOLEAN only (ParquetEncoding.java:105-115,198-212: bit width 1): a 4-byte length, then
         // the non-null rows' booleans as a hybrid stream
@@ -488,7 +557,7 @@ DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int3
         check_launch("parquet_place_booleans");
         return col;
     }
-    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY, DELTA_BINARY_PACKED; RLE for BOOLEAN)");
+    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY; RLE for BOOLEAN)");
     TG_CHECK_ARG(physical != PQ_BOOLEAN, "BOOLEAN columns have no dictionary encoding");
     // the dictionary page: PLAIN values without nulls (dictionary/*.java); the page: one byte of bit width, then the ids as a hybrid stream
     Present all;

@@ -59,6 +59,9 @@ def write_cases(tmp_dir, n=20_000):
     return out
 
 
+DELTA_WORDS = ["", "a", "BUILDING", "MACHINERY", "x" * 300, "héllo wörld", "AUTOMOBILE"]
+
+
 def write_delta_cases(tmp_dir, n=20_000):
     """INT32 / INT64 columns written DELTA_BINARY_PACKED (ParquetEncoding.java:146-154), both data page versions: random values (wide miniblocks), a
     sorted key column (narrow ones), dates, nullable and required, an all-null column"""
@@ -76,10 +79,14 @@ def write_delta_cases(tmp_dir, n=20_000):
             "i32": pa.array(nullable(rng.integers(-2**31, 2**31, n).tolist(), 5), type=pa.int32()),
             "date": pa.array(nullable(rng.integers(8000, 11000, n).tolist(), 11), type=pa.date32()),
             "all_null": pa.array([None] * n, type=pa.int32()),
+            # strings as DELTA_LENGTH_BYTE_ARRAY (ParquetEncoding.java:156-163)
+            "s": pa.array(nullable([DELTA_WORDS[int(x)] for x in rng.integers(0, len(DELTA_WORDS), n)], 4), type=pa.string()),
+            "s_required": pa.array([DELTA_WORDS[int(x)] for x in rng.integers(0, len(DELTA_WORDS), n)], type=pa.string()),
         })
+        t = t.cast(pa.schema([pa.field(f.name, f.type, nullable=f.name != "s_required") for f in t.schema]))
         path = os.path.join(str(tmp_dir), f"delta_{ver}.parquet")
         pq.write_table(t, path, compression="NONE", use_dictionary=False, data_page_version=ver, write_statistics=False, data_page_size=16384,
-                       column_encoding={c: "DELTA_BINARY_PACKED" for c in t.column_names})
+                       column_encoding={c: "DELTA_LENGTH_BYTE_ARRAY" if c.startswith("s") else "DELTA_BINARY_PACKED" for c in t.column_names})
         out.append((f"delta pages=V{ver[0]}", path, pq.read_table(path)))
     return out
 

@@ -138,6 +138,20 @@ def test_delta_binary_packed_pages(pkg, gpq, opq, ctx, tmp_path):
         vals = np.cumsum([0] + [int(x) for x in rng.integers(0, 1 << w, 300)]).tolist()
         sec = opq.delta_encode(vals, gpq.INT64, 256, 8)
         assert gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_BINARY_PACKED, len(vals), sec).to_host().getBlock(0).to_list() == vals, w
+    # DELTA_LENGTH_BYTE_ARRAY: empty and long values, every row null, one row, nulls; lengths that overrun the bytes are refused
+    words = [b"", b"a", b"x" * 5000, "héllo".encode("utf-8")]
+    for n, frac in ((1, 1.0), (1, 0.0), (1000, 0.0), (33, 1.0), (30_000, 0.7)):
+        present = (rng.random(n) < frac).astype(np.int32)
+        vals = [words[int(x)] for x in rng.integers(0, len(words), int(present.sum()))]
+        sec, dl = opq.delta_length_encode(vals), opq.hybrid_encode(present.tolist(), 1)
+        want = opq.decode_data_page(opq.BYTE_ARRAY, opq.DELTA_LENGTH_BYTE_ARRAY, n, sec, dl)
+        blk = gpq.decode_data_page(ctx, pkg.VARCHAR, gpq.BYTE_ARRAY, gpq.DELTA_LENGTH_BYTE_ARRAY, n, sec, dl).to_host().getBlock(0)
+        assert [None if v is None else v.encode("utf-8") for v in blk.to_list()] == want, (n, frac)
+    with pytest.raises(pkg.TgpuError):
+        gpq.decode_data_page(ctx, pkg.VARCHAR, gpq.BYTE_ARRAY, gpq.DELTA_LENGTH_BYTE_ARRAY, 2, opq.delta_length_encode([b"abc", b"defg"])[:-2])
+    with pytest.raises(pkg.TgpuError) as e:
+        gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_LENGTH_BYTE_ARRAY, 2, opq.delta_length_encode([b"abc", b"defg"]))
+    assert e.value.code == -8
     sec = opq.delta_encode(list(range(300)), gpq.INT64)
     with pytest.raises(pkg.TgpuError):
         gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_BINARY_PACKED, 300, sec[:len(sec) // 2])

@@ -63,7 +63,7 @@ def test_delta_binary_packed_pages_written_by_arrow_and_of_chosen_shapes(opq, tm
     for label, path, table in cases.write_delta_cases(tmp_path):
         for chunk in pp.column_chunks(path):
             assert same(decode_chunk(opq, chunk), cases.expected_column(table, chunk["name"], chunk["physical"])), (label, chunk["name"])
-            assert all(p_["encoding"] == opq.DELTA_BINARY_PACKED for p_ in chunk["pages"])
+            assert all(p_["encoding"] == (opq.DELTA_LENGTH_BYTE_ARRAY if chunk["name"].startswith("s") else opq.DELTA_BINARY_PACKED) for p_ in chunk["pages"])
             pages += len(chunk["pages"])
     assert pages >= 20
     rng = np.random.default_rng(11)
@@ -84,6 +84,13 @@ def test_delta_binary_packed_pages_written_by_arrow_and_of_chosen_shapes(opq, tm
         opq.delta_binary_packed(opq.INT64, sec, 301)                                     # fewer values than wanted
     with pytest.raises(ValueError):
         opq.delta_binary_packed(opq.DOUBLE, sec, 300)                                    # ParquetEncoding.java:151
+    # DELTA_LENGTH_BYTE_ARRAY: lengths, then the bytes; lengths that overrun the bytes are refused
+    words = [b"", b"a", b"x" * 700, "héllo".encode("utf-8")]
+    for n in (0, 1, 33, 1000):
+        vals = [words[int(x)] for x in rng.integers(0, len(words), n)]
+        assert opq.delta_length_byte_array(opq.delta_length_encode(vals), n) == vals
+    with pytest.raises(ValueError):
+        opq.delta_length_byte_array(opq.delta_length_encode([b"abc", b"defg"])[:-2], 2)
 
 
 def test_hybrid_streams_of_every_width_and_their_failure_modes(opq):
