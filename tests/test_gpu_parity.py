@@ -1435,6 +1435,50 @@ def test_fused_aggregation_one_launch_per_page_equals_the_two_launch_path(pkg, m
         assert ulp_diff([np.nan if x is None else x for x in ra[2:6]], [np.nan if x is None else x for x in rb[2:6]]).max() == 0
 
 
+@pytest.mark.parametrize("late", [{}, {5: "X", 6: "Y", 9: "Z"}])
+def test_fused_one_pass_launches_with_min_and_max(pkg, monkeypatch, late):
+    """min(bigint) / max(bigint) in the one-launch-per-page protocol: their rows go straight to the state word (no pending copy), so a page
+    that brings a new group -- its totals are dropped, the page is run again -- applies the rows of its known groups twice: idempotent.
+    Expected values: min / max per group over the selected, non-null rows; next to them a sum and a count, which must NOT see a row twice"""
+    monkeypatch.setenv("TGPU_MODE_PREFIX_ROWS", "5000")
+    monkeypatch.setenv("TGPU_ONEPASS_BATCH_ROWS", "1")
+    rng = np.random.default_rng(43)
+    V, DT, B = pkg.VARCHAR, pkg.DATE, pkg.BIGINT
+    rows_per_page, pages, host = 9000, [], []
+    for i in range(12):
+        a = [("A", "N", "R")[x] for x in rng.integers(0, 3, rows_per_page)]
+        b = [("F", "O")[x] for x in rng.integers(0, 2, rows_per_page)]
+        if i in late:                       # a few rows of a group nobody has seen, in the middle of the page
+            for r in (rows_per_page // 2, rows_per_page // 2 + 7):
+                a[r] = late[i]
+        val = rng.integers(-10**12, 10**12, rows_per_page).astype(np.int64)
+        nulls = (rng.random(rows_per_page) < 0.05).astype(np.uint8)
+        small = rng.integers(0, 100, rows_per_page).astype(np.int64)
+        ship = rng.integers(8036, 10562, rows_per_page).astype(np.int32)
+        pages.append(pkg.Page(pkg.Block(V, a), pkg.Block(V, b), pkg.Block(B, val, nulls), pkg.Block(B, small), pkg.Block(DT, ship)))
+        host.append((a, b, val, nulls, small, ship))
+    f = pkg.field
+    T = [V, V, B, B, DT]
+    aggs = [(pkg.MIN_BIGINT, 2), (pkg.MAX_BIGINT, 2), (pkg.MAX_BIGINT, 3), (pkg.SUM_BIGINT, 3), (pkg.COUNT_ALL, -1), (pkg.COUNT_COLUMN, 2)]
+    ctx = pkg.Context(0)
+    ctx.profile_enable(True)
+    fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, T, f(4, DT) <= 10471, [f(0, V), f(1, V), f(2, B), f(3, B)], [V, V], [0, 1], aggs)
+    rows = [r for p_ in pkg.to_pages(fac.createOperator(), pages) for r in p_.rows()]
+    assert ctx.profile().get("fused_filter_group_accumulate_onepass", {"count": 0})["count"] >= 12 - 3 - 2 * len(late)
+    ctx.close()
+    want = {}
+    for a, b, val, nulls, small, ship in host:
+        for i in np.nonzero(ship <= 10471)[0]:
+            w = want.setdefault((a[i], b[i]), [None, None, int(small[i]), 0, 0, 0])
+            if not nulls[i]:
+                v = int(val[i])
+                w[0], w[1], w[5] = (v if w[0] is None else min(w[0], v)), (v if w[1] is None else max(w[1], v)), w[5] + 1
+            w[2], w[3], w[4] = max(w[2], int(small[i])), w[3] + int(small[i]), w[4] + 1
+    assert len(rows) == len(want) >= 6 + len(set(late.values()))
+    for r in rows:
+        assert list(r[2:8]) == want[(r[0], r[1])], r
+
+
 def test_fused_aggregation_launch_over_ragged_pages_with_and_without_null_vectors(pkg, monkeypatch):
     """one launch over a list of pages (fq_onepass_multi): page sizes around the 2048-row tile (1, 2047, 2048, 2049 rows ...), pages whose
     columns carry null vectors next to pages that carry none, launches of 1 to 64 pages -- bit for bit the two-launch path"""
