@@ -1,6 +1,8 @@
 // context.cpp -- Context: device/stream binding, caching allocator, pinned staging, HIP-event kernel timer.
 #include "common.h"
 
+#include <execinfo.h>
+
 #include <sstream>
 
 namespace tgpu {
@@ -278,12 +280,24 @@ void Context::upload(void *dst, const void *src, size_t bytes)
     HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
 }
 
+// TGPU_DEBUG_READBACKS: who waits for the device (a stack trace per host <- device round trip, to stderr)
+static void trace_readback(const char *what)
+{
+    static const bool on = getenv("TGPU_DEBUG_READBACKS") != nullptr;
+    if (!on) return;
+    void *bt[10];
+    const int n = backtrace(bt, 10);
+    fprintf(stderr, "[tgpu] read-back (%s)\n", what);
+    backtrace_symbols_fd(bt + 1, n - 1, 2);
+}
+
 void Context::download(void *dst, const void *src, size_t bytes)
 {
     if (!bytes) return;
     // handles of one context may be driven by different threads (tgpu.h threading rule): they share the staging buffer
     std::lock_guard<std::recursive_mutex> io(io_mu_);
     readbacks_++;
+    trace_readback("download");
     if (bytes <= (64u << 10)) {
         // the small read-backs between kernels (counts, flags, key ranges) go through the pinned staging buffer: a copy into
         // pageable memory (a stack variable) takes the runtime's slow staged path, several times the latency of this one
@@ -319,6 +333,7 @@ Context::Signal Context::begin_signal()
         if (!read_busy_[i]) s.slot = i;
     if (s.slot < 0) return s;
     readbacks_++;
+    trace_readback("signal");
     read_busy_[s.slot] = true;
     s.host = reinterpret_cast<volatile unsigned long long *>(static_cast<uint8_t *>(read_slots_) + (size_t)s.slot * kReadSlotBytes);
     s.device = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(read_slots_device_) + (size_t)s.slot * kReadSlotBytes);
@@ -380,6 +395,7 @@ Context::AsyncRead Context::begin_read(const void *src, size_t bytes)
     TG_CHECK_STATE(bytes > 0 && bytes <= kReadSlotBytes, "asynchronous read-backs are at most 16 KB");
     std::lock_guard<std::recursive_mutex> io(io_mu_);
     readbacks_++;
+    trace_readback("async read");
     ensure_read_slots();
     AsyncRead r;
     r.bytes = bytes;
@@ -434,6 +450,7 @@ void Context::download_batch(const std::vector<Transfer> &transfers)
     if (!total) return;
     std::lock_guard<std::recursive_mutex> io(io_mu_);
     readbacks_++;
+    trace_readback("download batch");
     uint8_t *stage = static_cast<uint8_t *>(pinned(total));
     size_t off = 0;
     for (auto &t : transfers) {
