@@ -3149,6 +3149,58 @@ def test_hash_aggregation_golden_with_spill(pkg, oracle, hash_enabled, spill_ena
         assert np.all(np.diff(hk.astype(np.int64)) >= 0)
 
 
+@pytest.mark.parametrize("hash_enabled,spill_enabled,revoke", [(True, True, True), (True, True, False), (False, False, False), (False, True, True), (False, True, False)])
+def test_hash_builder_resize_golden(pkg, oracle, hash_enabled, spill_enabled, revoke):
+    """T/operator/TestHashAggregationOperator.java:360-400 testHashBuilderResize over its data provider: a group key of 200 000 bytes (larger than
+    a block builder's limit) between two pages of short keys.  The reference asserts that the operator gets through; here also the rows"""
+    case = GOLD["hash_aggregation"]["testHashBuilderResize"]
+    big = "\0" * case["big_value_bytes"]
+    pages = []
+    for keys in ([str(i) for i in range(100, 110)], [big], [str(i) for i in range(100, 110)]):
+        blocks = [pkg.Block(pkg.VARCHAR, keys)]
+        if hash_enabled:
+            blocks.append(pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, blocks[0])])))
+        pages.append(pkg.Page(*blocks))
+    ctx = pkg.Context(0)
+    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.VARCHAR], [0], [(pkg.COUNT_COLUMN, 0)], hash_channel=1 if hash_enabled else -1, expected_groups=100_000,
+                                             spill_enabled=spill_enabled)
+    op = fac.createOperator()
+    rows = _drive_with_revokes(op, pages, revoke)
+    op.close()
+    ctx.close()
+    assert sorted((r[0], r[-1]) for r in rows) == sorted([(str(i), 2) for i in range(100, 110)] + [(big, 1)])
+
+
+def test_hash_builder_resize_limit_and_memory_tracking_golden(pkg, ctx):
+    """T/operator/TestHashAggregationOperator.java:438-476 testHashBuilderResizeLimit and :697-746 testMemoryTracking.  The limit itself is the
+    engine's (a memory pool of 3 MB throws ExceededMemoryLimitException from the bytes the operator reports through its memory context,
+    INTEGRATION.md); what this side owes is the report: with the 5 000 000-byte key in, the operator accounts for more than the limit.
+    Memory tracking with LONG_MIN as written: > 0 after addInput, 0 once the output is drained and the operator closed"""
+    case = GOLD["hash_aggregation"]["testHashBuilderResizeLimit"]
+    fac = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.VARCHAR], [0], [(pkg.COUNT_COLUMN, 0)], expected_groups=100_000)
+    op = fac.createOperator()
+    op.addInput(pkg.Page(pkg.Block(pkg.VARCHAR, [str(i) for i in range(100, 110)])))
+    assert op.memoryBytes() < case["limit_bytes"]
+    op.addInput(pkg.Page(pkg.Block(pkg.VARCHAR, ["\0" * case["big_value_bytes"]])))
+    assert op.memoryBytes() > case["limit_bytes"]                       # the pool's reserve() would throw here
+    op.close()
+    track = GOLD["hash_aggregation"]["testMemoryTracking"]
+    op = pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [(pkg.MIN_BIGINT, 0)], expected_groups=100_000).createOperator()
+    assert op.needsInput()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(track["rows"], dtype=np.int64))))
+    assert op.memoryBytes() > 0
+    op.finish()
+    rows = []
+    while not op.isFinished():
+        o = op.getOutput()
+        if o is not None:
+            rows += o.to_host().rows()
+            o.release()
+    assert sorted(rows) == [(i, i) for i in range(track["rows"])]
+    assert op.memoryBytes() == 0
+    op.close()
+
+
 @pytest.mark.parametrize("groups", [5, 40_000])
 def test_hash_aggregation_spill_merges_exact_states(pkg, oracle, groups):
     """spilled runs carry the exact accumulator state: after any number of revokes double sums are still the correctly rounded exact sums

@@ -239,6 +239,20 @@ def test_hash_aggregation_sequence_fixtures(oracle, name, pages):
     assert np.array_equal(g.values()[0], np.arange(n)) and np.array_equal(mins, np.arange(n)) and np.all(seen == 1)
 
 
+def test_hash_builder_resize_fixture(oracle):
+    # T/operator/TestHashAggregationOperator.java:360-400: a 200 000-byte VARCHAR key between two pages of short keys -- the oracle's
+    # MultiChannelGroupByHash + count give the rows the GPU test expects
+    case = GOLD["hash_aggregation"]["testHashBuilderResize"]
+    big = b"\0" * case["big_value_bytes"]
+    g = oracle.MultiChannelGroupByHash([VARCHAR], 100_000)
+    counts = np.zeros(11, dtype=np.int64)
+    for keys in ([str(i).encode() for i in range(100, 110)], [big], [str(i).encode() for i in range(100, 110)]):
+        col = oracle.Col(VARCHAR, [k.decode("latin-1") for k in keys])
+        gids = g.get_group_ids([col], oracle.hash_rows([col]))
+        counts += np.bincount(gids, minlength=11)
+    assert g.group_count == 11 and counts.tolist() == [2] * 10 + [1]
+
+
 def test_long_min_max_restates_compare_and_update_state(oracle):
     # AbstractMinMaxAggregationFunction.java:274-289 on a few rows by hand: nulls and masked rows leave the state alone, the first value is
     # taken whatever it is, ties keep the state; a group without values stays null (count 0)
