@@ -1005,8 +1005,10 @@ public:
     }
     ~LookupJoinOperator() override { close(); }
 
-    // blocked on lookupSourceProviderFuture until the build side lends the table (:235-243)
-    bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
+    // blocked on lookupSourceProviderFuture until the build side lends the table (:235-243) -- unless the probe side has ended: input is only
+    // taken once the table is there, so an operator that is finishing without it has had no page and finishes without the build side
+    // (TestHashJoinOperator.java:1241-1259 testInnerJoinWithBlockingLookupSourceAndEmptyProbe)
+    bool is_blocked() override { return !closed_ && !finishing_ && !bridge_->lookup_source(); }
     bool needs_input() override { return !finishing_ && !pending_ && !is_blocked(); }
 
     void add_input(const tgpu_page *page) override
@@ -1171,7 +1173,7 @@ public:
     }
     ~FusedFilterProjectJoinOperator() override { close(); }
 
-    bool is_blocked() override { return !closed_ && !bridge_->lookup_source(); }
+    bool is_blocked() override { return !closed_ && !finishing_ && !bridge_->lookup_source(); }   // (as LookupJoinOperator: a finishing probe never waits)
     bool needs_input() override { return !finishing_ && ready_.empty() && (int)inflight_.size() <= kDepth && !is_blocked(); }
 
     // Pages of up to kAsyncBelowRows (2^25) rows are probed asynchronously, kDepth pages deep: add_input prepares pass 1 of the new page and -- once

@@ -368,6 +368,32 @@ def run_join(pkg, ctx, build_pages, probe_pages, types_b, types_p, key_b, key_p,
     return rows, stats
 
 
+def test_hash_join_empty_probe_and_blocking_lookup_source_golden(pkg, ctx):
+    """T/operator/TestHashJoinOperator.java:1200-1238 testInnerJoinWithNonEmptyLookupSourceAndEmptyProbe (build rows a, b, null, c; no probe page:
+    no output), :1241-1259 testInnerJoinWithBlockingLookupSourceAndEmptyProbe (the build never finishes: the probe operator does not need input;
+    finish() -> no output, not blocked any more, finished) and :1261-1277 testInnerJoinWithBlockingLookupSource (without finish(): no output,
+    blocked on the build side, not finished)"""
+    V = pkg.VARCHAR
+    rows, _ = run_join(pkg, ctx, [pkg.Page(pkg.Block(V, ["a", "b", None, "c"]))], [], [V], [V], [0], [0])
+    assert rows == []
+    for finish_probe in (True, False):
+        bf = pkg.HashBuilderOperatorFactory(ctx, 1, [V], [0], [0])
+        jf = pkg.LookupJoinOperatorFactory(ctx, 2, bf.lookup_source_factory, [V], [0])
+        build = bf.createOperator()                      # (fed nothing and never finished: the lookup source future stays open)
+        probe = jf.createOperator()
+        jf.noMoreOperators()
+        assert not probe.needsInput()
+        if finish_probe:
+            probe.finish()
+            assert probe.getOutput() is None and probe.getOutput() is None
+            assert not probe.isBlocked() and probe.isFinished()
+        else:
+            assert probe.getOutput() is None
+            assert probe.isBlocked() and not probe.isFinished()
+        probe.close()
+        build.close()
+
+
 @pytest.mark.parametrize("probe_hash,build_hash", [(False, False), (True, True), (True, False)])
 def test_hash_join_inner_golden(pkg, ctx, oracle, probe_hash, build_hash):
     # T/operator/TestHashJoinOperator.java:164-199
