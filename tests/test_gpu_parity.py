@@ -110,6 +110,55 @@ def test_group_by_hash_varchar_append_to(pkg, ctx, oracle):
     assert g2.getCapacity() == 256
 
 
+def test_group_by_hash_contains_multiple_columns_golden(pkg, ctx, oracle):
+    """T/operator/TestGroupByHash.java:221-235 testContainsMultipleColumns: (DOUBLE, VARCHAR) keys with the precomputed hash as channel 2"""
+    d = pkg.Block(pkg.DOUBLE, sequence_values(pkg.DOUBLE, 0, 10))
+    v = pkg.Block(pkg.VARCHAR, sequence_values(pkg.VARCHAR, 0, 10))
+    h = pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, d), ocol(oracle, v)]))
+    gbh = pkg.GroupByHash(ctx, [pkg.DOUBLE, pkg.VARCHAR], [0, 1], input_hash_channel=2, expected_size=100)
+    assert list(gbh.getGroupIds(pkg.Page(d, v, h))) == list(range(10))
+    td, tv = pkg.Block(pkg.DOUBLE, [3.0]), pkg.Block(pkg.VARCHAR, ["3"])
+    th = pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, td), ocol(oracle, tv)]))
+    assert gbh.contains(0, pkg.Page(td, tv, th)) is GOLD["group_by_hash"]["testContainsMultipleColumns"]["expect_contains"]
+    td = pkg.Block(pkg.DOUBLE, [3.0])
+    tv = pkg.Block(pkg.VARCHAR, ["4"])                                    # (one column off: not a group)
+    th = pkg.Block(pkg.BIGINT, oracle.hash_rows([ocol(oracle, td), ocol(oracle, tv)]))
+    assert not gbh.contains(0, pkg.Page(td, tv, th))
+
+
+def test_aggregation_operator_golden(pkg, ctx):
+    """T/operator/TestAggregationOperator.java: the aggregation without group-by channels.  testMaskWithDirtyNulls (:90-118): a mask whose null
+    rows carry non-zero bytes and whose true is any non-zero byte; testAggregation (:119-157) without its max(varchar) / REAL columns;
+    testMemoryTracking (:158-198)"""
+    G = GOLD["aggregation_operator"]
+    case = G["testMaskWithDirtyNulls"]
+    mask = pkg.Block(pkg.BOOLEAN, np.array(case["mask_bytes"], dtype=np.uint8), np.array(case["mask_nulls"], dtype=np.uint8))
+    page = pkg.Page(pkg.Block(pkg.BIGINT, np.array([1, 2, 3, 4], dtype=np.int64)), mask)
+    rows = run_agg(pkg, ctx, [page], [], [], [(pkg.COUNT_COLUMN, 0, 1)])
+    assert [list(r) for r in rows] == case["expected_rows"]
+    case = G["testAggregation"]
+    types = [pkg.VARCHAR, pkg.BIGINT, pkg.VARCHAR, pkg.BIGINT, pkg.DOUBLE, pkg.DOUBLE, pkg.VARCHAR]     # (channel 4 is REAL in the reference: not read here)
+    page = pkg.Page(*blocks_of(pkg, types, sequence_page(types, case["rows"], 0, 0, 300, 500, 400, 500, 500)))
+    aggs = [(pkg.COUNT_COLUMN, 0), (pkg.SUM_BIGINT, 1), (pkg.AVG_BIGINT, 1), (pkg.COUNT_COLUMN, 0), (pkg.SUM_BIGINT, 3), (pkg.SUM_DOUBLE, 5)]
+    (row,) = run_agg(pkg, ctx, [page], [], [], aggs)
+    e = case["expected_row_subset"]
+    assert list(row) == [e["count"], e["long_sum_1"], e["long_average_1"], e["count_varchar"], e["long_sum_3"], e["double_sum_5"]]
+    case = G["testMemoryTracking"]
+    op = pkg.HashAggregationOperatorFactory(ctx, 0, [], [], [(pkg.SUM_BIGINT, 0)]).createOperator()
+    assert op.needsInput()
+    op.addInput(pkg.Page(pkg.Block(pkg.BIGINT, np.arange(case["rows"], dtype=np.int64))))
+    assert op.memoryBytes() > 0
+    op.finish()
+    out = []
+    while not op.isFinished():
+        o = op.getOutput()
+        if o is not None:
+            out += o.to_host().rows()
+            o.release()
+    assert out == [(4950,)] and op.memoryBytes() == 0
+    op.close()
+
+
 @pytest.mark.parametrize("types,domains", [
     (["BIGINT"], [(0, 3000)]),
     (["VARCHAR"], [(0, 500)]),
