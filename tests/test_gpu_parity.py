@@ -2685,6 +2685,20 @@ def _run_fp_counting(pkg, ctx, pages, types, filt, projs):
     return [r for pg in outs for r in pg.rows()], dict_pages
 
 
+def test_columnar_page_processor_golden(pkg, ctx):
+    """T/operator/TestColumnarPageProcessor.java:46-86 testProcess / testProcessWithDictionary: the identity projection of a (BIGINT, VARCHAR)
+    sequence page, flat and as dictionary blocks (20 entries, ids i % 20): one output page equal to the input"""
+    n = GOLD["page_processor"]["TestColumnarPageProcessor"]["positions"]
+    f = pkg.field
+    fac = pkg.FilterAndProjectOperatorFactory(ctx, 0, [pkg.BIGINT, pkg.VARCHAR], None, [f(0, pkg.BIGINT), f(1, pkg.VARCHAR)])
+    flat = pkg.Page(pkg.Block(pkg.BIGINT, np.arange(n, dtype=np.int64)), pkg.Block(pkg.VARCHAR, [str(i) for i in range(n)]))
+    ids = (np.arange(n) % (n // 5)).astype(np.int32)
+    dic = pkg.Page(pkg.DictionaryBlock(pkg.Block(pkg.BIGINT, np.arange(n // 5, dtype=np.int64)), ids), pkg.DictionaryBlock(pkg.Block(pkg.VARCHAR, [str(i) for i in range(n // 5)]), ids))
+    for page, want in ((flat, [(i, str(i)) for i in range(n)]), (dic, [(i % (n // 5), str(i % (n // 5))) for i in range(n)])):
+        out = pkg.to_pages(fac.createOperator(), [page])
+        assert len(out) == 1 and out[0].rows() == want
+
+
 def test_dictionary_aware_filter_project_equals_flat_path(pkg, ctx, monkeypatch):
     rng = np.random.default_rng(12)
     n = 50_000
