@@ -2688,7 +2688,7 @@ def _run_fp_counting(pkg, ctx, pages, types, filt, projs):
 def test_columnar_page_processor_golden(pkg, ctx):
     """T/operator/TestColumnarPageProcessor.java:46-86 testProcess / testProcessWithDictionary: the identity projection of a (BIGINT, VARCHAR)
     sequence page, flat and as dictionary blocks (20 entries, ids i % 20): one output page equal to the input"""
-    n = GOLD["page_processor"]["TestColumnarPageProcessor"]["positions"]
+    n = GOLD["columnar_page_processor"]["positions"]
     f = pkg.field
     fac = pkg.FilterAndProjectOperatorFactory(ctx, 0, [pkg.BIGINT, pkg.VARCHAR], None, [f(0, pkg.BIGINT), f(1, pkg.VARCHAR)])
     flat = pkg.Page(pkg.Block(pkg.BIGINT, np.arange(n, dtype=np.int64)), pkg.Block(pkg.VARCHAR, [str(i) for i in range(n)]))
