@@ -211,8 +211,9 @@ typedef struct tgpu_agg_spec {
 typedef enum tgpu_agg_step { TGPU_STEP_SINGLE = 0, TGPU_STEP_PARTIAL = 1, TGPU_STEP_FINAL = 2 } tgpu_agg_step;
 
 /* HashAggregationOperatorFactory (M/operator/HashAggregationOperator.java:54-262).  Output channels: group-by keys,
- * [hash channel if hash_channel >= 0], then one channel per aggregate (PARTIAL: two channels per sum/avg = count BIGINT,
- * sum DOUBLE|BIGINT -- the flattened LongDoubleState / LongLongState; FINAL consumes that layout). */
+ * [hash channel if hash_channel >= 0], then one channel per aggregate (PARTIAL: two channels per sum / avg / min / max = count BIGINT,
+ * sum DOUBLE|BIGINT or the extreme BIGINT -- the flattened LongDoubleState / LongLongState / NullableLongState, count 0 = null state;
+ * FINAL consumes that layout). */
 int32_t tgpu_hash_aggregation_factory_create(tgpu_context *ctx, int32_t operator_id,
                                              int32_t group_by_count, const int32_t *group_by_types, const int32_t *group_by_channels,
                                              int32_t hash_channel /* -1 = none */, int32_t step,
