@@ -1,7 +1,9 @@
 """Ad-hoc large-size checks against numpy (needs a GPU): PartitionedOutputOperator with 1024 partitions and replicated null-key rows
 (5 M rows), byte-exact serde of a page with nulls, a FULL_OUTER join of 2 x 10 M probe rows against 5 M build rows + LookupOuterOperator."""
-import importlib, sys, numpy as np
+import argparse, importlib, sys, numpy as np
 sys.path.insert(0, '/root/repo')
+import bench                       # (torch first: its HIP runtime has to be the one the process starts with)
+bb = bench.Bench(argparse.Namespace())
 pkg = importlib.import_module("presto-1_amd")
 from oracle import oracle
 ctx = pkg.Context(0)
@@ -162,3 +164,47 @@ for pg in pages:
 assert np.array_equal(gk, np.concatenate(wk)) and np.array_equal(gd, np.concatenate(wd)) and np.array_equal(gb, np.concatenate(wb))
 assert len(outs) < len(pages) // 4, len(outs)       # pages shared launches
 print("fused join over", len(pages), "small pages ok:", len(gk), "pairs in", len(outs), "output pages")
+
+# the strict Java order at size: Q1's program over 30 M rows (bench.py's generator and operator, TGPU_SUM_ORDER_JAVA: one workgroup per group, the
+# sums as chains fed from LDS) -- the four sums and three averages of every group BIT FOR BIT the sequential (numpy cumsum) sums; then a
+# skewed 400 K-group input whose heavy group's lane hands over to a chain
+n1 = 30_000_000
+bb.ctx.set_double_sum_order(pkg.SUM_ORDER_JAVA)
+try:
+    bb.setup_q1(n1)
+    bb.step_q1()
+finally:
+    bb.ctx.set_double_sum_order(pkg.SUM_ORDER_EXACT)
+rows = [r for pg in bb.q1_result for r in pg]
+t = {k: v.cpu().numpy() for k, v in bb.q1.items()}
+sel = t["shipdate"] <= 10471
+bits = lambda x: np.float64(x).view(np.int64)
+for r in rows:
+    m = sel & (t["returnflag"] == ord(r[0])) & (t["linestatus"] == ord(r[1]))
+    q, e, d, x = t["quantity"][m], t["extendedprice"][m], t["discount"][m], t["tax"][m]
+    dp = e * (1.0 - d)
+    ch = dp * (1.0 + x)
+    want = [np.cumsum(q)[-1], np.cumsum(e)[-1], np.cumsum(dp)[-1], np.cumsum(ch)[-1]]
+    cnt = int(m.sum())
+    want += [want[0] / cnt, want[1] / cnt, np.cumsum(d)[-1] / cnt]
+    assert [int(bits(v)) for v in r[2:9]] == [int(bits(v)) for v in want] and r[9] == cnt, (r[:2], r[2:9], want)
+print("Q1 in the Java order over", n1, "rows: 7 double aggregates x", len(rows), "groups bit-identical to the sequential sums")
+bb.q1_result = None
+n2, g2 = 20_000_000, 400_000
+k2 = rng.integers(0, g2, n2).astype(np.int64)
+k2[rng.random(n2) < 0.25] = 7                        # one heavy group: 5 M rows
+v2 = rng.standard_normal(n2) * 10.0 ** rng.integers(-6, 7, n2)
+rows2 = [r for p_ in pkg.to_pages(pkg.HashAggregationOperatorFactory(ctx, 0, [pkg.BIGINT], [0], [(pkg.SUM_DOUBLE, 1), (pkg.COUNT_ALL, -1), (pkg.MAX_BIGINT, 0)],
+                                                                     expected_groups=g2).createOperator(),
+                                  [pkg.Page(pkg.Block(pkg.BIGINT, k2[a:a + 5_000_000]), pkg.Block(pkg.DOUBLE, v2[a:a + 5_000_000])) for a in range(0, n2, 5_000_000)])
+         for r in p_.rows()]
+order = np.argsort(k2, kind="stable")
+ks, vs = k2[order], v2[order]
+starts = np.flatnonzero(np.r_[True, ks[1:] != ks[:-1]])
+ends = np.r_[starts[1:], len(ks)]
+want2 = {int(ks[s]): (float(np.cumsum(vs[s:e])[-1]), int(e - s)) for s, e in zip(starts, ends) if e - s > 3000 or ks[s] % 1000 == 0}
+got2 = {r[0]: r for r in rows2}
+assert len(rows2) == len(starts)
+for k_, (s_, c_) in want2.items():
+    assert int(bits(got2[k_][1])) == int(bits(s_)) and got2[k_][2] == c_ and got2[k_][3] == k_, (k_, got2[k_], s_, c_)
+print("skewed ORDERED aggregation:", len(rows2), "groups, heavy group", want2[7][1], "rows, sums in row order bit-identical (", len(want2), "groups checked )")
