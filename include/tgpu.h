@@ -566,7 +566,7 @@ int32_t tgpu_orc_decode_direct_string_column(tgpu_context *ctx, int32_t encoding
  * width 1 WITHOUT the 4-byte length a V1 page carries in front of it, NULL for a required column; `values` = the value section;
  * `dictionary` / `dictionary_count` = the column chunk's PLAIN dictionary page for the dictionary encodings, else NULL / 0.
  * `physical` = parquet.thrift Type (0 BOOLEAN, 1 INT32, 2 INT64, 5 DOUBLE, 6 BYTE_ARRAY) with `type` INTEGER / DATE, BIGINT, DOUBLE, BOOLEAN, VARCHAR;
- * `encoding` = parquet.thrift Encoding (0 PLAIN, 2 PLAIN_DICTIONARY, 8 RLE_DICTIONARY; 3 RLE for BOOLEAN values; 5 DELTA_BINARY_PACKED for INT32 and INT64, 6 DELTA_LENGTH_BYTE_ARRAY for BYTE_ARRAY); anything else: TGPU_ERR_NOT_SUPPORTED.  *out = a one-channel page. */
+ * `encoding` = parquet.thrift Encoding (0 PLAIN, 2 PLAIN_DICTIONARY, 8 RLE_DICTIONARY; 3 RLE for BOOLEAN values; 5 DELTA_BINARY_PACKED for INT32 and INT64, 6 DELTA_LENGTH_BYTE_ARRAY and 7 DELTA_BYTE_ARRAY for BYTE_ARRAY); anything else: TGPU_ERR_NOT_SUPPORTED.  *out = a one-channel page. */
 int32_t tgpu_parquet_decode_data_page(tgpu_context *ctx, int32_t type, int32_t physical, int32_t encoding, int32_t position_count, const void *definition_levels,
                                       int64_t definition_levels_len, const void *values, int64_t values_len, const void *dictionary, int64_t dictionary_len,
                                       int32_t dictionary_count, tgpu_output_page **out);

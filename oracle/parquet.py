@@ -8,7 +8,7 @@ import numpy as np
 from . import oracle as _o
 
 BOOLEAN, INT32, INT64, DOUBLE, BYTE_ARRAY = 0, 1, 2, 5, 6
-PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY, RLE_DICTIONARY = 0, 2, 3, 5, 6, 8
+PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY, RLE_DICTIONARY = 0, 2, 3, 5, 6, 7, 8
 
 
 def _lib():
@@ -16,7 +16,7 @@ def _lib():
     if not getattr(L, "_pq_ready", False):
         i32, i64, vp = C.c_int32, C.c_int64, C.c_void_p
         for name, res, args in (("o_pq_hybrid", i64, [vp, i64, i32, vp, i64]), ("o_pq_plain_byte_array", i64, [vp, i64, i64, vp, vp, i64]), ("o_pq_plain_boolean", i64, [vp, i64, i64, vp]),
-                                ("o_pq_delta_binary_packed", i64, [vp, i64, i64, i32, vp, vp])):
+                                ("o_pq_delta_binary_packed", i64, [vp, i64, i64, i32, vp, vp]), ("o_pq_delta_byte_array", i64, [vp, i64, i64, vp, vp, vp, i64])):
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         L._pq_ready = True
@@ -62,6 +62,23 @@ def delta_length_byte_array(data, count):
     return out
 
 
+def delta_byte_array(data, count, pool_cap=None):
+    """DELTA_BYTE_ARRAY (Encodings.md "Delta Strings"; ParquetEncoding.java:165-173): prefix lengths, then the suffixes as DELTA_LENGTH_BYTE_ARRAY"""
+    a, p = _bytes(data)
+    if pool_cap is None:       # the decoded size: the sum of the prefix and suffix lengths (shared prefixes make it far larger than the section)
+        prefixes, used = delta_binary_packed(INT32, data, count, with_end=True)
+        pool_cap = 64 + sum(max(x, 0) for x in prefixes) + sum(max(x, 0) for x in delta_binary_packed(INT32, data[used:], count))
+    cap = pool_cap
+    scratch = np.zeros(max(2 * count, 1), dtype=np.int64)
+    off = np.zeros(count + 1, dtype=np.int32)
+    pool = np.zeros(cap, dtype=np.uint8)
+    used = _lib().o_pq_delta_byte_array(p, len(data), count, scratch.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), cap)
+    if used < 0:
+        raise ValueError("corrupt DELTA_BYTE_ARRAY section")
+    raw = pool.tobytes()
+    return [raw[off[i]:off[i + 1]] for i in range(count)]
+
+
 def plain_values(physical, data, count):
     """`count` PLAIN values as a python list"""
     if physical == BYTE_ARRAY:
@@ -97,6 +114,10 @@ def decode_data_page(physical, encoding, n, values, definition_levels=None, dict
         if physical != BYTE_ARRAY:
             raise ValueError("DELTA_LENGTH_BYTE_ARRAY is for BYTE_ARRAY columns")     # ParquetEncoding.java:160
         vals = delta_length_byte_array(values, nn)
+    elif encoding == DELTA_BYTE_ARRAY:
+        if physical != BYTE_ARRAY:
+            raise ValueError("DELTA_BYTE_ARRAY is for BYTE_ARRAY columns here")     # (ParquetEncoding.java:170 also allows FIXED_LEN_BYTE_ARRAY: not a type of this library)
+        vals = delta_byte_array(values, nn)
     elif encoding == RLE:   # ParquetEncoding.RLE for VALUES: BOOLEAN only (bit width 1), a 4-byte length in front of the hybrid stream (ParquetEncoding.java:105-115,198-212)
         if physical != BOOLEAN:
             raise ValueError("RLE value encoding is for BOOLEAN columns")
@@ -210,6 +231,20 @@ def delta_encode(values, physical, block_size=128, miniblocks=4):
 
 def delta_length_encode(values):
     return delta_encode([len(b) for b in values], INT32) + b"".join(bytes(b) for b in values)
+
+
+def delta_byte_array_encode(values):
+    """prefix = the longest common prefix with the value before (what the writers do); any prefix <= that would be valid"""
+    prefixes, suffixes, prev = [], [], b""
+    for v in values:
+        v = bytes(v)
+        k = 0
+        while k < min(len(prev), len(v)) and prev[k] == v[k]:
+            k += 1
+        prefixes.append(k)
+        suffixes.append(v[k:])
+        prev = v
+    return delta_encode(prefixes, INT32) + delta_length_encode(suffixes)
 
 
 def plain_encode(physical, values):

@@ -143,3 +143,29 @@ int64_t o_pq_delta_binary_packed(const uint8_t *bytes, int64_t len, int64_t want
     if (consumed) *consumed = at;
     return n;
 }
+
+/* DELTA_BYTE_ARRAY (Encodings.md "Delta Strings"; ParquetEncoding.java:165-173 -> parquet-mr's DeltaByteArrayReader): the prefix lengths as a
+ * DELTA_BINARY_PACKED section, then the suffixes as a DELTA_LENGTH_BYTE_ARRAY section; value[i] = value[i - 1][0 .. prefix[i]) ++ suffix[i].
+ * offsets[count + 1] into pool; returns the bytes written or -1. */
+int64_t o_pq_delta_byte_array(const uint8_t *bytes, int64_t len, int64_t count, int64_t *scratch /* 2 * count */, int32_t *offsets, uint8_t *pool, int64_t pool_cap)
+{
+    int64_t used_a = 0, used_b = 0;
+    int64_t *prefix = scratch, *slen = scratch + count;
+    offsets[0] = 0;
+    if (count == 0) return 0;
+    if (o_pq_delta_binary_packed(bytes, len, count, 32, prefix, &used_a) != count) return -1;
+    if (o_pq_delta_binary_packed(bytes + used_a, len - used_a, count, 32, slen, &used_b) != count) return -1;
+    int64_t at = used_a + used_b, out = 0, prev = 0, prev_len = 0;
+    for (int64_t i = 0; i < count; i++) {
+        if (prefix[i] < 0 || prefix[i] > prev_len || slen[i] < 0 || at + slen[i] > len || out + prefix[i] + slen[i] > pool_cap) return -1;
+        memmove(pool + out, pool + prev, (size_t)prefix[i]);
+        memcpy(pool + out + prefix[i], bytes + at, (size_t)slen[i]);
+        at += slen[i];
+        prev = out;
+        prev_len = prefix[i] + slen[i];
+        out += prev_len;
+        if (out > 0x7fffffffLL) return -1;
+        offsets[i + 1] = (int32_t)out;
+    }
+    return out;
+}

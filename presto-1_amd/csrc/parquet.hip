@@ -1,7 +1,7 @@
 // parquet.hip -- scan-side decode, the second columnar format the reference reads: the data pages of a flat Parquet column
 // decoded on the device into flat HBM columns.  Reference (lib/trino-parquet/src/main/java/io/trino/parquet/): reader/PrimitiveColumnReader.java
 // (readPageV1 / readPageV2 / initDataReader: levels, then the value reader of the page's encoding), reader/LevelRLEReader.java,
-// ParquetEncoding.java (PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY / DELTA_BINARY_PACKED -> value readers and dictionaries), dictionary/*.java (PLAIN dictionary
+// ParquetEncoding.java (PLAIN / PLAIN_DICTIONARY / RLE_DICTIONARY / the DELTA encodings -> value readers and dictionaries), dictionary/*.java (PLAIN dictionary
 // pages), reader/{Int,Long,Double,Boolean,Binary}ColumnReader.java.  The byte-level decoders those classes call are NOT in the reference tree:
 // org.apache.parquet (parquet-mr) classes out of io.prestosql.hive:hive-apache 3.1.2-6, the shaded bundle the reference's root pom.xml:537-538 pins
 // -- RunLengthBitPackingHybridDecoder, the Plain*ValuesReaders -- so their algorithm is restated from the public Parquet format specification (Encodings.md: "RLE / bit-packing
@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kWave = 64;
 enum Physical : int32_t { PQ_BOOLEAN = 0, PQ_INT32 = 1, PQ_INT64 = 2, PQ_DOUBLE = 5, PQ_BYTE_ARRAY = 6 };          // parquet.thrift Type
-enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_DELTA_BINARY_PACKED = 5, PQ_DELTA_LENGTH_BYTE_ARRAY = 6, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
+enum Encoding : int32_t { PQ_PLAIN = 0, PQ_PLAIN_DICTIONARY = 2, PQ_RLE = 3, PQ_DELTA_BINARY_PACKED = 5, PQ_DELTA_LENGTH_BYTE_ARRAY = 6, PQ_DELTA_BYTE_ARRAY = 7, PQ_RLE_DICTIONARY = 8 };                           // parquet.thrift Encoding
 
 struct Run {
     int64_t in_off;    // bit-packed run: first byte of the packed values
@@ -512,6 +512,112 @@ DeviceColumn delta_length_strings(Context *ctx, int32_t type, int32_t physical, 
     return col;
 }
 
+// DELTA_BYTE_ARRAY (Encodings.md "Delta Strings"; ParquetEncoding.java:165-173 -> parquet-mr's DeltaByteArrayReader): prefix lengths as a
+// DELTA_BINARY_PACKED section, then the suffixes as a DELTA_LENGTH_BYTE_ARRAY section; value[i] = value[i - 1][0 .. prefix[i]) ++ suffix[i].
+// Byte j of value i is byte j - prefix[k] of suffix k for the LAST k <= i with prefix[k] <= j (every value in between took that byte over from
+// its predecessor): one workgroup per byte position j runs a max-scan of "k if prefix[k] <= j" along the values and copies the byte --
+// no value waits for the one before it.
+__global__ void __launch_bounds__(256) dba_prepare_kernel(const long long *__restrict__ prefix, const long long *__restrict__ slen, int64_t count, int32_t *__restrict__ len32,
+                                                          int32_t *__restrict__ slen32, unsigned int *__restrict__ status /* [0] error, [1] longest value */)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+        const long long p = prefix[i], sl = slen[i];
+        const long long before = i ? prefix[i - 1] + slen[i - 1] : 0;
+        const bool bad = p < 0 || sl < 0 || p > before || p + sl > 0x7fffffffLL;
+        if (bad) status[0] = 1u;
+        len32[i] = bad ? 0 : (int32_t)(p + sl);
+        slen32[i] = bad ? 0 : (int32_t)sl;
+        if (!bad) atomicMax(&status[1], (unsigned int)(p + sl));
+    }
+}
+
+__global__ void __launch_bounds__(256) dba_resolve_kernel(const long long *__restrict__ prefix, const int32_t *__restrict__ len32, const int32_t *__restrict__ soff,
+                                                          const int32_t *__restrict__ voff, const uint8_t *__restrict__ suffixes, int64_t count, uint8_t *__restrict__ pool)
+{
+    __shared__ int scan[256];
+    const int j = blockIdx.x;          // the byte position this workgroup resolves
+    int carry = -1;                    // last k before this chunk with prefix[k] <= j
+    for (int64_t base = 0; base < count; base += 256) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < count;
+        scan[threadIdx.x] = (live && prefix[i] <= j) ? (int)i : -1;
+        __syncthreads();
+#pragma unroll
+        for (int d = 1; d < 256; d <<= 1) {
+            const int other = threadIdx.x >= d ? scan[threadIdx.x - d] : -1;
+            __syncthreads();
+            scan[threadIdx.x] = other > scan[threadIdx.x] ? other : scan[threadIdx.x];
+            __syncthreads();
+        }
+        const int k = scan[threadIdx.x] > carry ? scan[threadIdx.x] : carry;
+        if (live && len32[i] > j && k >= 0) pool[(size_t)voff[i] + j] = suffixes[(size_t)soff[k] + (j - (int)prefix[k])];
+        const int last = scan[255];
+        __syncthreads();
+        carry = last > carry ? last : carry;
+    }
+}
+
+DeviceColumn delta_strings(Context *ctx, int32_t type, int32_t physical, const uint8_t *bytes, int64_t len, int64_t n, const Present &p)
+{
+    if (physical != PQ_BYTE_ARRAY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet DELTA_BYTE_ARRAY is decoded for BYTE_ARRAY columns");   // (ParquetEncoding.java:170: and FIXED_LEN_BYTE_ARRAY, not a type here)
+    DeviceColumn col;
+    col.type = type;
+    col.n = n;
+    const uint8_t *nulls = p.nulls && p.non_null < n ? p.nulls->as<uint8_t>() : nullptr;
+    const int32_t *rank = nulls ? p.rank->as<int32_t>() : nullptr;
+    if (nulls) {
+        col.nulls_buf = p.nulls;
+        col.nulls = nulls;
+    }
+    col.offsets_buf = ctx->alloc((size_t)(n + 1) * 4);
+    col.offsets = col.offsets_buf->as<int32_t>();
+    col.pool_exact = true;
+    const int64_t want = p.non_null;
+    if (n == 0 || want == 0) {
+        HIP_CHECK(hipMemsetAsync(col.offsets_buf->ptr(), 0, (size_t)(n + 1) * 4, ctx->stream()));
+        col.values_buf = ctx->alloc(1);
+        col.values = col.values_buf->ptr();
+        col.pool_bytes = 0;
+        return col;
+    }
+    int64_t a = 0, b = 0;
+    BufferPtr prefix = delta_values(ctx, bytes, len, want, &a);
+    BufferPtr slen = delta_values(ctx, bytes + a, len - a, want, &b);
+    const int64_t sfx_bytes = len - a - b;
+    BufferPtr len32 = ctx->alloc((size_t)want * 4), slen32 = ctx->alloc((size_t)want * 4), soff = ctx->alloc((size_t)want * 4), voff = ctx->alloc((size_t)want * 4),
+              status = ctx->alloc_zero(8), total_s = ctx->alloc(8), total_v = ctx->alloc(8);
+    dba_prepare_kernel<<<grid_for(ctx, want), 256, 0, ctx->stream()>>>(prefix->as<long long>(), slen->as<long long>(), want, len32->as<int32_t>(), slen32->as<int32_t>(),
+                                                                        status->as<unsigned int>());
+    check_launch("parquet_delta_strings_prepare");
+    k::exclusive_scan_i32(ctx, slen32->as<int32_t>(), soff->as<int32_t>(), want, total_s->as<int64_t>());
+    k::exclusive_scan_i32(ctx, len32->as<int32_t>(), voff->as<int32_t>(), want, total_v->as<int64_t>());
+    unsigned int st[2];
+    ctx->download(st, status->ptr(), 8);
+    const int64_t suffix_total = ctx->read_scalar(total_s->as<int64_t>()), pool_bytes = ctx->read_scalar(total_v->as<int64_t>());
+    TG_CHECK_ARG(st[0] == 0 && suffix_total <= sfx_bytes, "Parquet DELTA_BYTE_ARRAY prefix / suffix lengths do not fit the values before them or the bytes that follow");
+    TG_CHECK_ARG(pool_bytes <= 0x7fffffffLL, "Parquet page holds more than 2 GB of string bytes");
+    col.values_buf = ctx->alloc((size_t)(pool_bytes > 0 ? pool_bytes : 1));
+    col.values = col.values_buf->ptr();
+    col.pool_bytes = pool_bytes;
+    const int64_t longest = st[1];
+    if (longest > 0) {
+        BufferPtr sfx = upload_padded(ctx, bytes + a + b, sfx_bytes);
+        ProfileScope ps(ctx, "parquet_delta_strings_resolve");
+        dba_resolve_kernel<<<(int)longest, 256, 0, ctx->stream()>>>(prefix->as<long long>(), len32->as<int32_t>(), soff->as<int32_t>(), voff->as<int32_t>(), sfx->as<uint8_t>(), want,
+                                                                    col.values_buf->as<uint8_t>());
+        check_launch("parquet_delta_strings_resolve");
+    }
+    // row offsets: a null row has no bytes, so the values' pool is the column's pool
+    BufferPtr row_len = ctx->alloc((size_t)n * 4), total = ctx->alloc(8);
+    place_kernel<int32_t><<<grid_for(ctx, n), 256, 0, ctx->stream()>>>(len32->as<int32_t>(), rank, nulls, n, row_len->as<int32_t>());
+    check_launch("parquet_place_lengths");
+    k::exclusive_scan_i32(ctx, row_len->as<int32_t>(), const_cast<int32_t *>(col.offsets), n, total->as<int64_t>());
+    const int32_t end = (int32_t)pool_bytes;
+    ctx->upload(const_cast<int32_t *>(col.offsets) + n, &end, 4);
+    ctx->sync();
+    return col;
+}
+
 void check_types(int32_t type, int32_t physical)
 {
     const bool ok = (physical == PQ_INT32 && (type == TGPU_INTEGER || type == TGPU_DATE)) || (physical == PQ_INT64 && type == TGPU_BIGINT) || (physical == PQ_DOUBLE && type == TGPU_DOUBLE) ||
@@ -530,6 +636,7 @@ DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int3
     if (encoding == PQ_PLAIN) return plain_column(ctx, type, physical, values, values_len, n, p);
     if (encoding == PQ_DELTA_BINARY_PACKED) return delta_column(ctx, type, physical, values, values_len, n, p);
     if (encoding == PQ_DELTA_LENGTH_BYTE_ARRAY) return delta_length_strings(ctx, type, physical, values, values_len, n, p);
+    if (encoding == PQ_DELTA_BYTE_ARRAY) return delta_strings(ctx, type, physical, values, values_len, n, p);
     if (encoding == PQ_RLE) {
         // ParquetEncoding.RLE as a VALUE encoding exists for BOOLEAN only (ParquetEncoding.java:105-115,198-212: bit width 1): a 4-byte length, then
         // the non-null rows' booleans as a hybrid stream
@@ -557,7 +664,7 @@ DeviceColumn decode_data_page(Context *ctx, int32_t type, int32_t physical, int3
         check_launch("parquet_place_booleans");
         return col;
     }
-    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY; RLE for BOOLEAN)");
+    if (encoding != PQ_PLAIN_DICTIONARY && encoding != PQ_RLE_DICTIONARY) fail(TGPU_ERR_NOT_SUPPORTED, "Parquet value encoding not decoded on the device (PLAIN, PLAIN_DICTIONARY, RLE_DICTIONARY, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY; RLE for BOOLEAN)");
     TG_CHECK_ARG(physical != PQ_BOOLEAN, "BOOLEAN columns have no dictionary encoding");
     // the dictionary page: PLAIN values without nulls (dictionary/*.java); the page: one byte of bit width, then the ids as a hybrid stream
     Present all;

@@ -7,7 +7,7 @@ from . import _lib
 from .spi import OutputPage
 
 BOOLEAN, INT32, INT64, DOUBLE, BYTE_ARRAY = 0, 1, 2, 5, 6          # parquet.thrift Type
-PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY, RLE_DICTIONARY = 0, 2, 3, 5, 6, 8   # parquet.thrift Encoding (RLE as a value encoding: BOOLEAN; DELTA_BINARY_PACKED: INT32 / INT64; DELTA_LENGTH_BYTE_ARRAY: BYTE_ARRAY)
+PLAIN, PLAIN_DICTIONARY, RLE, DELTA_BINARY_PACKED, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY, RLE_DICTIONARY = 0, 2, 3, 5, 6, 7, 8   # parquet.thrift Encoding (RLE as a value encoding: BOOLEAN; DELTA_BINARY_PACKED: INT32 / INT64; DELTA_LENGTH_BYTE_ARRAY / DELTA_BYTE_ARRAY: BYTE_ARRAY)
 
 
 def _buf(b):

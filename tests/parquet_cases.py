@@ -60,6 +60,7 @@ def write_cases(tmp_dir, n=20_000):
 
 
 DELTA_WORDS = ["", "a", "BUILDING", "MACHINERY", "x" * 300, "héllo wörld", "AUTOMOBILE"]
+PREFIX_WORDS = ["", "a", "BUILD", "BUILDING", "MACHINE", "MACHINERY", "x" * 300, "x" * 299 + "y", "héllo wörld", "héllo", "AUTO", "AUTOMOBILE"]
 
 
 def write_delta_cases(tmp_dir, n=20_000):
@@ -82,11 +83,14 @@ def write_delta_cases(tmp_dir, n=20_000):
             # strings as DELTA_LENGTH_BYTE_ARRAY (ParquetEncoding.java:156-163)
             "s": pa.array(nullable([DELTA_WORDS[int(x)] for x in rng.integers(0, len(DELTA_WORDS), n)], 4), type=pa.string()),
             "s_required": pa.array([DELTA_WORDS[int(x)] for x in rng.integers(0, len(DELTA_WORDS), n)], type=pa.string()),
+            # strings as DELTA_BYTE_ARRAY (ParquetEncoding.java:165-173): a sorted key column (long shared prefixes) and words with nulls
+            "p_sorted": pa.array(sorted("key%07d" % int(x) for x in rng.integers(0, 10**6, n)), type=pa.string()),
+            "p": pa.array(nullable([PREFIX_WORDS[int(x)] for x in rng.integers(0, len(PREFIX_WORDS), n)], 6), type=pa.string()),
         })
         t = t.cast(pa.schema([pa.field(f.name, f.type, nullable=f.name != "s_required") for f in t.schema]))
         path = os.path.join(str(tmp_dir), f"delta_{ver}.parquet")
         pq.write_table(t, path, compression="NONE", use_dictionary=False, data_page_version=ver, write_statistics=False, data_page_size=16384,
-                       column_encoding={c: "DELTA_LENGTH_BYTE_ARRAY" if c.startswith("s") else "DELTA_BINARY_PACKED" for c in t.column_names})
+                       column_encoding={c: "DELTA_LENGTH_BYTE_ARRAY" if c.startswith("s") else "DELTA_BYTE_ARRAY" if c.startswith("p") else "DELTA_BINARY_PACKED" for c in t.column_names})
         out.append((f"delta pages=V{ver[0]}", path, pq.read_table(path)))
     return out
 
@@ -101,4 +105,4 @@ def expected_column(table, name, physical):
     return col
 
 
-TYPE_OF = {"i64": "BIGINT", "i64_runs": "BIGINT", "i32": "INTEGER", "date": "DATE", "f64": "DOUBLE", "flag": "BOOLEAN", "s": "VARCHAR", "s_required": "VARCHAR", "all_null": "INTEGER"}
+TYPE_OF = {"p": "VARCHAR", "p_sorted": "VARCHAR", "i64": "BIGINT", "i64_runs": "BIGINT", "i32": "INTEGER", "date": "DATE", "f64": "DOUBLE", "flag": "BOOLEAN", "s": "VARCHAR", "s_required": "VARCHAR", "all_null": "INTEGER"}

@@ -152,6 +152,18 @@ def test_delta_binary_packed_pages(pkg, gpq, opq, ctx, tmp_path):
     with pytest.raises(pkg.TgpuError) as e:
         gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_LENGTH_BYTE_ARRAY, 2, opq.delta_length_encode([b"abc", b"defg"]))
     assert e.value.code == -8
+    # DELTA_BYTE_ARRAY: sorted values (long chains of shared prefixes), unsorted ones, nulls, a 40 000-byte value among short ones
+    pw = [w.encode("utf-8") for w in cases.PREFIX_WORDS] + [b"z" * 40_000, b"z" * 39_999 + b"!"]
+    for n, frac, srt in ((1, 1.0, False), (1, 0.0, False), (2, 1.0, True), (700, 0.0, False), (257, 1.0, True), (30_000, 0.7, True), (30_000, 0.9, False)):
+        present = (rng.random(n) < frac).astype(np.int32)
+        vals = [pw[int(x)] for x in rng.integers(0, len(pw) - (0 if n < 1000 else 2), int(present.sum()))]
+        vals = sorted(vals) if srt else vals
+        sec, dl = opq.delta_byte_array_encode(vals), opq.hybrid_encode(present.tolist(), 1)
+        want = opq.decode_data_page(opq.BYTE_ARRAY, opq.DELTA_BYTE_ARRAY, n, sec, dl)
+        blk = gpq.decode_data_page(ctx, pkg.VARCHAR, gpq.BYTE_ARRAY, gpq.DELTA_BYTE_ARRAY, n, sec, dl).to_host().getBlock(0)
+        assert [None if v is None else v.encode("utf-8") for v in blk.to_list()] == want, (n, frac, srt)
+    with pytest.raises(pkg.TgpuError):
+        gpq.decode_data_page(ctx, pkg.VARCHAR, gpq.BYTE_ARRAY, gpq.DELTA_BYTE_ARRAY, 2, opq.delta_encode([0, 5], opq.INT32) + opq.delta_length_encode([b"abc", b"d"]))
     sec = opq.delta_encode(list(range(300)), gpq.INT64)
     with pytest.raises(pkg.TgpuError):
         gpq.decode_data_page(ctx, pkg.BIGINT, gpq.INT64, gpq.DELTA_BINARY_PACKED, 300, sec[:len(sec) // 2])

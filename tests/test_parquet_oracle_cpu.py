@@ -63,7 +63,8 @@ def test_delta_binary_packed_pages_written_by_arrow_and_of_chosen_shapes(opq, tm
     for label, path, table in cases.write_delta_cases(tmp_path):
         for chunk in pp.column_chunks(path):
             assert same(decode_chunk(opq, chunk), cases.expected_column(table, chunk["name"], chunk["physical"])), (label, chunk["name"])
-            assert all(p_["encoding"] == (opq.DELTA_LENGTH_BYTE_ARRAY if chunk["name"].startswith("s") else opq.DELTA_BINARY_PACKED) for p_ in chunk["pages"])
+            want_enc = opq.DELTA_LENGTH_BYTE_ARRAY if chunk["name"].startswith("s") else opq.DELTA_BYTE_ARRAY if chunk["name"].startswith("p") else opq.DELTA_BINARY_PACKED
+            assert all(p_["encoding"] == want_enc for p_ in chunk["pages"])
             pages += len(chunk["pages"])
     assert pages >= 20
     rng = np.random.default_rng(11)
@@ -91,6 +92,16 @@ def test_delta_binary_packed_pages_written_by_arrow_and_of_chosen_shapes(opq, tm
         assert opq.delta_length_byte_array(opq.delta_length_encode(vals), n) == vals
     with pytest.raises(ValueError):
         opq.delta_length_byte_array(opq.delta_length_encode([b"abc", b"defg"])[:-2], 2)
+    # DELTA_BYTE_ARRAY: prefixes of the value before + suffixes; a prefix longer than the value before is refused
+    pw = [w.encode("utf-8") for w in cases.PREFIX_WORDS]
+    for n in (0, 1, 2, 33, 1000):
+        vals = sorted(pw[int(x)] for x in rng.integers(0, len(pw), n))
+        assert opq.delta_byte_array(opq.delta_byte_array_encode(vals), n) == vals
+        vals = [pw[int(x)] for x in rng.integers(0, len(pw), n)]
+        assert opq.delta_byte_array(opq.delta_byte_array_encode(vals), n) == vals
+    bad = opq.delta_encode([0, 5], opq.INT32) + opq.delta_length_encode([b"abc", b"d"])      # the second value claims 5 bytes of a 3-byte one
+    with pytest.raises(ValueError):
+        opq.delta_byte_array(bad, 2)
 
 
 def test_hybrid_streams_of_every_width_and_their_failure_modes(opq):
