@@ -199,7 +199,10 @@ typedef enum tgpu_agg_function {
     TGPU_AGG_AVG_BIGINT = 5,    /* avg(bigint)     AverageAggregations.java:35-80 */
     TGPU_AGG_AVG_DOUBLE = 6,    /* avg(double)     AverageAggregations.java:42-80 */
     TGPU_AGG_MIN_BIGINT = 7,    /* min(bigint)     AbstractMinMaxAggregationFunction.java:233-289 (LONG_INPUT / LONG_COMBINE, NullableLongState) */
-    TGPU_AGG_MAX_BIGINT = 8     /* max(bigint)     the same with the comparison turned round (MaxAggregationFunction.java) */
+    TGPU_AGG_MAX_BIGINT = 8,    /* max(bigint)     the same with the comparison turned round (MaxAggregationFunction.java) */
+    TGPU_AGG_MIN_DOUBLE = 9,    /* min(double)     :227-230,291-306 with Double.compare (DoubleType.java:194-198): -0.0 < +0.0, NaN above +inf */
+    TGPU_AGG_MAX_DOUBLE = 10    /* max(double)     M/util/MinMaxCompare.java maxDouble: value > state || isNaN(state).  A NaN result is the canonical NaN; among
+                                 *                 zeros of both signs as the maximum +0.0 is returned (the reference: the one that came first) */
 } tgpu_agg_function;
 
 typedef struct tgpu_agg_spec {

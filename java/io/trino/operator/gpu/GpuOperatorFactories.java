@@ -121,7 +121,7 @@ public final class GpuOperatorFactories
 
     /**
      * HashAggregationOperatorFactory (operator/HashAggregationOperator.java:54-262).  aggregates: {tgpu_agg_function, input channel, mask channel} triples
-     * resolved by the caller from the AccumulatorFactories' bound signatures (count / sum / avg over BIGINT and DOUBLE, min / max over BIGINT; anything else -> Optional.empty()).
+     * resolved by the caller from the AccumulatorFactories' bound signatures (count / sum / avg over BIGINT and DOUBLE, min / max over BIGINT and DOUBLE; anything else -> Optional.empty()).
      */
     public Optional<OperatorFactory> hashAggregation(int operatorId, PlanNodeId planNodeId, List<Type> inputTypes, List<Type> groupByTypes, List<Integer> groupByChannels, Step step,
             Optional<int[]> aggregates, Optional<Integer> hashChannel, int expectedGroups, boolean produceDefaultOutput, Optional<DataSize> maxPartialMemory, boolean spillEnabled)

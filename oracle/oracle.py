@@ -71,6 +71,7 @@ def lib():
             "o_agg_long_avg": (None, [vp, vp, vp, vp, i32, vp, vp]),
             "o_agg_long_sum": (i32, [vp, vp, vp, vp, i32, vp, vp]),
             "o_agg_long_minmax": (None, [vp, vp, vp, vp, i32, i32, vp, vp]),
+            "o_agg_double_minmax": (None, [vp, vp, vp, vp, i32, i32, vp, vp]),
             "o_agg_count": (None, [vp, vp, vp, i32, vp]),
             "o_exact_sum": (f64, [vp, i64]),
             "o_agg_double_sum_exact": (None, [vp, vp, vp, vp, i64, i32, vp, vp]),
@@ -307,6 +308,16 @@ def agg_long_minmax(gids, values, ngroups, is_min, nulls=None, mask=None):
     v = np.ascontiguousarray(values, dtype=np.int64)
     g = _gid(gids)
     lib().o_agg_long_minmax(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), 1 if is_min else 0, _ptr(counts), _ptr(out))
+    return counts, out
+
+
+def agg_double_minmax(gids, values, ngroups, is_min, nulls=None, mask=None):
+    """(counts, extremes) in the reference's row order semantics (first of equal values, NaN rules): meaningful where counts[g] > 0"""
+    counts = np.zeros(ngroups, dtype=np.int64)
+    out = np.zeros(ngroups, dtype=np.float64)
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    g = _gid(gids)
+    lib().o_agg_double_minmax(_ptr(g), _ptr(v), _ptr(nulls), _ptr(mask), len(v), 1 if is_min else 0, _ptr(counts), _ptr(out))
     return counts, out
 
 

@@ -641,6 +641,35 @@ void o_agg_long_minmax(const int64_t *gids, const int64_t *v, const uint8_t *nul
     }
 }
 
+/* min(double) / max(double): AbstractMinMaxAggregationFunction.java:227-230 -> :291-306 on a NullableDoubleState.  min: the comparison is
+ * Double.compare(value, state) < 0 (MinMaxCompare.getMinMaxCompare over DoubleType.java:194-198 comparisonOperator): a total order with
+ * -0.0 < +0.0 and NaN above everything; max: M/util/MinMaxCompare.java maxDouble = (value > state) || isNaN(state) -- plain IEEE >, a NaN
+ * state gives way to whatever comes next. */
+static int o_double_compare(double a, double b)   /* java.lang.Double.compare */
+{
+    if (a < b) return -1;
+    if (a > b) return 1;
+    int64_t x, y;
+    memcpy(&x, &a, 8);
+    memcpy(&y, &b, 8);
+    if (a != a) x = 0x7ff8000000000000LL;   /* doubleToLongBits: every NaN is the canonical one */
+    if (b != b) y = 0x7ff8000000000000LL;
+    return x == y ? 0 : (x < y ? -1 : 1);
+}
+
+void o_agg_double_minmax(const int64_t *gids, const double *v, const uint8_t *nulls, const uint8_t *mask, int32_t n, int32_t is_min,
+                         int64_t *counts, double *values)
+{
+    for (int32_t i = 0; i < n; i++) {
+        if (mask && !mask[i]) continue;
+        if (nulls && nulls[i]) continue;
+        int64_t g = gids ? gids[i] : 0;
+        if (counts[g] == 0) values[g] = v[i];
+        else if (is_min ? o_double_compare(v[i], values[g]) < 0 : (v[i] > values[g] || values[g] != values[g])) values[g] = v[i];
+        counts[g] += 1;
+    }
+}
+
 void o_agg_count(const int64_t *gids, const uint8_t *nulls, const uint8_t *mask, int32_t n, int64_t *counts)
 {
     for (int32_t i = 0; i < n; i++) {

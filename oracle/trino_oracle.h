@@ -105,6 +105,8 @@ void o_agg_long_avg(const int64_t *gids, const int64_t *v, const uint8_t *nulls,
 /* sum(bigint): LongSumAggregation.java:34-39 ; returns -2 (NUMERIC_VALUE_OUT_OF_RANGE) on overflow */
 int32_t o_agg_long_sum(const int64_t *gids, const int64_t *v, const uint8_t *nulls, const uint8_t *mask,
                        int32_t n, int64_t *counts, int64_t *sums);
+void o_agg_double_minmax(const int64_t *gids, const double *v, const uint8_t *nulls, const uint8_t *mask, int32_t n, int32_t is_min,
+                         int64_t *counts, double *values);
 void o_agg_long_minmax(const int64_t *gids, const int64_t *v, const uint8_t *nulls, const uint8_t *mask, int32_t n, int32_t is_min,
                        int64_t *counts, int64_t *values);
 /* count(*) / count(col): CountAggregation.java:34-38, CountColumn.java */

@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
                 if (cnt == 0) continue;  // empty partial state
                 atomicAdd((unsigned long long *)&a.counts[g], (unsigned long long)cnt);
                 if (a.function == TGPU_AGG_SUM_BIGINT) i128_add(&a.i128[g * 2], ((const long long *)a.input2)[r]);
-                else if (tg_is_minmax(a.function)) tg_minmax_update(&a.i128[g * 2], tg_minmax_code(((const long long *)a.input2)[r], a.function == TGPU_AGG_MIN_BIGINT));
+                else if (tg_is_minmax(a.function)) tg_minmax_update(&a.i128[g * 2], tg_minmax_encode(a.function, ((const unsigned long long *)a.input2)[r]));
                 else kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input2)[r]);
                 continue;
             }
@@ -71,7 +71,9 @@ __global__ void __launch_bounds__(kBlock) agg_accumulate_kernel(AggArgs args, co
             switch (a.function) {
             case TGPU_AGG_SUM_BIGINT: i128_add(&a.i128[g * 2], ((const long long *)a.input)[r]); break;
             case TGPU_AGG_MIN_BIGINT:
-            case TGPU_AGG_MAX_BIGINT: tg_minmax_update(&a.i128[g * 2], tg_minmax_code(((const long long *)a.input)[r], a.function == TGPU_AGG_MIN_BIGINT)); break;
+            case TGPU_AGG_MAX_BIGINT:
+            case TGPU_AGG_MIN_DOUBLE:
+            case TGPU_AGG_MAX_DOUBLE: tg_minmax_update(&a.i128[g * 2], tg_minmax_encode(a.function, ((const unsigned long long *)a.input)[r])); break;
             case TGPU_AGG_SUM_DOUBLE:
             case TGPU_AGG_AVG_DOUBLE: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], ((const double *)a.input)[r]); break;
             case TGPU_AGG_AVG_BIGINT: kulisch_add(&a.limbs[g * kLimbs], &a.special[g], (double)((const long long *)a.input)[r]); break;
@@ -146,7 +148,7 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
                     cnt += c;
                     if (a.function == TGPU_AGG_SUM_BIGINT) big += ((const long long *)a.input2)[r];
                     else if (tg_is_minmax(a.function)) {
-                        const unsigned long long c_ = tg_minmax_code(((const long long *)a.input2)[r], a.function == TGPU_AGG_MIN_BIGINT);
+                        const unsigned long long c_ = tg_minmax_encode(a.function, ((const unsigned long long *)a.input2)[r]);
                         best = c_ > best ? c_ : best;
                     }
                     else if (a.function != TGPU_AGG_COUNT_ALL && a.function != TGPU_AGG_COUNT_COLUMN) s += ((const double *)a.input2)[r];
@@ -158,8 +160,10 @@ __global__ void __launch_bounds__(kBlock) agg_ordered_kernel(AggArgs args, const
                 switch (a.function) {
                 case TGPU_AGG_SUM_BIGINT: big += ((const long long *)a.input)[r]; break;
                 case TGPU_AGG_MIN_BIGINT:
-                case TGPU_AGG_MAX_BIGINT: {
-                    const unsigned long long c_ = tg_minmax_code(((const long long *)a.input)[r], a.function == TGPU_AGG_MIN_BIGINT);
+                case TGPU_AGG_MAX_BIGINT:
+                case TGPU_AGG_MIN_DOUBLE:
+                case TGPU_AGG_MAX_DOUBLE: {
+                    const unsigned long long c_ = tg_minmax_encode(a.function, ((const unsigned long long *)a.input)[r]);
                     best = c_ > best ? c_ : best;
                     break;
                 }
@@ -245,7 +249,7 @@ __device__ inline void ordered_chain_group(const AggArgs &args, const OrdChainPl
                     }
                 }
                 else if (tg_is_minmax(a.function)) {
-                    if (take) tg_minmax_update(&a.i128[g * 2], tg_minmax_code(((const long long *)a.input)[row], a.function == TGPU_AGG_MIN_BIGINT));
+                    if (take) tg_minmax_update(&a.i128[g * 2], tg_minmax_encode(a.function, ((const unsigned long long *)a.input)[row]));
                 }
                 else if (plan.slot[k] >= 0 && live) {
                     double x = -0.0;
@@ -332,7 +336,7 @@ __global__ void __launch_bounds__(kBlock) agg_lowcard_kernel(AggArgs args, LowCa
             if (a.function != TGPU_AGG_COUNT_ALL && a.input_nulls && a.input_nulls[r]) continue;
             cnt_base[plan.cnt_slot[k] * kBlock + threadIdx.x] += 1u;
             if (tg_is_minmax(a.function)) {   // (no lane-private slot: almost no row improves a group's extreme, see tg_minmax_update)
-                tg_minmax_update(&a.i128[(size_t)g * 2], tg_minmax_code(((const long long *)a.input)[r], a.function == TGPU_AGG_MIN_BIGINT));
+                tg_minmax_update(&a.i128[(size_t)g * 2], tg_minmax_encode(a.function, ((const unsigned long long *)a.input)[r]));
                 continue;
             }
             const int w = plan.wide_slot[k];
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(kBlock) agg_evaluate_kernel(EvalArgs args, int
         }
         double dsum = 0.0;
         long long lsum = 0;
-        if (tg_is_minmax(a.function)) lsum = tg_minmax_value(a.i128[g * 2], a.function == TGPU_AGG_MIN_BIGINT);
+        if (tg_is_minmax(a.function)) lsum = (long long)tg_minmax_decode(a.function, a.i128[g * 2]);   // (DOUBLE: the value's bits)
         else if (a.function == TGPU_AGG_SUM_BIGINT) {
             const unsigned long long lo = a.i128[g * 2], hi = a.i128[g * 2 + 1];
             lsum = (long long)lo;
@@ -480,6 +484,8 @@ __global__ void __launch_bounds__(kBlock) agg_evaluate_kernel(EvalArgs args, int
         switch (a.function) {
         case TGPU_AGG_MIN_BIGINT:
         case TGPU_AGG_MAX_BIGINT:
+        case TGPU_AGG_MIN_DOUBLE:
+        case TGPU_AGG_MAX_DOUBLE:
         case TGPU_AGG_SUM_BIGINT: ((long long *)a.out0)[g] = cnt ? lsum : 0; break;
         case TGPU_AGG_SUM_DOUBLE: ((double *)a.out0)[g] = cnt ? dsum : 0.0; break;
         default: ((double *)a.out0)[g] = cnt ? dsum / (double)cnt : 0.0; break;
@@ -497,8 +503,10 @@ int grid_for(Context *ctx, int64_t n)
 
 bool is_double_state(int32_t f) { return f == TGPU_AGG_SUM_DOUBLE || f == TGPU_AGG_AVG_DOUBLE || f == TGPU_AGG_AVG_BIGINT; }
 bool is_count(int32_t f) { return f == TGPU_AGG_COUNT_ALL || f == TGPU_AGG_COUNT_COLUMN; }
-bool is_minmax(int32_t f) { return f == TGPU_AGG_MIN_BIGINT || f == TGPU_AGG_MAX_BIGINT; }
+bool is_minmax(int32_t f) { return f >= TGPU_AGG_MIN_BIGINT && f <= TGPU_AGG_MAX_DOUBLE; }
 bool is_bigint_state(int32_t f) { return f == TGPU_AGG_SUM_BIGINT || is_minmax(f); }   // two 64-bit words per group (128-bit sum / extreme code)
+// the type of the aggregate's value channel (input, PARTIAL's second channel, output)
+bool bigint_valued(int32_t f) { return f == TGPU_AGG_SUM_BIGINT || f == TGPU_AGG_MIN_BIGINT || f == TGPU_AGG_MAX_BIGINT; }
 
 // the regions a round of state growth has to clear, zeroed by ONE launch (an operator with 8 aggregates grows ~24 arrays: one
 // memset each would cost more in launch gaps than the clearing itself)
@@ -534,7 +542,7 @@ GroupedAccumulators::GroupedAccumulators(Context *ctx, std::vector<tgpu_agg_spec
 {
     TG_CHECK_ARG((int)specs.size() <= kMaxAggs, "at most 16 aggregates per operator");
     for (auto &s : specs) {
-        TG_CHECK_ARG(s.function >= TGPU_AGG_COUNT_ALL && s.function <= TGPU_AGG_MAX_BIGINT, "unknown aggregate function");
+        TG_CHECK_ARG(s.function >= TGPU_AGG_COUNT_ALL && s.function <= TGPU_AGG_MAX_DOUBLE, "unknown aggregate function");
         State st;
         st.spec = s;
         states_.push_back(st);
@@ -925,7 +933,8 @@ void GroupedAccumulators::add_input(const int32_t *gids, int64_t n, const Device
         a.function = st.spec.function;
         if (st.spec.function != TGPU_AGG_COUNT_ALL) {
             int32_t want = 0;
-            if (is_bigint_state(st.spec.function) || st.spec.function == TGPU_AGG_AVG_BIGINT) want = TGPU_BIGINT;
+            if (bigint_valued(st.spec.function) || st.spec.function == TGPU_AGG_AVG_BIGINT) want = TGPU_BIGINT;
+            if (st.spec.function == TGPU_AGG_MIN_DOUBLE || st.spec.function == TGPU_AGG_MAX_DOUBLE) want = TGPU_DOUBLE;
             if (st.spec.function == TGPU_AGG_SUM_DOUBLE || st.spec.function == TGPU_AGG_AVG_DOUBLE) want = TGPU_DOUBLE;
             check_channel(page, st.spec.input_channel, want, "aggregate input");
             a.input = page.cols[st.spec.input_channel].values;
@@ -1041,7 +1050,7 @@ void GroupedAccumulators::add_intermediate(const int32_t *gids, int64_t n, const
         a.input = page.cols[ch].values;
         ch++;
         if (!is_count(st.spec.function)) {
-            check_channel(page, ch, is_bigint_state(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE, "intermediate sum");
+            check_channel(page, ch, bigint_valued(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE, "intermediate sum");
             a.input2 = page.cols[ch].values;
             ch++;
         }
@@ -1096,7 +1105,7 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
             if (partial && !is_count(st.spec.function)) {
                 DeviceColumn c1;
                 c1.n = groups;
-                c1.type = is_bigint_state(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE;
+                c1.type = bigint_valued(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE;
                 c1.values_buf = ctx_->alloc((size_t)alloc_n * 8);
                 c1.values = c1.values_buf->ptr();
                 a.out1 = c1.values_buf->ptr();
@@ -1104,7 +1113,7 @@ void GroupedAccumulators::evaluate(int64_t groups, std::vector<DeviceColumn> &ou
             }
         }
         else {
-            c0.type = is_bigint_state(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE;
+            c0.type = bigint_valued(st.spec.function) ? TGPU_BIGINT : TGPU_DOUBLE;
             c0.nulls_buf = ctx_->alloc((size_t)alloc_n);
             c0.nulls = c0.nulls_buf->as<uint8_t>();
             a.out0_nulls = c0.nulls_buf->as<uint8_t>();

@@ -15,6 +15,8 @@
 #define TG_AGG_AVG_DOUBLE 6
 #define TG_AGG_MIN_BIGINT 7
 #define TG_AGG_MAX_BIGINT 8
+#define TG_AGG_MIN_DOUBLE 9
+#define TG_AGG_MAX_DOUBLE 10
 
 // per-aggregate state arrays in HBM, indexed by group id
 struct TgAggState {
@@ -60,19 +62,34 @@ __device__ inline void tg_i128_add(unsigned long long *acc, long long v)
     if (hi_add) atomicAdd(&acc[1], hi_add);
 }
 
-// min(bigint) / max(bigint) (AbstractMinMaxAggregationFunction.java:274-289: keep the value the comparison prefers).  The state word --
+// min / max over BIGINT and DOUBLE (AbstractMinMaxAggregationFunction.java:274-306: keep the value the comparison prefers).  The state word --
 // word 0 of the aggregate's two i128 words -- holds the running extreme in an unsigned code that preserves (max) or reverses (min) the
 // order, so one unsigned atomicMax serves both and a zero word is the identity (no value yet; the count says whether there is one).
 // Order independent and exact: every path (lane-private, global, row-order, one-pass re-runs) may apply a row any number of times.
-__device__ inline bool tg_is_minmax(int function) { return function == TG_AGG_MIN_BIGINT || function == TG_AGG_MAX_BIGINT; }
-__device__ inline unsigned long long tg_minmax_code(long long v, bool is_min)
+__device__ inline bool tg_is_minmax(int function) { return function >= TG_AGG_MIN_BIGINT && function <= TG_AGG_MAX_DOUBLE; }
+// raw = the value's 8 bytes (BIGINT or DOUBLE).  DOUBLE: the usual total-order key of the bits (negatives reversed below the positives: -0.0 <
+// +0.0, as Double.compare has it), with NaN where the reference's comparison puts it -- min: MinMaxCompare.min over Double.compare
+// (DoubleType.java:194-198), NaN above +inf, so NaN maps to the top key = code 0: it wins only when nothing else comes; max:
+// MinMaxCompare.maxDouble (`left > right || isNaN(right)`), a NaN state gives way to any value and never replaces one: key 0 = code 0.
+// Either way "only NaNs" is code 0 with a count, decoded as NaN (the canonical one: a NaN's payload is not kept).
+__device__ inline unsigned long long tg_minmax_encode(int function, unsigned long long raw)
 {
-    const unsigned long long u = (unsigned long long)v ^ 0x8000000000000000ULL;
-    return is_min ? ~u : u;
+    const unsigned long long sign = 0x8000000000000000ULL;
+    if (function <= TG_AGG_MAX_BIGINT) {
+        const unsigned long long u = raw ^ sign;
+        return function == TG_AGG_MIN_BIGINT ? ~u : u;
+    }
+    if ((raw & ~sign) > 0x7ff0000000000000ULL) return 0ULL;                     // NaN
+    const unsigned long long key = (raw & sign) ? ~raw : (raw | sign);
+    return function == TG_AGG_MIN_DOUBLE ? ~key : key;
 }
-__device__ inline long long tg_minmax_value(unsigned long long code, bool is_min)
+__device__ inline unsigned long long tg_minmax_decode(int function, unsigned long long code)
 {
-    return (long long)((is_min ? ~code : code) ^ 0x8000000000000000ULL);
+    const unsigned long long sign = 0x8000000000000000ULL;
+    if (function <= TG_AGG_MAX_BIGINT) return (function == TG_AGG_MIN_BIGINT ? ~code : code) ^ sign;
+    if (code == 0ULL) return 0x7ff8000000000000ULL;                             // NaN (or no value: the count decides)
+    const unsigned long long key = function == TG_AGG_MIN_DOUBLE ? ~code : code;
+    return (key & sign) ? (key & ~sign) : ~key;
 }
 // (the plain read first: after a group's first few rows almost no row improves the extreme, and a stale read can only be too small)
 __device__ inline void tg_minmax_update(unsigned long long *word, unsigned long long code)

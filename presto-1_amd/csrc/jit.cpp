@@ -2622,12 +2622,12 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
     supported_ = true;
     const int np = (int)proj_roots_.size();
     for (auto &a : aggs_) {
-        TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_MAX_BIGINT, "unknown aggregate function");
+        TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_MAX_DOUBLE, "unknown aggregate function");
         if (a.function != TGPU_AGG_COUNT_ALL) {
             TG_CHECK_ARG(a.input_channel >= 0 && a.input_channel < np, "aggregate input channel out of range");
             const int32_t t = proj_types_[(size_t)a.input_channel];
             const bool want_bigint = a.function == TGPU_AGG_SUM_BIGINT || a.function == TGPU_AGG_AVG_BIGINT || a.function == TGPU_AGG_MIN_BIGINT || a.function == TGPU_AGG_MAX_BIGINT;
-            const bool want_double = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE;
+            const bool want_double = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE || a.function == TGPU_AGG_MIN_DOUBLE || a.function == TGPU_AGG_MAX_DOUBLE;
             TG_CHECK_ARG(!(want_bigint && t != TGPU_BIGINT) && !(want_double && t != TGPU_DOUBLE), "aggregate input type mismatch");
             if (a.function == TGPU_AGG_COUNT_COLUMN && t == TGPU_VARCHAR) supported_ = supported_ && nodes_[(size_t)proj_roots_[(size_t)a.input_channel]].kind == TGPU_EX_INPUT;
         }
@@ -2692,7 +2692,7 @@ FusedAggGpu::FusedAggGpu(std::vector<int32_t> input_types, const tgpu_page_proce
     for (size_t k = 0; k < aggs_.size(); k++) {
         const tgpu_agg_spec &a = aggs_[k];
         // (min / max keep no lane-private sum either: their rows go straight to the state word, device_agg.h tg_minmax_update)
-        const bool count_only = a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN || a.function == TGPU_AGG_MIN_BIGINT || a.function == TGPU_AGG_MAX_BIGINT;
+        const bool count_only = a.function == TGPU_AGG_COUNT_ALL || a.function == TGPU_AGG_COUNT_COLUMN || (a.function >= TGPU_AGG_MIN_BIGINT && a.function <= TGPU_AGG_MAX_DOUBLE);
         const int in_root = a.function == TGPU_AGG_COUNT_ALL ? -1 : proj_roots_[(size_t)a.input_channel];
         const int mask_root = a.mask_channel >= 0 ? proj_roots_[(size_t)a.mask_channel] : -1;
         const int kind = a.function == TGPU_AGG_SUM_BIGINT ? 1 : (a.function == TGPU_AGG_AVG_BIGINT ? 2 : 0);
@@ -2777,9 +2777,10 @@ void FusedAggGpu::generate()
         const int w = wide_slot_[k];
         const bool is_dbl = a.function == TGPU_AGG_SUM_DOUBLE || a.function == TGPU_AGG_AVG_DOUBLE || a.function == TGPU_AGG_AVG_BIGINT;
         const bool is_big = a.function == TGPU_AGG_SUM_BIGINT;
-        const bool is_mm = a.function == TGPU_AGG_MIN_BIGINT || a.function == TGPU_AGG_MAX_BIGINT;
+        const bool is_mm = a.function >= TGPU_AGG_MIN_BIGINT && a.function <= TGPU_AGG_MAX_DOUBLE;
+        const bool mm_dbl = a.function == TGPU_AGG_MIN_DOUBLE || a.function == TGPU_AGG_MAX_DOUBLE;
         const std::string mm_word = "&F.st[" + std::to_string(k) + "].i128[(size_t)g * 2]";
-        const std::string mm_code = "tg_minmax_code(y" + std::to_string(k) + ", " + (a.function == TGPU_AGG_MIN_BIGINT ? "true" : "false") + ")";
+        const std::string mm_code = "tg_minmax_encode(" + std::to_string(a.function) + ", (unsigned long long)y" + std::to_string(k) + ")";
         eval << "  bool t" << k << " = true; double x" << k << " = 0.0; long long y" << k << " = 0; (void)x" << k << "; (void)y" << k << ";\n  {\n";
         gr.os.str("");
         if (a.mask_channel >= 0) {
@@ -2794,6 +2795,7 @@ void FusedAggGpu::generate()
             gr.os.str("");
             eval << "      if (" << v.n << ") t" << k << " = false;\n";
             if (is_dbl) eval << "      else x" << k << " = " << (a.function == TGPU_AGG_AVG_BIGINT ? "(double)" : "") << v.v << ";\n";
+            else if (mm_dbl) eval << "      else y" << k << " = __double_as_longlong(" << v.v << ");\n";
             else if (is_big || is_mm) eval << "      else y" << k << " = " << v.v << ";\n";
             eval << "    }\n";
         }

@@ -726,7 +726,7 @@ HashAggregationOperatorFactory::HashAggregationOperatorFactory(Context *ctx, int
     TG_CHECK_ARG((int)cfg_.group_by_types.size() <= kMaxKeyChannels, "at most 8 group-by channels");
     TG_CHECK_ARG((int)cfg_.aggs.size() <= kMaxAggs, "at most 16 aggregates");
     TG_CHECK_ARG(cfg_.expected_groups > 0, "expectedGroups must be positive");
-    for (auto &a : cfg_.aggs) TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_MAX_BIGINT, "unknown aggregate function");
+    for (auto &a : cfg_.aggs) TG_CHECK_ARG(a.function >= TGPU_AGG_COUNT_ALL && a.function <= TGPU_AGG_MAX_DOUBLE, "unknown aggregate function");
 }
 
 std::unique_ptr<Operator> HashAggregationOperatorFactory::create_operator()

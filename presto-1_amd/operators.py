@@ -14,7 +14,7 @@ from . import _lib
 from .expressions import FlatProgram
 from .spi import OutputPage, Page
 
-COUNT_ALL, COUNT_COLUMN, SUM_BIGINT, SUM_DOUBLE, AVG_BIGINT, AVG_DOUBLE, MIN_BIGINT, MAX_BIGINT = 1, 2, 3, 4, 5, 6, 7, 8
+COUNT_ALL, COUNT_COLUMN, SUM_BIGINT, SUM_DOUBLE, AVG_BIGINT, AVG_DOUBLE, MIN_BIGINT, MAX_BIGINT, MIN_DOUBLE, MAX_DOUBLE = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 SINGLE, PARTIAL, FINAL = 0, 1, 2
 # S/connector/SortOrder.java:18-21
 ASC_NULLS_FIRST, ASC_NULLS_LAST, DESC_NULLS_FIRST, DESC_NULLS_LAST = 0, 1, 2, 3

@@ -1436,6 +1436,85 @@ def test_min_max_bigint_every_path(pkg, oracle, groups, plan):
         assert by_key[1][1] is None and by_key[1][2] is None and by_key[1][8] == 0
 
 
+@pytest.mark.parametrize("plan", ["single", "partial_final", "fused", "spilled"])
+@pytest.mark.parametrize("groups", [3, 300, 50_000])
+def test_min_max_double_every_path(pkg, oracle, groups, plan):
+    """min(double) / max(double) (AbstractMinMaxAggregationFunction.java:227-230,291-306; Double.compare for min, MinMaxCompare.maxDouble for
+    max) through the accumulation paths, bit for bit the oracle's row-at-a-time restatement: infinities, NaN (above everything for min, below
+    everything for max: a group of NaNs only answers NaN), -0.0, nulls, masks, all-null groups.  Inputs hold -0.0 but no +0.0: see the
+    deviation pinned in test_max_double_of_zeros_of_both_signs"""
+    rng = np.random.default_rng(700 + groups)
+    B, D, BO = pkg.BIGINT, pkg.DOUBLE, pkg.BOOLEAN
+    n, npages = 40_000, 6
+    cols = []
+    for page in range(npages):
+        keys = rng.integers(0, groups, n).astype(np.int64)
+        vals = rng.standard_normal(n) * 10.0 ** rng.integers(-300, 300, n)
+        for special in (np.inf, -np.inf, np.nan, -0.0):
+            vals[rng.integers(0, n, 40)] = special
+        if groups > 3:
+            vals[keys == 2] = np.nan                 # a group of NaNs only
+        nulls = (rng.random(n) < 0.2).astype(np.uint8)
+        if groups > 3:
+            nulls[keys == 1] = 1                     # a group whose values are all null
+        mask = rng.integers(0, 2, n).astype(np.uint8)
+        cols.append((keys, vals, nulls, mask))
+    aggs = [(pkg.MIN_DOUBLE, 1), (pkg.MAX_DOUBLE, 1), (pkg.MAX_DOUBLE, 1, 2), (pkg.COUNT_COLUMN, 1), (pkg.SUM_DOUBLE, 1, 2)]
+    pages = [pkg.Page(pkg.Block(B, k), pkg.Block(D, v, nl), pkg.Block(BO, m)) for k, v, nl, m in cols]
+    ctx = pkg.Context(0)
+    f = pkg.field
+    if plan == "single":
+        rows = run_agg(pkg, ctx, pages, [B], [0], aggs[:4], expected=groups)
+    elif plan == "partial_final":
+        partials = []
+        for pg in pages:
+            op = pkg.HashAggregationOperatorFactory(ctx, 0, [B], [0], aggs[:4], step=pkg.PARTIAL, expected_groups=groups).createOperator()
+            partials += pkg.to_pages(op, [pg])
+            op.close()
+        fin, ch = [], 1
+        for a in aggs[:4]:
+            fin.append((a[0], ch))
+            ch += 1 if a[0] in (pkg.COUNT_ALL, pkg.COUNT_COLUMN) else 2
+        rows = run_agg(pkg, ctx, partials, [B], [0], fin, step=pkg.FINAL, expected=groups)
+    elif plan == "fused":
+        fac = pkg.FilterProjectHashAggregationOperatorFactory(ctx, 0, [B, D, BO], None, [f(0, B), f(1, D), f(2, BO)], [B], [0], aggs[:4])
+        rows = [r for p_ in pkg.to_pages(fac.createOperator(), pages) for r in p_.rows()]
+    else:
+        op = pkg.HashAggregationOperatorFactory(ctx, 0, [B], [0], aggs[:4], expected_groups=groups, spill_enabled=True).createOperator()
+        rows = _drive_with_revokes(op, pages, True)
+        op.close()
+    ctx.close()
+    keys, vals, nulls, mask = (np.concatenate([c[i] for c in cols]) for i in range(4))
+    o = oracle.BigintGroupByHash(groups)
+    gids = o.get_group_ids(oracle.Col(B, keys))
+    ng = o.group_count
+    assert len(rows) == ng
+    by_key = {r[0]: r for r in rows}
+    first = {}
+    for k_, g_ in zip(keys.tolist(), gids.tolist()):
+        first.setdefault(g_, k_)
+    c_min, mins = oracle.agg_double_minmax(gids, vals, ng, True, nulls=nulls)
+    c_max, maxs = oracle.agg_double_minmax(gids, vals, ng, False, nulls=nulls)
+    c_mm, mmax = oracle.agg_double_minmax(gids, vals, ng, False, nulls=nulls, mask=mask)
+    canon = lambda x: None if x is None else (0x7ff8000000000000 if x != x else int(np.float64(x).view(np.int64)))
+    for g_ in range(ng):
+        r = by_key[first[g_]]
+        want = [mins[g_] if c_min[g_] else None, maxs[g_] if c_max[g_] else None, mmax[g_] if c_mm[g_] else None]
+        assert [canon(x) for x in r[1:4]] == [canon(x) for x in want] and r[4] == c_min[g_], (g_, r, want)
+    if groups > 3:
+        assert by_key[1][1] is None and by_key[2][1] != by_key[2][1] and by_key[2][2] != by_key[2][2]
+
+
+def test_max_double_of_zeros_of_both_signs(pkg, ctx, oracle):
+    """the one place where max(double) is NOT the reference's bits, pinned knowingly (tgpu.h TGPU_AGG_MAX_DOUBLE): MinMaxCompare.maxDouble
+    keeps the zero that came first (-0.0 > +0.0 is false both ways), an order-independent maximum has to choose: +0.0.  Equal under =.
+    min is exact: Double.compare puts -0.0 below +0.0"""
+    page = pkg.Page(pkg.Block(pkg.BIGINT, np.zeros(4, dtype=np.int64)), pkg.Block(pkg.DOUBLE, np.array([-0.0, 0.0, -0.0, -1.0])))
+    ((_, mn, mx),) = run_agg(pkg, ctx, [page], [pkg.BIGINT], [0], [(pkg.MIN_DOUBLE, 1), (pkg.MAX_DOUBLE, 1)])
+    _, java_max = oracle.agg_double_minmax(np.zeros(4, dtype=np.int64), page.getBlock(1).values, 1, False)
+    assert mn == -1.0 and mx == 0.0 and not np.signbit(mx) and np.signbit(java_max[0]) and java_max[0] == mx
+
+
 def _onepass_pages(pkg, rng, npages, rows, late_groups, error_page=None):
     """pages of a Q1-like program: 2 varchar(1) keys (3 x 2 values), some pages add a new key value late in the stream"""
     pages = []
