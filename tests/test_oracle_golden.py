@@ -253,6 +253,19 @@ def test_hash_builder_resize_fixture(oracle):
     assert g.group_count == 11 and counts.tolist() == [2] * 10 + [1]
 
 
+def test_double_min_max_restates_the_references_comparisons(oracle):
+    # min: Double.compare (DoubleType.java:194-198) -- -0.0 below +0.0, NaN above +inf; max: MinMaxCompare.maxDouble -- value > state ||
+    # isNaN(state): the first of equal zeros stays, a NaN state gives way to anything, a NaN never replaces a value
+    gids = np.array([0, 0, 0, 1, 1, 1, 2, 2, 3, 4, 4], dtype=np.int64)
+    vals = np.array([np.nan, 1.0, -0.0, 0.0, -0.0, np.nan, -np.inf, np.inf, np.nan, -0.0, 0.0])
+    c, mn = oracle.agg_double_minmax(gids, vals, 5, True)
+    c2, mx = oracle.agg_double_minmax(gids, vals, 5, False)
+    assert c.tolist() == [3, 3, 2, 1, 2]
+    bits = lambda a: [int(x) for x in np.asarray(a, dtype=np.float64).view(np.int64)]
+    assert bits(mn[:3]) == bits([-0.0, -0.0, -np.inf]) and np.isnan(mn[3]) and bits(mn[4:]) == bits([-0.0])
+    assert bits(mx[:3]) == bits([1.0, 0.0, np.inf]) and np.isnan(mx[3]) and bits(mx[4:]) == bits([-0.0])     # group 4: the zero that came first
+
+
 def test_long_min_max_restates_compare_and_update_state(oracle):
     # AbstractMinMaxAggregationFunction.java:274-289 on a few rows by hand: nulls and masked rows leave the state alone, the first value is
     # taken whatever it is, ties keep the state; a group without values stays null (count 0)
